@@ -1,0 +1,172 @@
+/* recguru_hip.h -- C ABI of librecguru_hip.so (gfx950 / MI355X).
+ *
+ * The reference (Chain123/RecGURU) has no operator / FFI layer: its hot path is torch.nn modules
+ * (SURVEY.md 8b).  This header is therefore the native boundary the build defines: one launcher
+ * per fused op of the AE+GAN training step, forward and backward.  Each entry point names the
+ * reference code it replaces (paths relative to /root/reference/GURU).
+ *
+ * Conventions: plain pointers and sizes, no torch types.  All pointers are DEVICE pointers unless
+ * a parameter is documented as host.  The caller owns every buffer; kernels never allocate, never
+ * synchronise and run on the stream passed as `void* stream` (a hipStream_t; NULL = default).
+ * `dtype` selects the activation/operand tier: RG_F32 (exact f32 MFMA, parity tier) or RG_BF16
+ * (bf16 MFMA operands, f32 accumulation/softmax/LayerNorm).  Parameters, gradients, optimizer
+ * state, losses and statistics are always f32.  Return 0 on success, a negative RG_ERR_* code
+ * otherwise; rg_last_error() gives the message (thread-local).
+ */
+#ifndef RECGURU_HIP_H
+#define RECGURU_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RG_F32 0
+#define RG_BF16 1
+
+#define RG_ERR_INVALID (-1)
+#define RG_ERR_UNSUPPORTED (-2)
+#define RG_ERR_HIP (-3)
+
+const char* rg_last_error(void);
+int rg_version(void);
+
+/* ---- generic Linear-shaped GEMMs --------------------------------------------------------------
+ * replaces nn.Linear forward / backward in MultiHeadAttention (Transformer/transformer.py:136-161),
+ * PositionWiseFeedForwardNet (:173-188) and Discriminator (tools/utils.py:41-57). */
+#define RG_PRO_NONE 0
+#define RG_PRO_GELU 1 /* operand = gelu_tanh(stored pre-activation), transformer.py:81-84 */
+
+#define RG_EPI_NONE 0        /* C = acc + bias */
+#define RG_EPI_RELU 1        /* C = max(acc + bias, 0)                       tools/utils.py:43 */
+#define RG_EPI_MUL_POSMASK 2 /* C = (acc + bias) * [aux > 0]   (ReLU backward / GP mask chain) */
+#define RG_EPI_GELU_GRAD 3   /* C = (acc + bias) * gelu'(aux)                (FFN backward)   */
+#define RG_EPI_ADD 4         /* C = acc + bias + aux                         (residual grads) */
+#define RG_EPI_RESID_LN 5    /* C = LayerNorm(acc + bias + aux; gamma, beta, eps) * rowmask;
+                                rstd_out[m] saved.  transformer.py:161,188 and :594,:539      */
+
+typedef struct {
+  const void* A; int lda;     /* [M,K] dtype */
+  const void* W; int ldw;     /* [N,K] dtype (torch Linear layout [out,in]) */
+  const float* bias;          /* [N] or NULL */
+  void* C; int ldc;           /* [M,N] dtype, or f32 if c_is_f32 */
+  int c_is_f32;
+  int M, N, K;                /* K multiple of 32 */
+  int prologue, epilogue;
+  const void* aux; int ldaux; /* [M,N] dtype */
+  const float* gamma; const float* beta; const float* rowmask; float* rstd_out; float ln_eps;
+} rg_gemm_nt_args;
+int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
+
+typedef struct {
+  const void* Y; int ldy;     /* [T,N1] dtype  (upstream gradient) */
+  const void* X; int ldx;     /* [T,N2] dtype  (layer input; prologue_x applied) */
+  float* dW; int lddw;        /* [N1,N2] f32, ACCUMULATED into (atomics) */
+  float* colsum;              /* [N1] f32 += sum_t Y[t,:]  (bias gradient) or NULL */
+  int T, N1, N2;
+  int prologue_x;
+  float scale;
+  int splits;                 /* token splits (0 = auto) */
+  int use_tr;                 /* bf16: 1 = ds_read_tr16_b64 fragments, 0 = scalar LDS reads */
+} rg_gemm_tn_args;
+int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
+
+
+/* ---- attention core (d_k = d_v = 32) --------------------------------------------------------------
+ * replaces ScaledDotProductAttention.forward (Transformer/transformer.py:119-129) + the mask
+ * builders get_attn_pad_mask / get_attn_subsequent_mask (:54-78) + head repeat (:157).
+ * masked(q,key) = (key_ids[b,key] == pad_value) || (causal && key > q); masked scores are REPLACED
+ * by -1e9 before softmax.  qkv: [B,L,3*H*32] (Q|K|V), ctx: [B,L,H*32], lse: [B,H,L] f32. */
+typedef struct {
+  const void* qkv;
+  const int64_t* key_ids; int64_t pad_value; int causal;
+  void* ctx; float* lse;      /* lse may be NULL (inference) */
+  int B, L, H, dk;
+  float scale;                /* 1/sqrt(d_k), transformer.py:120 */
+} rg_attn_args;
+int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
+
+typedef struct {
+  const void* qkv; const void* dctx; const void* ctx; const float* lse;
+  const int64_t* key_ids; int64_t pad_value; int causal;
+  void* dqkv;                 /* [B,L,3*H*32] dtype, fully overwritten */
+  int B, L, H, dk;
+  float scale;
+} rg_attn_bwd_args;
+int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream);
+
+/* ---- K1: embedding gather + positional add + pad mask, and its scatter-add backward ---------------
+ * replaces nn.Embedding lookups (AutoEnc4Rec.py:180,192; AutoEnc4Rec_cross.py:98,101,124,127) fused
+ * with PositionalEncoding.forward (Transformer/transformer.py:104-106).
+ * table: [rows,d] dtype (operand-tier copy of the f32 master), pe: [>=L,d] f32, ids: [ntok] i64,
+ * mask: [ntok] f32, out: [ntok,d] dtype.  Backward accumulates dx*mask into the dense f32 gradient
+ * dE[rows,d]; skip_row (e.g. padding_idx 0 of AutoEnc4Rec.py:153) receives nothing (-1 = none). */
+int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
+                    long long ntok, int L, int d, int dtype, void* stream);
+int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
+                         long long skip_row, int dtype, void* stream);
+
+/* ---- LayerNorm backward (from the saved output y and rstd) ---------------------------------------
+ * replaces autograd of nn.LayerNorm(d, eps=1e-8) at transformer.py:161,188 incl. the row mask of
+ * :594/:539.  dz fully overwritten; dgamma/dbeta ACCUMULATED (atomics). */
+typedef struct {
+  const void* dy; const void* y; const float* rstd; const float* gamma; const float* beta;
+  const float* rowmask;       /* [M] or NULL */
+  void* dz; float* dgamma; float* dbeta;
+  long long M; int N; int ld;
+} rg_ln_bwd_args;
+int rg_ln_bwd(const rg_ln_bwd_args* args /* host */, int dtype, void* stream);
+
+/* ---- collapsed decoder cross-attention (quirk Q1) ---------------------------------------------------
+ * MultiHeadAttention(Q=x, K=V=rep(u)) of transformer.py:259 with AutoEnc4Rec_cross.py:122: context is
+ * WV u + bV for every query, so the block is y = LayerNorm(x + o[b]) with o = linear(WV u + bV).
+ * rg_bcast_add_ln: x [B*L,N] dtype, o [B,N] f32 -> y dtype, rstd f32.  rg_seq_sum: out[b,:] = sum_t x[b,t,:]. */
+int rg_bcast_add_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
+                    long long M, int L, int N, float eps, int dtype, void* stream);
+int rg_seq_sum(const void* x, float* out, int B, int L, int N, int dtype, void* stream);
+
+/* ---- discriminator / W-GAN gradient-penalty helpers ----------------------------------------------
+ * tools/utils.py:41-57 and gan_training.py:38-55 (closed-form double backward). */
+int rg_colsum(const void* x, const void* aux /* or NULL */, float* out, long long M, int N, int ld, float scale,
+              int dtype, void* stream);                       /* out[n] += scale*sum_m x[m,n]*[aux>0] */
+int rg_outer_posmask(const float* coef /* [M] or NULL */, const float* w /* [N] */, const void* aux, void* out,
+                     long long M, int N, int dtype, void* stream); /* out = coef[m]*w[n]*[aux>0]       */
+int rg_interpolate(const float* alpha, const void* real, const void* fake, void* out, long long B, int d,
+                   int dtype, void* stream);                   /* gan_training.py:39-43               */
+int rg_gp_penalty(const float* g, void* dg, float* gp, long long B, int d, float lambda, int dtype,
+                  void* stream);                               /* gan_training.py:54 + d/dg           */
+int rg_sum(const float* x, float* out, long long n, float scale, void* stream); /* out[0] += scale*sum */
+
+/* ---- optimizer ---------------------------------------------------------------------------------
+ * torch.optim.Adam as configured at train_gan.py:126-134 / gan_training.py:359 (no amsgrad / decay).
+ * step counts from 1.  shadow (optional): operand-tier copy refreshed in the same pass. */
+int rg_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long long n, float lr,
+            float beta1, float beta2, float eps, int step, void* stream);
+int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
+
+/* ---- K7/K8: fused gather-dot-loss over the item catalogue --------------------------------------
+ * mode RG_LOSS_SAMPLED_CE: AutoEnc4Rec_cross.py:201-215 + tools/lossfunctions.py:36-49 (label 0).
+ * mode RG_LOSS_BPR:        tools/utils.py:114-126 + tools/lossfunctions.py:56-72.
+ * sums[0] += sum_t mask*loss_t, sums[1] += sum_t mask (caller zeroes sums; loss = sums[0]/sums[1]).
+ * aux_tok[t] saves the per-position log-sum-exp (CE) or score margin (BPR) for the backward.
+ * Backward: dh fully overwritten; dE ACCUMULATED with gout[0]/sums[1] folded in. */
+#define RG_LOSS_SAMPLED_CE 0
+#define RG_LOSS_BPR 1
+typedef struct {
+  const void* h;              /* [ntok,d] dtype : decoder states */
+  const void* table;          /* [rows,d] dtype */
+  const int64_t* pos;         /* [ntok] */
+  const int64_t* neg;         /* [ntok,k] */
+  const float* mask;          /* [ntok] */
+  float* aux_tok;             /* [ntok] */
+  float* sums;                /* [2] */
+  const float* gout;          /* [1] upstream gradient (backward only) */
+  void* dh; float* dE;        /* backward outputs */
+  long long ntok; int d; int k; int mode; long long skip_row;
+} rg_item_loss_args;
+int rg_item_loss_fwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
+int rg_item_loss_bwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

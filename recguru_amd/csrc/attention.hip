@@ -1,0 +1,347 @@
+// Scaled-dot-product attention core for d_k = d_v = 32 (hard-coded in the reference,
+// config_auto4rec.py:35-36), forward and backward, one workgroup per (sequence, head).
+//
+// Replaces ScaledDotProductAttention.forward (Transformer/transformer.py:119-129) and the mask
+// materialisation around it (:54-78, :157; AutoEnc4Rec_cross.py:103-107,130-134): the key-pad /
+// causal mask is evaluated in-kernel from the key ids, nothing of size L x L ever reaches HBM, and
+// the returned attention map (never consumed on the hot path) is not produced.
+//
+// Semantics kept bit-for-bit in spirit: scores/sqrt(d_k), then REPLACE-fill -1e9 where masked
+// (so a fully masked row is uniform over all L keys, quirk Q3), softmax in f32.
+//
+// Layout: qkv is [B, L, 3P] row-major (P = H*32): Q | K | V column blocks, head h at h*32.
+// Whole key range of one head lives on chip (L <= 16*NKT): S^T = K.Q^T accumulators (key on the
+// register axis, query on the lane) are exponentiated in place and fed straight back as the B
+// operand of O^T = V^T.P^T (rg_common.cuh, stacked-accumulator mapping) -- P never touches LDS.
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define DK 32
+#define NEG_FILL (-1e9f)
+
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
+  constexpr int LPK = NKT * 16;       // padded key count (multiple of 32)
+  constexpr int LDK = DK + 8;         // K rows [key][dk]
+  constexpr int LDV = LPK + 8;        // V^T rows [dv][key]
+  __shared__ __align__(16) T Ks[LPK * LDK];
+  __shared__ __align__(16) T Vt[DK * LDV];
+  __shared__ unsigned char kpad[LPK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.L, P = a.H * DK, ld = 3 * P;
+  const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
+
+  // ---- stage K (row-major) and V (transposed) of this head, and the key-pad flags
+  for (int c = tid; c < LPK * 4; c += 256) {
+    const int key = c >> 2, c8 = (c & 3) * 8;
+    float kv[8], vv[8];
+    if (key < L) {
+      load8(kv, qkv + (size_t)key * ld + P + h * DK + c8);
+      load8(vv, qkv + (size_t)key * ld + 2 * P + h * DK + c8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kv[j] = 0.f; vv[j] = 0.f; }
+    }
+    store8(Ks + key * LDK + c8, kv);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Vt[(c8 + j) * LDV + key] = (T)vv[j];
+  }
+  for (int key = tid; key < LPK; key += 256)
+    kpad[key] = (key < L && a.key_ids[(size_t)b * L + key] == a.pad_value) ? 1 : 0;
+  __syncthreads();
+
+  const int nqt = (L + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int q = qt * 16 + li;            // this lane's query (column of S^T)
+    Frag<T> qf;
+    if (q < L) load_frag(qf, qkv + (size_t)q * ld + h * DK + 8 * lg);
+    else frag_zero(qf);
+
+    f32x4 s[NKT];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt < nkt) {
+        Frag<T> kf;
+        load_frag(kf, Ks + (kt * 16 + li) * LDK + 8 * lg);
+        mma(kf, qf, s[kt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * lg + r;
+          float v = s[kt][r] * a.scale;
+          if (key >= L) v = -INFINITY;
+          else if (kpad[key] || (a.causal && key > q)) v = NEG_FILL;
+          s[kt][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+      if (kt < nkt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __expf(s[kt][r] - mx);
+          s[kt][r] = p;
+          sum += p;
+        }
+      }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    const float inv = 1.f / sum;
+
+    f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int ks = 0; ks < NKT / 2; ++ks)
+      if (2 * ks < nkt) {
+        Frag<T> pf;
+        acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          Frag<T> vf;
+          const T* vp = Vt + (dt * 16 + li) * LDV + ks * 32 + 4 * lg;
+          load_frag_2x4(vf, vp, vp + 16);
+          mma(vf, pf, o[dt]);
+        }
+      }
+    if (q < L) {
+      T* __restrict__ ctx = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
+        store4(ctx + dt * 16 + 4 * lg, v);
+      }
+      if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = mx + __logf(sum);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward.  Phase 1 (dK, dV): waves own key tiles and sweep query pairs with S = Q.K^T (query on
+// the register axis).  Phase 2 (dQ): waves own query tiles and sweep key pairs with S^T = K.Q^T.
+// Recomputing S/dP in both orientations (7 products instead of 5) removes every LDS transpose of
+// P/dS and every cross-workgroup reduction.  Gradients do not flow through replaced (masked)
+// scores: dS = 0 there, exactly like masked_fill_ in the reference.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NKT>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
+  constexpr int LPK = NKT * 16;
+  constexpr int LDT = LPK + 8;        // transposed images [32][LPK]
+  __shared__ __align__(16) T Qt[DK * LDT];
+  __shared__ __align__(16) T dOt[DK * LDT];
+  __shared__ __align__(16) T Kt[DK * LDT];
+  __shared__ float lse_s[LPK];
+  __shared__ float dl_s[LPK];
+  __shared__ unsigned char kpad[LPK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.L, P = a.H * DK, ld = 3 * P;
+  const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
+  const T* __restrict__ O = reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK;
+  T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
+  const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
+
+  for (int c = tid; c < LPK * 4; c += 256) {
+    const int row = c >> 2, c8 = (c & 3) * 8;
+    float qv[8], kv[8], gv[8], ov[8];
+    if (row < L) {
+      load8(qv, qkv + (size_t)row * ld + h * DK + c8);
+      load8(kv, qkv + (size_t)row * ld + P + h * DK + c8);
+      load8(gv, dO + (size_t)row * P + c8);
+      load8(ov, O + (size_t)row * P + c8);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { qv[j] = 0.f; kv[j] = 0.f; gv[j] = 0.f; ov[j] = 0.f; }
+    }
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      Qt[(c8 + j) * LDT + row] = (T)qv[j];
+      Kt[(c8 + j) * LDT + row] = (T)kv[j];
+      dOt[(c8 + j) * LDT + row] = (T)gv[j];
+      d += gv[j] * ov[j];
+    }
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    if ((c & 3) == 0) dl_s[row] = d;
+  }
+  for (int r = tid; r < LPK; r += 256) {
+    lse_s[r] = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
+    kpad[r] = (r < L && a.key_ids[(size_t)b * L + r] == a.pad_value) ? 1 : 0;
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- phase 1: dK, dV
+  for (int kt = wave; kt < nt; kt += 4) {
+    const int key = kt * 16 + li;      // this lane's key (column of S)
+    Frag<T> kf, vf;
+    if (key < L) {
+      load_frag(kf, qkv + (size_t)key * ld + P + h * DK + 8 * lg);
+      load_frag(vf, qkv + (size_t)key * ld + 2 * P + h * DK + 8 * lg);
+    } else { frag_zero(kf); frag_zero(vf); }
+    const bool kmask = (key >= L) || kpad[key];
+    f32x4 dk[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dv[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int qs = 0; qs < nt / 2; ++qs) {
+      f32x4 p[2], ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int qrow = qs * 32 + u * 16 + li;     // A-operand row of this lane
+        Frag<T> qf, gf;
+        if (qrow < L) {
+          load_frag(qf, qkv + (size_t)qrow * ld + h * DK + 8 * lg);
+          load_frag(gf, dO + (size_t)qrow * P + 8 * lg);
+        } else { frag_zero(qf); frag_zero(gf); }
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma(qf, kf, sv);
+        mma(gf, vf, dp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qs * 32 + u * 16 + 4 * lg + r;   // accumulator row
+          const bool masked = kmask || (a.causal && key > q);
+          const float sc = masked ? NEG_FILL : sv[r] * a.scale;
+          // fully masked row: lse = -1e9 + log L rounds to -1e9 in f32, the row is uniform 1/L (Q3)
+          const float lq = lse_s[min(q, LPK - 1)];
+          float pv = (q < L && key < L) ? (lq < -5e8f ? 1.f / (float)L : __expf(sc - lq)) : 0.f;
+          p[u][r] = pv;
+          ds[u][r] = masked ? 0.f : pv * (dp[r] - dl_s[q]) * a.scale;
+        }
+      }
+      Frag<T> pf, dsf;
+      acc_to_frag(pf, p[0], p[1]);
+      acc_to_frag(dsf, ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> gtf, qtf;
+        const T* gp = dOt + (dt * 16 + li) * LDT + qs * 32 + 4 * lg;
+        const T* qp = Qt + (dt * 16 + li) * LDT + qs * 32 + 4 * lg;
+        load_frag_2x4(gtf, gp, gp + 16);
+        load_frag_2x4(qtf, qp, qp + 16);
+        mma(pf, gtf, dv[dt]);     // dV[key][dv] += sum_q P[q][key] dO[q][dv]
+        mma(dsf, qtf, dk[dt]);    // dK[key][dk] += sum_q dS[q][key] Q[q][dk]
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int krow = kt * 16 + 4 * lg + r;
+        if (krow < L) {
+          dqkv[(size_t)krow * ld + P + h * DK + dt * 16 + li] = (T)dk[dt][r];
+          dqkv[(size_t)krow * ld + 2 * P + h * DK + dt * 16 + li] = (T)dv[dt][r];
+        }
+      }
+  }
+
+  // ---------------------------------------------------------------- phase 2: dQ
+  for (int qt = wave; qt < nt; qt += 4) {
+    const int q = qt * 16 + li;        // this lane's query (column of S^T)
+    Frag<T> qf, gf;
+    if (q < L) {
+      load_frag(qf, qkv + (size_t)q * ld + h * DK + 8 * lg);
+      load_frag(gf, dO + (size_t)q * P + 8 * lg);
+    } else { frag_zero(qf); frag_zero(gf); }
+    const float lse_q = lse_s[min(q, LPK - 1)], dl_q = dl_s[min(q, LPK - 1)];
+    f32x4 dq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int ks = 0; ks < nt / 2; ++ks) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int krow = ks * 32 + u * 16 + li;
+        Frag<T> kf, vf;
+        if (krow < L) {
+          load_frag(kf, qkv + (size_t)krow * ld + P + h * DK + 8 * lg);
+          load_frag(vf, qkv + (size_t)krow * ld + 2 * P + h * DK + 8 * lg);
+        } else { frag_zero(kf); frag_zero(vf); }
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma(kf, qf, sv);          // S^T[key][q]
+        mma(vf, gf, dp);          // dP^T[key][q]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = ks * 32 + u * 16 + 4 * lg + r;
+          const bool masked = (key >= L) || kpad[key] || (a.causal && key > q);
+          const float pv = (q < L && key < L && !masked) ? __expf(sv[r] * a.scale - lse_q) : 0.f;
+          ds[u][r] = pv * (dp[r] - dl_q) * a.scale;
+        }
+      }
+      Frag<T> dsf;
+      acc_to_frag(dsf, ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> ktf;
+        const T* kp = Kt + (dt * 16 + li) * LDT + ks * 32 + 4 * lg;
+        load_frag_2x4(ktf, kp, kp + 16);
+        mma(dsf, ktf, dq[dt]);    // dQ[q][dk] += sum_key dS[q][key] K[key][dk]
+      }
+    }
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = qt * 16 + 4 * lg + r;
+        if (qrow < L) dqkv[(size_t)qrow * ld + h * DK + dt * 16 + li] = (T)dq[dt][r];
+      }
+  }
+}
+
+template <typename T>
+static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
+  const int nkt = (a.L + 31) / 32 * 2;
+  dim3 grid(a.B * a.H), block(256);
+#define RG_FWD(N) hipLaunchKernelGGL((attn_fwd_kernel<T, N>), grid, block, 0, s, a)
+  if (nkt <= 2) RG_FWD(2);
+  else if (nkt <= 4) RG_FWD(4);
+  else if (nkt <= 8) RG_FWD(8);
+  else if (nkt <= 14) RG_FWD(14);
+  else if (nkt <= 16) RG_FWD(16);
+  else if (nkt <= 26) RG_FWD(26);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: L > 416 not supported yet");
+#undef RG_FWD
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+template <typename T>
+static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
+  const int nkt = (a.L + 31) / 32 * 2;
+  dim3 grid(a.B * a.H), block(256);
+#define RG_BWD(N) hipLaunchKernelGGL((attn_bwd_kernel<T, N>), grid, block, 0, s, a)
+  if (nkt <= 2) RG_BWD(2);
+  else if (nkt <= 4) RG_BWD(4);
+  else if (nkt <= 8) RG_BWD(8);
+  else if (nkt <= 14) RG_BWD(14);
+  else if (nkt <= 16) RG_BWD(16);
+  else if (nkt <= 26 && sizeof(T) == 2) {
+    if constexpr (sizeof(T) == 2) RG_BWD(26);   // three f32 images of 416 keys exceed 160 KB LDS
+  } else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 (bf16) / 256 (f32) not supported yet");
+#undef RG_BWD
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_attn_fwd(const rg_attn_args* a, int dtype, void* stream) {
+  if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: empty problem");
+  if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: d_k must be 32");
+  if (dtype == RG_BF16) return launch_fwd<__bf16>(*a, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_fwd<float>(*a, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: bad dtype");
+}
+extern "C" int rg_attn_bwd(const rg_attn_bwd_args* a, int dtype, void* stream) {
+  if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: empty problem");
+  if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: d_k must be 32");
+  if (dtype == RG_BF16) return launch_bwd<__bf16>(*a, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_bwd<float>(*a, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: bad dtype");
+}

@@ -1,0 +1,441 @@
+// HBM-bound kernels of the path: embedding gather / scatter, LayerNorm backward, the collapsed
+// cross-attention broadcast+LayerNorm, gradient-penalty helpers, Adam, casts and reductions.
+// All of them move 8-16 bytes per lane per access with lanes on consecutive addresses.
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(long long work_items, int per_block) {
+  long long g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  if (g > 256LL * 16) g = 256LL * 16;  // grid-stride beyond ~16 blocks per CU
+  return (int)g;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1: x[b,t,:] = (E[ids[b,t],:] + pe[t,:]) * mask[b,t]       (PE added BEFORE masking, quirk Q6)
+// nn.Embedding lookup + PositionalEncoding.forward, transformer.py:104-106, AutoEnc4Rec_cross.py:98-102
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restrict__ table, const float* __restrict__ pe,
+                                                               const int64_t* __restrict__ ids,
+                                                               const float* __restrict__ mask, T* __restrict__ out,
+                                                               long long ntok, int L, int d) {
+  const int cpr = d >> 3;
+  const long long total = ntok * cpr;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const long long tok = i / cpr;
+    const int c8 = (int)(i - tok * cpr) * 8;
+    const float m = mask[tok];
+    float v[8];
+    if (m != 0.f) {
+      float p[8];
+      load8(v, table + (size_t)ids[tok] * d + c8);
+      load8(p, pe + (size_t)(tok % L) * d + c8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    }
+    store8(out + (size_t)tok * d + c8, v);
+  }
+}
+
+// dE[ids[b,t],:] += dx[b,t,:] * mask[b,t]  -- one wave per token row, 256 contiguous bytes per
+// atomic wave-instruction (the shape the memory-side f32 atomic unit runs at full rate).
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ ids,
+                                                                    const float* __restrict__ mask, float* __restrict__ dE,
+                                                                    long long ntok, int d, long long skip_row) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * EW_BLOCK + threadIdx.x) >> 6;
+  const long long nwaves = ((long long)gridDim.x * EW_BLOCK) >> 6;
+  for (long long tok = wave; tok < ntok; tok += nwaves) {
+    const float m = mask[tok];
+    const long long row = ids[tok];
+    if (m == 0.f || row == skip_row) continue;
+    for (int e = lane; e < d; e += 64) atomicAdd(dE + (size_t)row * d + e, (float)dx[(size_t)tok * d + e] * m);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm backward from the saved OUTPUT: xhat = (y - beta) / gamma, rstd saved by the forward.
+//   g = dy * rowmask * gamma ; dz = rstd * (g - mean(g) - xhat * mean(g * xhat))
+//   dgamma += sum_rows dy*rowmask*xhat ; dbeta += sum_rows dy*rowmask
+// nn.LayerNorm(eps=1e-8) backward at transformer.py:161,188; rows with rowmask == 0 (the
+// `* pad_mask` of :594/:539) get dz = 0.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NPL>
+__global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
+  __shared__ float red[2][4][64 * NPL];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.y);
+  T* __restrict__ dz = reinterpret_cast<T*>(a.dz);
+  const int N = a.N;
+  const float invn = 1.f / (float)N;
+  float gam[NPL], bet[NPL], dg[NPL], db[NPL];
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) {
+    const int n = lane + 64 * j;
+    gam[j] = n < N ? a.gamma[n] : 1.f;
+    bet[j] = n < N ? a.beta[n] : 0.f;
+    dg[j] = 0.f; db[j] = 0.f;
+  }
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  for (long long m = gw; m < a.M; m += nw) {
+    const float rm = a.rowmask ? a.rowmask[m] : 1.f;
+    if (rm == 0.f) {
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const int n = lane + 64 * j;
+        if (n < N) dz[(size_t)m * a.ld + n] = (T)0.f;
+      }
+      continue;
+    }
+    const float rstd = a.rstd[m];
+    float g[NPL], xh[NPL];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int n = lane + 64 * j;
+      if (n < N) {
+        const float d = (float)dy[(size_t)m * a.ld + n] * rm;
+        xh[j] = ((float)y[(size_t)m * a.ld + n] / rm - bet[j]) / gam[j];
+        g[j] = d * gam[j];
+        dg[j] += d * xh[j];
+        db[j] += d;
+      } else { g[j] = 0.f; xh[j] = 0.f; }
+      s1 += g[j];
+      s2 += g[j] * xh[j];
+    }
+    s1 = wave_sum(s1) * invn;
+    s2 = wave_sum(s2) * invn;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int n = lane + 64 * j;
+      if (n < N) dz[(size_t)m * a.ld + n] = (T)(rstd * (g[j] - s1 - xh[j] * s2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NPL; ++j) { red[0][wave][lane + 64 * j] = dg[j]; red[1][wave][lane + 64 * j] = db[j]; }
+  __syncthreads();
+  for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
+    const float sg = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
+    const float sb = red[1][0][n] + red[1][1][n] + red[1][2][n] + red[1][3][n];
+    if (a.dgamma) atomicAdd(a.dgamma + n, sg);
+    if (a.dbeta) atomicAdd(a.dbeta + n, sb);
+  }
+}
+
+// y[b,t,:] = LayerNorm(x[b,t,:] + o[b,:]) * rowmask : the collapsed decoder cross-attention (Q1):
+// context = WV u + bV for every query, so MultiHeadAttention reduces to a per-sequence vector o.
+template <typename T, int NPL>
+__global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_kernel(const T* __restrict__ x, const float* __restrict__ o,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ y, float* __restrict__ rstd_out, long long M,
+                                                               int L, int N, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invn = 1.f / (float)N;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  for (long long m = gw; m < M; m += nw) {
+    const long long b = m / L;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int n = lane + 64 * j;
+      v[j] = n < N ? (float)x[(size_t)m * N + n] + o[(size_t)b * N + n] : 0.f;
+      s += v[j];
+    }
+    const float mean = wave_sum(s) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int n = lane + 64 * j;
+      const float dd = n < N ? v[j] - mean : 0.f;
+      q += dd * dd;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const int n = lane + 64 * j;
+      if (n < N) y[(size_t)m * N + n] = (T)((v[j] - mean) * rstd * gamma[n] + beta[n]);
+    }
+    if (lane == 0) rstd_out[m] = rstd;
+  }
+}
+
+// out[b,:] (f32) = sum_t x[b,t,:]
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void seq_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int L, int N) {
+  const int b = blockIdx.x;
+  for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
+    float s = 0.f;
+    for (int t = 0; t < L; ++t) s += (float)x[((size_t)b * L + t) * N + n];
+    out[(size_t)b * N + n] = s;
+  }
+}
+
+// out[n] += scale * sum_m x[m,n] * (aux ? [aux[m,n] > 0] : 1)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ x, const T* __restrict__ aux, float* __restrict__ out,
+                                                         long long M, int N, int ld, float scale) {
+  const int n = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  float s = 0.f;
+  if (n < N)
+    for (long long m = (long long)blockIdx.y * 4 + part; m < M; m += (long long)gridDim.y * 4) {
+      float v = (float)x[(size_t)m * ld + n];
+      if (aux && !((float)aux[(size_t)m * ld + n] > 0.f)) v = 0.f;
+      s += v;
+    }
+  red[part][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (part == 0 && n < N) atomicAdd(out + n, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+}
+
+// out[m,n] = coef[m] * w[n] * [aux[m,n] > 0]      (seed of the ReLU-mask chains, tools/utils.py:41-52)
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void outer_posmask_kernel(const float* __restrict__ coef, const float* __restrict__ w,
+                                                                const T* __restrict__ aux, T* __restrict__ out, long long M, int N) {
+  const long long total = M * N;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const long long m = i / N;
+    const int n = (int)(i - m * N);
+    const float c = coef ? coef[m] : 1.f;
+    out[i] = (T)(((float)aux[i] > 0.f) ? c * w[n] : 0.f);
+  }
+}
+
+// xhat = alpha[b] * real + (1 - alpha[b]) * fake      gan_training.py:39-43
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void interpolate_kernel(const float* __restrict__ alpha, const T* __restrict__ real,
+                                                              const T* __restrict__ fake, T* __restrict__ out, long long B, int d) {
+  const long long total = B * d;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const float al = alpha[i / d];
+    out[i] = (T)(al * (float)real[i] + (1.f - al) * (float)fake[i]);
+  }
+}
+
+// gp += lambda/B * sum_b (||g_b|| - 1)^2 ; dg_b = lambda * 2/B * (||g_b|| - 1)/||g_b|| * g_b
+// gan_training.py:54 and its analytic derivative
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void gp_penalty_kernel(const float* __restrict__ g, T* __restrict__ dg, float* __restrict__ gp,
+                                                             long long B, int d, float lambda) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  float acc = 0.f;
+  for (long long b = gw; b < B; b += nw) {
+    float s = 0.f;
+    for (int e = lane; e < d; e += 64) { const float v = g[(size_t)b * d + e]; s += v * v; }
+    const float nrm = sqrtf(wave_sum(s));
+    const float c = lambda * 2.f / (float)B * (nrm - 1.f) / nrm;
+    for (int e = lane; e < d; e += 64) dg[(size_t)b * d + e] = (T)(c * g[(size_t)b * d + e]);
+    acc += (nrm - 1.f) * (nrm - 1.f);
+  }
+  if (lane == 0 && acc != 0.f) atomicAdd(gp, acc * lambda / (float)B);
+}
+
+// out[0] += scale * sum(x)
+__global__ __launch_bounds__(EW_BLOCK) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, long long n, float scale) {
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * EW_BLOCK) s += x[i];
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(out, s * scale);
+}
+
+// torch.optim.Adam (no amsgrad, no weight decay), one tensor; optionally refreshes the operand-tier
+// shadow copy (bf16) of the parameter in the same pass.     train_gan.py:126-134, gan_training.py:359
+template <typename S>
+__global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, S* __restrict__ shadow, long long n, float lr,
+                                                       float b1, float b2, float eps, float bc1, float bc2_sqrt) {
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * EW_BLOCK) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    const float pi = p[i] - (lr / bc1) * (mi / denom);
+    p[i] = pi;
+    if (shadow) shadow[i] = (S)pi;
+  }
+}
+
+// dst[c,r] (or dst[r,c]) = (T) src[r,c]
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int transpose) {
+  if (!transpose) {
+    const long long total = (long long)R * C;
+    for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) dst[i] = (T)src[i];
+    return;
+  }
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int tiles_c = (C + 31) / 32, tiles_r = (R + 31) / 32;
+  for (int t = blockIdx.x; t < tiles_c * tiles_r; t += gridDim.x) {
+    const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    for (int k = ty; k < 32; k += 8) tile[k][tx] = (r0 + k < R && c0 + tx < C) ? src[(size_t)(r0 + k) * C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8)
+      if (c0 + k < C && r0 + tx < R) dst[(size_t)(c0 + k) * R + r0 + tx] = (T)tile[tx][k];
+    __syncthreads();
+  }
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+#define DISPATCH_T(dtype, CALL_BF16, CALL_F32, name)                                     \
+  if ((dtype) == RG_BF16) { CALL_BF16; } else if ((dtype) == RG_F32) { CALL_F32; }        \
+  else return rg_set_error_msg(RG_ERR_INVALID, name ": bad dtype");                       \
+  RG_CHECK_LAUNCH(); return 0;
+
+extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
+                               long long ntok, int L, int d, int dtype, void* stream) {
+  if (ntok <= 0) return 0;
+  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(ntok * (d >> 3), EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_pe_fwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)table, pe, ids, mask, (__bf16*)out, ntok, L, d),
+             hipLaunchKernelGGL(embed_pe_fwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)table, pe, ids, mask, (float*)out, ntok, L, d),
+             "embed_pe_fwd")
+}
+
+extern "C" int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
+                                    long long skip_row, int dtype, void* stream) {
+  if (ntok <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(ntok, 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(embed_scatter_bwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)dx, ids, mask, dE, ntok, d, skip_row),
+             hipLaunchKernelGGL(embed_scatter_bwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)dx, ids, mask, dE, ntok, d, skip_row),
+             "embed_scatter_bwd")
+}
+
+template <typename T>
+static int launch_ln_bwd(const rg_ln_bwd_args& a, hipStream_t s) {
+  const int grid = ew_grid(a.M, 16);
+  if (a.N <= 64) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else if (a.N <= 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else if (a.N <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ln_bwd: N > 256");
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rg_ln_bwd(const rg_ln_bwd_args* a, int dtype, void* stream) {
+  if (!a || a->M <= 0) return 0;
+  if (dtype == RG_BF16) return launch_ln_bwd<__bf16>(*a, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_ln_bwd<float>(*a, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "ln_bwd: bad dtype");
+}
+
+template <typename T>
+static int launch_bcast_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
+                           long long M, int L, int N, float eps, hipStream_t s) {
+  const int grid = ew_grid(M, 16);
+#define RG_BL(NPL) hipLaunchKernelGGL((bcast_add_ln_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)x, o, gamma, beta, (T*)y, rstd, M, L, N, eps)
+  if (N <= 64) RG_BL(1);
+  else if (N <= 128) RG_BL(2);
+  else if (N <= 256) RG_BL(4);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "bcast_add_ln: N > 256");
+#undef RG_BL
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rg_bcast_add_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
+                               long long M, int L, int N, float eps, int dtype, void* stream) {
+  if (M <= 0) return 0;
+  if (dtype == RG_BF16) return launch_bcast_ln<__bf16>(x, o, gamma, beta, y, rstd, M, L, N, eps, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_bcast_ln<float>(x, o, gamma, beta, y, rstd, M, L, N, eps, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "bcast_add_ln: bad dtype");
+}
+
+extern "C" int rg_seq_sum(const void* x, float* out, int B, int L, int N, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(seq_sum_kernel<__bf16>, dim3(B), dim3(EW_BLOCK), 0, s, (const __bf16*)x, out, L, N),
+             hipLaunchKernelGGL(seq_sum_kernel<float>, dim3(B), dim3(EW_BLOCK), 0, s, (const float*)x, out, L, N),
+             "seq_sum")
+}
+
+extern "C" int rg_colsum(const void* x, const void* aux, float* out, long long M, int N, int ld, float scale, int dtype, void* stream) {
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  long long gy = (M + 255) / 256; if (gy > 512) gy = 512; if (gy < 1) gy = 1;
+  dim3 grid((N + 63) / 64, (int)gy);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(EW_BLOCK), 0, s, (const __bf16*)x, (const __bf16*)aux, out, M, N, ld, scale),
+             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(EW_BLOCK), 0, s, (const float*)x, (const float*)aux, out, M, N, ld, scale),
+             "colsum")
+}
+
+extern "C" int rg_outer_posmask(const float* coef, const float* w, const void* aux, void* out, long long M, int N, int dtype, void* stream) {
+  if (M <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(M * N, EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(outer_posmask_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const __bf16*)aux, (__bf16*)out, M, N),
+             hipLaunchKernelGGL(outer_posmask_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const float*)aux, (float*)out, M, N),
+             "outer_posmask")
+}
+
+extern "C" int rg_interpolate(const float* alpha, const void* real, const void* fake, void* out, long long B, int d, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(B * d, EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(interpolate_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, alpha, (const __bf16*)real, (const __bf16*)fake, (__bf16*)out, B, d),
+             hipLaunchKernelGGL(interpolate_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, alpha, (const float*)real, (const float*)fake, (float*)out, B, d),
+             "interpolate")
+}
+
+extern "C" int rg_gp_penalty(const float* g, void* dg, float* gp, long long B, int d, float lambda, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(B, 4);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(gp_penalty_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, g, (__bf16*)dg, gp, B, d, lambda),
+             hipLaunchKernelGGL(gp_penalty_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, g, (float*)dg, gp, B, d, lambda),
+             "gp_penalty")
+}
+
+extern "C" int rg_sum(const float* x, float* out, long long n, float scale, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(sum_kernel, dim3(ew_grid(n, EW_BLOCK * 4)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, out, n, scale);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long long n, float lr,
+                       float beta1, float beta2, float eps, int step, void* stream) {
+  if (n <= 0) return 0;
+  if (step < 1) return rg_set_error_msg(RG_ERR_INVALID, "adam: step counts from 1");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(n, EW_BLOCK);
+  if (shadow && shadow_dtype == RG_BF16)
+    hipLaunchKernelGGL(adam_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, p, g, m, v, (__bf16*)shadow, n, lr, beta1, beta2, eps, bc1, bc2s);
+  else
+    hipLaunchKernelGGL(adam_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, p, g, m, v, (float*)nullptr, n, lr, beta1, beta2, eps, bc1, bc2s);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream) {
+  if (R <= 0 || C <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = transpose ? min(((C + 31) / 32) * ((R + 31) / 32), 4096) : ew_grid((long long)R * C, EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(cast_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, src, (__bf16*)dst, R, C, transpose),
+             hipLaunchKernelGGL(cast_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, src, (float*)dst, R, C, transpose),
+             "cast")
+}

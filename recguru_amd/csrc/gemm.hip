@@ -1,0 +1,328 @@
+// Generic MFMA GEMM kernels for the token-parallel parts of the path.
+//
+//  rg_gemm_nt : C[M,N] = epi( pro(A[M,K]) . W[N,K]^T + bias )     (Linear forward, dX, GP chains)
+//  rg_gemm_tn : dW[N1,N2] += sum_t Y[t,n1] . pro(X[t,n2])          (weight gradients; + column sums)
+//
+// NT: one workgroup = 4 waves = a 64-row x (64*NTW)-column tile.  The activation chunk [64 x 128]
+// is staged in LDS (padded rows -> conflict-free ds_read_b128 fragments); the four waves split the
+// columns, so each weight element is fetched exactly once per workgroup, straight from L2 into its
+// B fragment (torch Linear weights are [out,in] = [N][K]: 8 consecutive k are 16 contiguous bytes).
+// The residual+LayerNorm epilogue needs whole rows and therefore a tile that spans N.
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define TM 64
+#define KC 128
+#define APAD 8
+
+template <typename T, int NTW>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
+  constexpr int TN = 64 * NTW;
+  constexpr int LDA = KC + APAD;
+  constexpr int A_BYTES = TM * LDA * (int)sizeof(T);
+  constexpr int Z_LD = TN + 4;
+  constexpr int Z_BYTES = TM * Z_LD * 4;
+  constexpr int SMEM = A_BYTES > Z_BYTES ? A_BYTES : Z_BYTES;
+  __shared__ __align__(16) unsigned char smem[SMEM];
+  T* As = reinterpret_cast<T*>(smem);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int m0 = blockIdx.x * TM;
+  const int nb0 = blockIdx.y * TN + wave * NTW * 16;
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+
+  f32x4 acc[4][NTW];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int kc = 0; kc < a.K; kc += KC) {
+    const int klen = min(KC, a.K - kc);
+    const int ksteps = klen >> 5;
+    // weight fragments for the whole chunk: issued first so they fly while A is staged
+    Frag<T> bf[4][NTW];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = nb0 + j * 16 + li;
+        if (ks < ksteps && n < a.N)
+          load_frag(bf[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
+        else
+          frag_zero(bf[ks][j]);
+      }
+    // stage pro(A[m0:m0+64, kc:kc+klen]) into LDS
+    const int cpr = klen >> 3;  // 8-element chunks per row
+    for (int c = tid; c < TM * cpr; c += 256) {
+      const int r = c / cpr, c8 = (c - r * cpr) * 8;
+      float v[8];
+      if (m0 + r < a.M) {
+        load8(v, A + (size_t)(m0 + r) * a.lda + kc + c8);
+        if (a.prologue == RG_PRO_GELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+      }
+      store8(As + r * LDA + c8, v);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < ksteps) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          Frag<T> af;
+          load_frag(af, As + (rt * 16 + li) * LDA + ks * 32 + 8 * lg);
+#pragma unroll
+          for (int j = 0; j < NTW; ++j) mma(af, bf[ks][j], acc[rt][j]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ------------------------------------------------------------------ epilogue
+  const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
+  if (a.epilogue != RG_EPI_RESID_LN) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int j = 0; j < NTW; ++j) {
+        const int n = nb0 + j * 16 + li;
+        if (n >= a.N) continue;
+        const float b = a.bias ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + rt * 16 + 4 * lg + r;
+          if (m >= a.M) continue;
+          float v = acc[rt][j][r] + b;
+          switch (a.epilogue) {
+            case RG_EPI_RELU: v = fmaxf(v, 0.f); break;
+            case RG_EPI_MUL_POSMASK: v = ((float)aux[(size_t)m * a.ldaux + n] > 0.f) ? v : 0.f; break;
+            case RG_EPI_GELU_GRAD: v *= gelu_grad_f((float)aux[(size_t)m * a.ldaux + n]); break;
+            case RG_EPI_ADD: v += (float)aux[(size_t)m * a.ldaux + n]; break;
+            default: break;
+          }
+          if (a.c_is_f32) reinterpret_cast<float*>(a.C)[(size_t)m * a.ldc + n] = v;
+          else reinterpret_cast<T*>(a.C)[(size_t)m * a.ldc + n] = (T)v;
+        }
+      }
+    return;
+  }
+  // residual + LayerNorm(eps) [* rowmask]: whole rows live in this workgroup (gridDim.y == 1)
+  float* Z = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = nb0 + j * 16 + li;
+      const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rt * 16 + 4 * lg + r;
+        const int m = m0 + row;
+        float v = acc[rt][j][r] + b;
+        if (m < a.M && n < a.N) v += (float)aux[(size_t)m * a.ldaux + n];
+        Z[row * Z_LD + n] = v;   // gridDim.y == 1, so n is the tile column
+      }
+    }
+  __syncthreads();
+  const float invn = 1.f / (float)a.N;
+  for (int i = 0; i < 16; ++i) {
+    const int row = wave * 16 + i;
+    const int m = m0 + row;
+    if (m >= a.M) break;
+    float x[NTW];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = lane + 64 * j;
+      x[j] = (n < a.N) ? Z[row * Z_LD + n] : 0.f;
+      s += x[j];
+    }
+    const float mean = wave_sum(s) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = lane + 64 * j;
+      const float d = (n < a.N) ? x[j] - mean : 0.f;
+      q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invn + a.ln_eps);
+    const float rm = a.rowmask ? a.rowmask[m] : 1.f;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int n = lane + 64 * j;
+      if (n < a.N) {
+        const float y = ((x[j] - mean) * rstd * a.gamma[n] + a.beta[n]) * rm;
+        if (a.c_is_f32) reinterpret_cast<float*>(a.C)[(size_t)m * a.ldc + n] = y;
+        else reinterpret_cast<T*>(a.C)[(size_t)m * a.ldc + n] = (T)y;
+      }
+    }
+    if (lane == 0 && a.rstd_out) a.rstd_out[m] = rstd;
+  }
+}
+
+template <typename T>
+static int launch_nt(const rg_gemm_nt_args& a, hipStream_t s) {
+  const int ntw = (a.epilogue == RG_EPI_RESID_LN) ? (a.N <= 64 ? 1 : (a.N <= 128 ? 2 : 4))
+                                                   : (a.N <= 64 ? 1 : 2);
+  const int tn = 64 * ntw;
+  dim3 grid((a.M + TM - 1) / TM, (a.N + tn - 1) / tn);
+  if (a.epilogue == RG_EPI_RESID_LN && grid.y != 1)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: RESID_LN needs N <= 256");
+  if (ntw == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), grid, dim3(256), 0, s, a);
+  else if (ntw == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 2>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_nt_kernel<T, 4>), grid, dim3(256), 0, s, a);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
+  if (!a || a->M <= 0 || a->N <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: empty problem");
+  if (a->K <= 0 || (a->K & 31)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: K must be a multiple of 32");
+  if ((a->lda & 7) || (a->ldw & 7)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: lda/ldw must be multiples of 8");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == RG_BF16) return launch_nt<__bf16>(*a, s);
+  if (dtype == RG_F32) return launch_nt<float>(*a, s);
+  return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: bad dtype");
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN (weight gradient).  Tile 64 (n1) x 64 (n2); tokens split over gridDim.z; f32 atomics at the
+// end (one 256-byte-shaped add per accumulator register).  Row-major token chunks sit in LDS and
+// the token-major fragments are read with the gfx950 transposing LDS read (bf16) or strided
+// ds_read_b32 (f32 tier).  Column sums (bias gradients) come from one extra MFMA against a ones
+// fragment in the n2-tile-0 workgroups.
+// ------------------------------------------------------------------------------------------------
+#define TT 64
+#define TPAD 8
+
+// fragment whose 8 slots (g, j) are rows t0 + 8g + j of column c of a row-major LDS tile
+__device__ __forceinline__ void load_frag_tr(Frag<float>& f, const float* tile, int ld, int t0, int c0,
+                                             int li, int lg, int use_tr) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = tile[(t0 + 8 * lg + j) * ld + c0 + li];
+}
+__device__ __forceinline__ void load_frag_tr(Frag<__bf16>& f, const __bf16* tile, int ld, int t0, int c0,
+                                             int li, int lg, int use_tr) {
+  if (use_tr) {
+    // lane 4q+p of each 16-lane group addresses row q, columns 4p..4p+3 of a 4x16 block and
+    // receives column (lane&15) of the 4 rows.
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int q = li >> 2, p = li & 3;
+    const __bf16* p0 = tile + (t0 + 8 * lg + q) * ld + c0 + 4 * p;
+    const __bf16* p1 = p0 + 4 * ld;
+    s16x4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    s16x4 r1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+    union { s16x4 s; bf16x4_t b; } u0, u1;
+    u0.s = r0; u1.s = r1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f.v[j] = tile[(t0 + 8 * lg + j) * ld + c0 + li];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_tn_kernel(rg_gemm_tn_args a) {
+  constexpr int LD = 64 + TPAD;
+  __shared__ __align__(16) T Ys[TT * LD];
+  __shared__ __align__(16) T Xs[TT * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int n1_0 = blockIdx.x * 64, n2_0 = blockIdx.y * 64;
+  const T* __restrict__ Y = reinterpret_cast<const T*>(a.Y);
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+  const int per = (a.T + gridDim.z - 1) / gridDim.z;
+  const int per64 = ((per + TT - 1) / TT) * TT;
+  const int t_beg = blockIdx.z * per64;
+  const int t_end = min(a.T, t_beg + per64);
+  const bool do_colsum = (a.colsum != nullptr) && blockIdx.y == 0;
+
+  f32x4 acc[4];
+  f32x4 csum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  Frag<T> ones;
+  frag_fill(ones, 1.f);
+
+  for (int t0 = t_beg; t0 < t_end; t0 += TT) {
+    for (int c = tid; c < TT * 8; c += 256) {
+      const int r = c >> 3, c8 = (c & 7) * 8;
+      const int t = t0 + r;
+      float v[8], w[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = 0.f; w[j] = 0.f; }
+      if (t < t_end) {
+        if (n1_0 + c8 < a.N1) load8(v, Y + (size_t)t * a.ldy + n1_0 + c8);
+        if (n2_0 + c8 < a.N2) {
+          load8(w, X + (size_t)t * a.ldx + n2_0 + c8);
+          if (a.prologue_x == RG_PRO_GELU) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) w[j] = gelu_f(w[j]);
+          }
+        }
+      }
+      store8(Ys + r * LD + c8, v);
+      store8(Xs + r * LD + c8, w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < TT / 32; ++ks) {
+      Frag<T> af;
+      load_frag_tr(af, Ys, LD, ks * 32, wave * 16, li, lg, a.use_tr);
+      if (do_colsum) mma(af, ones, csum);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        Frag<T> bf;
+        load_frag_tr(bf, Xs, LD, ks * 32, j * 16, li, lg, a.use_tr);
+        mma(af, bf, acc[j]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int n2 = n2_0 + j * 16 + li;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1_0 + wave * 16 + 4 * lg + r;
+      if (n1 < a.N1 && n2 < a.N2) atomicAdd(a.dW + (size_t)n1 * a.lddw + n2, acc[j][r] * a.scale);
+    }
+  }
+  if (do_colsum && li == 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int n1 = n1_0 + wave * 16 + 4 * lg + r;
+      if (n1 < a.N1) atomicAdd(a.colsum + n1, csum[r] * a.scale);
+    }
+  }
+}
+
+extern "C" int rg_gemm_tn(const rg_gemm_tn_args* a, int dtype, void* stream) {
+  if (!a || a->T <= 0 || a->N1 <= 0 || a->N2 <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: empty problem");
+  if ((a->N1 & 7) || (a->N2 & 7) || (a->ldy & 7) || (a->ldx & 7))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn: N1/N2/ld must be multiples of 8");
+  hipStream_t s = (hipStream_t)stream;
+  const int g1 = (a->N1 + 63) / 64, g2 = (a->N2 + 63) / 64;
+  int splits = a->splits;
+  if (splits <= 0) {
+    const int chunks = (a->T + TT - 1) / TT;
+    splits = max(1, min(chunks, 2048 / (g1 * g2)));
+  }
+  dim3 grid(g1, g2, splits);
+  if (dtype == RG_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, s, *a);
+  else if (dtype == RG_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, *a);
+  else return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: bad dtype");
+  RG_CHECK_LAUNCH();
+  return 0;
+}

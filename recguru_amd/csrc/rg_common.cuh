@@ -1,0 +1,145 @@
+// Common device helpers for the RecGURU gfx950 kernels.
+//
+// One tile vocabulary for both precision tiers:
+//   * T = __bf16 : v_mfma_f32_16x16x32_bf16 (perf tier; operands bf16, accumulation f32)
+//   * T = float  : 8 x v_mfma_f32_16x16x4_f32 (parity tier; bit-exact f32 fma chain)
+// A "k-step" is always 32 contraction elements.  Within a k-step lane l = 16*g + i owns the 8
+// slots (g, j), j = 0..7 of row/column i.  Which physical k a slot means is up to the caller as
+// long as the A and the B fragment agree:
+//   * contiguous mapping : slot (g, j) <-> k = 8*g + j                    (load_frag)
+//   * stacked-accumulator mapping: slot (g, j) <-> k = 16*(j>>2) + 4*g + (j&3), which is what
+//     two vertically stacked 16x16 accumulator tiles already hold (rows 4g+r of tile j>>2), so an
+//     accumulator can be fed back as an operand with no data movement (acc_to_frag, load_frag_2x4).
+// Accumulator tile map (both MFMAs): reg r of lane l holds D[row 4*(l>>4) + r][col l & 15].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
+
+#define RG_F32 0
+#define RG_BF16 1
+#define RG_WAVE 64
+
+template <typename T> struct Frag;
+template <> struct Frag<float> { float v[8]; };
+template <> struct Frag<__bf16> { bf16x8_t v; };
+
+__device__ __forceinline__ void mma(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
+}
+__device__ __forceinline__ void mma(const Frag<float>& a, const Frag<float>& b, f32x4& c) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
+}
+
+template <typename T> __device__ __forceinline__ void frag_zero(Frag<T>& f);
+template <> __device__ __forceinline__ void frag_zero<float>(Frag<float>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
+template <> __device__ __forceinline__ void frag_zero<__bf16>(Frag<__bf16>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (__bf16)0.f;
+}
+template <typename T> __device__ __forceinline__ void frag_fill(Frag<T>& f, float x) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = (T)x;
+}
+
+// 8 contiguous elements starting at p (16-byte aligned for bf16, 32-byte for f32).
+__device__ __forceinline__ void load_frag(Frag<__bf16>& f, const __bf16* p) {
+  f.v = *reinterpret_cast<const bf16x8_t*>(p);
+}
+__device__ __forceinline__ void load_frag(Frag<float>& f, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+// two runs of 4 contiguous elements: slots j<4 from p0, j>=4 from p1 (stacked-accumulator mapping)
+__device__ __forceinline__ void load_frag_2x4(Frag<__bf16>& f, const __bf16* p0, const __bf16* p1) {
+  const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p0);
+  const bf16x4_t b = *reinterpret_cast<const bf16x4_t*>(p1);
+  f.v[0] = a[0]; f.v[1] = a[1]; f.v[2] = a[2]; f.v[3] = a[3];
+  f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
+}
+__device__ __forceinline__ void load_frag_2x4(Frag<float>& f, const float* p0, const float* p1) {
+  const float4 a = *reinterpret_cast<const float4*>(p0);
+  const float4 b = *reinterpret_cast<const float4*>(p1);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+// two stacked accumulator tiles (rows 0..15 = lo, 16..31 = hi of a 32-deep k-step) -> operand
+template <typename T>
+__device__ __forceinline__ void acc_to_frag(Frag<T>& f, const f32x4& lo, const f32x4& hi) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = (T)lo[j]; f.v[4 + j] = (T)hi[j]; }
+}
+
+// 8 contiguous elements <-> float[8]
+__device__ __forceinline__ void load8(float* o, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+__device__ __forceinline__ void load8(float* o, const __bf16* p) {
+  const bf16x8_t a = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
+}
+__device__ __forceinline__ void store8(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(__bf16* p, const float* v) {
+  bf16x8_t a;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
+  *reinterpret_cast<bf16x8_t*>(p) = a;
+}
+__device__ __forceinline__ void store4(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(__bf16* p, const float* v) {
+  bf16x4_t a;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) a[j] = (__bf16)v[j];
+  *reinterpret_cast<bf16x4_t*>(p) = a;
+}
+
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) x = fmaxf(x, __shfl_xor(x, o));
+  return x;
+}
+
+// tanh-approximation GELU (reference transformer.py:81-84) and its derivative
+__device__ __forceinline__ float gelu_f(float x) {
+  const float c = 0.7978845608028654f;
+  const float u = c * (x + 0.044715f * x * x * x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float gelu_grad_f(float x) {
+  const float c = 0.7978845608028654f;
+  const float x2 = x * x;
+  const float u = c * (x + 0.044715f * x * x2);
+  const float t = tanhf(u);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * x2);
+}
+
+#define RG_CHECK_LAUNCH()                                   \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return rg_set_error(e__, __func__); \
+  } while (0)
+
+int rg_set_error(hipError_t e, const char* where);
+int rg_set_error_msg(int code, const char* msg);

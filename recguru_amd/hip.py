@@ -1,0 +1,289 @@
+"""ctypes binding of librecguru_hip.so (include/recguru_hip.h).
+
+PyTorch is used only for device memory and streams: every wrapper takes torch CUDA tensors, passes
+raw device pointers + the current HIP stream to the C ABI and returns torch tensors it allocated.
+There is NO fallback: a missing library or a CPU tensor raises.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librecguru_hip.so")
+_lib = None
+
+F32, BF16 = 0, 1
+PRO_NONE, PRO_GELU = 0, 1
+EPI_NONE, EPI_RELU, EPI_MUL_POSMASK, EPI_GELU_GRAD, EPI_ADD, EPI_RESID_LN = 0, 1, 2, 3, 4, 5
+
+c_p, c_i, c_f, c_l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+
+
+class GemmNtArgs(ctypes.Structure):
+    _fields_ = [("A", c_p), ("lda", c_i), ("W", c_p), ("ldw", c_i), ("bias", c_p), ("C", c_p), ("ldc", c_i),
+                ("c_is_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("prologue", c_i), ("epilogue", c_i),
+                ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
+                ("rstd_out", c_p), ("ln_eps", c_f)]
+
+
+class GemmTnArgs(ctypes.Structure):
+    _fields_ = [("Y", c_p), ("ldy", c_i), ("X", c_p), ("ldx", c_i), ("dW", c_p), ("lddw", c_i), ("colsum", c_p),
+                ("T", c_i), ("N1", c_i), ("N2", c_i), ("prologue_x", c_i), ("scale", c_f), ("splits", c_i),
+                ("use_tr", c_i)]
+
+
+class AttnArgs(ctypes.Structure):
+    _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
+                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f)]
+
+
+class AttnBwdArgs(ctypes.Structure):
+    _fields_ = [("qkv", c_p), ("dctx", c_p), ("ctx", c_p), ("lse", c_p), ("key_ids", c_p), ("pad_value", c_l),
+                ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f)]
+
+
+# every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
+SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
+           "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
+           "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
+           "rg_item_loss_fwd", "rg_item_loss_bwd"]
+LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
+c_ll = ctypes.c_longlong
+
+
+class LnBwdArgs(ctypes.Structure):
+    _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
+                ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i)]
+
+
+class ItemLossArgs(ctypes.Structure):
+    _fields_ = [("h", c_p), ("table", c_p), ("pos", c_p), ("neg", c_p), ("mask", c_p), ("aux_tok", c_p),
+                ("sums", c_p), ("gout", c_p), ("dh", c_p), ("dE", c_p), ("ntok", c_ll), ("d", c_i), ("k", c_i),
+                ("mode", c_i), ("skip_row", c_ll)]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("recguru_amd: %s is missing -- run `python -m recguru_amd.build` "
+                               "(there is no CPU fallback)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.rg_last_error.restype = ctypes.c_char_p
+        for name in SYMBOLS:
+            getattr(_lib, name)
+    return _lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed (%d): %s" % (what, rc, lib().rg_last_error().decode()))
+
+
+def dt_of(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError("recguru_amd: activations must be float32 or bfloat16, got %s" % t.dtype)
+
+
+def _p(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("recguru_amd: tensor is not on the GPU (there is no CPU path)")
+    return t.data_ptr()
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _rowmajor(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D view"
+    return t.stride(0)
+
+
+def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
+            gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8):
+    """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N]."""
+    M, K = A.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and W.dtype == A.dtype
+    if out is None:
+        out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+    if M == 0:
+        return out
+    a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
+                   1 if out.dtype == torch.float32 else 0,
+                   M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
+                   _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps)
+    _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
+    return out
+
+
+def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1):
+    """dW[N1,N2] += Y[T,N1].T @ pro(X[T,N2]) (f32, accumulated); colsum[N1] += Y.sum(0)."""
+    T, N1 = Y.shape
+    N2 = X.shape[1]
+    assert X.shape[0] == T and X.dtype == Y.dtype
+    if dW is None:
+        dW = torch.zeros(N1, N2, device=Y.device, dtype=torch.float32)
+    if T == 0:
+        return dW
+    a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
+                   prologue_x, scale, splits, use_tr)
+    _check(lib().rg_gemm_tn(ctypes.byref(a), dt_of(Y), _stream()), "rg_gemm_tn")
+    return dW
+
+
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True):
+    """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32)."""
+    B, L, P3 = qkv.shape
+    assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
+    ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
+    lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
+    a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
+                 1.0 / (32 ** 0.5))
+    _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
+    return ctx, lse
+
+
+def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H):
+    B, L, _ = qkv.shape
+    assert dctx.is_contiguous() and ctx.is_contiguous() and qkv.is_contiguous()
+    dqkv = torch.empty_like(qkv)
+    a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
+                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5))
+    _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
+    return dqkv
+
+
+def _vp(t):
+    return ctypes.c_void_p(_p(t))
+
+
+def embed_pe_fwd(table, pe, ids, mask, L):
+    """(table[ids] + pe[t]) * mask -> [ntok, d] in table.dtype."""
+    ntok, d = ids.numel(), table.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and mask.dtype == torch.float32 and mask.numel() == ntok
+    assert pe.dtype == torch.float32 and pe.shape[1] == d and pe.is_contiguous() and table.is_contiguous()
+    out = torch.empty(ntok, d, device=table.device, dtype=table.dtype)
+    _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, dt_of(table),
+                                 _stream()), "rg_embed_pe_fwd")
+    return out
+
+
+def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1):
+    ntok, d = ids.numel(), dx.shape[-1]
+    assert dx.is_contiguous() and dE.dtype == torch.float32 and dE.is_contiguous()
+    _check(lib().rg_embed_scatter_bwd(_vp(dx), _vp(ids), _vp(mask), _vp(dE), c_ll(ntok), d, c_ll(skip_row), dt_of(dx),
+                                      _stream()), "rg_embed_scatter_bwd")
+    return dE
+
+
+def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta):
+    """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place."""
+    M, N = dy.shape
+    assert dy.is_contiguous() and y.is_contiguous() and dy.dtype == y.dtype
+    dz = torch.empty_like(dy)
+    a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N)
+    _check(lib().rg_ln_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_ln_bwd")
+    return dz
+
+
+def bcast_add_ln(x, o, gamma, beta, L, eps=1e-8):
+    M, N = x.shape
+    assert x.is_contiguous() and o.dtype == torch.float32 and o.is_contiguous()
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _check(lib().rg_bcast_add_ln(_vp(x), _vp(o), _vp(gamma), _vp(beta), _vp(y), _vp(rstd), c_ll(M), L, N,
+                                 c_f(eps), dt_of(x), _stream()), "rg_bcast_add_ln")
+    return y, rstd
+
+
+def seq_sum(x, B, L):
+    N = x.shape[-1]
+    assert x.is_contiguous()
+    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    _check(lib().rg_seq_sum(_vp(x), _vp(out), B, L, N, dt_of(x), _stream()), "rg_seq_sum")
+    return out
+
+
+def colsum(x, out, aux=None, scale=1.0):
+    M, N = x.shape
+    _check(lib().rg_colsum(_vp(x), _vp(aux), _vp(out), c_ll(M), N, _rowmajor(x), c_f(scale), dt_of(x), _stream()),
+           "rg_colsum")
+    return out
+
+
+def outer_posmask(coef, w, aux):
+    M, N = aux.shape
+    assert aux.is_contiguous() and w.dtype == torch.float32 and w.numel() == N
+    out = torch.empty_like(aux)
+    _check(lib().rg_outer_posmask(_vp(coef), _vp(w), _vp(aux), _vp(out), c_ll(M), N, dt_of(aux), _stream()),
+           "rg_outer_posmask")
+    return out
+
+
+def interpolate(alpha, real, fake):
+    B, d = real.shape
+    assert real.is_contiguous() and fake.is_contiguous() and alpha.dtype == torch.float32 and alpha.numel() == B
+    out = torch.empty_like(real)
+    _check(lib().rg_interpolate(_vp(alpha), _vp(real), _vp(fake), _vp(out), c_ll(B), d, dt_of(real), _stream()),
+           "rg_interpolate")
+    return out
+
+
+def gp_penalty(g, gp, lam, dtype):
+    B, d = g.shape
+    assert g.dtype == torch.float32 and g.is_contiguous()
+    dg = torch.empty(B, d, device=g.device, dtype=dtype)
+    _check(lib().rg_gp_penalty(_vp(g), _vp(dg), _vp(gp), c_ll(B), d, c_f(lam), dt_of(dg), _stream()), "rg_gp_penalty")
+    return dg
+
+
+def sum_into(x, out, scale=1.0):
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _check(lib().rg_sum(_vp(x), _vp(out), c_ll(x.numel()), c_f(scale), _stream()), "rg_sum")
+    return out
+
+
+def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step):
+    assert p.dtype == torch.float32 and g.dtype == torch.float32 and p.is_contiguous() and g.is_contiguous()
+    sd = dt_of(shadow) if shadow is not None else 0
+    _check(lib().rg_adam(_vp(p), _vp(g), _vp(m), _vp(v), _vp(shadow), sd, c_ll(p.numel()), c_f(lr), c_f(beta1),
+                         c_f(beta2), c_f(eps), int(step), _stream()), "rg_adam")
+
+
+def cast(src, dtype, transpose=False):
+    """f32 [R,C] -> dtype [R,C] or [C,R]."""
+    assert src.dtype == torch.float32 and src.is_contiguous()
+    src2 = src.reshape(src.shape[0], -1) if src.dim() > 1 else src.reshape(1, -1)
+    R, C = src2.shape
+    dst = torch.empty((C, R) if transpose else (R, C), device=src.device, dtype=dtype)
+    _check(lib().rg_cast(_vp(src2), _vp(dst), R, C, int(transpose), dt_of(dst), _stream()), "rg_cast")
+    return dst if (transpose or src.dim() > 1) else dst.reshape(src.shape)
+
+
+def item_loss_fwd(h, table, pos, neg, mask, k, mode):
+    ntok, d = h.shape
+    assert h.is_contiguous() and table.is_contiguous() and table.dtype == h.dtype
+    assert pos.dtype == torch.int64 and neg.dtype == torch.int64 and pos.numel() == ntok and neg.numel() == ntok * k
+    aux = torch.empty(ntok, device=h.device, dtype=torch.float32)
+    sums = torch.zeros(2, device=h.device, dtype=torch.float32)
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(aux), _p(sums), None, None, None, ntok, d, k,
+                     mode, -1)
+    _check(lib().rg_item_loss_fwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_fwd")
+    return sums, aux
+
+
+def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_row=-1):
+    ntok, d = h.shape
+    dh = torch.empty_like(h)
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(aux), _p(sums), _p(gout), _p(dh), _p(dE), ntok,
+                     d, k, mode, skip_row)
+    _check(lib().rg_item_loss_bwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_bwd")
+    return dh

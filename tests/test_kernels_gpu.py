@@ -1,0 +1,315 @@
+"""GPU unit tests: each HIP kernel against a plain torch fp32 statement of the same op.
+f32 tier: tight tolerances (exact-f32 MFMA).  bf16 tier: inputs are bf16-rounded first, so the
+only difference left is accumulation order / output rounding."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def tol(dt):
+    return dict(rtol=2e-5, atol=2e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+
+
+def rnd(*shape, dt, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dt).cuda()
+
+
+def gelu_tanh(x):
+    return 0.5 * x * (1 + torch.tanh(math.sqrt(2 / math.pi) * (x + 0.044715 * x ** 3)))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (100, 384, 128), (257, 128, 512), (37, 1, 640), (130, 640, 1280),
+                                   (16, 48, 64)])
+def test_gemm_nt_bias_relu(dt, M, N, K):
+    from recguru_amd import hip
+    A = rnd(M, K, dt=dt, seed=1)
+    # asymmetric, non-random structure too: catches transposed fragment maps
+    W = rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    b = rnd(N, dt=torch.float32, seed=3)
+    ref = A.float() @ W.float().T + b
+    out = hip.gemm_nt(A, W, b)
+    torch.testing.assert_close(out.float(), ref, **tol(dt))
+    out = hip.gemm_nt(A, W, b, epilogue=hip.EPI_RELU, out_f32=True)
+    assert out.dtype == torch.float32
+    torch.testing.assert_close(out, ref.clamp_min(0), **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_identity_asymmetric(dt):
+    """A = I against an asymmetric integer W: exact in both tiers, catches row/col swaps."""
+    from recguru_amd import hip
+    K = 64
+    A = torch.eye(K, dtype=dt).cuda()
+    W = (torch.arange(48 * K).reshape(48, K) % 61 - 30).to(dt).cuda()
+    out = hip.gemm_nt(A, W, out_f32=True)
+    torch.testing.assert_close(out, W.float().T.contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gemm_nt_epilogues(dt):
+    from recguru_amd import hip
+    M, N, K = 150, 512, 128
+    A = rnd(M, K, dt=dt, seed=1)
+    W = rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    aux = rnd(M, N, dt=dt, seed=4)
+    ref = A.float() @ W.float().T
+    o = hip.gemm_nt(A, W, epilogue=hip.EPI_ADD, aux=aux, out_f32=True)
+    torch.testing.assert_close(o, ref + aux.float(), **tol(dt))
+    o = hip.gemm_nt(A, W, epilogue=hip.EPI_MUL_POSMASK, aux=aux, out_f32=True)
+    torch.testing.assert_close(o, ref * (aux.float() > 0), **tol(dt))
+    x = aux.float().requires_grad_(True)
+    gelu_tanh(x).sum().backward()
+    o = hip.gemm_nt(A, W, epilogue=hip.EPI_GELU_GRAD, aux=aux, out_f32=True)
+    torch.testing.assert_close(o, ref * x.grad, **tol(dt))
+    # GELU prologue: C = gelu(A) @ W.T
+    o = hip.gemm_nt(A, W, prologue=hip.PRO_GELU, out_f32=True)
+    ga = gelu_tanh(A.float())
+    if dt == torch.bfloat16:
+        ga = ga.bfloat16().float()
+    torch.testing.assert_close(o, ga @ W.float().T, **tol(dt))
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N", [32, 64, 128, 256])
+def test_gemm_nt_resid_ln(dt, N):
+    from recguru_amd import hip
+    M, K = 203, 128
+    A = rnd(M, K, dt=dt, seed=1)
+    W = rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    b = rnd(N, dt=torch.float32, seed=3)
+    res = rnd(M, N, dt=dt, seed=5)
+    g = 1 + 0.1 * rnd(N, dt=torch.float32, seed=6)
+    be = 0.1 * rnd(N, dt=torch.float32, seed=7)
+    rm = (torch.arange(M) % 3 != 0).float().cuda()
+    rstd = torch.empty(M, device="cuda")
+    z = A.float() @ W.float().T + b + res.float()
+    ref = torch.nn.functional.layer_norm(z, (N,), g, be, 1e-8) * rm[:, None]
+    o = hip.gemm_nt(A, W, b, epilogue=hip.EPI_RESID_LN, aux=res, gamma=g, beta=be, rowmask=rm, rstd_out=rstd,
+                    out_f32=True)
+    torch.testing.assert_close(o, ref, **tol(dt))
+    torch.testing.assert_close(rstd, 1 / torch.sqrt(z.var(1, unbiased=False) + 1e-8),
+                               rtol=1e-4 if dt == torch.float32 else 2e-2, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("use_tr", [0, 1])
+@pytest.mark.parametrize("T,N1,N2", [(64, 64, 64), (1000, 128, 384), (333, 512, 128), (4096, 8, 640), (70, 640, 1280)])
+def test_gemm_tn(dt, use_tr, T, N1, N2):
+    from recguru_amd import hip
+    Y = rnd(T, N1, dt=dt, seed=1)
+    X = rnd(T, N2, dt=dt, seed=2)
+    dW = torch.zeros(N1, N2, device="cuda")
+    cs = torch.zeros(N1, device="cuda")
+    hip.gemm_tn(Y, X, dW, cs, use_tr=use_tr)
+    ref = Y.float().T @ X.float()
+    t = dict(rtol=1e-4, atol=1e-3) if dt == torch.float32 else dict(rtol=2e-2, atol=5e-2)
+    torch.testing.assert_close(dW, ref, **t)
+    torch.testing.assert_close(cs, Y.float().sum(0), **t)
+    # accumulate + gelu prologue + scale
+    hip.gemm_tn(Y, X, dW, None, prologue_x=hip.PRO_GELU, scale=0.5, use_tr=use_tr)
+    gx = gelu_tanh(X.float())
+    if dt == torch.bfloat16:
+        gx = gx.bfloat16().float()
+    torch.testing.assert_close(dW, ref + 0.5 * (Y.float().T @ gx), **t)
+
+
+def _attn_ref(qkv, key_ids, pad_value, causal, H):
+    B, L, P3 = qkv.shape
+    P = P3 // 3
+    q, k, v = [t.reshape(B, L, H, 32).transpose(1, 2) for t in qkv.float().split(P, dim=2)]
+    s = q @ k.transpose(-1, -2) / math.sqrt(32)
+    m = key_ids.eq(pad_value)[:, None, None, :].expand(B, H, L, L)
+    if causal:
+        m = m | torch.ones(L, L, dtype=torch.bool, device=qkv.device).triu(1)
+    s = s.masked_fill(m, -1e9)
+    a = torch.softmax(s, -1)
+    return (a @ v).transpose(1, 2).reshape(B, L, P), torch.logsumexp(s, -1)
+
+
+def _ids(B, L, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1, 50, (B, L), generator=g)
+    for b in range(B):
+        npad = int(torch.randint(0, L, (1,), generator=g))
+        ids[b, :npad] = 0            # left padding -> fully masked causal rows (Q3)
+    return ids.cuda()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,L,H,causal", [(3, 12, 2, True), (2, 16, 4, False), (2, 50, 1, True), (2, 200, 4, True),
+                                          (1, 100, 2, False), (1, 256, 1, True), (1, 400, 2, True)])
+def test_attn_fwd_bwd(dt, B, L, H, causal):
+    from recguru_amd import hip
+    if dt == torch.float32 and L > 256:
+        pytest.skip("f32 backward holds three f32 images in LDS: L <= 256")
+    qkv = rnd(B, L, 3 * H * 32, dt=dt, seed=L)
+    ids = _ids(B, L, L + 1)
+    ctx, lse = hip.attn_fwd(qkv, ids, 0, causal, H)
+    x = qkv.float().requires_grad_(True)
+    ref, ref_lse = _attn_ref(x, ids, 0, causal, H)
+    torch.testing.assert_close(ctx.float(), ref, **tol(dt))
+    torch.testing.assert_close(lse, ref_lse, rtol=1e-4, atol=1e-3 if dt == torch.float32 else 3e-2)
+    dctx = rnd(B, L, H * 32, dt=dt, seed=7)
+    ref.backward(dctx.float())
+    dqkv = hip.attn_bwd(qkv, dctx, ctx, lse, ids, 0, causal, H)
+    t = dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(dqkv.float(), x.grad, **t)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d", [32, 64, 128, 256])
+def test_embed_fwd_bwd(dt, d):
+    from recguru_amd import hip
+    B, L, V = 5, 23, 60
+    table = rnd(V + 2, d, dt=dt, seed=1)
+    pe = rnd(64, d, dt=torch.float32, seed=2)
+    ids = _ids(B, L, 3)
+    mask = (ids != 0).float().reshape(-1)
+    mask[5] = 0.5                                   # the reference mask is an arbitrary float vector
+    out = hip.embed_pe_fwd(table, pe, ids, mask, L)
+    ref = (table.float()[ids] + pe[:L][None]) * mask.view(B, L, 1)
+    torch.testing.assert_close(out.float().view(B, L, d), ref, **tol(dt))
+    dx = rnd(B * L, d, dt=dt, seed=4)
+    dE = torch.zeros(V + 2, d, device="cuda")
+    hip.embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1)
+    refE = torch.zeros(V + 2, d, device="cuda").index_add_(0, ids.view(-1), dx.float() * mask[:, None])
+    torch.testing.assert_close(dE, refE, rtol=1e-5, atol=1e-5)
+    dE.zero_()
+    hip.embed_scatter_bwd(dx, ids, torch.ones_like(mask), dE, skip_row=0)
+    refE = torch.zeros(V + 2, d, device="cuda").index_add_(0, ids.view(-1), dx.float())
+    refE[0] = 0
+    torch.testing.assert_close(dE, refE, rtol=1e-5, atol=1e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("N", [32, 64, 128, 256])
+def test_ln_bwd(dt, N):
+    from recguru_amd import hip
+    M = 77
+    z = rnd(M, N, dt=torch.float32, seed=1).requires_grad_(True)
+    g = (1 + 0.1 * rnd(N, dt=torch.float32, seed=2)).requires_grad_(True)
+    b = (0.1 * rnd(N, dt=torch.float32, seed=3)).requires_grad_(True)
+    rm = (torch.arange(M) % 4 != 1).float().cuda()
+    y = torch.nn.functional.layer_norm(z, (N,), g, b, 1e-8) * rm[:, None]
+    dy = rnd(M, N, dt=dt, seed=4)
+    y.backward(dy.float())
+    rstd = 1 / torch.sqrt(z.detach().var(1, unbiased=False) + 1e-8)
+    dg = torch.zeros(N, device="cuda")
+    db = torch.zeros(N, device="cuda")
+    dz = hip.ln_bwd(dy, y.detach().to(dt), rstd, g.detach(), b.detach(), rm, dg, db)
+    t = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(dz.float(), z.grad, **t)
+    t2 = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=1e-1)
+    torch.testing.assert_close(dg, g.grad, **t2)
+    torch.testing.assert_close(db, b.grad, **t2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_bcast_add_ln_seq_sum(dt):
+    from recguru_amd import hip
+    B, L, N = 3, 11, 128
+    x = rnd(B * L, N, dt=dt, seed=1)
+    o = rnd(B, N, dt=torch.float32, seed=2)
+    g = 1 + 0.1 * rnd(N, dt=torch.float32, seed=3)
+    b = 0.1 * rnd(N, dt=torch.float32, seed=4)
+    y, rstd = hip.bcast_add_ln(x, o, g, b, L)
+    z = x.float().view(B, L, N) + o[:, None]
+    ref = torch.nn.functional.layer_norm(z, (N,), g, b, 1e-8)
+    torch.testing.assert_close(y.float().view(B, L, N), ref, **tol(dt))
+    torch.testing.assert_close(rstd.view(B, L), 1 / torch.sqrt(z.var(2, unbiased=False) + 1e-8), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hip.seq_sum(x, B, L), x.float().view(B, L, N).sum(1), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+def test_gp_helpers(dt):
+    from recguru_amd import hip
+    B, d, N = 37, 64, 320
+    aux = rnd(B, N, dt=dt, seed=1)
+    x = rnd(B, N, dt=dt, seed=2)
+    w = rnd(N, dt=torch.float32, seed=3)
+    coef = rnd(B, dt=torch.float32, seed=4)
+    out = torch.zeros(N, device="cuda")
+    hip.colsum(x, out, aux=aux, scale=0.5)
+    torch.testing.assert_close(out, 0.5 * (x.float() * (aux.float() > 0)).sum(0), rtol=1e-4, atol=1e-4)
+    out.zero_()
+    hip.colsum(x, out)
+    torch.testing.assert_close(out, x.float().sum(0), rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(hip.outer_posmask(coef, w, aux).float(),
+                               coef[:, None] * w[None] * (aux.float() > 0), **tol(dt))
+    torch.testing.assert_close(hip.outer_posmask(None, w, aux).float(), w[None] * (aux.float() > 0), **tol(dt))
+    a, f = rnd(B, d, dt=dt, seed=5), rnd(B, d, dt=dt, seed=6)
+    al = torch.rand(B, device="cuda")
+    torch.testing.assert_close(hip.interpolate(al, a, f).float(), al[:, None] * a.float() + (1 - al[:, None]) * f.float(),
+                               **tol(dt))
+    g = rnd(B, d, dt=torch.float32, seed=7).requires_grad_(True)
+    gp_ref = ((g.norm(2, dim=1) - 1) ** 2).mean() * 0.1
+    gp_ref.backward()
+    gp = torch.zeros(1, device="cuda")
+    dg = hip.gp_penalty(g.detach(), gp, 0.1, dt)
+    torch.testing.assert_close(gp[0], gp_ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(dg.float(), g.grad, **(dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else tol(dt)))
+    s = torch.zeros(1, device="cuda")
+    v = rnd(100000, dt=torch.float32, seed=8)
+    hip.sum_into(v, s, scale=2.0)
+    torch.testing.assert_close(s[0], 2 * v.double().sum().float(), rtol=1e-4, atol=1e-2)
+
+
+def test_adam_and_cast():
+    from recguru_amd import hip
+    n = 10007
+    p = rnd(n, dt=torch.float32, seed=1)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([ref], lr=1e-3, betas=(0.9, 0.98), eps=1e-9)
+    m = torch.zeros(n, device="cuda")
+    v = torch.zeros(n, device="cuda")
+    sh = torch.empty(n, device="cuda", dtype=torch.bfloat16)
+    for step in range(1, 4):
+        g = rnd(n, dt=torch.float32, seed=10 + step)
+        ref.grad = g.clone()
+        opt.step()
+        hip.adam(p, g, m, v, sh, 1e-3, 0.9, 0.98, 1e-9, step)
+        torch.testing.assert_close(p, ref.detach(), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(sh, p.bfloat16(), rtol=0, atol=0)
+    W = rnd(70, 130, dt=torch.float32, seed=3)
+    torch.testing.assert_close(hip.cast(W, torch.bfloat16), W.bfloat16(), rtol=0, atol=0)
+    torch.testing.assert_close(hip.cast(W, torch.bfloat16, transpose=True), W.T.contiguous().bfloat16(), rtol=0, atol=0)
+    torch.testing.assert_close(hip.cast(W, torch.float32, transpose=True), W.T.contiguous(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d,k,mode", [(64, 3, 0), (128, 30, 0), (256, 7, 0), (32, 5, 1), (128, 5, 1)])
+def test_item_loss(dt, d, k, mode):
+    from recguru_amd import hip
+    ntok, V = 61, 97
+    g0 = torch.Generator().manual_seed(d + k)
+    h = rnd(ntok, d, dt=dt, scale=0.3, seed=1)
+    table = rnd(V + 2, d, dt=dt, seed=2)
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.3).float().cuda()
+    hf = h.float().requires_grad_(True)
+    tf = table.float().requires_grad_(True)
+    lp = (hf * tf[pos]).sum(1, keepdim=True)
+    ln_ = torch.einsum("td,tkd->tk", hf, tf[neg])
+    if mode == 0:
+        lt = torch.logsumexp(torch.cat([lp, ln_], 1), 1) - lp[:, 0]
+    else:
+        lt = -torch.log(torch.sigmoid(lp[:, 0] - ln_.mean(1)))
+    ref = (lt * mask).sum() / mask.sum()
+    (ref * 1.7).backward()
+    sums, aux = hip.item_loss_fwd(h, table, pos, neg, mask, k, mode)
+    loss = sums[0] / sums[1]
+    torch.testing.assert_close(loss, ref.detach(), rtol=1e-5 if dt == torch.float32 else 2e-2, atol=1e-5)
+    dE = torch.zeros(V + 2, d, device="cuda")
+    gout = torch.full((1,), 1.7, device="cuda")
+    dh = hip.item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE)
+    t = dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-3)
+    torch.testing.assert_close(dh.float(), hf.grad, **t)
+    torch.testing.assert_close(dE, tf.grad, **t)
