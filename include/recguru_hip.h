@@ -122,12 +122,13 @@ int rg_ln_bwd(const rg_ln_bwd_args* args /* host */, int dtype, void* stream);
  * rg_bcast_add_ln: x [B*L,N] dtype, o [B,N] f32 -> y dtype, rstd f32.  rg_seq_sum: out[b,:] = sum_t x[b,t,:]. */
 int rg_bcast_add_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
                     long long M, int L, int N, float eps, int dtype, void* stream);
-int rg_seq_sum(const void* x, float* out, int B, int L, int N, int dtype, void* stream);
+int rg_seq_sum(const void* x, void* out /* [B,N] dtype */, int B, int L, int N, int dtype, void* stream);
 
 /* ---- discriminator / W-GAN gradient-penalty helpers ----------------------------------------------
  * tools/utils.py:41-57 and gan_training.py:38-55 (closed-form double backward). */
-int rg_colsum(const void* x, const void* aux /* or NULL */, float* out, long long M, int N, int ld, float scale,
-              int dtype, void* stream);                       /* out[n] += scale*sum_m x[m,n]*[aux>0] */
+int rg_colsum(const void* x, const void* aux /* or NULL */, const float* coef /* [M] or NULL */, float* out,
+              long long M, int N, int ld, float scale, int dtype,
+              void* stream);                     /* out[n] += scale*sum_m coef[m]*x[m,n]*[aux[m,n]>0] */
 int rg_outer_posmask(const float* coef /* [M] or NULL */, const float* w /* [N] */, const void* aux, void* out,
                      long long M, int N, int dtype, void* stream); /* out = coef[m]*w[n]*[aux>0]       */
 int rg_interpolate(const float* alpha, const void* real, const void* fake, void* out, long long B, int d,

@@ -167,21 +167,21 @@ __global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_kernel(const T* __restr
   }
 }
 
-// out[b,:] (f32) = sum_t x[b,t,:]
+// out[b,:] = sum_t x[b,t,:]   (f32 accumulation, tier-dtype result: it feeds the next GEMM)
 template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void seq_sum_kernel(const T* __restrict__ x, float* __restrict__ out, int L, int N) {
+__global__ __launch_bounds__(EW_BLOCK) void seq_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int N) {
   const int b = blockIdx.x;
   for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
     float s = 0.f;
     for (int t = 0; t < L; ++t) s += (float)x[((size_t)b * L + t) * N + n];
-    out[(size_t)b * N + n] = s;
+    out[(size_t)b * N + n] = (T)s;
   }
 }
 
-// out[n] += scale * sum_m x[m,n] * (aux ? [aux[m,n] > 0] : 1)
+// out[n] += scale * sum_m coef[m] * x[m,n] * (aux ? [aux[m,n] > 0] : 1)
 template <typename T>
-__global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ x, const T* __restrict__ aux, float* __restrict__ out,
-                                                         long long M, int N, int ld, float scale) {
+__global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ x, const T* __restrict__ aux, const float* __restrict__ coef,
+                                                         float* __restrict__ out, long long M, int N, int ld, float scale) {
   const int n = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   __shared__ float red[4][64];
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ 
     for (long long m = (long long)blockIdx.y * 4 + part; m < M; m += (long long)gridDim.y * 4) {
       float v = (float)x[(size_t)m * ld + n];
       if (aux && !((float)aux[(size_t)m * ld + n] > 0.f)) v = 0.f;
+      if (coef) v *= coef[m];
       s += v;
     }
   red[part][threadIdx.x & 63] = s;
@@ -357,23 +358,24 @@ extern "C" int rg_bcast_add_ln(const void* x, const float* o, const float* gamma
   return rg_set_error_msg(RG_ERR_INVALID, "bcast_add_ln: bad dtype");
 }
 
-extern "C" int rg_seq_sum(const void* x, float* out, int B, int L, int N, int dtype, void* stream) {
+extern "C" int rg_seq_sum(const void* x, void* out, int B, int L, int N, int dtype, void* stream) {
   if (B <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(seq_sum_kernel<__bf16>, dim3(B), dim3(EW_BLOCK), 0, s, (const __bf16*)x, out, L, N),
-             hipLaunchKernelGGL(seq_sum_kernel<float>, dim3(B), dim3(EW_BLOCK), 0, s, (const float*)x, out, L, N),
+             hipLaunchKernelGGL(seq_sum_kernel<__bf16>, dim3(B), dim3(EW_BLOCK), 0, s, (const __bf16*)x, (__bf16*)out, L, N),
+             hipLaunchKernelGGL(seq_sum_kernel<float>, dim3(B), dim3(EW_BLOCK), 0, s, (const float*)x, (float*)out, L, N),
              "seq_sum")
 }
 
-extern "C" int rg_colsum(const void* x, const void* aux, float* out, long long M, int N, int ld, float scale, int dtype, void* stream) {
+extern "C" int rg_colsum(const void* x, const void* aux, const float* coef, float* out, long long M, int N, int ld, float scale,
+                         int dtype, void* stream) {
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   long long gy = (M + 255) / 256; if (gy > 512) gy = 512; if (gy < 1) gy = 1;
   dim3 grid((N + 63) / 64, (int)gy);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(EW_BLOCK), 0, s, (const __bf16*)x, (const __bf16*)aux, out, M, N, ld, scale),
-             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(EW_BLOCK), 0, s, (const float*)x, (const float*)aux, out, M, N, ld, scale),
+             hipLaunchKernelGGL(colsum_kernel<__bf16>, grid, dim3(EW_BLOCK), 0, s, (const __bf16*)x, (const __bf16*)aux, coef, out, M, N, ld, scale),
+             hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(EW_BLOCK), 0, s, (const float*)x, (const float*)aux, coef, out, M, N, ld, scale),
              "colsum")
 }
 

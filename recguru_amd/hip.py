@@ -207,15 +207,15 @@ def bcast_add_ln(x, o, gamma, beta, L, eps=1e-8):
 def seq_sum(x, B, L):
     N = x.shape[-1]
     assert x.is_contiguous()
-    out = torch.empty(B, N, device=x.device, dtype=torch.float32)
+    out = torch.empty(B, N, device=x.device, dtype=x.dtype)
     _check(lib().rg_seq_sum(_vp(x), _vp(out), B, L, N, dt_of(x), _stream()), "rg_seq_sum")
     return out
 
 
-def colsum(x, out, aux=None, scale=1.0):
+def colsum(x, out, aux=None, scale=1.0, coef=None):
     M, N = x.shape
-    _check(lib().rg_colsum(_vp(x), _vp(aux), _vp(out), c_ll(M), N, _rowmajor(x), c_f(scale), dt_of(x), _stream()),
-           "rg_colsum")
+    _check(lib().rg_colsum(_vp(x), _vp(aux), _vp(coef), _vp(out), c_ll(M), N, _rowmajor(x), c_f(scale), dt_of(x),
+                           _stream()), "rg_colsum")
     return out
 
 

@@ -1,0 +1,354 @@
+"""Block-granular autograd functions over the HIP kernels (recguru_amd.hip).
+
+PyTorch contributes the autograd tape between blocks, device memory and the stream; every
+arithmetic step of forward AND backward is a launch into librecguru_hip.so.  Parameters stay f32
+(as in the reference, train_gan.py:123); GEMM operands use the compute tier chosen with
+set_compute_dtype(): torch.bfloat16 (bf16 MFMA, default) or torch.float32 (exact-f32 MFMA, the
+parity tier).  Tier copies ("shadows") of the weights, plain and transposed, are cached per
+parameter version so they are rebuilt only after an optimizer step.
+"""
+import torch
+
+from . import hip
+
+_COMPUTE = torch.bfloat16
+LN_EPS = 1e-8       # Transformer/transformer.py:142,177
+GP_LAMBDA = 0.1     # gan_training.py:21
+
+
+def set_compute_dtype(dt):
+    global _COMPUTE
+    assert dt in (torch.float32, torch.bfloat16)
+    _COMPUTE = dt
+    _SHADOWS.clear()
+
+
+def compute_dtype():
+    return _COMPUTE
+
+
+# ------------------------------------------------------------------------------------------------
+# shadow weights
+# ------------------------------------------------------------------------------------------------
+_SHADOWS = {}
+
+
+def bump(p):
+    """Called by the optimizer after an in-place HIP update (raw-pointer writes do not bump _version)."""
+    p._rg_gen = getattr(p, "_rg_gen", 0) + 1
+
+
+def _ver(p):
+    return (p.data_ptr(), p._version, getattr(p, "_rg_gen", 0))
+
+
+def shadow(p, transpose=False):
+    """Operand-tier copy of a 2-D f32 parameter: [out,in] or, transposed, [in,out]."""
+    if _COMPUTE == torch.float32 and not transpose:
+        return p.detach()
+    key = (id(p), transpose, _COMPUTE)
+    ent = _SHADOWS.get(key)
+    ver = _ver(p)
+    if ent is None or ent[0] != ver:
+        ent = (ver, hip.cast(p.detach(), _COMPUTE, transpose=transpose))
+        _SHADOWS[key] = ent
+    return ent[1]
+
+
+def shadow_cat(ps, transpose=False):
+    """Shadow of torch.cat(ps, 0) (the fused QKV weight [3P, d])."""
+    key = (tuple(id(p) for p in ps), transpose, _COMPUTE, "cat")
+    ver = tuple(_ver(p) for p in ps)
+    ent = _SHADOWS.get(key)
+    if ent is None or ent[0] != ver:
+        w = torch.cat([p.detach() for p in ps], 0).contiguous()
+        ent = (ver, hip.cast(w, _COMPUTE, transpose=transpose) if (transpose or _COMPUTE != torch.float32) else w)
+        _SHADOWS[key] = ent
+    return ent[1]
+
+
+def _z(n, like):
+    return torch.zeros(n, device=like.device, dtype=torch.float32)
+
+
+# ------------------------------------------------------------------------------------------------
+# K1: embedding + positional encoding + mask
+# ------------------------------------------------------------------------------------------------
+class EmbedPE(torch.autograd.Function):
+    """nn.Embedding lookup + PositionalEncoding.forward (transformer.py:104-106): (E[ids]+pe)*mask."""
+
+    @staticmethod
+    def forward(ctx, table, pe, ids, mask, skip_row):
+        B, L = ids.shape
+        ids = ids.contiguous()
+        mask = mask.reshape(-1).contiguous()
+        out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L)
+        ctx.save_for_backward(ids, mask)
+        ctx.shape = table.shape
+        ctx.skip_row = skip_row
+        return out.view(B, L, -1)
+
+    @staticmethod
+    def backward(ctx, dx):
+        ids, mask = ctx.saved_tensors
+        dE = torch.zeros(ctx.shape, device=dx.device, dtype=torch.float32)
+        hip.embed_scatter_bwd(dx.contiguous().view(-1, dx.shape[-1]), ids, mask, dE, ctx.skip_row)
+        return dE, None, None, None, None
+
+
+def embed_pe(table, pe, ids, mask, skip_row=-1):
+    return EmbedPE.apply(table, pe, ids, mask, skip_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# attention / FFN building blocks (plain functions over explicit tensors; used by the layer Functions)
+# ------------------------------------------------------------------------------------------------
+def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad):
+    """MultiHeadAttention.forward (transformer.py:151-161): returns y and what backward needs."""
+    wqkv = shadow_cat((Wq, Wk, Wv))
+    bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+    qkv = hip.gemm_nt(x2, wqkv, bqkv)
+    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad)
+    rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
+    y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
+                    gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
+    return y, (qkv, ctx_, lse, rstd)
+
+
+def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, Wk, Wv, Wo, g, be):
+    """Backward of the block above.  Returns dx and the parameter gradients in declaration order."""
+    qkv, ctx_, lse, rstd = saved
+    d = x2.shape[1]
+    P = Wo.shape[1]
+    dg, dbe = _z(d, dy), _z(d, dy)
+    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), None, dg, dbe)
+    dWo, dbo = torch.zeros(d, P, device=dy.device), _z(d, dy)
+    hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo)
+    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
+    dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H)
+    dqkv2 = dqkv.view(B * L, 3 * P)
+    dWqkv, dbqkv = torch.zeros(3 * P, d, device=dy.device), _z(3 * P, dy)
+    hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
+    dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz)
+    dWq, dWk, dWv = dWqkv[:P], dWqkv[P:2 * P], dWqkv[2 * P:]
+    dbq, dbk, dbv = dbqkv[:P], dbqkv[P:2 * P], dbqkv[2 * P:]
+    return dx, (dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, dg, dbe)
+
+
+def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
+    """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539."""
+    h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
+    rstd = torch.empty(y.shape[0], device=y.device, dtype=torch.float32)
+    out = hip.gemm_nt(h1, shadow(W2), b2.detach(), prologue=hip.PRO_GELU, epilogue=hip.EPI_RESID_LN, aux=y,
+                      gamma=g.detach(), beta=be.detach(), rowmask=rowmask, rstd_out=rstd, eps=LN_EPS)
+    return out, (h1, rstd)
+
+
+def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be):
+    h1, rstd = saved
+    d, dff = W2.shape
+    dg, dbe = _z(d, dout), _z(d, dout)
+    dz = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
+    dW2, db2 = torch.zeros(d, dff, device=dout.device), _z(d, dout)
+    hip.gemm_tn(dz, h1, dW2, db2, prologue_x=hip.PRO_GELU)
+    dh1 = hip.gemm_nt(dz, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1)
+    dW1, db1 = torch.zeros(dff, d, device=dout.device), _z(dff, dout)
+    hip.gemm_tn(dh1, y, dW1, db1)
+    dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
+    return dy, (dW1, db1, dW2, db2, dg, dbe)
+
+
+class EncoderLayerFn(torch.autograd.Function):
+    """EncoderLayer.forward + `* pad_mask` (transformer.py:202-207,:592-594)."""
+
+    @staticmethod
+    def forward(ctx, x, key_ids, rowmask, pad_value, causal, H,
+                Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
+        B, L, d = x.shape
+        need = any(ctx.needs_input_grad)
+        x2 = x.contiguous().view(B * L, d)
+        key_ids = key_ids.contiguous()
+        rowmask = rowmask.reshape(-1).contiguous()
+        y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
+        out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
+        if need:
+            ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf, Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
+            ctx.meta = (B, L, pad_value, causal, H)
+        return out.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2,
+         Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
+        B, L, pad_value, causal, H = ctx.meta
+        d = x2.shape[1]
+        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, W1, W2, g2, be2)
+        dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
+                                 Wq, Wk, Wv, Wo, g1, be1)
+        return (dx.view(B, L, d), None, None, None, None, None) + ga + gf
+
+
+class DecoderLayerFn(torch.autograd.Function):
+    """DecoderLayer.forward + `* pad_m` (transformer.py:257-261,:533-539) with the decoder-encoder
+    attention in its collapsed form (quirk Q1): K/V are L copies of u = enc_out[:, -1], so
+    context = WV u + bV for every query and WQ/WK of that block are dead (exactly-zero gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, u, key_ids, rowmask, H,
+                Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1,
+                cWv, cbv, cWo, cbo, cg, cbe,
+                W1, b1, W2, b2, g2, be2):
+        B, L, d = x.shape
+        need = any(ctx.needs_input_grad)
+        x2 = x.contiguous().view(B * L, d)
+        key_ids = key_ids.contiguous()
+        rowmask = rowmask.reshape(-1).contiguous()
+        u = u.contiguous()
+        y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
+        c = hip.gemm_nt(u, shadow(cWv), cbv.detach())                        # [B, P]
+        o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)          # [B, d] f32
+        y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
+        out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
+        if need:
+            ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf,
+                                  Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2)
+            ctx.meta = (B, L, H)
+        return out.view(B, L, d)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2,
+         Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2) = ctx.saved_tensors
+        B, L, H = ctx.meta
+        d = x2.shape[1]
+        P = cWv.shape[0]
+        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, W1, W2, g2, be2)
+        dcg, dcbe = _z(d, dout), _z(d, dout)
+        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), None, dcg, dcbe)   # residual: dz == dy1
+        do = hip.seq_sum(dy1, B, L)                                                     # [B, d] tier dtype
+        dcWo, dcbo = torch.zeros(d, P, device=dout.device), _z(d, dout)
+        hip.gemm_tn(do, c, dcWo, dcbo)
+        dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                               # [B, P]
+        dcWv, dcbv = torch.zeros(P, d, device=dout.device), _z(P, dout)
+        hip.gemm_tn(dc, u, dcWv, dcbv)
+        du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                               # [B, d]
+        dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
+                                 Wq, Wk, Wv, Wo, g1, be1)
+        return ((dx.view(B, L, d), du, None, None, None) + ga + (dcWv, dcbv, dcWo, dcbo, dcg, dcbe) + gf)
+
+
+# ------------------------------------------------------------------------------------------------
+# K7 / K8: sampled-softmax / BPR loss over the item catalogue
+# ------------------------------------------------------------------------------------------------
+class ItemLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, table, pos, neg, mask, k, mode, skip_row):
+        d = h.shape[-1]
+        h2 = h.contiguous().view(-1, d)
+        pos = pos.contiguous().view(-1)
+        neg = neg.contiguous().view(-1)
+        mask = mask.reshape(-1).contiguous()
+        tab = shadow(table)
+        sums, aux = hip.item_loss_fwd(h2, tab, pos, neg, mask, k, mode)
+        ctx.save_for_backward(h2, pos, neg, mask, aux, sums, table)
+        ctx.meta = (k, mode, skip_row, h.shape)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, gout):
+        h2, pos, neg, mask, aux, sums, table = ctx.saved_tensors
+        k, mode, skip_row, shape = ctx.meta
+        dE = torch.zeros(table.shape, device=h2.device, dtype=torch.float32)
+        g1 = gout.reshape(1).to(torch.float32).contiguous()
+        dh = hip.item_loss_bwd(h2, shadow(table), pos, neg, mask, k, mode, aux, sums, g1, dE, skip_row)
+        return dh.view(shape), dE, None, None, None, None, None, None
+
+
+def sampled_softmax_loss(h, table, pos, neg, mask, k, skip_row=-1):
+    return ItemLoss.apply(h, table, pos, neg, mask, k, hip.LOSS_SAMPLED_CE, skip_row)
+
+
+def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1):
+    return ItemLoss.apply(h, table, pos, neg, mask, k, hip.LOSS_BPR, skip_row)
+
+
+# ------------------------------------------------------------------------------------------------
+# K9-K11: discriminator MLP and the W-GAN gradient penalty
+# ------------------------------------------------------------------------------------------------
+def _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4):
+    h1 = hip.gemm_nt(x, shadow(W1), b1.detach(), epilogue=hip.EPI_RELU)
+    h2 = hip.gemm_nt(h1, shadow(W2), b2.detach(), epilogue=hip.EPI_RELU)
+    h3 = hip.gemm_nt(h2, shadow(W3), b3.detach(), epilogue=hip.EPI_RELU)
+    out = hip.gemm_nt(h3, shadow(W4), b4.detach(), out_f32=True)
+    return h1, h2, h3, out.view(-1)
+
+
+class DiscriminatorFn(torch.autograd.Function):
+    """Discriminator.forward in eval mode (tools/utils.py:41-57) -> [B] f32."""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4):
+        x = x.contiguous()
+        h1, h2, h3, out = _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4)
+        ctx.save_for_backward(x, h1, h2, h3, W1, W2, W3, W4)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, h1, h2, h3, W1, W2, W3, W4 = ctx.saved_tensors
+        need_w = ctx.needs_input_grad[1]
+        dout = dout.to(torch.float32).contiguous()
+        dev = x.device
+        e3 = hip.outer_posmask(dout, W4.detach().view(-1), h3)
+        e2 = hip.gemm_nt(e3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
+        e1 = hip.gemm_nt(e2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        dx = hip.gemm_nt(e1, shadow(W1, transpose=True)) if ctx.needs_input_grad[0] else None
+        if not need_w:
+            return (dx,) + (None,) * 8
+        dW4 = torch.zeros(W4.shape, device=dev)
+        hip.colsum(h3, dW4.view(-1), coef=dout)
+        db4 = torch.zeros(1, device=dev)
+        hip.sum_into(dout, db4)
+        dW3, db3 = torch.zeros(W3.shape, device=dev), _z(W3.shape[0], x)
+        hip.gemm_tn(e3, h2, dW3, db3)
+        dW2, db2 = torch.zeros(W2.shape, device=dev), _z(W2.shape[0], x)
+        hip.gemm_tn(e2, h1, dW2, db2)
+        dW1, db1 = torch.zeros(W1.shape, device=dev), _z(W1.shape[0], x)
+        hip.gemm_tn(e1, x, dW1, db1)
+        return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4
+
+
+class GradientPenaltyFn(torch.autograd.Function):
+    """calc_gradient_penalty (gan_training.py:38-55) with its double backward in closed form
+    (SURVEY Q13): forward returns lambda*mean((||dD/dxhat|| - 1)^2) and already holds dGP/dW_i;
+    GP has no bias gradient and real/fake are treated as constants (they are detached at :408,:427)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, alpha, W1, b1, W2, b2, W3, b3, W4, b4):
+        dev = real.device
+        xh = hip.interpolate(alpha.reshape(-1).to(torch.float32).contiguous(), real.contiguous(), fake.contiguous())
+        h1, h2, h3, _ = _disc_fwd(xh, W1, b1, W2, b2, W3, b3, W4, b4)
+        u3 = hip.outer_posmask(None, W4.detach().view(-1), h3)
+        u2 = hip.gemm_nt(u3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
+        u1 = hip.gemm_nt(u2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        g = hip.gemm_nt(u1, shadow(W1, transpose=True), out_f32=True)
+        gp = torch.zeros(1, device=dev)
+        dg = hip.gp_penalty(g, gp, GP_LAMBDA, xh.dtype)
+        dW1 = torch.zeros(W1.shape, device=dev)
+        hip.gemm_tn(u1, dg, dW1)
+        e1 = hip.gemm_nt(dg, shadow(W1), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        dW2 = torch.zeros(W2.shape, device=dev)
+        hip.gemm_tn(u2, e1, dW2)
+        e2 = hip.gemm_nt(e1, shadow(W2), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
+        dW3 = torch.zeros(W3.shape, device=dev)
+        hip.gemm_tn(u3, e2, dW3)
+        e3 = hip.gemm_nt(e2, shadow(W3), epilogue=hip.EPI_MUL_POSMASK, aux=h3)
+        dW4 = torch.zeros(W4.shape, device=dev)
+        hip.colsum(e3, dW4.view(-1))
+        ctx.save_for_backward(dW1, dW2, dW3, dW4)
+        return gp[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        dW1, dW2, dW3, dW4 = ctx.saved_tensors
+        return (None, None, None, dW1 * gout, None, dW2 * gout, None, dW3 * gout, None, dW4 * gout, None)

@@ -1,0 +1,289 @@
+"""Training drivers of the hot path, same names and call signatures as the reference:
+
+  get_next_batch, loss_ae, loss_bpr_func          GURU/tools/utils.py:15-27, :60-87, :90-127
+  calc_gradient_penalty, get_user_embed,
+  get_pad_mask, load_batch_data                    GURU/gan_training.py:38-55, :152-162, :347-350, :338-344
+  train_recon_x (phase 1)                          GURU/gan_training.py:818-892
+  train_gan_all (phase 2 W-GAN + phase 3 BPR tune) GURU/gan_training.py:353-587
+  main_2                                           GURU/gan_training.py:998-1010
+
+All arithmetic runs in the HIP library via recguru_amd.ops; this file is control flow only.
+Data-parallel runs pass a recguru_amd.dist.DataParallel as `dp`: mean-type losses are pre-divided
+by the world size, masked means use the global mask count, and gradients are sum-all-reduced over
+RCCL before every optimizer step.
+"""
+import os
+import sys
+
+import torch
+
+from . import ops
+from .optim import Adam
+
+LAMBDA = .1         # gan_training.py:21
+CRITIC_ITERS = 5    # gan_training.py:22
+date = "1209"       # gan_training.py:24 (series-name suffix)
+
+
+class ScalarLog(object):
+    """Device-side stand-in for tools/plot.py: keeps the series as device scalars and converts on
+    flush only (the reference forces 5 host syncs per iteration, gan_training.py:524-528)."""
+
+    def __init__(self):
+        self.series = {}
+
+    def plot(self, name, value):
+        self.series.setdefault(name, []).append(value.detach() if torch.is_tensor(value) else value)
+
+    def flush(self):
+        return {k: [float(v) for v in vs] for k, vs in self.series.items()}
+
+
+plot = ScalarLog()
+
+
+def get_next_batch(dataloader_iterator, device):
+    seqs, n_items, val, test = next(dataloader_iterator)
+    n_items, val, test = n_items.to(device), val.to(device), test.to(device)
+    enc_in, dec_in, dec_out = seqs[0].to(device), seqs[1].to(device), seqs[2].to(device)
+    bs, sl = dec_out.shape[0], dec_out.shape[1]
+    return enc_in, dec_in, dec_out, n_items, val, test, bs, sl
+
+
+def load_batch_data(data_iterator, data, device):
+    try:
+        enc_in, dec_in, dec_out, n_items, _, _, bs, sl = get_next_batch(data_iterator, device)
+    except StopIteration:
+        data_iterator = iter(data)
+        enc_in, dec_in, dec_out, n_items, _, _, bs, sl = get_next_batch(data_iterator, device)
+    return enc_in, dec_in, dec_out, n_items, data_iterator
+
+
+def get_pad_mask(seq, pad_index, device):
+    return (seq != pad_index).reshape(-1).to(torch.float32).to(device)
+
+
+def _unwrap(model):
+    return model.module if hasattr(model, "module") else model
+
+
+def loss_ae(model, enc_in, dec_in, dec_out, n_items, neg_sample, bs, sl, param, mask, device, domain="a"):
+    """Reconstruction loss: masked sampled-softmax CE with label 0 (tools/utils.py:60-87)."""
+    if not neg_sample:
+        raise NotImplementedError("full-vocabulary softmax (neg_sample=False) is outside the hot path")
+    return _unwrap(model)(enc_in, dec_in, dec_out, n_items, domain, mask).loss(mask)
+
+
+def loss_bpr_func(model_train, enc_in, dec_in, dec_out, n_items, mask, domain, param):
+    """BPR loss over recommend_forward (tools/utils.py:90-127)."""
+    m = _unwrap(model_train)
+    h = m.recommend_forward(enc_in, dec_in, domain, mask.view(-1, param.rec_maxlen))
+    return ops.bpr_loss(h, m.item_table(domain), dec_out, n_items, mask, param.n_bpr_neg)
+
+
+def get_user_embed(model, seq, domain, param, device, pad_idx):
+    """gan_training.py:152-162: natural (seq != pad) mask, last position of the encoder output."""
+    seq = seq.to(device)
+    mask = get_pad_mask(seq, pad_idx, device)
+    out = _unwrap(model).get_seq_embed(seq, domain=domain, mask=mask.view(-1, param.rec_maxlen))
+    return out[:, -1, :].contiguous()
+
+
+class _Mean(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        from . import hip
+        out = torch.zeros(1, device=x.device, dtype=torch.float32)
+        hip.sum_into(x.contiguous(), out, 1.0 / x.numel())
+        ctx.n = x.numel()
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        return (g / ctx.n).expand(ctx.n)
+
+
+def mean(x):
+    return _Mean.apply(x)
+
+
+def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, device):
+    """gan_training.py:38-55.  alpha ~ U[0,1) from the CPU default generator, as there (Q13)."""
+    alpha = torch.rand(BATCH_SIZE, 1).to(device)
+    return ops.GradientPenaltyFn.apply(real_data, fake_data, alpha, *_unwrap(netD).params())
+
+
+class _NoDP(object):
+    world = 1
+
+    def scale_mean(self, loss):
+        return loss
+
+    def sync_grads(self, params):
+        pass
+
+
+def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True, loss_type="s_soft", opt_type="org",
+                  dp=None, log_every=50, verbose=True):
+    """Phase 1: reconstruction pre-training over both domains (gan_training.py:818-892)."""
+    dp = dp or _NoDP()
+    model_train.train()
+    it_a, it_b = iter(data[0]), iter(data[1])
+    seqs, _, _, _ = next(it_a)                                  # the reference consumes one a-batch here (:837)
+    bs, sl = seqs[2].shape[0], seqs[2].shape[1]
+    params = [p for p in model_train.parameters()]
+    losses = []
+    for i in range(steps):
+        enc_a, din_a, dout_a, n_a, it_a = load_batch_data(it_a, data[0], device)
+        enc_b, din_b, dout_b, n_b, it_b = load_batch_data(it_b, data[1], device)
+        mask_a = get_pad_mask(dout_a, param.pad_index, device)
+        mask_b = get_pad_mask(dout_b, param.pad_index, device)
+        opt.zero_grad()
+        if loss_type == "s_soft":
+            loss_a = loss_ae(model_train, enc_a, din_a, dout_a, n_a, neg_sample, bs, sl, param, mask_a, device, "a")
+            loss_b = loss_ae(model_train, enc_b, din_b, dout_b, n_b, neg_sample, bs, sl, param, mask_b, device, "b")
+        elif loss_type == "bpr":
+            loss_a = loss_bpr_func(model_train, enc_a, din_a, dout_a, n_a, mask_a, "a", param)
+            loss_b = loss_bpr_func(model_train, enc_b, din_b, dout_b, n_b, mask_b, "b", param)
+        else:
+            print("loss configuration error")
+            sys.exit()
+        loss_a.backward()
+        loss_b.backward()
+        dp.sync_grads(params)
+        if opt_type == "org":
+            opt.step()
+        else:
+            opt.step_and_update_lr()
+        losses.append((loss_a.detach(), loss_b.detach()))
+        if log_every and i % log_every == log_every - 1:
+            la, lb = float(loss_a), float(loss_b)
+            if verbose:
+                print("%s loss after %d batch" % ("reconstruction" if loss_type == "s_soft" else "BPR", i), la, lb)
+            tag = "reconstruct_loss" if loss_type == "s_soft" else "bpr_loss"
+            plot.plot(param.result_path + "/%s_a_%s" % (tag, param.date), la)
+            plot.plot(param.result_path + "/%s_b_%s" % (tag, param.date), lb)
+    return losses
+
+
+def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp):
+    """One critic update (gan_training.py:399-449): two no-grad encoder passes, W-loss, GP, Adam(D)."""
+    with torch.no_grad():
+        ae = get_user_embed(netG, in_seq_a, "a", param, device, param.pad_index)
+        be = get_user_embed(netG, in_seq_b, "b", param, device, param.pad_index)
+    opt_d.zero_grad()
+    D_real = netD(ae)
+    D_fake = netD(be)
+    real_loss, fake_loss = mean(D_real), mean(D_fake)
+    dis_loss = fake_loss - real_loss
+    dp.scale_mean(dis_loss).backward()
+    gradient_penalty = calc_gradient_penalty(netD, ae, be, ae.shape[0], device)
+    dp.scale_mean(gradient_penalty).backward()
+    D_cost = dis_loss.detach() + gradient_penalty.detach()
+    Wasserstein_D = -dis_loss.detach()
+    dp.sync_grads(list(netD.parameters()))
+    opt_d.step()
+    return D_cost, Wasserstein_D
+
+
+def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, g_params=None):
+    """Generator update (gan_training.py:455-523, overlap=False): W-loss through D into the encoder,
+    plus the reconstruction loss of both domains; batch = (enc_in, dec_in, dec_out, n_items, bs, sl)."""
+    for p in netD.parameters():
+        p.requires_grad = False
+    opt_g.zero_grad()
+    in_a, din_a, dout_a, n_a, bs, sl = batch_a
+    in_b, din_b, dout_b, n_b, bs, sl = batch_b
+    ae = get_user_embed(netG, in_a, "a", param, device, 0)
+    be = get_user_embed(netG, in_b, "b", param, device, 0)
+    g_dis_loss = mean(netD(ae)) - mean(netD(be))
+    dp.scale_mean(g_dis_loss).backward()
+    mask_a = get_pad_mask(dout_a, param.pad_index, device)
+    loss_recon_a = loss_ae(netG, in_a, din_a, dout_a, n_a, True, bs, sl, param, mask_a, device, domain="a")
+    mask_b = get_pad_mask(dout_b, param.pad_index, device)
+    loss_recon_b = loss_ae(netG, in_b, din_b, dout_b, n_b, True, bs, sl, param, mask_b, device, domain="b")
+    loss_recon_a.backward()
+    loss_recon_b.backward()
+    dp.sync_grads(g_params if g_params is not None else list(netG.parameters()))
+    opt_g.step()
+    for p in netD.parameters():
+        p.requires_grad = True
+    return g_dis_loss.detach(), loss_recon_a.detach(), loss_recon_b.detach()
+
+
+class _Cycler(object):
+    """try: next(it) / except StopIteration: it = iter(loader) -- the reference's loader idiom."""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, iter(loader)
+
+    def next(self, device):
+        try:
+            return get_next_batch(self.it, device)
+        except StopIteration:
+            self.it = iter(self.loader)
+            return get_next_batch(self.it, device)
+
+
+def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iterations, train_overlap, rec_loaders,
+                  test_loaders, domain="a", overlap=True, dp=None, evaluate=None):
+    """Phases 2 and 3 (gan_training.py:353-587).  `evaluate(netG)` (optional) is called at the
+    reference's evaluation points; the ranking evaluation itself is a 'next' row."""
+    if overlap:
+        raise NotImplementedError("overlap=True (MSE on overlapped users) is off in main_2 (gan_training.py:1010)")
+    dp = dp or _NoDP()
+    g_params = list(netG.parameters())
+    opt_final_rec = Adam(g_params, lr=0.001, betas=(0.9, 0.98))
+    a_iter, b_iter = _Cycler(gan_loader[0]), _Cycler(gan_loader[1])
+    rec_task = _Cycler(rec_loaders[0]) if rec_loaders is not None else None
+    rec_iter = _Cycler(gan_loader[0] if domain == "a" else gan_loader[1])
+    history = []
+    for iteration in range(int(iterations * 1.2)):
+        if iteration < int(iterations * 0.6):                                   # phase 2
+            for p in netD.parameters():
+                p.requires_grad = True
+            for _ in range(CRITIC_ITERS):
+                in_seq_a = a_iter.next(device)[0]
+                in_seq_b = b_iter.next(device)[0]
+                D_cost, Wasserstein_D = critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp)
+            ba = a_iter.next(device)
+            bb = b_iter.next(device)
+            g_dis, lra, lrb = generator_iteration(netG, netD, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param,
+                                                  device, dp, g_params)
+            plot.plot(param.result_path + "/disc cost_%s" % date, D_cost)
+            plot.plot(param.result_path + "/wasserstein distance_%s" % date, Wasserstein_D)
+            plot.plot(param.result_path + "/join_recon_a%s" % date, lra)
+            plot.plot(param.result_path + "/join_recon_b%s" % date, lrb)
+            plot.plot(param.result_path + "/gen cost_%s" % date, g_dis)
+            history.append((D_cost, Wasserstein_D, lra, lrb, g_dis))
+        else:                                                                   # phase 3
+            opt_final_rec.zero_grad()
+            enc_in, dec_in, dec_out, n_items, _, _, bs, sl = rec_task.next(device)
+            in_r, din_r, dout_r, n_r, _, _, bs, sl = rec_iter.next(device)
+            mask_rec = get_pad_mask(dout_r, param.pad_index, device)
+            loss_recon_rec = loss_ae(netG, in_r, din_r, dout_r, n_r, True, bs, sl, param, mask_rec, device, domain)
+            loss_recon_rec.backward()
+            mask = get_pad_mask(dec_out, param.pad_index, device)
+            loss_recommend = loss_bpr_func(netG, enc_in, dec_in, dec_out, n_items, mask, domain, param)
+            loss_recommend.backward()
+            dp.sync_grads(g_params)
+            opt_final_rec.step()
+            plot.plot(param.result_path + "/tuning_recommendation_loss", loss_recommend)
+        if evaluate is not None and iteration > int(iterations * 0.8) and iteration % 30 == 29:
+            netG.eval()
+            evaluate(netG)
+            netG.train()
+    return history
+
+
+def main_2(auto_cross, opt_rec, netD, opt_gen, opt_dis, param, device_t, ae_loaders, rec_loaders, test_loaders,
+           train_overlap, dp=None, phase1_steps=200):
+    """gan_training.py:998-1010: phase 1 (200 steps), checkpoint, phases 2+3."""
+    print("============ Reconstruction pre-training (Phase 1).")
+    train_recon_x(auto_cross, opt_rec, phase1_steps, ae_loaders, param, device_t, neg_sample=True,
+                  loss_type="s_soft", opt_type="schedule", dp=dp)
+    if dp is None or dp.rank == 0:
+        torch.save(_unwrap(auto_cross).state_dict(), os.path.join(param.model_path, "pre_model"))
+    print("============ Adversarial and recommendation training (phase 2 and phase 3).")
+    return train_gan_all(auto_cross, netD, ae_loaders, opt_dis, opt_gen, device_t, param, param.training_steps_tune,
+                         train_overlap, rec_loaders, test_loaders, domain=param.target_domain, overlap=False, dp=dp)

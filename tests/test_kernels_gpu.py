@@ -224,7 +224,8 @@ def test_bcast_add_ln_seq_sum(dt):
     ref = torch.nn.functional.layer_norm(z, (N,), g, b, 1e-8)
     torch.testing.assert_close(y.float().view(B, L, N), ref, **tol(dt))
     torch.testing.assert_close(rstd.view(B, L), 1 / torch.sqrt(z.var(2, unbiased=False) + 1e-8), rtol=1e-4, atol=1e-5)
-    torch.testing.assert_close(hip.seq_sum(x, B, L), x.float().view(B, L, N).sum(1), rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(hip.seq_sum(x, B, L).float(), x.float().view(B, L, N).sum(1),
+                               **(dict(rtol=1e-5, atol=1e-4) if dt == torch.float32 else tol(dt)))
 
 
 @pytest.mark.parametrize("dt", DTYPES)
@@ -241,6 +242,9 @@ def test_gp_helpers(dt):
     out.zero_()
     hip.colsum(x, out)
     torch.testing.assert_close(out, x.float().sum(0), rtol=1e-4, atol=1e-4)
+    out.zero_()
+    hip.colsum(x, out, coef=coef)
+    torch.testing.assert_close(out, (x.float() * coef[:, None]).sum(0), rtol=1e-4, atol=1e-4)
     torch.testing.assert_close(hip.outer_posmask(coef, w, aux).float(),
                                coef[:, None] * w[None] * (aux.float() > 0), **tol(dt))
     torch.testing.assert_close(hip.outer_posmask(None, w, aux).float(), w[None] * (aux.float() > 0), **tol(dt))

@@ -1,0 +1,235 @@
+"""GPU parity: the HIP path (through the C ABI) against the golden vectors captured from the
+reference and against the CPU oracle, on the same inputs and weights.
+
+Tolerance (BASELINE.json north_star): rtol=1e-3 / atol=1e-5 on user embeddings, reconstruction loss
+and discriminator loss for the f32 tier.  Gradients are compared relative to each tensor's scale.
+The bf16 tier is run on the same cases and held to a looser, stated bound (operands carry 8
+mantissa bits); its measured drift is printed.
+"""
+import numpy as np
+import pytest
+import torch
+
+from golden_util import load_case, sample
+from parity_util import batches, build_cross, case_param, max_err, state_of
+
+pytestmark = pytest.mark.gpu
+CASES = ["case1", "case2"]
+DEAD = ("dec_enc_attn.WQ", "dec_enc_attn.WK")
+NOISE = DEAD + ("WK.bias",)
+
+
+@pytest.fixture(autouse=True)
+def _f32_tier():
+    from recguru_amd import ops
+    ops.set_compute_dtype(torch.float32)
+    yield
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def np_(t):
+    return t.detach().float().cpu().numpy()
+
+
+def check_grads(module, z, prefix, rtol=2e-3, skip=DEAD, min_n=8):
+    n = 0
+    for k, p in module.named_parameters():
+        key = prefix + k
+        if key not in z or any(s in k for s in skip):
+            continue
+        assert p.grad is not None, k
+        ref = z[key]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        np.testing.assert_allclose(sample(np_(p.grad)), ref, rtol=rtol, atol=2e-6 + 2e-4 * scale, err_msg=k)
+        n += 1
+    assert n >= min_n
+
+
+def close_frac(a, b, rtol, atol, bad_frac=0.005, msg=""):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    bad = np.abs(a - b) > atol + rtol * np.abs(b)
+    assert bad.mean() <= bad_frac, "%s: %d/%d differ (max %g)" % (msg, bad.sum(), bad.size, np.abs(a - b).max())
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_user_embeddings(name):
+    from recguru_amd import training as T
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    with torch.no_grad():
+        ue_a = T.get_user_embed(G, bt["a"][0], "a", param, "cuda", 0)
+        ue_b = T.get_user_embed(G, bt["b"][0], "b", param, "cuda", 0)
+    np.testing.assert_allclose(np_(ue_a), z["user_embed.a"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np_(ue_b), z["user_embed.b"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_decoder_states_and_recon_loss(name):
+    from recguru_amd import training as T
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    enc_in, dec_in, dec_out, n_items = bt["a"]
+    mask = T.get_pad_mask(dec_out, 0, "cuda")
+    with torch.no_grad():
+        h, _, _ = G.get_dec_out(enc_in, dec_in, "a", mask)
+    d_mask = (enc_in != 0).float().unsqueeze(2).cpu().numpy()
+    N = param.num_blocks
+    np.testing.assert_allclose(np_(h), z["tap.ae_dec_layer%d.a" % (N - 1)] * d_mask, rtol=1e-3, atol=2e-5)
+    B, L = enc_in.shape
+    la = T.loss_ae(G, *bt["a"], True, B, L, param, mask, "cuda", domain="a")
+    mask_b = T.get_pad_mask(bt["b"][2], 0, "cuda")
+    lb = T.loss_ae(G, *bt["b"], True, B, L, param, mask_b, "cuda", domain="b")
+    np.testing.assert_allclose(float(la.detach()), float(z["loss_ae.a"]), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(float(lb.detach()), float(z["loss_ae.b"]), rtol=1e-3, atol=1e-5)
+    la.backward()
+    lb.backward()
+    check_grads(G, z, "gradG_recon.")
+    for k, p in G.named_parameters():       # dead parameters: no gradient at all in the collapsed form
+        if any(s in k for s in DEAD):
+            assert p.grad is None
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_phase1_step_noam_adam(name):
+    from recguru_amd import training as T
+    from recguru_amd.blocks import ScheduledOptim
+    from recguru_amd.optim import Adam
+    from recguru_amd.synthetic import TensorLoader
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    doms = {}
+    for dom in "ab":
+        doms[dom] = {k: z["%s.%s" % (k, dom)] for k in ("enc_in", "dec_in", "dec_out", "n_items")}
+        B = doms[dom]["enc_in"].shape[0]
+        doms[dom]["val"] = np.zeros(B, np.int64)
+        doms[dom]["test"] = np.zeros(B, np.int64)
+    loaders = [TensorLoader(doms["a"], B, "cuda"), TensorLoader(doms["b"], B, "cuda")]
+    opt = ScheduledOptim(Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-09), 1.0, param.d_model, 7)
+    losses = T.train_recon_x(G, opt, 1, loaders, param, "cuda", loss_type="s_soft", opt_type="schedule", log_every=0)
+    np.testing.assert_allclose(float(losses[0][0]), float(z["loss_ae.a"]), rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(opt.get_lr(), z["noam_lr"][0], rtol=1e-12)
+    lr = opt.get_lr()
+    for k, p in G.named_parameters():
+        if any(s in k for s in NOISE) or k.startswith("recommend"):
+            continue
+        close_frac(sample(np_(p)), z["G_after_recon_step." + k], rtol=1e-4, atol=2e-4 * lr + 1e-6, msg=k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_critic_losses_grads_step(name):
+    from recguru_amd import ops, training as T
+    from recguru_amd.optim import Adam
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    ae = torch.as_tensor(z["user_embed.a"]).cuda()
+    be = torch.as_tensor(z["user_embed.b"]).cuda()
+    d_real, d_fake = D(ae), D(be)
+    np.testing.assert_allclose(np_(d_real), z["D_real"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(np_(d_fake), z["D_fake"], rtol=1e-3, atol=1e-5)
+    dis_loss = T.mean(d_fake) - T.mean(d_real)
+    np.testing.assert_allclose(float(dis_loss), float(z["dis_loss"]), rtol=1e-3, atol=1e-5)
+    dis_loss.backward()
+    alpha = torch.as_tensor(z["alpha"]).cuda()
+    gp = ops.GradientPenaltyFn.apply(ae, be, alpha, *D.params())
+    np.testing.assert_allclose(float(gp), float(z["gp"]), rtol=1e-3, atol=1e-6)
+    gp.backward()
+    check_grads(D, z, "gradD_critic.", rtol=2e-3, skip=())
+    opt = Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    opt.step()
+    for k, p in D.state_dict().items():
+        close_frac(sample(np_(p)), z["D_after_critic_step." + k], rtol=1e-4, atol=2e-6, msg=k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_generator_step(name):
+    from recguru_amd import training as T
+    from recguru_amd.optim import Adam
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    B, L = bt["a"][0].shape
+    # W-loss through the frozen discriminator into the encoder
+    for p in D.parameters():
+        p.requires_grad = False
+    ae = T.get_user_embed(G, bt["a"][0], "a", param, "cuda", 0)
+    be = T.get_user_embed(G, bt["b"][0], "b", param, "cuda", 0)
+    g_dis = T.mean(D(ae)) - T.mean(D(be))
+    np.testing.assert_allclose(float(g_dis), float(z["g_dis_loss"]), rtol=1e-3, atol=1e-5)
+    g_dis.backward()
+    check_grads(G, z, "gradG_gdis.")
+    G.zero_grad(set_to_none=True)
+    opt_g = Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    T.generator_iteration(G, D, bt["a"] + (B, L), bt["b"] + (B, L), opt_g, param, "cuda", T._NoDP())
+    for k, p in G.named_parameters():
+        if any(s in k for s in NOISE) or k.startswith("recommend"):
+            continue
+        close_frac(sample(np_(p)), z["G_after_gen_step." + k], rtol=1e-4, atol=1e-5, msg=k)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_phase3_bpr(name):
+    from recguru_amd import training as T
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    enc_in, dec_in, dec_out, _ = bt["a"]
+    nb = torch.as_tensor(z["n_items_bpr.a"]).cuda()
+    mask = T.get_pad_mask(dec_out, 0, "cuda")
+    loss = T.loss_bpr_func(G, enc_in, dec_in, dec_out, nb, mask, "a", param)
+    np.testing.assert_allclose(float(loss), float(z["loss_bpr.a"]), rtol=1e-3, atol=1e-5)
+    loss.backward()
+    check_grads(G, z, "gradG_bpr.")
+    assert G.encoder.layers[0].pos_ffn.l1.weight.grad is None       # fixed_enc: encoder detached
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_single_domain_myrec(name):
+    from recguru_amd.models import MyRec
+    z = load_case(name)
+    param = case_param(z)
+    R = MyRec("cuda", param, None, dec_rec=False, fix_enc=False, sas=False, pos_train=False).to(torch.float32)
+    R.load_state_dict(state_of(z, "R"), strict=False)
+    R = R.cuda()
+    bt = batches(z, "cuda")
+    enc_in, dec_in, dec_out, n_items = bt["a"]
+    m_in = (dec_in != 0).float().view(-1)                           # train_auto.py:109-110
+    loss = R(enc_in, dec_in, dec_out, n_items, recon=True).loss(m_in)
+    np.testing.assert_allclose(float(loss), float(z["single.loss_ae"]), rtol=1e-3, atol=1e-5)
+    loss.backward()
+    check_grads(R, z, "gradR_recon.")
+    assert float(R.AutoEnc.src_emb.weight.grad[0].abs().max()) == 0.0      # padding_idx row
+    nb = torch.as_tensor(z["n_items_bpr.a"]).cuda()
+    with torch.no_grad():
+        bpr = R(enc_in, dec_in, dec_out, nb, recon=False).bpr(m_in)
+    np.testing.assert_allclose(float(bpr), float(z["single.loss_bpr"]), rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_bf16_tier_drift(name, capsys):
+    """The perf tier on the same case: bounded, reported drift (not the 1e-3 gate)."""
+    from recguru_amd import ops, training as T
+    ops.set_compute_dtype(torch.bfloat16)
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    with torch.no_grad():
+        ue = T.get_user_embed(G, bt["a"][0], "a", param, "cuda", 0)
+    B, L = bt["a"][0].shape
+    mask = T.get_pad_mask(bt["a"][2], 0, "cuda")
+    la = T.loss_ae(G, *bt["a"], True, B, L, param, mask, "cuda", domain="a")
+    e_abs, e_rel = max_err(np_(ue), z["user_embed.a"])
+    l_rel = abs(float(la) - float(z["loss_ae.a"])) / abs(float(z["loss_ae.a"]))
+    with capsys.disabled():
+        print("\n[bf16 tier %s] user_embed max|err|=%.3g (rel-to-max %.3g)  loss_ae rel err=%.3g" % (name, e_abs, e_rel, l_rel))
+    assert e_rel < 0.08 and l_rel < 0.05
+    la.backward()
+    mask_b = T.get_pad_mask(bt["b"][2], 0, "cuda")
+    T.loss_ae(G, *bt["b"], True, B, L, param, mask_b, "cuda", domain="b").backward()
+    g = G.encoder.layers[0].pos_ffn.l1.weight.grad
+    ref = z["gradG_recon.encoder.layers.0.pos_ffn.l1.weight"]
+    g_rel = max_err(sample(np_(g)), ref)[1]
+    with capsys.disabled():
+        print("[bf16 tier %s] encoder l1.weight grad max err rel-to-max %.3g" % (name, g_rel))
+    assert g_rel < 0.15
