@@ -1,0 +1,238 @@
+#!/usr/bin/env python
+"""bench.py -- user-sequences/sec of the AE+GAN step (BASELINE.json metric) on N MI355X.
+
+A "step" is ONE phase-2 iteration of train_gan_all (reference GURU/gan_training.py:382-528):
+CRITIC_ITERS=5 critic updates (2 no-grad encoder passes + D(real), D(fake) + W-loss + gradient
+penalty + Adam(D)) followed by one generator update (2 encoder passes with grad + W-loss through D
++ reconstruction loss of both domains with encoder AND decoder + Adam(G)).  It draws 12*B user
+sequences from the loaders; value = 12*B*N / t  (SURVEY.md 8d).  Workload = BASELINE.json
+configs[2] ("cross-domain RecGURU, two 100k-item domains, 1xMI355X") at the metric's shape
+seq_len=200 / hidden=128 / batch=4096 per GPU; per-GPU work is fixed as N grows (weak scaling).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  The `roofline` object is measured live in this process with HIP
+events on the launch stream around every launch of the dominant kernel (an instrumented pass of the
+same step after the timed region); `cpu_baseline` times the CPU oracle (oracle/recguru_oracle.py,
+a port of the reference arithmetic) on a bounded sample of the same workload on the host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="users per domain per GPU per draw")
+    ap.add_argument("--seq_len", type=int, default=200)
+    ap.add_argument("--d_model", type=int, default=128)
+    ap.add_argument("--n_head", type=int, default=4)
+    ap.add_argument("--n_blocks", type=int, default=3)
+    ap.add_argument("--items", type=int, default=100000)
+    ap.add_argument("--n_negs", type=int, default=30)
+    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--batches_per_domain", type=int, default=2, help="distinct synthetic batches cycled")
+    ap.add_argument("--no_cpu_baseline", action="store_true")
+    ap.add_argument("--cpu_batch", type=int, default=8)
+    ap.add_argument("--no_roofline", action="store_true")
+    return ap.parse_args()
+
+
+def build(args, device, rank, world):
+    from recguru_amd import config, models, optim, synthetic
+    a = argparse.Namespace(date="bench", d_model=args.d_model, n_head=args.n_head, d_ff=512, n_negs=args.n_negs,
+                           decoder_neg=True, fix_enc=True, lr=0.01, batch_size=args.batch, batch_size_val=256,
+                           dataset_pick=1, run=1, target_domain="a", cross="True", sas="False",
+                           result_path="/tmp/rg_bench", seq_len=args.seq_len, vocab_size_a=args.items,
+                           vocab_size_b=args.items, n_blocks=args.n_blocks, dropout=0.0)
+    param = config.get_param(a, make_dirs=False)
+    torch.manual_seed(0)
+    G = models.MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32).to(device)
+    D = models.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
+    opt_g = optim.Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:128
+    opt_d = optim.Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:134
+    n_users = args.batch * args.batches_per_domain * world
+    loaders = []
+    for i, seed in enumerate((1, 2)):
+        dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed)
+        loaders.append(synthetic.TensorLoader(dom, args.batch, device, rank=rank, world=world))
+    return param, G, D, opt_g, opt_d, loaders
+
+
+def make_step(param, G, D, opt_g, opt_d, loaders, device, dp):
+    from recguru_amd import training as T
+    a_iter, b_iter = T._Cycler(loaders[0]), T._Cycler(loaders[1])
+    g_params = list(G.parameters())
+    ndp = dp or T._NoDP()
+
+    def step():
+        for _ in range(T.CRITIC_ITERS):
+            in_a = a_iter.next(device)[0]
+            in_b = b_iter.next(device)[0]
+            d_cost, w_d = T.critic_iteration(G, D, in_a, in_b, opt_d, param, device, ndp)
+        ba = a_iter.next(device)
+        bb = b_iter.next(device)
+        g_dis, lra, lrb = T.generator_iteration(G, D, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param, device, ndp,
+                                                g_params)
+        return d_cost, w_d, g_dis, lra, lrb
+    return step
+
+
+def cpu_baseline(args):
+    """The CPU oracle on the same workload shape with a small batch (memory: SURVEY.md 6)."""
+    import numpy as np
+    from oracle import recguru_oracle as O
+    from recguru_amd import synthetic
+    torch.manual_seed(0)
+    B, L, d, H, N, V, k = args.cpu_batch, args.seq_len, args.d_model, args.n_head, args.n_blocks, args.items, args.n_negs
+    cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
+    P = H * 32
+
+    def lin(o, i):
+        return torch.randn(o, i) / i ** 0.5
+
+    pG = {}
+    for dom in "ab":
+        pG["src_emb_%s.weight" % dom] = torch.randn(V + 2, d)
+        pG["pos_emb_%s.pe" % dom] = O.positional_table(5000, d).unsqueeze(0)
+
+    def mha(pre):
+        for nm, (o, i) in (("WQ", (P, d)), ("WK", (P, d)), ("WV", (P, d)), ("linear", (d, P))):
+            pG[pre + nm + ".weight"], pG[pre + nm + ".bias"] = lin(o, i), torch.zeros(o)
+        pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+
+    def ffn(pre):
+        pG[pre + "l1.weight"], pG[pre + "l1.bias"] = lin(512, d), torch.zeros(512)
+        pG[pre + "l2.weight"], pG[pre + "l2.bias"] = lin(d, 512), torch.zeros(d)
+        pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+    for i in range(N):
+        mha("encoder.layers.%d.enc_self_attn." % i)
+        ffn("encoder.layers.%d.pos_ffn." % i)
+        for dec in ("decoder_a.", "decoder_b."):
+            mha("%slayers.%d.dec_self_attn." % (dec, i))
+            mha("%slayers.%d.dec_enc_attn." % (dec, i))
+            ffn("%slayers.%d.pos_ffn." % (dec, i))
+    pD = {}
+    for idx, (o, i) in zip((0, 3, 6, 9), ((5 * d, d), (10 * d, 5 * d), (5 * d, 10 * d), (1, 5 * d))):
+        pD["main.%d.weight" % idx], pD["main.%d.bias" % idx] = lin(o, i), torch.zeros(o)
+    pG, pD = O.leafify(pG), O.leafify(pD)
+    opt_g = O.Adam({k_: v for k_, v in pG.items() if v.requires_grad}, 1e-4, (0.5, 0.9))
+    opt_d = O.Adam(pD, 1e-4, (0.5, 0.9))
+    doms = [synthetic.make_domain(B, V, L, k, seed=s) for s in (1, 2)]
+    bt = [tuple(torch.as_tensor(dm[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items")) for dm in doms]
+    t0 = time.perf_counter()
+    for _ in range(O.CRITIC_ITERS):
+        O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
+    O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
+    dt = time.perf_counter() - t0
+    return {"value": 12 * B / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 AE+GAN iteration (5 critic + 1 generator), B=%d users/domain/draw, L=%d d=%d H=%d N=%d "
+                      "V=%d k=%d, fp32, dropout 0, torch %s CPU kernels, %.1f s"
+                      % (B, L, d, H, N, V, k, torch.__version__, dt)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
+                     % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py: no GPU visible -- the HIP path has no CPU fallback")
+    from recguru_amd import dist as rdist, hip, ops
+    dp = rdist.init_from_env("nccl") if world > 1 else None
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_data_parallel(dp)
+    param, G, D, opt_g, opt_d, loaders = build(args, device, rank, world)
+    step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp)
+
+    for _ in range(args.warmup):
+        out = step()
+    if dp:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        t = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    losses = [float(x) for x in out]
+
+    roof = None
+    if not args.no_roofline and rank == 0:
+        prof = hip.start_profile()
+        step()
+        agg = hip.stop_profile().summary()
+        top = max(agg.items(), key=lambda kv: kv[1]["ms"])
+        name, a = top
+        total_ms = sum(v["ms"] for v in agg.values())
+        if a["flops"] > 0 and name.startswith(("gemm", "attn")):
+            ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
+            peak = MFMA_PEAK_TFLOPS[args.dtype]
+            roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None}
+        else:
+            ach = a["bytes"] / (a["ms"] * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": name, "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        roof["launches_per_step"] = a["launches"]
+        roof["avg_launch_us"] = round(a["ms"] * 1e3 / a["launches"], 2)
+        roof["share_of_kernel_time"] = round(a["ms"] / total_ms, 3)
+        roof["kernels_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
+    if dp:
+        dp.barrier()
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args)
+
+    if rank == 0:
+        B = args.batch
+        line = {
+            "metric": "user-sequences/sec (AE+GAN step)", "value": round(12 * B * world * args.steps / dt, 1),
+            "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "cross-domain RecGURU AE+GAN phase-2 iteration (5 critic + 1 generator update), "
+                                   "two %d-item domains" % args.items,
+                       "per_gpu_batch": B, "seq_len": args.seq_len, "d_model": args.d_model, "n_head": args.n_head,
+                       "n_blocks": args.n_blocks, "d_ff": 512, "n_negs": args.n_negs, "dropout": 0.0,
+                       "sequences_per_step": 12 * B * world, "generator_step_sequences_per_sec":
+                           round(2 * B * world * args.steps / dt, 1),
+                       "parallelism": "dp%d" % world,
+                       "last_step": dict(zip(("D_cost", "Wasserstein_D", "g_dis", "recon_a", "recon_b"), losses))},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if dp:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

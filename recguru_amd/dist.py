@@ -1,0 +1,81 @@
+"""Data parallelism: one process per GPU, users sharded rank::world, one gradient exchange per
+optimizer step.  Replaces the reference's single-process nn.DataParallel
+(train_gan.py:124-133), which re-broadcasts all parameters on every forward.
+
+Backend "nccl" is RCCL on ROCm (xGMI inside a node); "gloo" is used by the CPU tests.
+Exactness versus a single full batch:
+  * masked-mean losses (recon / BPR, quirk Q12) divide by the GLOBAL mask count (global_count),
+  * plain-mean losses (W-loss, gradient penalty; equal shard sizes) are pre-divided by the world size
+    (scale_mean),
+so that a SUM all-reduce of the gradients reproduces the full-batch gradient.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return None
+    if not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend == "nccl":
+            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+        dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
+    return DataParallel()
+
+
+class DataParallel(object):
+    def __init__(self, group=None, bucket_bytes=128 << 20):
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.bucket_elems = bucket_bytes // 4
+
+    def scale_mean(self, loss):
+        return loss / self.world
+
+    def global_count(self, count):
+        """In-place SUM all-reduce of a (1-element) count tensor, e.g. sum(mask)."""
+        dist.all_reduce(count, op=dist.ReduceOp.SUM, group=self.group)
+        return count
+
+    def all_reduce_scalar_mean(self, x):
+        y = x.detach().clone().reshape(1)
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
+        return y[0] / self.world
+
+    def sync_grads(self, params):
+        """SUM all-reduce of every present gradient, in flat buckets (few large collectives:
+        xGMI links are point-to-point, so per-collective latency matters more than on a switch)."""
+        grads = [p.grad for p in params if p.grad is not None]
+        bucket, size = [], 0
+        for g in grads:
+            if bucket and size + g.numel() > self.bucket_elems:
+                self._reduce(bucket)
+                bucket, size = [], 0
+            bucket.append(g)
+            size += g.numel()
+        if bucket:
+            self._reduce(bucket)
+
+    def _reduce(self, bucket):
+        if len(bucket) == 1 and bucket[0].is_contiguous():
+            dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=self.group)
+            return
+        flat = torch.cat([g.reshape(-1) for g in bucket])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in bucket:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def barrier(self):
+        dist.barrier(group=self.group)

@@ -287,3 +287,114 @@ def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_r
                      d, k, mode, skip_row)
     _check(lib().rg_item_loss_bwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_bwd")
     return dh
+
+
+# ------------------------------------------------------------------------------------------------
+# live per-kernel timing (bench.py roofline): HIP events recorded on the launch stream around each
+# launch, with the ALGORITHMIC work of that launch computed from its shapes.
+# ------------------------------------------------------------------------------------------------
+class Profiler(object):
+    def __init__(self):
+        self.records = []      # (kernel name, flops, bytes, start event, end event)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for name, fl, by, e0, e1 in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            a["launches"] += 1
+            a["ms"] += e0.elapsed_time(e1)
+            a["flops"] += fl
+            a["bytes"] += by
+        return agg
+
+
+_PROF = None
+_ORIG = {}
+
+
+def _esize(t):
+    return t.element_size()
+
+
+def _work_gemm_nt(A, W, *a, **k):
+    M, K = A.shape
+    N = W.shape[0]
+    epi = k.get("epilogue", EPI_NONE)
+    ntw = (1 if N <= 64 else (2 if N <= 128 else 4)) if epi == EPI_RESID_LN else (1 if N <= 64 else 2)
+    by = (M * K + N * K + M * N) * _esize(A) + (M * N * _esize(A) if k.get("aux") is not None else 0)
+    return "gemm_nt_kernel<%s,%d>" % ("bf16" if A.dtype == torch.bfloat16 else "f32", ntw), 2.0 * M * N * K, by
+
+
+def _work_gemm_tn(Y, X, *a, **k):
+    T, N1 = Y.shape
+    N2 = X.shape[1]
+    return ("gemm_tn_kernel<%s>" % ("bf16" if Y.dtype == torch.bfloat16 else "f32"), 2.0 * T * N1 * N2,
+            T * (N1 + N2) * _esize(Y) + N1 * N2 * 4)
+
+
+def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, **k):
+    B, L, P3 = qkv.shape
+    return ("attn_fwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 4.0 * B * H * L * L * 32,
+            B * L * (P3 + P3 // 3) * _esize(qkv))
+
+
+def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H):
+    B, L, P3 = qkv.shape
+    return ("attn_bwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 10.0 * B * H * L * L * 32,
+            B * L * (2 * P3 + 2 * P3 // 3) * _esize(qkv))
+
+
+def _work_embed_fwd(table, pe, ids, mask, L):
+    n, d = ids.numel(), table.shape[1]
+    return "embed_pe_fwd_kernel", 0.0, n * d * 2 * _esize(table) + n * 12
+
+
+def _work_item_loss(h, table, pos, neg, mask, k, mode, *a, **kw):
+    n, d = h.shape
+    return "item_loss_kernel", 2.0 * n * (k + 1) * d, n * (k + 2) * d * _esize(table) + n * (k + 1) * 8
+
+
+_WORK = {"gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
+         "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
+_PLAIN = ["embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+          "gp_penalty", "sum_into", "adam", "cast"]
+
+
+def start_profile():
+    """Wrap every launcher with HIP-event timing; returns the Profiler.  stop_profile() undoes it."""
+    global _PROF
+    import sys
+    mod = sys.modules[__name__]
+    _PROF = Profiler()
+
+    def wrap(name, fn, work):
+        def timed(*a, **k):
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            kname, fl, by = work(*a, **k) if work else (name + "_kernel", 0.0, 0.0)
+            if name == "item_loss_bwd":
+                kname, fl = "item_loss_bwd_kernel", fl * 2
+            elif name == "item_loss_fwd":
+                kname = "item_loss_fwd_kernel"
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            _PROF.records.append((kname, fl, by, e0, e1))
+            return out
+        return timed
+    for name in list(_WORK) + _PLAIN:
+        _ORIG[name] = getattr(mod, name)
+        setattr(mod, name, wrap(name, _ORIG[name], _WORK.get(name)))
+    return _PROF
+
+
+def stop_profile():
+    global _PROF
+    import sys
+    mod = sys.modules[__name__]
+    for name, fn in _ORIG.items():
+        setattr(mod, name, fn)
+    _ORIG.clear()
+    p, _PROF = _PROF, None
+    return p

@@ -31,6 +31,13 @@ def compute_dtype():
 # shadow weights
 # ------------------------------------------------------------------------------------------------
 _SHADOWS = {}
+_DP = None          # recguru_amd.dist.DataParallel or None
+
+
+def set_data_parallel(dp):
+    """Masked-mean losses divide by the global mask count when a DataParallel is installed."""
+    global _DP
+    _DP = dp
 
 
 def bump(p):
@@ -250,6 +257,8 @@ class ItemLoss(torch.autograd.Function):
         mask = mask.reshape(-1).contiguous()
         tab = shadow(table)
         sums, aux = hip.item_loss_fwd(h2, tab, pos, neg, mask, k, mode)
+        if _DP is not None and _DP.world > 1:
+            _DP.global_count(sums[1:2])          # Q12: sum(l*m) / GLOBAL sum(m); grads are SUM-reduced
         ctx.save_for_backward(h2, pos, neg, mask, aux, sums, table)
         ctx.meta = (k, mode, skip_row, h.shape)
         return sums[0] / sums[1]
