@@ -54,6 +54,7 @@ typedef struct {
   int prologue, epilogue;
   const void* aux; int ldaux; /* [M,N] dtype */
   const float* gamma; const float* beta; const float* rowmask; float* rstd_out; float ln_eps;
+  int debug_ablate;           /* 0 in production; tools/kbench.py phase ablation bits */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 
@@ -166,6 +167,24 @@ typedef struct {
 } rg_item_loss_args;
 int rg_item_loss_fwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
 int rg_item_loss_bwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
+
+/* ---- fused post-attention block, forward -------------------------------------------------------------
+ * y = LN(ctx.Wo^T + bo + x) [; y = LN(y + o_bcast[b])] ; out = LN(gelu(y.W1^T + b1).W2^T + b2 + y) * rowmask
+ * = MultiHeadAttention tail (Transformer/transformer.py:160-161) [+ collapsed dec_enc_attn, :259, Q1]
+ *   + PositionWiseFeedForwardNet (:179-188) + the `* pad_mask` of :594 / :539, in ONE launch.
+ * Needs d == P == 128 and d_ff % 128 == 0.  *_save / rstd* may be NULL (inference: nothing but `out`
+ * is written).  Weights in torch Linear layout, operand dtype; biases / LN parameters f32. */
+typedef struct {
+  const void* ctx; const void* x;                       /* [M,P], [M,d] dtype */
+  const void* Wo; const float* bo; const float* g1; const float* be1;
+  const float* o_bcast; const float* gc; const float* bec; int L;   /* optional cross stage: o [M/L, d] f32 */
+  const void* W1; const float* b1; const void* W2; const float* b2; const float* g2; const float* be2;
+  const float* rowmask;                                  /* [M] or NULL */
+  void* out;                                             /* [M,d] dtype */
+  void* y_save; float* rstd1; void* y2_save; float* rstd_c; void* h1_save; float* rstd2;
+  int M, d, P, dff; float eps;
+} rg_post_attn_args;
+int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

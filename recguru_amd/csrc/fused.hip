@@ -1,0 +1,394 @@
+// Fused post-attention block, forward:  one launch computes, for a 64-token tile,
+//
+//   y   = LayerNorm(ctx.Wo^T + bo + x)                      MultiHeadAttention tail  transformer.py:160-161
+//  [y   = LayerNorm(y + o[b])                               collapsed decoder cross-attention (Q1), :259]
+//   h1  = y.W1^T + b1 ; g = gelu_tanh(h1)                   PositionWiseFeedForwardNet  transformer.py:181-184
+//   out = LayerNorm(g.W2^T + b2 + y) * rowmask              :185-188 and the `* pad_mask` of :594 / :539
+//
+// with every intermediate resident in LDS / registers: per token the kernel reads ctx and x
+// (2*d*sizeof(T) bytes) and writes out (d*sizeof(T)); the [tile, d_ff] activation never reaches HBM
+// unless the training path asks for it (h1_save) -- 2*(d*P + 2*d*d_ff) FLOP per token against
+// 3*d*sizeof(T) bytes = 341 FLOP/B at d=128, d_ff=512, bf16: MFMA-bound, unlike the four separate
+// GEMMs (43-102 FLOP/B each).
+//
+// MFMA orientation: the WEIGHT fragment is the A operand (rows = output features) and the
+// activation fragment the B operand (columns = tokens), so an accumulator register holds 4
+// CONSECUTIVE FEATURES of one token: every LDS / global write of an intermediate is one packed
+// 8- or 16-byte vector, never a 2-byte scatter.  The four waves split the output features; each
+// weight element is fetched from L2 exactly once per tile, straight into its fragment.
+// LDS (bf16): ctx tile + g chunk + y tile = 3 x 17 KB; the f32 LayerNorm staging tile aliases the
+// first two (dead at those points) -> 52 KB per workgroup, 3 workgroups per CU.
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define FT_M 64      // tokens per tile
+#define FD 128       // d_model == P == chunk width
+#define FPAD 8
+#define FLD (FD + FPAD)
+#define FZLD (FD + 4)
+
+// One GEMM step = a set of 8 weight fragments (4 k-steps x 2 feature tiles of this wave), loaded
+// straight from L2 one GEMM ahead of its use (software pipelining: the load of set s+1 is issued
+// before the MFMAs of set s), against a [64 x 128] activation tile in LDS.
+template <typename T> struct WSet { Frag<T> f[4][2]; };
+
+template <typename T>
+__device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, int ldw, int row0, int k0, int li, int lg) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) load_frag(w.f[ks][ct], W + (size_t)(row0 + ct * 16 + li) * ldw + k0 + ks * 32 + 8 * lg);
+}
+
+// acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
+template <typename T>
+__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][4], const WSet<T>& w, const T* __restrict__ Act, int li, int lg) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    Frag<T> af[4];                          // the k-step's four token-tile fragments in one LDS burst
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], Act + (rt * 16 + li) * FLD + ks * 32 + 8 * lg);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) mma(w.f[ks][ct], af[rt], acc[ct][rt]);
+  }
+}
+
+// accumulators start at the bias of their 4 features (bias add costs nothing afterwards)
+__device__ __forceinline__ void init_acc(f32x4 (&acc)[2][4], const float* __restrict__ bias_lds, int n0, int lg) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float b[4];
+    load4f(b, bias_lds + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b[0], b[1], b[2], b[3]};
+  }
+}
+
+// 4 consecutive elements of a tile row -> float[4]
+__device__ __forceinline__ void load4t(float* o, const float* p) { load4f(o, p); }
+__device__ __forceinline__ void load4t(float* o, const __bf16* p) {
+  const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (float)a[j];
+}
+
+// LayerNorm on the accumulator registers.  Lane (li, lg) of wave w holds, for token rt*16+li, the 8
+// features w*32 + ct*16 + 4*lg + r: row statistics = in-lane sum, 2 shuffles across lg, then a
+// [64 tokens x 4 waves] exchange through LDS.  Two-pass (mean, then centred second moment) like
+// torch's LayerNorm.  On return v holds (v - mean) * rstd * gamma + beta and rstd[rt] the row rstd.
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], const float* __restrict__ gamma_lds,
+                                        const float* __restrict__ beta_lds, float* __restrict__ redA, float* __restrict__ redB,
+                                        float eps, int n0, int wave, int li, int lg) {
+  float s[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float t = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t += v[ct][rt][r];
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    s[rt] = t;
+  }
+  if (lg == 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) redA[(rt * 16 + li) * 4 + wave] = s[rt];
+  }
+  lds_barrier();
+  float mean[4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float p[4];
+    load4f(p, redA + (rt * 16 + li) * 4);
+    mean[rt] = (p[0] + p[1] + p[2] + p[3]) * (1.f / FD);
+  }
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float t = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { v[ct][rt][r] -= mean[rt]; t += v[ct][rt][r] * v[ct][rt][r]; }
+    t += __shfl_xor(t, 16);
+    t += __shfl_xor(t, 32);
+    s[rt] = t;
+  }
+  if (lg == 0) {
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) redB[(rt * 16 + li) * 4 + wave] = s[rt];
+  }
+  lds_barrier();
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) {
+    float p[4];
+    load4f(p, redB + (rt * 16 + li) * 4);
+    rstd[rt] = rsqrtf((p[0] + p[1] + p[2] + p[3]) * (1.f / FD) + eps);
+  }
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct) {
+    float g[4], b[4];
+    load4f(g, gamma_lds + n0 + ct * 16 + 4 * lg);
+    load4f(b, beta_lds + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[ct][rt][r] = v[ct][rt][r] * rstd[rt] * g[r] + b[r];
+  }
+}
+
+// registers -> tile in LDS (4 consecutive features per store)
+template <typename T>
+__device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restrict__ tile, int n0, int li, int lg) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float t[4] = {v[ct][rt][0], v[ct][rt][1], v[ct][rt][2], v[ct][rt][3]};
+      store4(tile + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg, t);
+    }
+}
+
+// cooperative, coalesced copy of a [64 x 128] LDS tile to rows m0.. of a row-major HBM matrix
+template <typename T>
+__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, int m0, int M, int tid) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+    if (m0 + r < M)
+      *reinterpret_cast<Frag<T>*>(dst + (size_t)(m0 + r) * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + r * FLD + c8);
+  }
+}
+
+#ifdef RG_STAMP
+#define STAMP(i) do { unsigned long long t1__ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tacc[i] += t1__ - t0__; t0__ = t1__; } while (0)
+#else
+#define STAMP(i)
+#endif
+
+template <typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
+#ifdef RG_STAMP
+  unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0__ = __builtin_amdgcn_s_memtime();
+#endif
+  // LDS: ctx tile (later: out staging) | x tile (later: g chunk) | y tile | params | row-stat exchange | [h1 chunk]
+  constexpr int ACT_BYTES = FT_M * FLD * (int)sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Actx = reinterpret_cast<T*>(smem);
+  T* Ag = reinterpret_cast<T*>(smem + ACT_BYTES);
+  T* Ay = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
+  float* prm = reinterpret_cast<float*>(smem + 3 * ACT_BYTES);           // 8*128 + dff floats
+  float* redA = prm + 8 * FD + a.dff;                                     // [64][4]
+  float* redB = redA + FT_M * 4;
+  T* Ah = reinterpret_cast<T*>(redB + FT_M * 4);                          // only when h1_save != NULL
+  float *p_bo = prm, *p_g1 = prm + FD, *p_be1 = prm + 2 * FD, *p_b2 = prm + 3 * FD, *p_g2 = prm + 4 * FD,
+        *p_be2 = prm + 5 * FD, *p_gc = prm + 6 * FD, *p_bec = prm + 7 * FD, *p_b1 = prm + 8 * FD;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const T* __restrict__ ctx = reinterpret_cast<const T*>(a.ctx);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ Wo = reinterpret_cast<const T*>(a.Wo);
+  const T* __restrict__ W1 = reinterpret_cast<const T*>(a.W1);
+  const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
+  T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  T* __restrict__ ysave = reinterpret_cast<T*>(a.y_save);
+  T* __restrict__ y2save = reinterpret_cast<T*>(a.y2_save);
+  T* __restrict__ h1save = reinterpret_cast<T*>(a.h1_save);
+  const int n0 = wave * 32;                 // this wave's 32 output features of every 128-wide block
+  const int ntiles = (a.M + FT_M - 1) / FT_M;
+  const int nchunk = a.dff / FD;
+
+  // ---- once per workgroup: parameters -> LDS
+  for (int i = tid; i < FD; i += 256) {
+    p_bo[i] = a.bo[i]; p_g1[i] = a.g1[i]; p_be1[i] = a.be1[i]; p_b2[i] = a.b2[i]; p_g2[i] = a.g2[i]; p_be2[i] = a.be2[i];
+    p_gc[i] = a.gc ? a.gc[i] : 1.f; p_bec[i] = a.bec ? a.bec[i] : 0.f;
+  }
+  for (int i = tid; i < a.dff; i += 256) p_b1[i] = a.b1[i];
+
+  WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
+  Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
+  int tile = blockIdx.x;
+  if (tile < ntiles) {
+    load_wset(wp, Wo, FD, n0, 0, li, lg);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+      if (tile * FT_M + r < a.M) {
+        load_frag(cpre[i], ctx + (size_t)(tile * FT_M + r) * FD + c8);
+        load_frag(xpre[i], x + (size_t)(tile * FT_M + r) * FD + c8);
+      } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
+    }
+  }
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * FT_M;
+    const int next_tile = tile + gridDim.x;
+    // ---- ctx and x tiles: registers -> LDS (x parks in the g-chunk buffer, free until the FFN)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+      *reinterpret_cast<Frag<T>*>(Actx + r * FLD + c8) = cpre[i];
+      *reinterpret_cast<Frag<T>*>(Ag + r * FLD + c8) = xpre[i];
+    }
+    float rm4[4];
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int m = m0 + rt * 16 + li;
+      rm4[rt] = (a.rowmask && m < a.M) ? a.rowmask[m] : 1.f;
+    }
+    lds_barrier();
+    STAMP(0);
+    // ---- attention output projection (weights already in wp), bias folded into the accumulators
+    f32x4 acc[2][4];
+    init_acc(acc, p_bo, n0, lg);
+    mma_wset<T>(acc, wp, Actx, li, lg);
+    load_wset(wp, W1, FD, n0, 0, li, lg);               // prefetch FFN chunk 0 (hidden behind LN1)
+    // + residual x (from LDS), LayerNorm 1 on the registers
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        float r4[4];
+        load4t(r4, Ag + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[ct][rt][r] += r4[r];
+      }
+    STAMP(1);
+    float rstd[4];
+    ln_regs(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
+    if (a.rstd1 && wave == 0 && lg == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        if (m0 + rt * 16 + li < a.M) a.rstd1[m0 + rt * 16 + li] = rstd[rt];
+    }
+    regs_to_tile<T>(acc, Ay, n0, li, lg);
+    STAMP(2);
+    if (a.o_bcast) {
+      // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
+      if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, m0, a.M, tid); }
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const int m = min(m0 + rt * 16 + li, a.M - 1);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          float o4[4], y4[4];
+          load4f(o4, a.o_bcast + (size_t)(m / a.L) * FD + n0 + ct * 16 + 4 * lg);
+          load4t(y4, Ay + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);     // the ROUNDED y1, as the unfused path sees it
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[r];
+        }
+      }
+      lds_barrier();                                    // ysave copy done before the tile is overwritten
+      ln_regs(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
+      if (a.rstd_c && wave == 0 && lg == 0) {
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+          if (m0 + rt * 16 + li < a.M) a.rstd_c[m0 + rt * 16 + li] = rstd[rt];
+      }
+      regs_to_tile<T>(acc, Ay, n0, li, lg);
+    }
+    lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
+    if (a.o_bcast ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, a.o_bcast ? y2save : ysave, FD, 0, m0, a.M, tid);
+    STAMP(3);
+    // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
+    f32x4 acc2[2][4];
+    init_acc(acc2, p_b2, n0, lg);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      load_wset(wq, W2, a.dff, n0, ch * FD, li, lg);    // needed after the GELU below
+      init_acc(acc, p_b1 + ch * FD, n0, lg);
+      mma_wset<T>(acc, wp, Ay, li, lg);                 // h1 chunk = y . W1[chunk]^T + b1
+      if (ch + 1 < nchunk) load_wset(wp, W1, FD, (ch + 1) * FD + n0, 0, li, lg);
+      else if (next_tile < ntiles) load_wset(wp, Wo, FD, n0, 0, li, lg);
+      STAMP(4);
+      if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
+      STAMP(5);
+      if (h1save) regs_to_tile<T>(acc, Ah, n0, li, lg);
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[ct][rt][r] = gelu_t<Precise<T>::value>(acc[ct][rt][r]);
+      regs_to_tile<T>(acc, Ag, n0, li, lg);
+      STAMP(6);
+      lds_barrier();
+      STAMP(7);
+      if (h1save) tile_to_hbm<T>(Ah, h1save, a.dff, ch * FD, m0, a.M, tid);
+      mma_wset<T>(acc2, wq, Ag, li, lg);                // out += g . W2[:, chunk]^T
+      STAMP(8);
+    }
+    // prefetch the next tile's ctx / x rows while the second LayerNorm runs
+    if (next_tile < ntiles) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+        if (next_tile * FT_M + r < a.M) {
+          load_frag(cpre[i], ctx + (size_t)(next_tile * FT_M + r) * FD + c8);
+          load_frag(xpre[i], x + (size_t)(next_tile * FT_M + r) * FD + c8);
+        } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
+      }
+    }
+    // ---- + residual y (LDS), LayerNorm 2 on the registers, * rowmask, out via the (free) ctx tile
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        float r4[4];
+        load4t(r4, Ay + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
+      }
+    ln_regs(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
+    if (a.rstd2 && wave == 0 && lg == 0) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+        if (m0 + rt * 16 + li < a.M) a.rstd2[m0 + rt * 16 + li] = rstd[rt];
+    }
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= rm4[rt];
+    regs_to_tile<T>(acc2, Actx, n0, li, lg);
+    STAMP(9);
+    lds_barrier();
+    tile_to_hbm<T>(Actx, out, FD, 0, m0, a.M, tid);
+    lds_barrier();                                      // before the next tile overwrites Actx / Ag / Ay
+    STAMP(10);
+  }
+#ifdef RG_STAMP
+  if (a.rstd_c == nullptr && a.o_bcast == nullptr && a.y2_save != nullptr && (tid & 63) == 0) {
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.y2_save) + (size_t)(blockIdx.x * 4 + wave) * 12;
+    for (int i = 0; i < 12; ++i) dbg[i] = tacc[i];
+  }
+#endif
+}
+
+extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* stream) {
+  if (!a || a->M <= 0) return 0;
+  if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
+  if (a->o_bcast && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: o_bcast needs L");
+  hipStream_t s = (hipStream_t)stream;
+  const int ntiles = (a->M + FT_M - 1) / FT_M;
+  const int esz = dtype == RG_BF16 ? 2 : 4;
+  const int act = FT_M * FLD * esz;
+  const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * FT_M * 4 * 4 + (a->h1_save ? act : 0);
+  const int per_cu = (160 * 1024) / smem;
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+  if (grid > ntiles) grid = ntiles;
+  if (dtype == RG_BF16) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(post_attn_fwd_kernel<__bf16>, dim3(grid), dim3(256), smem, s, *a);
+  } else if (dtype == RG_F32) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(post_attn_fwd_kernel<float>, dim3(grid), dim3(256), smem, s, *a);
+  } else return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: bad dtype");
+  RG_CHECK_LAUNCH();
+  return 0;
+}

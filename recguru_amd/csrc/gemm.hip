@@ -22,7 +22,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
   constexpr int A_BYTES = TM * LDA * (int)sizeof(T);
   constexpr int Z_LD = TN + 4;
   constexpr int Z_BYTES = TM * Z_LD * 4;
-  constexpr int SMEM = A_BYTES > Z_BYTES ? A_BYTES : Z_BYTES;
+  constexpr int SMEM = A_BYTES > Z_BYTES ? A_BYTES : Z_BYTES;   // A tile and the f32 epilogue tile alias
   __shared__ __align__(16) unsigned char smem[SMEM];
   T* As = reinterpret_cast<T*>(smem);
 
@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int n = nb0 + j * 16 + li;
-        if (ks < ksteps && n < a.N)
+        if (ks < ksteps && n < a.N && !(a.debug_ablate & 8))
           load_frag(bf[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
         else
           frag_zero(bf[ks][j]);
@@ -58,23 +58,29 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
     const int cpr = klen >> 3;  // 8-element chunks per row
     for (int c = tid; c < TM * cpr; c += 256) {
       const int r = c / cpr, c8 = (c - r * cpr) * 8;
-      float v[8];
-      if (m0 + r < a.M) {
-        load8(v, A + (size_t)(m0 + r) * a.lda + kc + c8);
-        if (a.prologue == RG_PRO_GELU) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_f(v[j]);
-        }
+      if (a.prologue == RG_PRO_NONE) {
+        // raw 16/32-byte copy, no conversion
+        Frag<T> raw;
+        if (m0 + r < a.M && !(a.debug_ablate & 1)) load_frag(raw, A + (size_t)(m0 + r) * a.lda + kc + c8);
+        else frag_zero(raw);
+        *reinterpret_cast<Frag<T>*>(As + r * LDA + c8) = raw;
       } else {
+        float v[8];
+        if (m0 + r < a.M) {
+          load8(v, A + (size_t)(m0 + r) * a.lda + kc + c8);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+          for (int j = 0; j < 8; ++j) v[j] = gelu_t<Precise<T>::value>(v[j]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        store8(As + r * LDA + c8, v);
       }
-      store8(As + r * LDA + c8, v);
     }
     __syncthreads();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < ksteps) {
+      if (ks < ksteps && !(a.debug_ablate & 2)) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           Frag<T> af;
@@ -88,35 +94,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
   }
 
   // ------------------------------------------------------------------ epilogue
+  // The accumulator tile (+bias) goes through LDS as f32 so that every global access of the
+  // epilogue (aux reads, C stores) is a 16-byte vector with consecutive lanes on consecutive bytes.
   const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
-  if (a.epilogue != RG_EPI_RESID_LN) {
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
-#pragma unroll
-      for (int j = 0; j < NTW; ++j) {
-        const int n = nb0 + j * 16 + li;
-        if (n >= a.N) continue;
-        const float b = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + rt * 16 + 4 * lg + r;
-          if (m >= a.M) continue;
-          float v = acc[rt][j][r] + b;
-          switch (a.epilogue) {
-            case RG_EPI_RELU: v = fmaxf(v, 0.f); break;
-            case RG_EPI_MUL_POSMASK: v = ((float)aux[(size_t)m * a.ldaux + n] > 0.f) ? v : 0.f; break;
-            case RG_EPI_GELU_GRAD: v *= gelu_grad_f((float)aux[(size_t)m * a.ldaux + n]); break;
-            case RG_EPI_ADD: v += (float)aux[(size_t)m * a.ldaux + n]; break;
-            default: break;
-          }
-          if (a.c_is_f32) reinterpret_cast<float*>(a.C)[(size_t)m * a.ldc + n] = v;
-          else reinterpret_cast<T*>(a.C)[(size_t)m * a.ldc + n] = (T)v;
-        }
-      }
-    return;
-  }
-  // residual + LayerNorm(eps) [* rowmask]: whole rows live in this workgroup (gridDim.y == 1)
   float* Z = reinterpret_cast<float*>(smem);
+  const int ncol0 = blockIdx.y * TN;
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -124,15 +106,53 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
       const int n = nb0 + j * 16 + li;
       const float b = (a.bias && n < a.N) ? a.bias[n] : 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rt * 16 + 4 * lg + r;
-        const int m = m0 + row;
-        float v = acc[rt][j][r] + b;
-        if (m < a.M && n < a.N) v += (float)aux[(size_t)m * a.ldaux + n];
-        Z[row * Z_LD + n] = v;   // gridDim.y == 1, so n is the tile column
-      }
+      for (int r = 0; r < 4; ++r) Z[(rt * 16 + 4 * lg + r) * Z_LD + (n - ncol0)] = acc[rt][j][r] + b;
     }
   __syncthreads();
+  if (a.epilogue != RG_EPI_RESID_LN) {
+    constexpr int CPR = TN / 8;
+    const bool vec = ((a.N & 7) == 0) && ((a.ldc & 7) == 0) && (a.aux == nullptr || (a.ldaux & 7) == 0);
+    for (int c = tid; c < TM * CPR; c += 256) {
+      const int row = c / CPR, c8 = (c - row * CPR) * 8;
+      const int m = m0 + row, n = ncol0 + c8;
+      if (m >= a.M || n >= a.N) continue;
+      if ((a.debug_ablate & 4) && c != 0) continue;
+      float v[8];
+      load8(v, Z + row * Z_LD + c8);
+      if (vec) {
+        if (a.epilogue == RG_EPI_RELU) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+        } else if (a.epilogue != RG_EPI_NONE) {
+          float x[8];
+          load8(x, aux + (size_t)m * a.ldaux + n);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] : 0.f;
+            else if (a.epilogue == RG_EPI_GELU_GRAD) v[j] *= gelu_grad_t<Precise<T>::value>(x[j]);
+            else v[j] += x[j];
+          }
+        }
+        if (a.c_is_f32) store8(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n, v);
+        else store8(reinterpret_cast<T*>(a.C) + (size_t)m * a.ldc + n, v);
+      } else {
+        for (int j = 0; j < 8 && n + j < a.N; ++j) {
+          float y = v[j];
+          switch (a.epilogue) {
+            case RG_EPI_RELU: y = fmaxf(y, 0.f); break;
+            case RG_EPI_MUL_POSMASK: y = ((float)aux[(size_t)m * a.ldaux + n + j] > 0.f) ? y : 0.f; break;
+            case RG_EPI_GELU_GRAD: y *= gelu_grad_f((float)aux[(size_t)m * a.ldaux + n + j]); break;
+            case RG_EPI_ADD: y += (float)aux[(size_t)m * a.ldaux + n + j]; break;
+            default: break;
+          }
+          if (a.c_is_f32) reinterpret_cast<float*>(a.C)[(size_t)m * a.ldc + n + j] = y;
+          else reinterpret_cast<T*>(a.C)[(size_t)m * a.ldc + n + j] = (T)y;
+        }
+      }
+    }
+    return;
+  }
+  // residual + LayerNorm(eps) [* rowmask]: whole rows live in this workgroup (gridDim.y == 1)
   const float invn = 1.f / (float)a.N;
   for (int i = 0; i < 16; ++i) {
     const int row = wave * 16 + i;
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
       const int n = lane + 64 * j;
-      x[j] = (n < a.N) ? Z[row * Z_LD + n] : 0.f;
+      x[j] = (n < a.N) ? Z[row * Z_LD + n] + (float)aux[(size_t)m * a.ldaux + n] : 0.f;
       s += x[j];
     }
     const float mean = wave_sum(s) * invn;
@@ -268,7 +288,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(rg_gemm_tn_args a) {
           load8(w, X + (size_t)t * a.ldx + n2_0 + c8);
           if (a.prologue_x == RG_PRO_GELU) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = gelu_f(w[j]);
+            for (int j = 0; j < 8; ++j) w[j] = gelu_t<Precise<T>::value>(w[j]);
           }
         }
       }

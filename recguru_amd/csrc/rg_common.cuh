@@ -100,6 +100,10 @@ __device__ __forceinline__ void store8(__bf16* p, const float* v) {
   for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
   *reinterpret_cast<bf16x8_t*>(p) = a;
 }
+__device__ __forceinline__ void load4f(float* o, const float* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+}
 __device__ __forceinline__ void store4(float* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
@@ -121,19 +125,45 @@ __device__ __forceinline__ float wave_max(float x) {
   return x;
 }
 
-// tanh-approximation GELU (reference transformer.py:81-84) and its derivative
-__device__ __forceinline__ float gelu_f(float x) {
+// tanh-approximation GELU (reference transformer.py:81-84) and its derivative.
+// PRECISE (f32 parity tier): libm tanhf.  Fast (bf16 tier): 0.5*(1+tanh u) == sigmoid(2u), one v_exp.
+template <bool PRECISE>
+__device__ __forceinline__ float gelu_t(float x) {
   const float c = 0.7978845608028654f;
-  const float u = c * (x + 0.044715f * x * x * x);
-  return 0.5f * x * (1.f + tanhf(u));
+  if (PRECISE) {
+    const float u = c * (x + 0.044715f * x * x * x);
+    return 0.5f * x * (1.f + tanhf(u));
+  }
+  // x * sigmoid(2u) with every constant folded: 7 VALU (mul, fma, mul, exp2, add, rcp, mul)
+  const float k1 = -2.f * 1.4426950408889634f * c;
+  const float k3 = k1 * 0.044715f;
+  const float e = __builtin_amdgcn_exp2f(x * fmaf(x * x, k3, k1));
+  return x * __builtin_amdgcn_rcpf(1.f + e);
 }
-__device__ __forceinline__ float gelu_grad_f(float x) {
+template <bool PRECISE>
+__device__ __forceinline__ float gelu_grad_t(float x) {
   const float c = 0.7978845608028654f;
   const float x2 = x * x;
-  const float u = c * (x + 0.044715f * x * x2);
-  const float t = tanhf(u);
-  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * x2);
+  if (PRECISE) {
+    const float u = c * (x + 0.044715f * x * x2);
+    const float t = tanhf(u);
+    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * x2);
+  }
+  // s = sigmoid(2u); d/dx [x s] = s + x s (1 - s) * 2 u'  with u' = c (1 + 3*0.044715 x^2)
+  const float k1 = -2.f * 1.4426950408889634f * c;
+  const float k3 = k1 * 0.044715f;
+  const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(x * fmaf(x2, k3, k1)));
+  return fmaf(x * sg * (1.f - sg), fmaf(x2, 6.f * 0.044715f * c, 2.f * c), sg);
 }
+__device__ __forceinline__ float gelu_f(float x) { return gelu_t<true>(x); }
+__device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<true>(x); }
+template <typename T> struct Precise { static constexpr bool value = true; };
+template <> struct Precise<__bf16> { static constexpr bool value = false; };
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release
+// fence, for which hipcc drains vmcnt(0) whenever a global store is outstanding -- and loads share that
+// counter, so every software-prefetched global load would be waited for at every barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 #define RG_CHECK_LAUNCH()                                   \
   do {                                                      \

@@ -1,0 +1,64 @@
+"""Loaders in the reference's on-disk / batch format (input side of the hot path).
+
+A domain pickle is {"seq": [[item,...],...], "len": [...], "val": [...], "test": [...]}
+(data_process/amazon_csv.py:251-280); files are discovered by substring exactly like
+train_gan.py:65-79.  Batches are pre-assembled host-side with numpy and staged on the GPU once
+(TensorLoader); negatives are uniform over 1..V (or freq^0.75-weighted) excluding the user's own
+items, like pickle_loader.__getitem__ (data/data_loader.py:276-316).  The reference's `val`
+shadowing quirk (Q14) only changes which single item is excluded and is not reproduced.
+"""
+import os
+import pickle
+
+import numpy as np
+
+from .synthetic import TensorLoader, pad_sequences
+
+
+def load_pickle(filename):
+    with open(filename, "rb") as f:
+        return pickle.load(f)
+
+
+def discover(data_path, name_a, name_b):
+    names = os.listdir(data_path)
+    pick = lambda pred: [os.path.join(data_path, n) for n in names if pred(n)]
+    return {"a": pick(lambda n: name_a in n and "_" not in n), "freq_a": pick(lambda n: name_a in n and "freq" in n),
+            "b": pick(lambda n: name_b in n and "_" not in n), "freq_b": pick(lambda n: name_b in n and "freq" in n),
+            "overlap": pick(lambda n: name_a in n and name_b in n)}
+
+
+def domain_from_pickles(files, L, eos, V, k, seed=0, wf=None):
+    seqs, val, test = [], [], []
+    for fn in files:
+        d = load_pickle(fn)
+        seqs.extend(d["seq"])
+        val.extend(d["val"])
+        test.extend(d["test"])
+    rng = np.random.default_rng(seed)
+    enc, dec_in, dec_out = pad_sequences(seqs, L, eos)
+    n = len(seqs)
+    p = None
+    if wf is not None:
+        p = np.power(np.asarray(wf, dtype=np.float64), 0.75)
+        p[0] = 0
+        p = p / p.sum()
+    neg = np.zeros((n, L * k), dtype=np.int64)
+    for i in range(n):
+        own = np.concatenate([np.asarray(seqs[i], dtype=np.int64), [val[i], test[i]]])
+        draw = (lambda m: rng.choice(len(p), size=m, p=p)) if p is not None else (lambda m: rng.integers(1, V + 1, size=m))
+        row = draw(L * k)
+        bad = np.isin(row, own)
+        while bad.any():
+            row[bad] = draw(int(bad.sum()))
+            bad = np.isin(row, own)
+        neg[i] = row
+    return {"enc_in": enc, "dec_in": dec_in, "dec_out": dec_out, "n_items": neg,
+            "val": np.asarray(val, dtype=np.int64), "test": np.asarray(test, dtype=np.int64)}
+
+
+def dataloader_gen(files, param, num_n, domain="a", device=None, rank=0, world=1, seed=0, wf=None, batch_size=None):
+    """Counterpart of Dataloader.dataloader_gen(train=True) (data/data_loader.py:455-483)."""
+    eos = param.vocab_size_a if domain == "a" else param.vocab_size_b
+    dom = domain_from_pickles(files, param.enc_maxlen, eos, eos - 1, num_n, seed, wf)
+    return TensorLoader(dom, batch_size or param.batch_size, device, rank, world)

@@ -24,7 +24,7 @@ class GemmNtArgs(ctypes.Structure):
     _fields_ = [("A", c_p), ("lda", c_i), ("W", c_p), ("ldw", c_i), ("bias", c_p), ("C", c_p), ("ldc", c_i),
                 ("c_is_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("prologue", c_i), ("epilogue", c_i),
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
-                ("rstd_out", c_p), ("ln_eps", c_f)]
+                ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -43,11 +43,20 @@ class AttnBwdArgs(ctypes.Structure):
                 ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f)]
 
 
+class PostAttnArgs(ctypes.Structure):
+    _fields_ = [("ctx", c_p), ("x", c_p), ("Wo", c_p), ("bo", c_p), ("g1", c_p), ("be1", c_p),
+                ("o_bcast", c_p), ("gc", c_p), ("bec", c_p), ("L", c_i),
+                ("W1", c_p), ("b1", c_p), ("W2", c_p), ("b2", c_p), ("g2", c_p), ("be2", c_p),
+                ("rowmask", c_p), ("out", c_p),
+                ("y_save", c_p), ("rstd1", c_p), ("y2_save", c_p), ("rstd_c", c_p), ("h1_save", c_p), ("rstd2", c_p),
+                ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f)]
+
+
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
            "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
-           "rg_item_loss_fwd", "rg_item_loss_bwd"]
+           "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -107,7 +116,7 @@ def _rowmajor(t):
 
 
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
-            gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8):
+            gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N]."""
     M, K = A.shape
     N = W.shape[0]
@@ -119,7 +128,7 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
-                   _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps)
+                   _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate)
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
     return out
 
@@ -289,6 +298,36 @@ def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_r
     return dh
 
 
+def post_attn_supported(d, P, dff):
+    return d == 128 and P == 128 and dff % 128 == 0 and dff > 0
+
+
+def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8):
+    """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta).
+    Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
+    M, P = ctx.shape
+    d = x.shape[1]
+    dff = W1.shape[0]
+    dev = ctx.device
+    out = torch.empty(M, d, device=dev, dtype=ctx.dtype)
+    sv = {}
+    if save:
+        sv["y"] = torch.empty(M, d, device=dev, dtype=ctx.dtype)
+        sv["rstd1"] = torch.empty(M, device=dev, dtype=torch.float32)
+        sv["h1"] = torch.empty(M, dff, device=dev, dtype=ctx.dtype)
+        sv["rstd2"] = torch.empty(M, device=dev, dtype=torch.float32)
+        if cross is not None:
+            sv["y2"] = torch.empty(M, d, device=dev, dtype=ctx.dtype)
+            sv["rstd_c"] = torch.empty(M, device=dev, dtype=torch.float32)
+    o, gc, bec = cross if cross is not None else (None, None, None)
+    a = PostAttnArgs(_p(ctx), _p(x), _p(Wo), _p(bo), _p(g1), _p(be1), _p(o), _p(gc), _p(bec), L,
+                     _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
+                     _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
+                     _p(sv.get("rstd2")), M, d, P, dff, eps)
+    _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
+    return out, sv
+
+
 # ------------------------------------------------------------------------------------------------
 # live per-kernel timing (bench.py roofline): HIP events recorded on the launch stream around each
 # launch, with the ALGORITHMIC work of that launch computed from its shapes.
@@ -355,7 +394,15 @@ def _work_item_loss(h, table, pos, neg, mask, k, mode, *a, **kw):
     return "item_loss_kernel", 2.0 * n * (k + 1) * d, n * (k + 2) * d * _esize(table) + n * (k + 1) * 8
 
 
-_WORK = {"gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
+def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
+    M, P = ctx.shape
+    d, dff = x.shape[1], W1.shape[0]
+    by = M * (P + 2 * d) * _esize(ctx) + (M * (d + dff) * _esize(ctx) if k.get("save") else 0)
+    return ("post_attn_fwd_kernel<%s>" % ("bf16" if ctx.dtype == torch.bfloat16 else "f32"),
+            2.0 * M * (d * P + 2 * d * dff), by)
+
+
+_WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast"]

@@ -165,6 +165,18 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be):
     return dy, (dW1, db1, dW2, db2, dg, dbe)
 
 
+def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad):
+    wqkv = shadow_cat((Wq, Wk, Wv))
+    bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+    qkv = hip.gemm_nt(x2, wqkv, bqkv)
+    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad)
+    return qkv, ctx_, lse
+
+
+def _fusable(x2, Wo, W1):
+    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """EncoderLayer.forward + `* pad_mask` (transformer.py:202-207,:592-594)."""
 
@@ -176,8 +188,16 @@ class EncoderLayerFn(torch.autograd.Function):
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
-        y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
-        out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
+        if _fusable(x2, Wo, W1):
+            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need)
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
+                                        rowmask, save=need, eps=LN_EPS)
+            if need:
+                y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
+        else:
+            y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
+            out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf, Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
             ctx.meta = (B, L, pad_value, causal, H)
@@ -211,11 +231,20 @@ class DecoderLayerFn(torch.autograd.Function):
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
         u = u.contiguous()
-        y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
         c = hip.gemm_nt(u, shadow(cWv), cbv.detach())                        # [B, P]
         o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)          # [B, d] f32
-        y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
-        out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
+        if _fusable(x2, Wo, W1):
+            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need)
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
+                                        rowmask, save=need, cross=(o, cg.detach(), cbe.detach()), L=L, eps=LN_EPS)
+            if need:
+                y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
+                sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
+        else:
+            y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
+            y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
+            out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
             ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf,
                                   Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2)

@@ -317,3 +317,47 @@ def test_item_loss(dt, d, k, mode):
     t = dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-3)
     torch.testing.assert_close(dh.float(), hf.grad, **t)
     torch.testing.assert_close(dE, tf.grad, **t)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,dff,cross,save", [(64, 128, False, False), (203, 512, False, True), (131, 512, True, True),
+                                               (1000, 256, True, False)])
+def test_post_attn_fused_vs_unfused(dt, M, dff, cross, save):
+    """The fused block against the composition of the (already validated) unfused kernels and against torch."""
+    from recguru_amd import hip
+    d = P = 128
+    L = 7
+    ctx, x = rnd(M, P, dt=dt, seed=1), rnd(M, d, dt=dt, seed=2)
+    Wo, W1, W2 = rnd(d, P, dt=dt, scale=P ** -0.5, seed=3), rnd(dff, d, dt=dt, scale=d ** -0.5, seed=4), \
+        rnd(d, dff, dt=dt, scale=dff ** -0.5, seed=5)
+    bo, b1, b2 = (0.1 * rnd(n, dt=torch.float32, seed=6 + i) for i, n in enumerate((d, dff, d)))
+    g1, g2, gc = (1 + 0.1 * rnd(d, dt=torch.float32, seed=10 + i) for i in range(3))
+    be1, be2, bec = (0.1 * rnd(d, dt=torch.float32, seed=20 + i) for i in range(3))
+    rm = (torch.arange(M) % 5 != 2).float().cuda()
+    nb = (M + L - 1) // L
+    o = rnd(nb, d, dt=torch.float32, seed=30) if cross else None
+    out, sv = hip.post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rm, save=save,
+                                cross=(o, gc, bec) if cross else None, L=L)
+    F = torch.nn.functional
+    z1 = ctx.float() @ Wo.float().T + bo + x.float()
+    y = F.layer_norm(z1, (d,), g1, be1, 1e-8)
+    y1 = y
+    if cross:
+        yq = y.to(dt).float()
+        zc = yq + o.repeat_interleave(L, 0)[:M]
+        y = F.layer_norm(zc, (d,), gc, bec, 1e-8)
+    yq = y.to(dt).float()
+    h1 = yq @ W1.float().T + b1
+    g = gelu_tanh(h1).to(dt).float()
+    z2 = g @ W2.float().T + b2 + yq
+    ref = F.layer_norm(z2, (d,), g2, be2, 1e-8) * rm[:, None]
+    t = dict(rtol=1e-4, atol=1e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(out.float(), ref, **t)
+    if save:
+        torch.testing.assert_close(sv["y"].float(), y1, **t)
+        torch.testing.assert_close(sv["h1"].float(), h1, **t)
+        torch.testing.assert_close(sv["rstd1"], 1 / torch.sqrt(z1.var(1, unbiased=False) + 1e-8), rtol=2e-2 if dt != torch.float32 else 1e-4, atol=1e-4)
+        torch.testing.assert_close(sv["rstd2"], 1 / torch.sqrt(z2.var(1, unbiased=False) + 1e-8), rtol=2e-2 if dt != torch.float32 else 1e-4, atol=1e-4)
+        if cross:
+            torch.testing.assert_close(sv["y2"].float(), y, **t)
+            torch.testing.assert_close(sv["rstd_c"], 1 / torch.sqrt(zc.var(1, unbiased=False) + 1e-8), rtol=2e-2 if dt != torch.float32 else 1e-4, atol=1e-4)

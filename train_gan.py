@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Cross-domain RecGURU training on MI355X -- entry point with the reference's flag surface
+(GURU/train_gan.py:30-140): flags -> get_param -> loaders -> MyAuto4Rec_c + Discriminator +
+three optimizers -> main_2 (phase 1 recon, phase 2 W-GAN, phase 3 BPR tune).
+
+Extra flags (next to the preserved ones): --seq_len --vocab_size_a/b --n_blocks --dropout --data_path
+--steps_tune --phase1_steps --dtype {bf16,f32} --synthetic N_USERS.  --n_gpu is real here: launch with
+`python -m torch.distributed.run --nproc-per-node N train_gan.py ...` (one process per GPU, RCCL).
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def str2bool_par(val):
+    return val == "True"
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--lr", type=float, default=0.01, help="learning rate")
+    p.add_argument("--date", type=str, default="sas_org", help="labeling")
+    p.add_argument("--d_model", type=int, default=32)
+    p.add_argument("--n_head", type=int, default=1)
+    p.add_argument("--d_ff", type=int, default=512)
+    p.add_argument("--n_negs", type=int, default=30)
+    p.add_argument("--decoder_neg", type=bool, default=True)
+    p.add_argument("--batch_size", type=int, default=1024)
+    p.add_argument("--batch_size_val", type=int, default=256)
+    p.add_argument("--target_domain", type=str, default="a")
+    p.add_argument("--dataset_pick", type=int, default=1)
+    p.add_argument("--run", type=int, default=1)
+    p.add_argument("--n_gpu", type=int, default=1)
+    p.add_argument("--result_path", type=str, default="/data/ceph/seqrec/torch/result/gur_s/non_shared/")
+    p.add_argument("--sas", type=str, default="False")
+    p.add_argument("--cross", type=str, default="False")
+    p.add_argument("--enc_share", type=str, default="True")
+    p.add_argument("--share_dec", type=str, default="False")
+    p.add_argument("--fix_enc", type=str, default="True")
+    # additions
+    p.add_argument("--seq_len", type=int, default=None)
+    p.add_argument("--vocab_size_a", type=int, default=None)
+    p.add_argument("--vocab_size_b", type=int, default=None)
+    p.add_argument("--n_blocks", type=int, default=None)
+    p.add_argument("--dropout", type=float, default=None)
+    p.add_argument("--data_path", type=str, default=None)
+    p.add_argument("--steps_tune", type=int, default=None)
+    p.add_argument("--phase1_steps", type=int, default=200)
+    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--synthetic", type=int, default=0, help="users per domain of generated data (0 = read data_path)")
+    return p.parse_args()
+
+
+def main():
+    args = parse()
+    args.fix_enc = str2bool_par(args.fix_enc)
+    if not torch.cuda.is_available():
+        sys.exit("train_gan.py: no GPU visible -- the HIP path has no CPU fallback")
+    from recguru_amd import blocks as all_module, config as param_c, data as Dataloader, dist as rdist
+    from recguru_amd import models as Model, ops, synthetic, training as gt
+    from recguru_amd.optim import Adam
+    if args.synthetic:
+        args.vocab_size_a = args.vocab_size_a or 100000
+        args.vocab_size_b = args.vocab_size_b or 100000
+        args.users_a = args.users_b = args.synthetic
+        args.overlap_users = max(1, args.synthetic // 10)
+    os.makedirs(args.result_path, exist_ok=True)
+    param = param_c.get_param(args)
+    dp = rdist.init_from_env("nccl")
+    rank, world = (dp.rank, dp.world) if dp else (0, 1)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_data_parallel(dp)
+
+    L, k = param.enc_maxlen, param.n_negs
+    if args.synthetic:
+        dom_a = synthetic.make_domain(args.synthetic, param.vocab_size_a - 1, L, k, seed=1)
+        dom_b = synthetic.make_domain(args.synthetic, param.vocab_size_b - 1, L, k, seed=2)
+        mk = lambda dom: synthetic.TensorLoader(dom, param.batch_size, device, rank, world)
+        ae_loaders = [mk(dom_a), mk(dom_b)]
+        rec_dom = synthetic.make_domain(args.synthetic, (param.vocab_size_a if args.target_domain == "a"
+                                                         else param.vocab_size_b) - 1, L, param.n_bpr_neg, seed=3)
+        rec_loaders = [mk(rec_dom), mk(rec_dom)]
+    else:
+        files = Dataloader.discover(param.data_path, param.domain_name_a, param.domain_name_b)
+        print("=================\n", files, "\n*****************")
+        ae_loaders = [Dataloader.dataloader_gen(files["a"], param, k, "a", device, rank, world),
+                      Dataloader.dataloader_gen(files["b"], param, k, "b", device, rank, world)]
+        t = args.target_domain
+        freq = Dataloader.load_pickle(files["freq_" + t][0])
+        rec_loaders = [Dataloader.dataloader_gen(files[t], param, param.n_bpr_neg, t, device, rank, world, seed=1),
+                       Dataloader.dataloader_gen(files[t], param, param.n_bpr_neg, t, device, rank, world, seed=2, wf=freq)]
+    torch.manual_seed(1)                                           # gan_training.py:20
+    enc_model = Model.MyAuto4Rec_c(device, param, wf=None, enc_share=args.enc_share != "False",
+                                   dec_rec=False).to(torch.float32).to(device)
+    opt_rec = all_module.ScheduledOptim(Adam(enc_model.parameters(), betas=(0.9, 0.98), eps=1e-09),
+                                        1.0, param.d_model, param.n_warmup_steps)
+    opt_gen = Adam(enc_model.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    netD = Model.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
+    opt_dis = Adam(netD.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    hist = gt.main_2(enc_model, opt_rec, netD, opt_gen, opt_dis, param, device, ae_loaders, rec_loaders, None, None,
+                     dp=dp, phase1_steps=args.phase1_steps)
+    if rank == 0:
+        log = gt.plot.flush()
+        import pickle
+        with open(os.path.join(param.result_path, "log.pkl"), "wb") as f:
+            pickle.dump(log, f)
+        if hist:
+            print("last phase-2 iteration: D_cost %.4f  W_D %.4f  recon_a %.4f  recon_b %.4f  g_dis %.4f"
+                  % tuple(float(x) for x in hist[-1]))
+    if dp:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
