@@ -204,11 +204,17 @@ static int launch_nt(const rg_gemm_nt_args& a, hipStream_t s) {
   return 0;
 }
 
+int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s);   // gemm_ws.hip
+
 extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0 || a->N <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: empty problem");
   if (a->K <= 0 || (a->K & 31)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: K must be a multiple of 32");
   if ((a->lda & 7) || (a->ldw & 7)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: lda/ldw must be multiples of 8");
   hipStream_t s = (hipStream_t)stream;
+  if (!(a->debug_ablate & 16)) {             // bit 16: force the generic kernel (tools/kbench.py A/B)
+    const int rc = rg_gemm_ws_try(a, dtype, s);
+    if (rc <= 0) return rc;
+  }
   if (dtype == RG_BF16) return launch_nt<__bf16>(*a, s);
   if (dtype == RG_F32) return launch_nt<float>(*a, s);
   return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: bad dtype");

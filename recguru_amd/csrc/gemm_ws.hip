@@ -1,0 +1,172 @@
+// Persistent, weight-stationary GEMM for the hot Linear shapes of the path (bf16 tier):
+//   C[M,N] = epi( A[M,K] . W[N,K]^T + bias ),  K, N multiples of 128, K*N <= 64K, (K==128 or N==128)
+// i.e. QKV projection (128->384), FFN backward (128->512 with GELU', 512->128 + residual),
+// attention backward-data (384->128 + residual, 128->128).
+//
+// Why a second GEMM kernel: at these shapes a tile has only 32..128 MFMAs per wave, so the generic
+// tile-per-workgroup kernel (gemm.hip) is dominated by per-tile fixed costs (weight-fragment
+// reloads, exposed staging latency, barrier drains).  Here a workgroup is persistent: every wave
+// loads ITS slice of W into registers once (K*N/512 VGPRs) and then streams 64-token tiles:
+// next tile's rows are prefetched into registers while the current tile is in the MFMA phase,
+// barriers order LDS only (lds_barrier), and -- weight fragment as the A operand -- each
+// accumulator register holds 4 consecutive features of one token, so results leave through a
+// packed LDS tile and 16-byte coalesced stores (aux operands are read the same way).
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define WS_M 64
+#define WS_LD (128 + 8)
+
+template <int NKC, int NCB>
+__global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
+  static_assert(NKC == 1 || NCB == 1, "either K or N spans a single 128-wide block");
+  typedef __bf16 T;
+  __shared__ __align__(16) T As[WS_M * WS_LD];
+  __shared__ __align__(16) T Cs[WS_M * WS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
+  const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
+  const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
+  T* __restrict__ C = reinterpret_cast<T*>(a.C);
+  const int n0 = wave * 32;
+  const int ntiles = (a.M + WS_M - 1) / WS_M;
+
+  // ---- stationary weights: w[cb][kc][ks][ct]
+  Frag<T> w[NCB][NKC][4][2];
+#pragma unroll
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct)
+          load_frag(w[cb][kc][ks][ct], W + (size_t)(cb * 128 + n0 + ct * 16 + li) * a.ldw + kc * 128 + ks * 32 + 8 * lg);
+  __shared__ __align__(16) float bs[NCB * 128];
+  for (int i = tid; i < NCB * 128; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;   // visible after the first barrier
+
+  // chunk (tile, kc) -> rows m0.., columns kc*128.. of A ; each thread stages 4 x 16 bytes
+  Frag<T> pre[4];
+  auto prefetch = [&](int tile, int kc) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+      const int m = tile * WS_M + r;
+      if (m < a.M) load_frag(pre[i], A + (size_t)m * a.lda + kc * 128 + c8);
+      else frag_zero(pre[i]);
+    }
+  };
+  int tile = blockIdx.x;
+  if (tile < ntiles) prefetch(tile, 0);
+  for (; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * WS_M;
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int kc = 0; kc < NKC; ++kc) {
+      // registers -> LDS, then immediately put the next chunk in flight
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+        *reinterpret_cast<Frag<T>*>(As + r * WS_LD + c8) = pre[i];
+      }
+      if (kc + 1 < NKC) prefetch(tile, kc + 1);
+      else if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, 0);
+      lds_barrier();
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        Frag<T> axf[4];                                   // aux rows of this block, in flight under the MFMAs
+        if (kc == NKC - 1 && a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+            const int m = m0 + r;
+            if (m < a.M) load_frag(axf[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
+            else frag_zero(axf[i]);
+          }
+        }
+        if (kc == 0) {
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float b4[4];
+            load4f(b4, bs + cb * 128 + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b4[0], b4[1], b4[2], b4[3]};
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          Frag<T> af[4];
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], As + (rt * 16 + li) * WS_LD + ks * 32 + 8 * lg);
+#pragma unroll
+          for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < 2; ++ct) mma(w[cb][kc][ks][ct], af[rt], acc[ct][rt]);
+        }
+        if (kc == NKC - 1) {
+          // ---- epilogue of this 128-feature block: packed tile -> coalesced 16-byte stores
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) {
+              float v[4] = {acc[ct][rt][0], acc[ct][rt][1], acc[ct][rt][2], acc[ct][rt][3]};
+              store4(Cs + (rt * 16 + li) * WS_LD + n0 + ct * 16 + 4 * lg, v);
+            }
+          lds_barrier();
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+            const int m = m0 + r;
+            if (m < a.M) {
+              const size_t off = (size_t)m * a.ldc + cb * 128 + c8;
+              if (a.epilogue == RG_EPI_NONE) {
+                *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
+              } else {
+                float v[8], x[8];
+                load8(v, Cs + r * WS_LD + c8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x[j] = (float)axf[i].v[j];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  if (a.epilogue == RG_EPI_GELU_GRAD) v[j] *= gelu_grad_t<false>(x[j]);
+                  else if (a.epilogue == RG_EPI_ADD) v[j] += x[j];
+                  else if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                  else v[j] = fmaxf(v[j], 0.f);
+                }
+                store8(C + off, v);
+              }
+            }
+          }
+          if (NCB > 1 && cb + 1 < NCB) lds_barrier();     // Cs is rewritten by the next block
+        }
+      }
+      if (NKC > 1 || true) lds_barrier();                 // As / Cs are rewritten by the next chunk / tile
+    }
+  }
+}
+
+template <int NKC, int NCB>
+static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s) {
+  const int ntiles = (a.M + WS_M - 1) / WS_M;
+  int grid = 512;
+  if (grid > ntiles) grid = ntiles;
+  hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB>), dim3(grid), dim3(256), 0, s, a);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+// returns 1 if the shape is not handled here (caller falls back to the generic kernel)
+int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
+  if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 1;
+  if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 1;
+  if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 1;
+  if (a->epilogue != RG_EPI_NONE && !a->aux) return 1;
+  const int nkc = a->K / 128, ncb = a->N / 128;
+  if (nkc == 1 && ncb == 1) return launch_ws<1, 1>(*a, s);
+  if (nkc == 1 && ncb == 3) return launch_ws<1, 3>(*a, s);
+  if (nkc == 1 && ncb == 4) return launch_ws<1, 4>(*a, s);
+  if (nkc == 3 && ncb == 1) return launch_ws<3, 1>(*a, s);
+  if (nkc == 4 && ncb == 1) return launch_ws<4, 1>(*a, s);
+  return 1;
+}

@@ -361,3 +361,36 @@ def test_post_attn_fused_vs_unfused(dt, M, dff, cross, save):
         if cross:
             torch.testing.assert_close(sv["y2"].float(), y, **t)
             torch.testing.assert_close(sv["rstd_c"], 1 / torch.sqrt(zc.var(1, unbiased=False) + 1e-8), rtol=2e-2 if dt != torch.float32 else 1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (128, 512), (384, 128), (512, 128)])
+@pytest.mark.parametrize("epi", ["none", "add", "gelu_grad", "posmask", "relu"])
+def test_gemm_ws_matches_generic(K, N, epi):
+    """Persistent weight-stationary path (bf16, M >= 4096) against the generic kernel and torch."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    M = 4096 + 77
+    A = rnd(M, K, dt=dt, seed=1)
+    W = rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    b = rnd(N, dt=torch.float32, seed=3)
+    aux = rnd(M, N, dt=dt, seed=4)
+    code = {"none": hip.EPI_NONE, "add": hip.EPI_ADD, "gelu_grad": hip.EPI_GELU_GRAD, "posmask": hip.EPI_MUL_POSMASK,
+            "relu": hip.EPI_RELU}[epi]
+    kw = dict(epilogue=code, aux=aux if epi in ("add", "gelu_grad", "posmask") else None)
+    if epi == "relu":
+        kw["aux"] = aux          # the ws path needs an aux pointer for non-NONE epilogues; relu ignores it
+    out_ws = hip.gemm_nt(A, W, b, **kw)
+    out_gen = hip.gemm_nt(A, W, b, debug_ablate=16, **kw)
+    ref = A.float() @ W.float().T + b
+    if epi == "add":
+        ref = ref + aux.float()
+    elif epi == "posmask":
+        ref = ref * (aux.float() > 0)
+    elif epi == "relu":
+        ref = ref.clamp_min(0)
+    elif epi == "gelu_grad":
+        x = aux.float().requires_grad_(True)
+        gelu_tanh(x).sum().backward()
+        ref = ref * x.grad
+    torch.testing.assert_close(out_ws.float(), ref, rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(out_ws.float(), out_gen.float(), rtol=2e-2, atol=2e-2)
