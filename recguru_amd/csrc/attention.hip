@@ -19,14 +19,62 @@
 #define DK 32
 #define NEG_FILL (-1e9f)
 
-template <typename T, int NKT>
+#ifdef RG_STAMP
+#define ASTAMP(i) do { unsigned long long t1__ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    tacc[i] += t1__ - t0__; t0__ = t1__; } while (0)
+#else
+#define ASTAMP(i)
+#endif
+
+// V operand of O^T = V^T.P^T for the stacked-accumulator slot map: lane (i = dv, g) needs
+// V[key = k0 + 4g + j][dv] (j<4) and V[key = k0 + 16 + 4g + j][dv].
+//  * bf16: V stays ROW-MAJOR in LDS ([key][32+8], filled with raw 16-byte copies) and the gfx950
+//    transposing read ds_read_b64_tr_b16 delivers exactly "4 consecutive rows of one column".
+//  * f32 : V is staged transposed ([dv][keys]) and read as two 4-runs.
+template <typename T> struct VStage;
+template <> struct VStage<__bf16> {
+  static constexpr bool TRANSPOSED = false;
+  static __device__ __forceinline__ void frag(Frag<__bf16>& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int q = li >> 2, p = li & 3;           // lane 4q+p of the 16-lane group -> row q, columns 4p..4p+3
+    const __bf16* p0 = V + (k0 + 4 * lg + q) * ldv + dv0 + 4 * p;
+    const __bf16* p1 = p0 + 16 * ldv;
+    union { s16x4 s; bf16x4_t b; } u0, u1;
+    u0.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+    u1.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
+  }
+};
+template <> struct VStage<float> {
+  static constexpr bool TRANSPOSED = true;
+  static __device__ __forceinline__ void frag(Frag<float>& f, const float* Vt, int ldv, int k0, int dv0, int li, int lg) {
+    const float* vp = Vt + (dv0 + li) * ldv + k0 + 4 * lg;
+    load_frag_2x4(f, vp, vp + 16);
+  }
+};
+
+// Masking is branch-free: kbias[key] in LDS is 0 for a live key, -1e30 for a replaced (pad) key and
+// -inf beyond L.  s + (-1e30) == -1e30 exactly in f32, so every replaced score is the same value --
+// the "replace-fill" semantics of masked_fill_(-1e9): a fully masked row is uniform over all L keys
+// (Q3).  Only the reported lse maps the sentinel back to the reference's -1e9.
+#define MASK_BIG (-1e30f)
+
+template <typename T, int NKT, bool CAUSAL>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
+#ifdef RG_STAMP
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long t0__ = __builtin_amdgcn_s_memtime();
+#endif
   constexpr int LPK = NKT * 16;       // padded key count (multiple of 32)
   constexpr int LDK = DK + 8;         // K rows [key][dk]
-  constexpr int LDV = LPK + 8;        // V^T rows [dv][key]
+  constexpr bool VT = VStage<T>::TRANSPOSED;
+  constexpr int LDV = VT ? LPK + 8 : DK + 8;
+  constexpr int VELEMS = VT ? DK * LDV : LPK * LDV;
   __shared__ __align__(16) T Ks[LPK * LDK];
-  __shared__ __align__(16) T Vt[DK * LDV];
-  __shared__ unsigned char kpad[LPK];
+  __shared__ __align__(16) T Vs[VELEMS];
+  __shared__ __align__(16) float kbias[LPK];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -34,53 +82,68 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
+  const int nqt = (L + 15) / 16;
 
-  // ---- stage K (row-major) and V (transposed) of this head, and the key-pad flags
+  // first Q fragment in flight during staging
+  Frag<T> qnext;
+  {
+    const int q = wave * 16 + li;
+    if (wave < nqt && q < L) load_frag(qnext, qkv + (size_t)q * ld + h * DK + 8 * lg);
+    else frag_zero(qnext);
+  }
+  // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
   for (int c = tid; c < LPK * 4; c += 256) {
     const int key = c >> 2, c8 = (c & 3) * 8;
-    float kv[8], vv[8];
+    Frag<T> kr, vr;
     if (key < L) {
-      load8(kv, qkv + (size_t)key * ld + P + h * DK + c8);
-      load8(vv, qkv + (size_t)key * ld + 2 * P + h * DK + c8);
+      load_frag(kr, qkv + (size_t)key * ld + P + h * DK + c8);
+      load_frag(vr, qkv + (size_t)key * ld + 2 * P + h * DK + c8);
+    } else { frag_zero(kr); frag_zero(vr); }
+    *reinterpret_cast<Frag<T>*>(Ks + key * LDK + c8) = kr;
+    if (VT) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Vs[(c8 + j) * LDV + key] = vr.v[j];
     } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { kv[j] = 0.f; vv[j] = 0.f; }
+      *reinterpret_cast<Frag<T>*>(Vs + key * LDV + c8) = vr;
     }
-    store8(Ks + key * LDK + c8, kv);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) Vt[(c8 + j) * LDV + key] = (T)vv[j];
   }
   for (int key = tid; key < LPK; key += 256)
-    kpad[key] = (key < L && a.key_ids[(size_t)b * L + key] == a.pad_value) ? 1 : 0;
-  __syncthreads();
+    kbias[key] = key >= L ? -INFINITY : (a.key_ids[(size_t)b * L + key] == a.pad_value ? MASK_BIG : 0.f);
+  lds_barrier();
+  ASTAMP(0);
 
-  const int nqt = (L + 15) / 16;
+  // scores stay RAW dot products; the reference's 1/sqrt(d_k) and log2(e) are folded into the exp2 argument
+  const float c2 = a.scale * 1.4426950408889634f;
   for (int qt = wave; qt < nqt; qt += 4) {
     const int q = qt * 16 + li;            // this lane's query (column of S^T)
-    Frag<T> qf;
-    if (q < L) load_frag(qf, qkv + (size_t)q * ld + h * DK + 8 * lg);
-    else frag_zero(qf);
-
+    const int qrel = q - 4 * lg;           // key (= kt*16 + 4*lg + r) > q  <=>  kt*16 + r > qrel
+    const Frag<T> qf = qnext;
+    if (qt + 4 < nqt) {
+      const int q2 = (qt + 4) * 16 + li;
+      if (q2 < L) load_frag(qnext, qkv + (size_t)q2 * ld + h * DK + 8 * lg);
+      else frag_zero(qnext);
+    }
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (kt < nkt) {
         Frag<T> kf;
         load_frag(kf, Ks + (kt * 16 + li) * LDK + 8 * lg);
+        float kb[4];
+        load4f(kb, kbias + kt * 16 + 4 * lg);
+        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         mma(kf, qf, s[kt]);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * lg + r;
-          float v = s[kt][r] * a.scale;
-          if (key >= L) v = -INFINITY;
-          else if (kpad[key] || (a.causal && key > q)) v = NEG_FILL;
+          float v = s[kt][r] + kb[r];
+          if (CAUSAL) v = (kt * 16 + r > qrel) ? fminf(v, MASK_BIG) : v;     // keeps -inf beyond L
           s[kt][r] = v;
           mx = fmaxf(mx, v);
         }
       }
     }
+    ASTAMP(1);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.f;
@@ -89,14 +152,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = __expf(s[kt][r] - mx);
+          // (s - mx) first: exact 0 for the -1e30 sentinel rows (an fma against -mx*c2 would leave a ~1e22 residual)
+          const float p = __builtin_amdgcn_exp2f((s[kt][r] - mx) * c2);
           s[kt][r] = p;
           sum += p;
         }
       }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float inv = 1.f / sum;
+    const float inv = __builtin_amdgcn_rcpf(sum);
+    ASTAMP(2);
 
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
@@ -107,11 +172,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           Frag<T> vf;
-          const T* vp = Vt + (dt * 16 + li) * LDV + ks * 32 + 4 * lg;
-          load_frag_2x4(vf, vp, vp + 16);
+          VStage<T>::frag(vf, Vs, LDV, ks * 32, dt * 16, li, lg);
           mma(vf, pf, o[dt]);
         }
       }
+    ASTAMP(3);
     if (q < L) {
       T* __restrict__ ctx = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
 #pragma unroll
@@ -121,9 +186,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
         for (int r = 0; r < 4; ++r) v[r] = o[dt][r] * inv;
         store4(ctx + dt * 16 + 4 * lg, v);
       }
-      if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = mx + __logf(sum);
+#ifndef RG_STAMP
+      if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = (mx < 0.5f * MASK_BIG ? NEG_FILL : mx * a.scale) + __logf(sum);
+#endif
     }
+    ASTAMP(4);
   }
+#ifdef RG_STAMP
+  if (a.lse != nullptr && blockIdx.x < 1024 && lane == 0) {   // diagnostic build: lse doubles as the stamp buffer
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.lse) + (size_t)(blockIdx.x * 4 + wave) * 8;
+    for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
+  }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -301,7 +375,11 @@ template <typename T>
 static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
   dim3 grid(a.B * a.H), block(256);
-#define RG_FWD(N) hipLaunchKernelGGL((attn_fwd_kernel<T, N>), grid, block, 0, s, a)
+#define RG_FWD(N)                                                                          \
+  do {                                                                                     \
+    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<T, N, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, N, false>), grid, block, 0, s, a);         \
+  } while (0)
   if (nkt <= 2) RG_FWD(2);
   else if (nkt <= 4) RG_FWD(4);
   else if (nkt <= 8) RG_FWD(8);
