@@ -371,6 +371,173 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward, bf16 tier: same two-phase algorithm, but every operand of the head lives in LDS
+// (Q, K, V, dO row-major, filled by raw 16-byte copies) -- no global loads inside the loops --,
+// stacked-slot operands come from the transposing LDS read, masking is the additive key-bias row,
+// and the products are oriented so that dK^T / dV^T / dQ^T land with 4 consecutive features per
+// lane: gradients leave as packed 8-byte stores.
+// ------------------------------------------------------------------------------------------------
+template <int NKT, bool CAUSAL>
+__global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
+  typedef __bf16 T;
+  constexpr int LPK = NKT * 16;
+  constexpr int LDR = DK + 8;
+  __shared__ __align__(16) T Qs[LPK * LDR];
+  __shared__ __align__(16) T Ks[LPK * LDR];
+  __shared__ __align__(16) T Vs[LPK * LDR];
+  __shared__ __align__(16) T Gs[LPK * LDR];     // dO
+  __shared__ __align__(16) float lse2_s[LPK];   // lse * log2(e)   (+inf marks a fully masked row)
+  __shared__ __align__(16) float dl_s[LPK];     // delta = rowsum(dO * O)
+  __shared__ __align__(16) float rowp_s[LPK];   // 1/L for fully masked rows, else 0
+  __shared__ __align__(16) float kbias[LPK];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int L = a.L, P = a.H * DK, ld = 3 * P;
+  const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
+  const T* __restrict__ O = reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK;
+  T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
+  const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
+  const float c2 = a.scale * 1.4426950408889634f;
+
+  for (int c = tid; c < LPK * 4; c += 256) {
+    const int row = c >> 2, c8 = (c & 3) * 8;
+    Frag<T> qr, kr, vr, gr, orow;
+    if (row < L) {
+      load_frag(qr, qkv + (size_t)row * ld + h * DK + c8);
+      load_frag(kr, qkv + (size_t)row * ld + P + h * DK + c8);
+      load_frag(vr, qkv + (size_t)row * ld + 2 * P + h * DK + c8);
+      load_frag(gr, dO + (size_t)row * P + c8);
+      load_frag(orow, O + (size_t)row * P + c8);
+    } else { frag_zero(qr); frag_zero(kr); frag_zero(vr); frag_zero(gr); frag_zero(orow); }
+    *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr;
+    *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr;
+    *reinterpret_cast<Frag<T>*>(Vs + row * LDR + c8) = vr;
+    *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr;
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += (float)gr.v[j] * (float)orow.v[j];
+    d += __shfl_xor(d, 1);
+    d += __shfl_xor(d, 2);
+    if ((c & 3) == 0) dl_s[row] = d;
+  }
+  for (int r = tid; r < LPK; r += 256) {
+    const float lse = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
+    const bool full = lse < -5e8f;                  // -1e9 + log L rounds to -1e9: row was uniform 1/L (Q3)
+    lse2_s[r] = (r < L && !full) ? lse * 1.4426950408889634f : INFINITY;     // exp2(x - inf) = 0
+    rowp_s[r] = (r < L && full) ? 1.f / (float)L : 0.f;
+    kbias[r] = r >= L ? -INFINITY : (a.key_ids[(size_t)b * L + r] == a.pad_value ? MASK_BIG : 0.f);
+  }
+  lds_barrier();
+
+  // ---------------------------------------------------------------- phase 1: dK^T, dV^T
+  for (int kt = wave; kt < nt; kt += 4) {
+    const int key = kt * 16 + li;                   // this lane's key (column of S)
+    Frag<T> kf, vf;
+    load_frag(kf, Ks + key * LDR + 8 * lg);
+    load_frag(vf, Vs + key * LDR + 8 * lg);
+    const float kb = kbias[key];
+    f32x4 dkt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int qs = 0; qs < nt / 2; ++qs) {
+      f32x4 p[2], ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int q0 = qs * 32 + u * 16;
+        Frag<T> qf, gf;
+        load_frag(qf, Qs + (q0 + li) * LDR + 8 * lg);
+        load_frag(gf, Gs + (q0 + li) * LDR + 8 * lg);
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma(qf, kf, sv);
+        mma(gf, vf, dp);
+        float l4[4], d4[4], r4[4];
+        load4f(l4, lse2_s + q0 + 4 * lg);
+        load4f(d4, dl_s + q0 + 4 * lg);
+        load4f(r4, rowp_s + q0 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = sv[r] + kb;                                        // -1e30 / -inf where replaced
+          if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
+          const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
+          ds[u][r] = pe * (dp[r] - d4[r]) * a.scale;
+          p[u][r] = pe + ((key < L) ? r4[r] : 0.f);                     // uniform 1/L rows (Q3)
+        }
+      }
+      Frag<T> pf, dsf;
+      acc_to_frag(pf, p[0], p[1]);
+      acc_to_frag(dsf, ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> gtf, qtf;
+        VStage<T>::frag(gtf, Gs, LDR, qs * 32, dt * 16, li, lg);
+        VStage<T>::frag(qtf, Qs, LDR, qs * 32, dt * 16, li, lg);
+        mma(gtf, pf, dvt[dt]);     // dV^T[dv][key] += sum_q dO[q][dv] P[q][key]
+        mma(qtf, dsf, dkt[dt]);    // dK^T[dk][key] += sum_q Q[q][dk] dS[q][key]
+      }
+    }
+    if (key < L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4] = {dkt[dt][0], dkt[dt][1], dkt[dt][2], dkt[dt][3]};
+        float w[4] = {dvt[dt][0], dvt[dt][1], dvt[dt][2], dvt[dt][3]};
+        store4(dqkv + (size_t)key * ld + P + h * DK + dt * 16 + 4 * lg, v);
+        store4(dqkv + (size_t)key * ld + 2 * P + h * DK + dt * 16 + 4 * lg, w);
+      }
+    }
+  }
+
+  // ---------------------------------------------------------------- phase 2: dQ^T
+  for (int qt = wave; qt < nt; qt += 4) {
+    const int q = qt * 16 + li;                     // this lane's query (column of S^T)
+    Frag<T> qf, gf;
+    load_frag(qf, Qs + q * LDR + 8 * lg);
+    load_frag(gf, Gs + q * LDR + 8 * lg);
+    const float lse_q = lse2_s[q], dl_q = dl_s[q];
+    const int qrel = q - 4 * lg;
+    f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int ks = 0; ks < nt / 2; ++ks) {
+      f32x4 ds[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k0 = ks * 32 + u * 16;
+        Frag<T> kf, vf;
+        load_frag(kf, Ks + (k0 + li) * LDR + 8 * lg);
+        load_frag(vf, Vs + (k0 + li) * LDR + 8 * lg);
+        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma(kf, qf, sv);           // S^T[key][q]
+        mma(vf, gf, dp);           // dP^T[key][q]
+        float kb4[4];
+        load4f(kb4, kbias + k0 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float sc = sv[r] + kb4[r];
+          if (CAUSAL) sc = (k0 + r > qrel) ? fminf(sc, MASK_BIG) : sc;
+          const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -lse_q));
+          ds[u][r] = pe * (dp[r] - dl_q) * a.scale;
+        }
+      }
+      Frag<T> dsf;
+      acc_to_frag(dsf, ds[0], ds[1]);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        Frag<T> ktf;
+        VStage<T>::frag(ktf, Ks, LDR, ks * 32, dt * 16, li, lg);
+        mma(ktf, dsf, dqt[dt]);    // dQ^T[dk][q] += sum_key K[key][dk] dS^T[key][q]
+      }
+    }
+    if (q < L) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        float v[4] = {dqt[dt][0], dqt[dt][1], dqt[dt][2], dqt[dt][3]};
+        store4(dqkv + (size_t)q * ld + h * DK + dt * 16 + 4 * lg, v);
+      }
+    }
+  }
+}
+
 template <typename T>
 static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
@@ -395,16 +562,30 @@ template <typename T>
 static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
   dim3 grid(a.B * a.H), block(256);
+  if constexpr (sizeof(T) == 2) {
+#define RG_BWD16(N)                                                                             \
+  do {                                                                                          \
+    if (a.causal) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, true>), grid, block, 0, s, a);    \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, false>), grid, block, 0, s, a);            \
+  } while (0)
+    if (nkt <= 2) RG_BWD16(2);
+    else if (nkt <= 4) RG_BWD16(4);
+    else if (nkt <= 8) RG_BWD16(8);
+    else if (nkt <= 14) RG_BWD16(14);
+    else if (nkt <= 16) RG_BWD16(16);
+    else if (nkt <= 26) RG_BWD16(26);
+    else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 not supported yet");
+#undef RG_BWD16
+  } else {
 #define RG_BWD(N) hipLaunchKernelGGL((attn_bwd_kernel<T, N>), grid, block, 0, s, a)
-  if (nkt <= 2) RG_BWD(2);
-  else if (nkt <= 4) RG_BWD(4);
-  else if (nkt <= 8) RG_BWD(8);
-  else if (nkt <= 14) RG_BWD(14);
-  else if (nkt <= 16) RG_BWD(16);
-  else if (nkt <= 26 && sizeof(T) == 2) {
-    if constexpr (sizeof(T) == 2) RG_BWD(26);   // three f32 images of 416 keys exceed 160 KB LDS
-  } else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 (bf16) / 256 (f32) not supported yet");
+    if (nkt <= 2) RG_BWD(2);
+    else if (nkt <= 4) RG_BWD(4);
+    else if (nkt <= 8) RG_BWD(8);
+    else if (nkt <= 14) RG_BWD(14);
+    else if (nkt <= 16) RG_BWD(16);
+    else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 256 (f32 tier) not supported yet");
 #undef RG_BWD
+  }
   RG_CHECK_LAUNCH();
   return 0;
 }
