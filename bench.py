@@ -192,7 +192,7 @@ def main():
         top = max(agg.items(), key=lambda kv: kv[1]["ms"])
         name, a = top
         total_ms = sum(v["ms"] for v in agg.values())
-        if a["flops"] > 0 and name.startswith(("gemm", "attn")):
+        if a["flops"] > 0 and name.startswith(("gemm", "attn", "post_attn")):
             ach = a["flops"] / (a["ms"] * 1e-3) / 1e12
             peak = MFMA_PEAK_TFLOPS[args.dtype]
             roof = {"bound": "mfma", "kernel": name, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",

@@ -334,11 +334,17 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(rg_gemm_tn_args a) {
   }
 }
 
+int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s);   // gemm_tn_big.hip
+
 extern "C" int rg_gemm_tn(const rg_gemm_tn_args* a, int dtype, void* stream) {
   if (!a || a->T <= 0 || a->N1 <= 0 || a->N2 <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: empty problem");
   if ((a->N1 & 7) || (a->N2 & 7) || (a->ldy & 7) || (a->ldx & 7))
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn: N1/N2/ld must be multiples of 8");
   hipStream_t s = (hipStream_t)stream;
+  if (a->splits == 0) {                        // an explicit split count forces the generic kernel
+    const int rc = rg_gemm_tn_big_try(a, dtype, s);
+    if (rc <= 0) return rc;
+  }
   const int g1 = (a->N1 + 63) / 64, g2 = (a->N2 + 63) / 64;
   int splits = a->splits;
   if (splits <= 0) {

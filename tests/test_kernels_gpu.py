@@ -394,3 +394,23 @@ def test_gemm_ws_matches_generic(K, N, epi):
         ref = ref * x.grad
     torch.testing.assert_close(out_ws.float(), ref, rtol=3e-2, atol=3e-2)
     torch.testing.assert_close(out_ws.float(), out_gen.float(), rtol=2e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("N1,N2,gelu", [(512, 128, False), (128, 512, True), (384, 128, False), (128, 128, False)])
+def test_gemm_tn_big_matches_generic(N1, N2, gelu):
+    """Whole-dW-per-workgroup wgrad path (bf16, T >= 8192) vs the generic 64x64-tile kernel and torch."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    T = 8192 + 333
+    Y = rnd(T, N1, dt=dt, seed=1)
+    X = rnd(T, N2, dt=dt, seed=2)
+    pro = hip.PRO_GELU if gelu else hip.PRO_NONE
+    dW, cs = torch.zeros(N1, N2, device="cuda"), torch.zeros(N1, device="cuda")
+    hip.gemm_tn(Y, X, dW, cs, prologue_x=pro, scale=0.5)
+    dW2, cs2 = torch.zeros(N1, N2, device="cuda"), torch.zeros(N1, device="cuda")
+    hip.gemm_tn(Y, X, dW2, cs2, prologue_x=pro, scale=0.5, splits=64)
+    xf = gelu_tanh(X.float()).bfloat16().float() if gelu else X.float()
+    ref = 0.5 * (Y.float().T @ xf)
+    torch.testing.assert_close(dW, ref, rtol=2e-2, atol=0.15)
+    torch.testing.assert_close(dW, dW2, rtol=1e-2, atol=5e-2)
+    torch.testing.assert_close(cs, 0.5 * Y.float().sum(0), rtol=2e-2, atol=5e-2)
