@@ -66,60 +66,71 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
 // nn.LayerNorm(eps=1e-8) backward at transformer.py:161,188; rows with rowmask == 0 (the
 // `* pad_mask` of :594/:539) get dz = 0.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NPL>
+// Row layout: LPR = N/8 lanes per row (8 features = one 16-byte bf16 / 32-byte f32 vector per lane),
+// 64/LPR rows per wave pass; row statistics by log2(LPR) shuffles.
+template <typename T, int LPR>
 __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
-  __shared__ float red[2][4][64 * NPL];
+  constexpr int RPW = 64 / LPR;                 // rows per wave pass
+  constexpr int N = LPR * 8;
+  __shared__ float red[2][4][N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int rr = lane / LPR, c8 = (lane % LPR) * 8;
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const T* __restrict__ y = reinterpret_cast<const T*>(a.y);
   T* __restrict__ dz = reinterpret_cast<T*>(a.dz);
-  const int N = a.N;
   const float invn = 1.f / (float)N;
-  float gam[NPL], bet[NPL], dg[NPL], db[NPL];
+  float gam[8], bet[8], dg[8], db[8];
+  load8(gam, a.gamma + c8);
+  load8(bet, a.beta + c8);
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) {
-    const int n = lane + 64 * j;
-    gam[j] = n < N ? a.gamma[n] : 1.f;
-    bet[j] = n < N ? a.beta[n] : 0.f;
-    dg[j] = 0.f; db[j] = 0.f;
-  }
+  for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
   const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
-  for (long long m = gw; m < a.M; m += nw) {
-    const float rm = a.rowmask ? a.rowmask[m] : 1.f;
-    if (rm == 0.f) {
-#pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const int n = lane + 64 * j;
-        if (n < N) dz[(size_t)m * a.ld + n] = (T)0.f;
-      }
-      continue;
-    }
-    const float rstd = a.rstd[m];
-    float g[NPL], xh[NPL];
+  for (long long m0 = gw * RPW; m0 < a.M; m0 += nw * RPW) {
+    const long long m = m0 + rr;
+    const bool live = m < a.M;
+    const float rm = live ? (a.rowmask ? a.rowmask[m] : 1.f) : 0.f;
+    float g[8], xh[8];
     float s1 = 0.f, s2 = 0.f;
+    if (rm != 0.f) {
+      float d8[8], y8[8];
+      load8(d8, dy + (size_t)m * a.ld + c8);
+      load8(y8, y + (size_t)m * a.ld + c8);
+      const float irm = 1.f / rm;
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int n = lane + 64 * j;
-      if (n < N) {
-        const float d = (float)dy[(size_t)m * a.ld + n] * rm;
-        xh[j] = ((float)y[(size_t)m * a.ld + n] / rm - bet[j]) / gam[j];
+      for (int j = 0; j < 8; ++j) {
+        const float d = d8[j] * rm;
+        xh[j] = (y8[j] * irm - bet[j]) / gam[j];
         g[j] = d * gam[j];
         dg[j] += d * xh[j];
         db[j] += d;
-      } else { g[j] = 0.f; xh[j] = 0.f; }
-      s1 += g[j];
-      s2 += g[j] * xh[j];
-    }
-    s1 = wave_sum(s1) * invn;
-    s2 = wave_sum(s2) * invn;
+        s1 += g[j];
+        s2 += g[j] * xh[j];
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < NPL; ++j) {
-      const int n = lane + 64 * j;
-      if (n < N) dz[(size_t)m * a.ld + n] = (T)(rstd * (g[j] - s1 - xh[j] * s2));
+      for (int j = 0; j < 8; ++j) { g[j] = 0.f; xh[j] = 0.f; }
+    }
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (live) {
+      const float rstd = rm != 0.f ? a.rstd[m] : 0.f;
+      s1 *= invn;
+      s2 *= invn;
+      float o8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
+      store8(dz + (size_t)m * a.ld + c8, o8);
     }
   }
+  // column sums: lanes with the same c8 (RPW of them per wave) -> LDS -> atomics
 #pragma unroll
-  for (int j = 0; j < NPL; ++j) { red[0][wave][lane + 64 * j] = dg[j]; red[1][wave][lane + 64 * j] = db[j]; }
+  for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] += __shfl_xor(dg[j], o); db[j] += __shfl_xor(db[j], o); }
+  if (rr == 0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[0][wave][c8 + j] = dg[j]; red[1][wave][c8 + j] = db[j]; }
+  }
   __syncthreads();
   for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
     const float sg = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
@@ -322,11 +333,12 @@ extern "C" int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const fl
 
 template <typename T>
 static int launch_ln_bwd(const rg_ln_bwd_args& a, hipStream_t s) {
-  const int grid = ew_grid(a.M, 16);
-  if (a.N <= 64) hipLaunchKernelGGL((ln_bwd_kernel<T, 1>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
-  else if (a.N <= 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 2>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
-  else if (a.N <= 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
-  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ln_bwd: N > 256");
+  const int grid = ew_grid(a.M, 64);
+  if (a.N == 32) hipLaunchKernelGGL((ln_bwd_kernel<T, 4>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else if (a.N == 64) hipLaunchKernelGGL((ln_bwd_kernel<T, 8>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else if (a.N == 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 16>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else if (a.N == 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 32>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ln_bwd: N must be 32, 64, 128 or 256");
   RG_CHECK_LAUNCH();
   return 0;
 }
