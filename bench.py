@@ -157,8 +157,9 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible -- the HIP path has no CPU fallback")
     from recguru_amd import dist as rdist, hip, ops
-    dp = rdist.init_from_env("nccl") if world > 1 else None
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    # RG_BENCH_BACKEND=gloo + RG_BENCH_SINGLE_DEVICE=1: debug aid to exercise the multi-process path on a 1-GPU box
+    dp = rdist.init_from_env(os.environ.get("RG_BENCH_BACKEND", "nccl")) if world > 1 else None
+    local = 0 if os.environ.get("RG_BENCH_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)

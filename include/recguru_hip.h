@@ -186,6 +186,16 @@ typedef struct {
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 
+/* ---- single-query attention for the last encoder layer --------------------------------------------
+ * Only enc_outputs[:, -1, :] is consumed on the hot path (AutoEnc4Rec_cross.py:122,154;
+ * gan_training.py:157-161): row L-1 of ScaledDotProductAttention (Transformer/transformer.py:119-129)
+ * with the key-pad replace-fill.  qlast [B,H*32], kv [B,L,2*H*32] (K | V), ctx / dq [B,H*32],
+ * dkv [B,L,2*H*32] fully overwritten. */
+int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids, int64_t pad_value, void* ctx,
+                      int B, int L, int H, float scale, int dtype, void* stream);
+int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
+                      void* dq, void* dkv, int B, int L, int H, float scale, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

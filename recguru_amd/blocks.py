@@ -120,6 +120,11 @@ class EncoderLayer(nn.Module):
                                         self.enc_self_attn.n_heads,
                                         *self.enc_self_attn.self_params(), *self.pos_ffn.params())
 
+    def forward_last(self, x, key_ids, pad_value, rowmask):
+        """Row L-1 of forward() only -> [B, d] (all the hot path ever reads of the last layer)."""
+        return ops.EncoderLastLayerFn.apply(x, key_ids, rowmask, int(pad_value), self.enc_self_attn.n_heads,
+                                            *self.enc_self_attn.self_params(), *self.pos_ffn.params())
+
 
 class DecoderLayer(nn.Module):
     def __init__(self, d_model, d_ff, d_k, d_v, n_heads, device, dropout):
@@ -146,10 +151,15 @@ class EncoderM(nn.Module):
         self.layers = nn.ModuleList([EncoderLayer(d_model, d_ff, d_k, d_v, n_heads, device, dropout)
                                      for _ in range(n_layers)])
 
-    def forward(self, x, key_ids, pad_value, pad_mask):
-        for layer in self.layers:
+    def forward(self, x, key_ids, pad_value, pad_mask, last_only=False):
+        """last_only=True returns enc_outputs[:, -1, :] ([B, d]) without computing the other rows of
+        the last layer (identical values and gradients)."""
+        n = len(self.layers)
+        for i, layer in enumerate(self.layers):
+            if last_only and i == n - 1:
+                return layer.forward_last(x, key_ids, pad_value, pad_mask)
             x = layer(x, key_ids, pad_value, pad_mask)
-        return x
+        return x[:, -1, :] if last_only else x
 
 
 class DecoderM(nn.Module):

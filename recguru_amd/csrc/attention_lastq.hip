@@ -1,0 +1,179 @@
+// Single-query attention for the LAST encoder layer.
+//
+// Every consumer of EncoderM's output on the hot path reads only position L-1
+// (enc_outputs[:, -1, :]: AutoEnc4Rec_cross.py:122,154; AutoEnc4Rec.py:188; gan_training.py:157-161),
+// so in the last layer only K and V are needed for all positions; Q, the softmax, the output
+// projection and the FFN are needed for ONE query per sequence.  Results are identical to row L-1 of
+// the full ScaledDotProductAttention (Transformer/transformer.py:119-129), incl. the -1e9 replace fill.
+// One wave per (sequence, head); lanes stride the keys; f32 math.
+#include "rg_common.cuh"
+#include "../../include/recguru_hip.h"
+
+#define DK 32
+#define NEG_FILL (-1e9f)
+#define MASK_BIG (-1e30f)
+#define MAXKPL 8       // keys per lane: L <= 512
+
+template <typename T>
+__device__ __forceinline__ void load_row32(float* o, const T* p) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) load8(o + 8 * c, p + 8 * c);
+}
+template <typename T>
+__device__ __forceinline__ void store_row32(T* p, const float* v) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) store8(p + 8 * c, v + 8 * c);
+}
+
+// scores of this lane's keys (raw dot * scale, replaced / -inf where masked), returns the row max
+template <typename T>
+__device__ __forceinline__ float lastq_scores(float (&s)[MAXKPL], const float* q, const T* __restrict__ kv, int ldkv, int koff,
+                                              const int64_t* __restrict__ ids, int64_t pad_value, int L, int lane, float scale) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) {
+    const int key = lane + 64 * i;
+    float v = -INFINITY;
+    if (key < L) {
+      float k[32];
+      load_row32(k, kv + (size_t)key * ldkv + koff);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) d += q[j] * k[j];
+      v = (ids[key] == pad_value) ? MASK_BIG : d * scale;
+    }
+    s[i] = v;
+    mx = fmaxf(mx, v);
+  }
+  return wave_max(mx);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
+                                                             const int64_t* __restrict__ key_ids, int64_t pad_value,
+                                                             T* __restrict__ ctx, int B, int L, int H, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= B * H) return;
+  const int b = wg / H, h = wg % H, P = H * DK;
+  float q[32];
+  load_row32(q, qlast + (size_t)b * P + h * DK);
+  const T* kvb = kv + (size_t)b * L * 2 * P;
+  float s[MAXKPL];
+  const float mx = lastq_scores<T>(s, q, kvb, 2 * P, h * DK, key_ids + (size_t)b * L, pad_value, L, lane, scale);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  float o[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) o[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) {
+    const int key = lane + 64 * i;
+    if (key < L) {
+      float v[32];
+      load_row32(v, kvb + (size_t)key * 2 * P + P + h * DK);
+      const float p = s[i] * inv;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) o[j] += p * v[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) o[j] = wave_sum(o[j]);
+  if (lane == 0) store_row32(ctx + (size_t)b * P + h * DK, o);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
+                                                             const T* __restrict__ dctx, const int64_t* __restrict__ key_ids,
+                                                             int64_t pad_value, T* __restrict__ dq, T* __restrict__ dkv,
+                                                             int B, int L, int H, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wg >= B * H) return;
+  const int b = wg / H, h = wg % H, P = H * DK;
+  float q[32], g[32];
+  load_row32(q, qlast + (size_t)b * P + h * DK);
+  load_row32(g, dctx + (size_t)b * P + h * DK);
+  const T* kvb = kv + (size_t)b * L * 2 * P;
+  T* dkvb = dkv + (size_t)b * L * 2 * P;
+  const int64_t* ids = key_ids + (size_t)b * L;
+  float s[MAXKPL];
+  const float mx = lastq_scores<T>(s, q, kvb, 2 * P, h * DK, ids, pad_value, L, lane, scale);
+  const bool full = mx < 0.5f * MASK_BIG;          // every key replaced: uniform row, no gradient to q / k (Q3)
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+  sum = wave_sum(sum);
+  const float inv = 1.f / sum;
+  float dp[MAXKPL];
+  float delta = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) {
+    const int key = lane + 64 * i;
+    dp[i] = 0.f;
+    s[i] *= inv;
+    if (key < L) {
+      float v[32], dv[32];
+      load_row32(v, kvb + (size_t)key * 2 * P + P + h * DK);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { d += g[j] * v[j]; dv[j] = s[i] * g[j]; }
+      dp[i] = d;
+      delta += s[i] * d;
+      store_row32(dkvb + (size_t)key * 2 * P + P + h * DK, dv);
+    }
+  }
+  delta = wave_sum(delta);
+  float dqa[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) dqa[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXKPL; ++i) {
+    const int key = lane + 64 * i;
+    if (key < L) {
+      const bool masked = full || ids[key] == pad_value;
+      const float ds = masked ? 0.f : s[i] * (dp[i] - delta) * scale;
+      float k[32], dk[32];
+      load_row32(k, kvb + (size_t)key * 2 * P + h * DK);
+#pragma unroll
+      for (int j = 0; j < 32; ++j) { dqa[j] += ds * k[j]; dk[j] = ds * q[j]; }
+      store_row32(dkvb + (size_t)key * 2 * P + h * DK, dk);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 32; ++j) dqa[j] = wave_sum(dqa[j]);
+  if (lane == 0) store_row32(dq + (size_t)b * P + h * DK, dqa);
+}
+
+extern "C" int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids, int64_t pad_value, void* ctx,
+                                 int B, int L, int H, float scale, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((B * H + 3) / 4), block(256);
+  if (dtype == RG_BF16)
+    hipLaunchKernelGGL(attn_lastq_fwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, key_ids, pad_value, (__bf16*)ctx, B, L, H, scale);
+  else if (dtype == RG_F32)
+    hipLaunchKernelGGL(attn_lastq_fwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, key_ids, pad_value, (float*)ctx, B, L, H, scale);
+  else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_fwd: bad dtype");
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
+                                 void* dq, void* dkv, int B, int L, int H, float scale, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((B * H + 3) / 4), block(256);
+  if (dtype == RG_BF16)
+    hipLaunchKernelGGL(attn_lastq_bwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, (const __bf16*)dctx, key_ids, pad_value, (__bf16*)dq, (__bf16*)dkv, B, L, H, scale);
+  else if (dtype == RG_F32)
+    hipLaunchKernelGGL(attn_lastq_bwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, (const float*)dctx, key_ids, pad_value, (float*)dq, (float*)dkv, B, L, H, scale);
+  else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_bwd: bad dtype");
+  RG_CHECK_LAUNCH();
+  return 0;
+}

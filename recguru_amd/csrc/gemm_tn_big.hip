@@ -154,6 +154,7 @@ int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
   if (a->N1 == 512 && a->N2 == 128) return launch_big<512, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 512) return launch_big<128, 512>(*a, s);
   if (a->N1 == 384 && a->N2 == 128) return launch_big<384, 128>(*a, s);
+  if (a->N1 == 256 && a->N2 == 128) return launch_big<256, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 128) return launch_big<128, 128>(*a, s);
   return 1;
 }

@@ -164,6 +164,8 @@ int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 1;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if (nkc == 1 && ncb == 1) return launch_ws<1, 1>(*a, s);
+  if (nkc == 1 && ncb == 2) return launch_ws<1, 2>(*a, s);
+  if (nkc == 2 && ncb == 1) return launch_ws<2, 1>(*a, s);
   if (nkc == 1 && ncb == 3) return launch_ws<1, 3>(*a, s);
   if (nkc == 1 && ncb == 4) return launch_ws<1, 4>(*a, s);
   if (nkc == 3 && ncb == 1) return launch_ws<3, 1>(*a, s);

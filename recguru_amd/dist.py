@@ -26,7 +26,7 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
-            torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(0 if os.environ.get("RG_BENCH_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend, rank=int(os.environ["RANK"]), world_size=world)
     return DataParallel()
 

@@ -56,7 +56,8 @@ class PostAttnArgs(ctypes.Structure):
 SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
            "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
-           "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd"]
+           "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
+           "rg_attn_lastq_fwd", "rg_attn_lastq_bwd"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -296,6 +297,26 @@ def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_r
                      d, k, mode, skip_row)
     _check(lib().rg_item_loss_bwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_bwd")
     return dh
+
+
+def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H):
+    """q_last [B,P], kv [B,L,2P] (K|V) -> ctx_last [B,P]: row L-1 of the attention."""
+    B, L, P2 = kv.shape
+    assert P2 == 2 * H * 32 and kv.is_contiguous() and q_last.is_contiguous() and key_ids.is_contiguous()
+    ctx = torch.empty_like(q_last)
+    _check(lib().rg_attn_lastq_fwd(_vp(q_last), _vp(kv), _vp(key_ids), c_l(int(pad_value)), _vp(ctx), B, L, H,
+                                   c_f(32 ** -0.5), dt_of(kv), _stream()), "rg_attn_lastq_fwd")
+    return ctx
+
+
+def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H):
+    B, L, P2 = kv.shape
+    assert dctx.is_contiguous()
+    dq = torch.empty_like(q_last)
+    dkv = torch.empty_like(kv)
+    _check(lib().rg_attn_lastq_bwd(_vp(q_last), _vp(kv), _vp(dctx), _vp(key_ids), c_l(int(pad_value)), _vp(dq), _vp(dkv),
+                                   B, L, H, c_f(32 ** -0.5), dt_of(kv), _stream()), "rg_attn_lastq_bwd")
+    return dq, dkv
 
 
 def post_attn_supported(d, P, dff):

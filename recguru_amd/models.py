@@ -115,18 +115,18 @@ class MyAuto4Rec_c(nn.Module):
         return self.encoder_a if domain == "a" else self.encoder_b
 
     # ---- reference surface --------------------------------------------------------------------
-    def get_seq_embed(self, enc_inputs, domain="a", mask=None):
-        """AutoEnc4Rec_cross.py:93-115.  The key-pad value is the EOS id vocab_size_{a|b} (quirk Q2)."""
+    def get_seq_embed(self, enc_inputs, domain="a", mask=None, last_only=False):
+        """AutoEnc4Rec_cross.py:93-115.  The key-pad value is the EOS id vocab_size_{a|b} (quirk Q2).
+        last_only=True returns just [:, -1, :] (what every hot-path caller slices out)."""
         L = enc_inputs.shape[1]
         mask = mask.reshape(-1, L)
         x = self._embed(enc_inputs, domain, mask)
         pad_value = self.param.vocab_size_a if domain == "a" else self.param.vocab_size_b
-        return self._encoder(domain)(x, enc_inputs, pad_value, mask)
+        return self._encoder(domain)(x, enc_inputs, pad_value, mask, last_only=last_only)
 
     def _decode(self, stack, enc_inputs, dec_inputs, domain, mask, d_mask, detach_enc=False):
         L = self.param.enc_maxlen
-        enc_outputs = self.get_seq_embed(enc_inputs, domain, mask.reshape(-1, L))
-        u = enc_outputs[:, -1, :]
+        u = self.get_seq_embed(enc_inputs, domain, mask.reshape(-1, L), last_only=True)
         if detach_enc:
             u = u.detach()
         x = self._embed(dec_inputs, domain, d_mask)
@@ -189,15 +189,14 @@ class MyAuto4Rec(nn.Module):
         # padding_idx row receives no gradient (AutoEnc4Rec.py:153)
         return ops.embed_pe(self.src_emb.weight, self.pos_emb.table(), ids, mask, skip_row=self.pad_index)
 
-    def get_seq_embed(self, enc_inputs):
+    def get_seq_embed(self, enc_inputs, last_only=False):
         """AutoEnc4Rec.py:175-184: real pad id for both the row mask and the key mask."""
         mask = _f32_mask(enc_inputs, self.pad_index)
         x = self._embed(enc_inputs, mask)
-        return self.encoder(x, enc_inputs, self.pad_index, mask), None
+        return self.encoder(x, enc_inputs, self.pad_index, mask, last_only=last_only), None
 
     def decode_with(self, stack, enc_inputs, dec_inputs, detach_enc=False):
-        enc_outputs, _ = self.get_seq_embed(enc_inputs)
-        u = enc_outputs[:, -1, :]
+        u, _ = self.get_seq_embed(enc_inputs, last_only=True)
         if detach_enc:
             u = u.detach()
         mask = _f32_mask(dec_inputs, self.pad_index)

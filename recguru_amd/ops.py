@@ -215,6 +215,69 @@ class EncoderLayerFn(torch.autograd.Function):
         return (dx.view(B, L, d), None, None, None, None, None) + ga + gf
 
 
+class EncoderLastLayerFn(torch.autograd.Function):
+    """Last EncoderLayer evaluated for position L-1 only -> [B, d].
+
+    Every consumer of EncoderM's output reads enc_outputs[:, -1, :] (AutoEnc4Rec_cross.py:122,154;
+    AutoEnc4Rec.py:188; gan_training.py:157-161), so in the last layer K and V are needed for all
+    positions but Q, softmax, output projection, FFN and both LayerNorms only for one row per
+    sequence.  Output and gradients equal row L-1 of EncoderLayerFn."""
+
+    @staticmethod
+    def forward(ctx, x, key_ids, rowmask, pad_value, H,
+                Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
+        B, L, d = x.shape
+        need = any(ctx.needs_input_grad)
+        x2 = x.contiguous().view(B * L, d)
+        key_ids = key_ids.contiguous()
+        rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
+        x_last = x[:, -1, :].contiguous()
+        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), torch.cat([bk.detach(), bv.detach()]))
+        q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
+        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H)
+        if _fusable(x_last, Wo, W1):
+            out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
+                                        rm_last, save=need, eps=LN_EPS)
+            if need:
+                y, rstd1, sf = sv["y"], sv["rstd1"], (sv["h1"], sv["rstd2"])
+        else:
+            rstd1 = torch.empty(B, device=x.device, dtype=torch.float32)
+            y = hip.gemm_nt(c_last, shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x_last,
+                            gamma=g1.detach(), beta=be1.detach(), rstd_out=rstd1, eps=LN_EPS)
+            out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2)
+        if need:
+            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf,
+                                  Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
+            ctx.meta = (B, L, pad_value, H)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2,
+         Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
+        B, L, pad_value, H = ctx.meta
+        d = x2.shape[1]
+        P = Wo.shape[1]
+        dev = dout.device
+        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, W1, W2, g2, be2)
+        dg1, dbe1 = _z(d, dout), _z(d, dout)
+        dz = hip.ln_bwd(dy, y, rstd1, g1.detach(), be1.detach(), None, dg1, dbe1)
+        dWo, dbo = torch.zeros(d, P, device=dev), _z(d, dout)
+        hip.gemm_tn(dz, c_last, dWo, dbo)
+        dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
+        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H)
+        dkv2 = dkv.view(B * L, 2 * P)
+        dWq, dbq = torch.zeros(P, d, device=dev), _z(P, dout)
+        hip.gemm_tn(dq_last, x_last, dWq, dbq)
+        dWkv, dbkv = torch.zeros(2 * P, d, device=dev), _z(2 * P, dout)
+        hip.gemm_tn(dkv2, x2, dWkv, dbkv)
+        dx = hip.gemm_nt(dkv2, shadow_cat((Wk, Wv), transpose=True)).view(B, L, d)
+        dx_last = hip.gemm_nt(dq_last, shadow(Wq, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
+        dx[:, -1, :] += dx_last
+        return ((dx, None, None, None, None, dWq, dbq, dWkv[:P], dbkv[:P], dWkv[P:], dbkv[P:], dWo, dbo, dg1, dbe1) + gf)
+
+
 class DecoderLayerFn(torch.autograd.Function):
     """DecoderLayer.forward + `* pad_m` (transformer.py:257-261,:533-539) with the decoder-encoder
     attention in its collapsed form (quirk Q1): K/V are L copies of u = enc_out[:, -1], so

@@ -85,8 +85,7 @@ def get_user_embed(model, seq, domain, param, device, pad_idx):
     """gan_training.py:152-162: natural (seq != pad) mask, last position of the encoder output."""
     seq = seq.to(device)
     mask = get_pad_mask(seq, pad_idx, device)
-    out = _unwrap(model).get_seq_embed(seq, domain=domain, mask=mask.view(-1, param.rec_maxlen))
-    return out[:, -1, :].contiguous()
+    return _unwrap(model).get_seq_embed(seq, domain=domain, mask=mask.view(-1, param.rec_maxlen), last_only=True)
 
 
 class _Mean(torch.autograd.Function):

@@ -414,3 +414,29 @@ def test_gemm_tn_big_matches_generic(N1, N2, gelu):
     torch.testing.assert_close(dW, ref, rtol=2e-2, atol=0.15)
     torch.testing.assert_close(dW, dW2, rtol=1e-2, atol=5e-2)
     torch.testing.assert_close(cs, 0.5 * Y.float().sum(0), rtol=2e-2, atol=5e-2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,L,H", [(3, 12, 2), (2, 200, 4), (2, 70, 1), (1, 400, 2)])
+def test_attn_lastq_matches_full_row(dt, B, L, H):
+    """Single-query kernels == row L-1 of the full attention (values and gradients)."""
+    from recguru_amd import hip
+    P = H * 32
+    qkv = rnd(B, L, 3 * P, dt=dt, seed=L)
+    ids = _ids(B, L, L + 3)
+    if B >= 2:
+        ids[0, :] = 7
+        ids[0, : L - 1] = 0          # only the last key is live
+        ids[1, :] = 0                # every key replaced: uniform row, no gradient into q / k (Q3)
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(x, ids, 0, False, H)
+    dctx = rnd(B, P, dt=dt, seed=5)
+    ref[:, -1, :].backward(dctx.float())
+    q_last = qkv[:, -1, :P].contiguous()
+    kv = qkv[:, :, P:].contiguous()
+    ctx = hip.attn_lastq_fwd(q_last, kv, ids, 0, H)
+    torch.testing.assert_close(ctx.float(), ref[:, -1, :].detach(), **tol(dt))
+    dq, dkv = hip.attn_lastq_bwd(q_last, kv, dctx, ids, 0, H)
+    t = dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(dq.float(), x.grad[:, -1, :P], **t)
+    torch.testing.assert_close(dkv.float(), x.grad[:, :, P:], **t)

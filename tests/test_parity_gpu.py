@@ -233,3 +233,26 @@ def test_bf16_tier_drift(name, capsys):
     with capsys.disabled():
         print("[bf16 tier %s] encoder l1.weight grad max err rel-to-max %.3g" % (name, g_rel))
     assert g_rel < 0.15
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_last_only_equals_full_encoder(name):
+    """EncoderM(last_only=True) == EncoderM(...)[:, -1, :], values and parameter gradients."""
+    z = load_case(name)
+    param, G, D = build_cross(z)
+    bt = batches(z, "cuda")
+    seq = bt["a"][0]
+    mask = (seq != 0).float()
+    full = G.get_seq_embed(seq, "a", mask)[:, -1, :]
+    w = torch.linspace(-1, 1, full.numel(), device="cuda").view_as(full)
+    (full * w).sum().backward()
+    gfull = {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None}
+    G.zero_grad(set_to_none=True)
+    last = G.get_seq_embed(seq, "a", mask, last_only=True)
+    torch.testing.assert_close(last, full.detach(), rtol=1e-4, atol=1e-5)
+    (last * w).sum().backward()
+    for k, p in G.named_parameters():
+        if k in gfull:
+            scale = float(gfull[k].abs().max())
+            # WK.bias is structurally gradient-free (softmax invariance): both paths give rounding noise
+            torch.testing.assert_close(p.grad, gfull[k], rtol=2e-3, atol=2e-4 * scale + 1e-6, msg=lambda m: k + ": " + m)
