@@ -83,6 +83,7 @@ typedef struct {
   void* ctx; float* lse;      /* lse may be NULL (inference) */
   int B, L, H, dk;
   float scale;                /* 1/sqrt(d_k), transformer.py:120 */
+  float drop_p; unsigned long long seed;   /* attention-probability dropout, transformer.py:126-127 */
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
 
@@ -92,6 +93,7 @@ typedef struct {
   void* dqkv;                 /* [B,L,3*H*32] dtype, fully overwritten */
   int B, L, H, dk;
   float scale;
+  float drop_p; unsigned long long seed;   /* must equal the forward's */
 } rg_attn_bwd_args;
 int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream);
 
@@ -102,9 +104,11 @@ int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream
  * mask: [ntok] f32, out: [ntok,d] dtype.  Backward accumulates dx*mask into the dense f32 gradient
  * dE[rows,d]; skip_row (e.g. padding_idx 0 of AutoEnc4Rec.py:153) receives nothing (-1 = none). */
 int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
-                    long long ntok, int L, int d, int dtype, void* stream);
+                    long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
 int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
-                         long long skip_row, int dtype, void* stream);
+                         long long skip_row, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* drop_p / seed: nn.Dropout of PositionalEncoding.forward (transformer.py:106); the mask is a stateless
+ * hash of (seed, element index), regenerated by the backward.  drop_p = 0 disables it. */
 
 /* ---- LayerNorm backward (from the saved output y and rstd) ---------------------------------------
  * replaces autograd of nn.LayerNorm(d, eps=1e-8) at transformer.py:161,188 incl. the row mask of
@@ -192,9 +196,10 @@ int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* 
  * with the key-pad replace-fill.  qlast [B,H*32], kv [B,L,2*H*32] (K | V), ctx / dq [B,H*32],
  * dkv [B,L,2*H*32] fully overwritten. */
 int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids, int64_t pad_value, void* ctx,
-                      int B, int L, int H, float scale, int dtype, void* stream);
+                      int B, int L, int H, float scale, float drop_p, unsigned long long seed, int dtype, void* stream);
 int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
-                      void* dq, void* dkv, int B, int L, int H, float scale, int dtype, void* stream);
+                      void* dq, void* dkv, int B, int L, int H, float scale, float drop_p, unsigned long long seed,
+                      int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
   const int nqt = (L + 15) / 16;
+  const DropCfg drop = make_drop(a.drop_p, a.seed);
 
   // first Q fragment in flight during staging
   Frag<T> qnext;
@@ -161,6 +162,15 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     const float inv = __builtin_amdgcn_rcpf(sum);
+    if (drop.thresh) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
+      const unsigned long long base = (((unsigned long long)b * a.H + h) * L + min(q, L - 1)) * L;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt)
+        if (kt < nkt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kt][r] *= rg_keep(drop, base + kt * 16 + 4 * lg + r);
+        }
+    }
     ASTAMP(2);
 
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -227,6 +237,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
   const T* __restrict__ O = reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK;
   T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
+  const DropCfg gdrop = make_drop(a.drop_p, a.seed);
+  const unsigned long long gbase = ((unsigned long long)b * a.H + h) * L;
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -290,8 +302,9 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
           // fully masked row: lse = -1e9 + log L rounds to -1e9 in f32, the row is uniform 1/L (Q3)
           const float lq = lse_s[min(q, LPK - 1)];
           float pv = (q < L && key < L) ? (lq < -5e8f ? 1.f / (float)L : __expf(sc - lq)) : 0.f;
-          p[u][r] = pv;
-          ds[u][r] = masked ? 0.f : pv * (dp[r] - dl_s[q]) * a.scale;
+          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * L + min(key, L - 1)) : 1.f;
+          p[u][r] = pv * ks;
+          ds[u][r] = masked ? 0.f : pv * (dp[r] * ks - dl_s[q]) * a.scale;
         }
       }
       Frag<T> pf, dsf;
@@ -348,7 +361,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
           const int key = ks * 32 + u * 16 + 4 * lg + r;
           const bool masked = (key >= L) || kpad[key] || (a.causal && key > q);
           const float pv = (q < L && key < L && !masked) ? __expf(sv[r] * a.scale - lse_q) : 0.f;
-          ds[u][r] = pv * (dp[r] - dl_q) * a.scale;
+          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * L + min(key, L - 1)) : 1.f;
+          ds[u][r] = pv * (dp[r] * ks - dl_q) * a.scale;
         }
       }
       Frag<T> dsf;
@@ -402,6 +416,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const float c2 = a.scale * 1.4426950408889634f;
+  const DropCfg drop = make_drop(a.drop_p, a.seed);
+  const unsigned long long dbase = ((unsigned long long)b * a.H + h) * L;
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -462,8 +478,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
           float sc = sv[r] + kb;                                        // -1e30 / -inf where replaced
           if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
-          ds[u][r] = pe * (dp[r] - d4[r]) * a.scale;
-          p[u][r] = pe + ((key < L) ? r4[r] : 0.f);                     // uniform 1/L rows (Q3)
+          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * L + min(key, L - 1)) : 1.f;
+          ds[u][r] = pe * (dp[r] * ks - d4[r]) * a.scale;
+          p[u][r] = (pe + ((key < L) ? r4[r] : 0.f)) * ks;              // uniform 1/L rows (Q3); dropped map feeds dV
         }
       }
       Frag<T> pf, dsf;
@@ -516,7 +533,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
           float sc = sv[r] + kb4[r];
           if (CAUSAL) sc = (k0 + r > qrel) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -lse_q));
-          ds[u][r] = pe * (dp[r] - dl_q) * a.scale;
+          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q, L - 1)) * L + min(k0 + 4 * lg + r, L - 1)) : 1.f;
+          ds[u][r] = pe * (dp[r] * ks - dl_q) * a.scale;
         }
       }
       Frag<T> dsf;

@@ -51,7 +51,7 @@ __device__ __forceinline__ float lastq_scores(float (&s)[MAXKPL], const float* q
 template <typename T>
 __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
                                                              const int64_t* __restrict__ key_ids, int64_t pad_value,
-                                                             T* __restrict__ ctx, int B, int L, int H, float scale) {
+                                                             T* __restrict__ ctx, int B, int L, int H, float scale, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wg >= B * H) return;
@@ -66,6 +66,11 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict
   for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
+  const unsigned long long dbase = (((unsigned long long)b * H + h) * L + (L - 1)) * L;   // same index space as the full kernel
+  if (drop.thresh) {
+#pragma unroll
+    for (int i = 0; i < MAXKPL; ++i) s[i] *= rg_keep(drop, dbase + min(lane + 64 * i, L - 1));
+  }
   float o[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) o[j] = 0.f;
@@ -89,11 +94,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
                                                              const T* __restrict__ dctx, const int64_t* __restrict__ key_ids,
                                                              int64_t pad_value, T* __restrict__ dq, T* __restrict__ dkv,
-                                                             int B, int L, int H, float scale) {
+                                                             int B, int L, int H, float scale, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wg >= B * H) return;
   const int b = wg / H, h = wg % H, P = H * DK;
+  const unsigned long long dbase = (((unsigned long long)b * H + h) * L + (L - 1)) * L;
   float q[32], g[32];
   load_row32(q, qlast + (size_t)b * P + h * DK);
   load_row32(g, dctx + (size_t)b * P + h * DK);
@@ -118,11 +124,12 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict
     if (key < L) {
       float v[32], dv[32];
       load_row32(v, kvb + (size_t)key * 2 * P + P + h * DK);
+      const float ks = drop.thresh ? rg_keep(drop, dbase + key) : 1.f;
       float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { d += g[j] * v[j]; dv[j] = s[i] * g[j]; }
-      dp[i] = d;
-      delta += s[i] * d;
+      for (int j = 0; j < 32; ++j) { d += g[j] * v[j]; dv[j] = s[i] * ks * g[j]; }
+      dp[i] = d * ks;            // d(loss)/d(undropped probability)
+      delta += s[i] * dp[i];
       store_row32(dkvb + (size_t)key * 2 * P + P + h * DK, dv);
     }
   }
@@ -149,30 +156,33 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict
 }
 
 extern "C" int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids, int64_t pad_value, void* ctx,
-                                 int B, int L, int H, float scale, int dtype, void* stream) {
+                                 int B, int L, int H, float scale, float drop_p, unsigned long long seed, int dtype, void* stream) {
   if (B <= 0) return 0;
+  const DropCfg drop = make_drop(drop_p, seed);
   if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((B * H + 3) / 4), block(256);
   if (dtype == RG_BF16)
-    hipLaunchKernelGGL(attn_lastq_fwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, key_ids, pad_value, (__bf16*)ctx, B, L, H, scale);
+    hipLaunchKernelGGL(attn_lastq_fwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, key_ids, pad_value, (__bf16*)ctx, B, L, H, scale, drop);
   else if (dtype == RG_F32)
-    hipLaunchKernelGGL(attn_lastq_fwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, key_ids, pad_value, (float*)ctx, B, L, H, scale);
+    hipLaunchKernelGGL(attn_lastq_fwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, key_ids, pad_value, (float*)ctx, B, L, H, scale, drop);
   else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_fwd: bad dtype");
   RG_CHECK_LAUNCH();
   return 0;
 }
 
 extern "C" int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
-                                 void* dq, void* dkv, int B, int L, int H, float scale, int dtype, void* stream) {
+                                 void* dq, void* dkv, int B, int L, int H, float scale, float drop_p, unsigned long long seed,
+                                 int dtype, void* stream) {
   if (B <= 0) return 0;
+  const DropCfg drop = make_drop(drop_p, seed);
   if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((B * H + 3) / 4), block(256);
   if (dtype == RG_BF16)
-    hipLaunchKernelGGL(attn_lastq_bwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, (const __bf16*)dctx, key_ids, pad_value, (__bf16*)dq, (__bf16*)dkv, B, L, H, scale);
+    hipLaunchKernelGGL(attn_lastq_bwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, (const __bf16*)dctx, key_ids, pad_value, (__bf16*)dq, (__bf16*)dkv, B, L, H, scale, drop);
   else if (dtype == RG_F32)
-    hipLaunchKernelGGL(attn_lastq_bwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, (const float*)dctx, key_ids, pad_value, (float*)dq, (float*)dkv, B, L, H, scale);
+    hipLaunchKernelGGL(attn_lastq_bwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, (const float*)dctx, key_ids, pad_value, (float*)dq, (float*)dkv, B, L, H, scale, drop);
   else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_bwd: bad dtype");
   RG_CHECK_LAUNCH();
   return 0;

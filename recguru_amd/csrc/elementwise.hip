@@ -20,7 +20,7 @@ template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restrict__ table, const float* __restrict__ pe,
                                                                const int64_t* __restrict__ ids,
                                                                const float* __restrict__ mask, T* __restrict__ out,
-                                                               long long ntok, int L, int d) {
+                                                               long long ntok, int L, int d, DropCfg drop) {
   const int cpr = d >> 3;
   const long long total = ntok * cpr;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
@@ -34,6 +34,10 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
       load8(p, pe + (size_t)(tok % L) * d + c8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
+      if (drop.thresh) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= rg_keep(drop, (unsigned long long)tok * d + c8 + j);
+      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
@@ -47,7 +51,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ ids,
                                                                     const float* __restrict__ mask, float* __restrict__ dE,
-                                                                    long long ntok, int d, long long skip_row) {
+                                                                    long long ntok, int d, long long skip_row, DropCfg drop) {
   const int lane = threadIdx.x & 63;
   const long long wave = ((long long)blockIdx.x * EW_BLOCK + threadIdx.x) >> 6;
   const long long nwaves = ((long long)gridDim.x * EW_BLOCK) >> 6;
@@ -55,7 +59,11 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
     const float m = mask[tok];
     const long long row = ids[tok];
     if (m == 0.f || row == skip_row) continue;
-    for (int e = lane; e < d; e += 64) atomicAdd(dE + (size_t)row * d + e, (float)dx[(size_t)tok * d + e] * m);
+    for (int e = lane; e < d; e += 64) {
+      float g = (float)dx[(size_t)tok * d + e] * m;
+      if (drop.thresh) g *= rg_keep(drop, (unsigned long long)tok * d + e);
+      atomicAdd(dE + (size_t)row * d + e, g);
+    }
   }
 }
 
@@ -309,25 +317,27 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict_
   RG_CHECK_LAUNCH(); return 0;
 
 extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
-                               long long ntok, int L, int d, int dtype, void* stream) {
+                               long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  const DropCfg drop = make_drop(drop_p, seed);
   if (ntok <= 0) return 0;
   if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(ntok * (d >> 3), EW_BLOCK);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_pe_fwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)table, pe, ids, mask, (__bf16*)out, ntok, L, d),
-             hipLaunchKernelGGL(embed_pe_fwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)table, pe, ids, mask, (float*)out, ntok, L, d),
+             hipLaunchKernelGGL(embed_pe_fwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)table, pe, ids, mask, (__bf16*)out, ntok, L, d, drop),
+             hipLaunchKernelGGL(embed_pe_fwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)table, pe, ids, mask, (float*)out, ntok, L, d, drop),
              "embed_pe_fwd")
 }
 
 extern "C" int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
-                                    long long skip_row, int dtype, void* stream) {
+                                    long long skip_row, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  const DropCfg drop = make_drop(drop_p, seed);
   if (ntok <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(ntok, 4);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_scatter_bwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)dx, ids, mask, dE, ntok, d, skip_row),
-             hipLaunchKernelGGL(embed_scatter_bwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)dx, ids, mask, dE, ntok, d, skip_row),
+             hipLaunchKernelGGL(embed_scatter_bwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)dx, ids, mask, dE, ntok, d, skip_row, drop),
+             hipLaunchKernelGGL(embed_scatter_bwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)dx, ids, mask, dE, ntok, d, skip_row, drop),
              "embed_scatter_bwd")
 }
 

@@ -160,6 +160,31 @@ __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<true>
 template <typename T> struct Precise { static constexpr bool value = true; };
 template <> struct Precise<__bf16> { static constexpr bool value = false; };
 
+// Dropout masks are stateless: keep(seed, idx) is a hash of a per-call seed and the element index,
+// so the backward kernels regenerate exactly the forward's mask (nn.Dropout semantics: element kept
+// with probability 1-p and scaled by 1/(1-p); only the random stream differs from torch's Philox).
+struct DropCfg {
+  unsigned long long seed;
+  unsigned int thresh;       // drop iff hash < thresh  (thresh = p * 2^32); 0 = dropout off
+  float inv_keep;            // 1 / (1 - p)
+};
+__device__ __forceinline__ unsigned int rg_hash(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;      // splitmix64 finaliser
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return (unsigned int)((z ^ (z >> 31)) >> 32);
+}
+__device__ __forceinline__ float rg_keep(const DropCfg& c, unsigned long long idx) {
+  return (c.thresh != 0u && rg_hash(c.seed, idx) < c.thresh) ? 0.f : c.inv_keep;
+}
+__host__ __device__ inline DropCfg make_drop(float p, unsigned long long seed) {
+  DropCfg c;
+  c.seed = seed;
+  c.thresh = p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u;
+  c.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  return c;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release
 // fence, for which hipcc drains vmcnt(0) whenever a global store is outstanding -- and loads share that
 // counter, so every software-prefetched global load would be waited for at every barrier.

@@ -18,6 +18,7 @@ PRO_NONE, PRO_GELU = 0, 1
 EPI_NONE, EPI_RELU, EPI_MUL_POSMASK, EPI_GELU_GRAD, EPI_ADD, EPI_RESID_LN = 0, 1, 2, 3, 4, 5
 
 c_p, c_i, c_f, c_l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
+c_u64 = ctypes.c_uint64
 
 
 class GemmNtArgs(ctypes.Structure):
@@ -35,12 +36,13 @@ class GemmTnArgs(ctypes.Structure):
 
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
-                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f)]
+                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64)]
 
 
 class AttnBwdArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("dctx", c_p), ("ctx", c_p), ("lse", c_p), ("key_ids", c_p), ("pad_value", c_l),
-                ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f)]
+                ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f),
+                ("drop_p", c_f), ("seed", c_u64)]
 
 
 class PostAttnArgs(ctypes.Structure):
@@ -149,24 +151,24 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     return dW
 
 
-def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True):
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0):
     """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32)."""
     B, L, P3 = qkv.shape
     assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
-                 1.0 / (32 ** 0.5))
+                 1.0 / (32 ** 0.5), drop_p, seed)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 
 
-def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H):
+def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0):
     B, L, _ = qkv.shape
     assert dctx.is_contiguous() and ctx.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty_like(qkv)
     a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
-                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5))
+                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed)
     _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
     return dqkv
 
@@ -175,22 +177,22 @@ def _vp(t):
     return ctypes.c_void_p(_p(t))
 
 
-def embed_pe_fwd(table, pe, ids, mask, L):
+def embed_pe_fwd(table, pe, ids, mask, L, drop_p=0.0, seed=0):
     """(table[ids] + pe[t]) * mask -> [ntok, d] in table.dtype."""
     ntok, d = ids.numel(), table.shape[1]
     assert ids.dtype == torch.int64 and ids.is_contiguous() and mask.dtype == torch.float32 and mask.numel() == ntok
     assert pe.dtype == torch.float32 and pe.shape[1] == d and pe.is_contiguous() and table.is_contiguous()
     out = torch.empty(ntok, d, device=table.device, dtype=table.dtype)
-    _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, dt_of(table),
-                                 _stream()), "rg_embed_pe_fwd")
+    _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, c_f(drop_p),
+                                 c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd")
     return out
 
 
-def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1):
+def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     ntok, d = ids.numel(), dx.shape[-1]
     assert dx.is_contiguous() and dE.dtype == torch.float32 and dE.is_contiguous()
-    _check(lib().rg_embed_scatter_bwd(_vp(dx), _vp(ids), _vp(mask), _vp(dE), c_ll(ntok), d, c_ll(skip_row), dt_of(dx),
-                                      _stream()), "rg_embed_scatter_bwd")
+    _check(lib().rg_embed_scatter_bwd(_vp(dx), _vp(ids), _vp(mask), _vp(dE), c_ll(ntok), d, c_ll(skip_row),
+                                      c_f(drop_p), c_u64(seed), dt_of(dx), _stream()), "rg_embed_scatter_bwd")
     return dE
 
 
@@ -299,23 +301,24 @@ def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_r
     return dh
 
 
-def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H):
+def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H, drop_p=0.0, seed=0):
     """q_last [B,P], kv [B,L,2P] (K|V) -> ctx_last [B,P]: row L-1 of the attention."""
     B, L, P2 = kv.shape
     assert P2 == 2 * H * 32 and kv.is_contiguous() and q_last.is_contiguous() and key_ids.is_contiguous()
     ctx = torch.empty_like(q_last)
     _check(lib().rg_attn_lastq_fwd(_vp(q_last), _vp(kv), _vp(key_ids), c_l(int(pad_value)), _vp(ctx), B, L, H,
-                                   c_f(32 ** -0.5), dt_of(kv), _stream()), "rg_attn_lastq_fwd")
+                                   c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream()), "rg_attn_lastq_fwd")
     return ctx
 
 
-def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H):
+def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H, drop_p=0.0, seed=0):
     B, L, P2 = kv.shape
     assert dctx.is_contiguous()
     dq = torch.empty_like(q_last)
     dkv = torch.empty_like(kv)
     _check(lib().rg_attn_lastq_bwd(_vp(q_last), _vp(kv), _vp(dctx), _vp(key_ids), c_l(int(pad_value)), _vp(dq), _vp(dkv),
-                                   B, L, H, c_f(32 ** -0.5), dt_of(kv), _stream()), "rg_attn_lastq_bwd")
+                                   B, L, H, c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream()),
+           "rg_attn_lastq_bwd")
     return dq, dkv
 
 
@@ -393,19 +396,19 @@ def _work_gemm_tn(Y, X, *a, **k):
             T * (N1 + N2) * _esize(Y) + N1 * N2 * 4)
 
 
-def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, **k):
+def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, *a, **k):
     B, L, P3 = qkv.shape
     return ("attn_fwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 4.0 * B * H * L * L * 32,
             B * L * (P3 + P3 // 3) * _esize(qkv))
 
 
-def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H):
+def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, *a, **k):
     B, L, P3 = qkv.shape
     return ("attn_bwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 10.0 * B * H * L * L * 32,
             B * L * (2 * P3 + 2 * P3 // 3) * _esize(qkv))
 
 
-def _work_embed_fwd(table, pe, ids, mask, L):
+def _work_embed_fwd(table, pe, ids, mask, L, *a, **k):
     n, d = ids.numel(), table.shape[1]
     return "embed_pe_fwd_kernel", 0.0, n * d * 2 * _esize(table) + n * 12
 

@@ -440,3 +440,87 @@ def test_attn_lastq_matches_full_row(dt, B, L, H):
     t = dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=5e-2, atol=5e-2)
     torch.testing.assert_close(dq.float(), x.grad[:, -1, :P], **t)
     torch.testing.assert_close(dkv.float(), x.grad[:, :, P:], **t)
+
+
+# ------------------------------------------------------------------------------------------------
+# dropout: masks are a stateless hash of (seed, element index), so forward/backward consistency is a
+# deterministic property: the analytic gradient must match a finite difference taken WITH THE SAME
+# SEED, and the forward must be an unbiased, 1/(1-p)-rescaled subsample.
+# ------------------------------------------------------------------------------------------------
+def test_embed_dropout_statistics_and_backward():
+    from recguru_amd import hip
+    dt = torch.float32
+    B, L, V, d, p = 64, 50, 60, 64, 0.5
+    table = rnd(V + 2, d, dt=dt, seed=1) + 3.0                # keep values away from 0
+    pe = torch.zeros(64, d, device="cuda")
+    ids = torch.randint(1, V, (B, L)).cuda()
+    mask = torch.ones(B * L, device="cuda")
+    ref = hip.embed_pe_fwd(table, pe, ids, mask, L)
+    out = hip.embed_pe_fwd(table, pe, ids, mask, L, drop_p=p, seed=1234)
+    kept = out != 0
+    assert abs(float(kept.float().mean()) - (1 - p)) < 0.01
+    torch.testing.assert_close(out[kept], (ref / (1 - p))[kept], rtol=1e-6, atol=1e-6)
+    out2 = hip.embed_pe_fwd(table, pe, ids, mask, L, drop_p=p, seed=1234)
+    assert torch.equal(out, out2)                              # same seed -> same mask
+    out3 = hip.embed_pe_fwd(table, pe, ids, mask, L, drop_p=p, seed=99)
+    assert abs(float(((out3 != 0) == kept).float().mean()) - 0.5) < 0.02   # independent masks
+    dx = rnd(B * L, d, dt=dt, seed=4)
+    dE = torch.zeros(V + 2, d, device="cuda")
+    hip.embed_scatter_bwd(dx, ids, mask, dE, drop_p=p, seed=1234)
+    refE = torch.zeros(V + 2, d, device="cuda").index_add_(0, ids.view(-1), dx * kept.float() / (1 - p))
+    torch.testing.assert_close(dE, refE, rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("causal", [False, True])
+def test_attn_dropout_consistency(dt, causal):
+    """ctx is linear in V given the (fixed-seed) dropped attention map A: recover A from unit-vector V's,
+    check its statistics against the undropped map, then check backward against autograd through A."""
+    from recguru_amd import hip
+    B, L, H, p = 2, 32, 1, 0.5
+    P = 32
+    qk = rnd(B, L, 2 * P, dt=dt, seed=3)
+    ids = _ids(B, L, 5)
+    seed = 777
+
+    def run(v, drop):
+        qkv = torch.cat([qk, v.to(dt)], 2).contiguous()
+        return hip.attn_fwd(qkv, ids, 0, causal, H, drop_p=drop, seed=seed)
+
+    # V = one-hot of the key index in channel j (L == dv == 32): ctx[b, q, j] == A[b, q, j]
+    eye = torch.eye(L, device="cuda").unsqueeze(0).expand(B, L, L).contiguous()
+    A_drop = run(eye, p)[0].float()
+    A_ref = run(eye, 0.0)[0].float()
+    kept = A_drop != 0
+    live = A_ref > 1e-6
+    frac = float((kept & live).float().sum() / live.float().sum())
+    assert abs(frac - (1 - p)) < 0.06
+    t = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+    torch.testing.assert_close(A_drop[kept], (A_ref / (1 - p))[kept], **t)
+    # backward vs autograd through the explicit dropped map
+    v = rnd(B, L, P, dt=dt, seed=9)
+    qkv = torch.cat([qk, v], 2).contiguous()
+    ctx, lse = hip.attn_fwd(qkv, ids, 0, causal, H, drop_p=p, seed=seed)
+    dctx = rnd(B, L, P, dt=dt, seed=11)
+    dqkv = hip.attn_bwd(qkv, dctx, ctx, lse, ids, 0, causal, H, drop_p=p, seed=seed)
+    x = qkv.float().requires_grad_(True)
+    q_, k_, v_ = x.split(P, dim=2)
+    sc = q_ @ k_.transpose(1, 2) / math.sqrt(32)
+    m = ids.eq(0)[:, None, :].expand(B, L, L)
+    if causal:
+        m = m | torch.ones(L, L, dtype=torch.bool, device="cuda").triu(1)
+    a = torch.softmax(sc.masked_fill(m, -1e9), -1) * kept.float() / (1 - p)
+    ((a @ v_) * dctx.float()).sum().backward(retain_graph=True)
+    t = dict(rtol=1e-3, atol=1e-4) if dt == torch.float32 else dict(rtol=5e-2, atol=5e-2)
+    torch.testing.assert_close(dqkv.float(), x.grad, **t)
+    # single-query kernels share the index space of the full kernel (row L-1)
+    if not causal:
+        q_last = qkv[:, -1, :P].contiguous()
+        kvt = qkv[:, :, P:].contiguous()
+        c_last = hip.attn_lastq_fwd(q_last, kvt, ids, 0, H, drop_p=p, seed=seed)
+        torch.testing.assert_close(c_last.float(), ctx[:, -1, :].float(), **(tol(dt)))
+        dq, dkv = hip.attn_lastq_bwd(q_last, kvt, dctx[:, -1, :].contiguous(), ids, 0, H, drop_p=p, seed=seed)
+        x.grad = None
+        ((a @ v_)[:, -1, :] * dctx[:, -1, :].float()).sum().backward()
+        torch.testing.assert_close(dq.float(), x.grad[:, -1, :P], **t)
+        torch.testing.assert_close(dkv.float(), x.grad[:, :, P:], **t)
