@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--n_negs", type=int, default=30)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dropout", type=float, default=0.5,
+                    help="transformer dropout (reference config_auto4rec.py:225: 0.5); the discriminator's 0.2 is active too")
     ap.add_argument("--batches_per_domain", type=int, default=2, help="distinct synthetic batches cycled")
     ap.add_argument("--no_cpu_baseline", action="store_true")
     ap.add_argument("--cpu_batch", type=int, default=8)
@@ -59,11 +61,16 @@ def build(args, device, rank, world):
                            decoder_neg=True, fix_enc=True, lr=0.01, batch_size=args.batch, batch_size_val=256,
                            dataset_pick=1, run=1, target_domain="a", cross="True", sas="False",
                            result_path="/tmp/rg_bench", seq_len=args.seq_len, vocab_size_a=args.items,
-                           vocab_size_b=args.items, n_blocks=args.n_blocks, dropout=0.0)
+                           vocab_size_b=args.items, n_blocks=args.n_blocks, dropout=args.dropout)
     param = config.get_param(a, make_dirs=False)
     torch.manual_seed(0)
     G = models.MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32).to(device)
     D = models.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
+    G.train()
+    if args.dropout > 0:
+        D.train()               # Dropout(0.2) active, as in the reference's training loop
+    else:
+        D.eval()
     opt_g = optim.Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:128
     opt_d = optim.Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:134
     n_users = args.batch * args.batches_per_domain * world
@@ -99,6 +106,8 @@ def cpu_baseline(args):
     from oracle import recguru_oracle as O
     from recguru_amd import synthetic
     torch.manual_seed(0)
+    O.DROPOUT = args.dropout
+    O.DROPOUT_D = 0.2 if args.dropout > 0 else 0.0
     B, L, d, H, N, V, k = args.cpu_batch, args.seq_len, args.d_model, args.n_head, args.n_blocks, args.items, args.n_negs
     cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
     P = H * 32
@@ -142,8 +151,8 @@ def cpu_baseline(args):
     dt = time.perf_counter() - t0
     return {"value": 12 * B / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
             "sample": "1 AE+GAN iteration (5 critic + 1 generator), B=%d users/domain/draw, L=%d d=%d H=%d N=%d "
-                      "V=%d k=%d, fp32, dropout 0, torch %s CPU kernels, %.1f s"
-                      % (B, L, d, H, N, V, k, torch.__version__, dt)}
+                      "V=%d k=%d, fp32, dropout %g (D: %g), torch %s CPU kernels, %.1f s"
+                      % (B, L, d, H, N, V, k, O.DROPOUT, O.DROPOUT_D, torch.__version__, dt)}
 
 
 def main():
@@ -164,6 +173,7 @@ def main():
     device = "cuda:%d" % local
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     ops.set_data_parallel(dp)
+    ops.manual_seed(0, rank)                  # independent dropout streams per rank
     param, G, D, opt_g, opt_d, loaders = build(args, device, rank, world)
     step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp)
 
@@ -223,7 +233,8 @@ def main():
             "config": {"workload": "cross-domain RecGURU AE+GAN phase-2 iteration (5 critic + 1 generator update), "
                                    "two %d-item domains" % args.items,
                        "per_gpu_batch": B, "seq_len": args.seq_len, "d_model": args.d_model, "n_head": args.n_head,
-                       "n_blocks": args.n_blocks, "d_ff": 512, "n_negs": args.n_negs, "dropout": 0.0,
+                       "n_blocks": args.n_blocks, "d_ff": 512, "n_negs": args.n_negs, "dropout": args.dropout,
+                       "discriminator_dropout": 0.2 if args.dropout > 0 else 0.0,
                        "sequences_per_step": 12 * B * world, "generator_step_sequences_per_sec":
                            round(2 * B * world * args.steps / dt, 1),
                        "parallelism": "dp%d" % world,

@@ -55,6 +55,11 @@ typedef struct {
   const void* aux; int ldaux; /* [M,N] dtype */
   const float* gamma; const float* beta; const float* rowmask; float* rstd_out; float ln_eps;
   int debug_ablate;           /* 0 in production; tools/kbench.py phase ablation bits */
+  /* dropout hooks (all off when 0): */
+  float epi_scale;            /* MUL_POSMASK: kept elements are multiplied by it (1/(1-p)); 0 means 1   */
+  float epi_nonzero_scale;    /* GELU_GRAD: also multiply by (aux != 0 ? this : 0) -- backward of the
+                                 dropout that precedes GELU (transformer.py:182-184), aux = dropped h1 */
+  float drop_p; unsigned long long drop_seed;   /* RELU: C = dropout(relu(.)), tools/utils.py:43-44 */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 
@@ -118,6 +123,8 @@ typedef struct {
   const float* rowmask;       /* [M] or NULL */
   void* dz; float* dgamma; float* dbeta;
   long long M; int N; int ld;
+  void* dz_drop; float drop_p; unsigned long long drop_seed;  /* optional 2nd output dz * dropmask/(1-p):
+                                 backward of the dropout on the l2 output (transformer.py:186-187) */
 } rg_ln_bwd_args;
 int rg_ln_bwd(const rg_ln_bwd_args* args /* host */, int dtype, void* stream);
 
@@ -135,7 +142,8 @@ int rg_colsum(const void* x, const void* aux /* or NULL */, const float* coef /*
               long long M, int N, int ld, float scale, int dtype,
               void* stream);                     /* out[n] += scale*sum_m coef[m]*x[m,n]*[aux[m,n]>0] */
 int rg_outer_posmask(const float* coef /* [M] or NULL */, const float* w /* [N] */, const void* aux, void* out,
-                     long long M, int N, int dtype, void* stream); /* out = coef[m]*w[n]*[aux>0]       */
+                     long long M, int N, float scale, int dtype,
+                     void* stream);                             /* out = scale*coef[m]*w[n]*[aux>0]     */
 int rg_interpolate(const float* alpha, const void* real, const void* fake, void* out, long long B, int d,
                    int dtype, void* stream);                   /* gan_training.py:39-43               */
 int rg_gp_penalty(const float* g, void* dg, float* gp, long long B, int d, float lambda, int dtype,
@@ -187,6 +195,12 @@ typedef struct {
   void* out;                                             /* [M,d] dtype */
   void* y_save; float* rstd1; void* y2_save; float* rstd_c; void* h1_save; float* rstd2;
   int M, d, P, dff; float eps;
+  /* training-mode dropout (transformer.py:182-183,186-187; all off when drop_p == 0).  With dropout
+   * the collapsed cross-attention is no longer one vector per sequence: the attention-map dropout
+   * leaves context = s[b,h,q] * (WV u + bV)_h, so the stage takes cross_s [M,H] (rg_cross_drop_scale),
+   * cross_oh [M/L, H, d] f32 (per-head output projections) and cross_bo [d] instead of o_bcast. */
+  float drop_p; unsigned long long seed_h1; unsigned long long seed_out;
+  const float* cross_s; const float* cross_oh; const float* cross_bo; int H;
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 
@@ -200,6 +214,15 @@ int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids,
 int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
                       void* dq, void* dkv, int B, int L, int H, float scale, float drop_p, unsigned long long seed,
                       int dtype, void* stream);
+
+/* ---- decoder cross-attention under dropout ---------------------------------------------------------
+ * s[b*L+q, h] = (1/n_b) * sum_{keys j live} keep(seed, ((b*H+h)*L+q)*L+j)   (keep = 0 or 1/(1-p)),
+ * n_b = number of live keys (enc_ids != pad; all L keys if none is live -- replace-fill, Q3):
+ * the sum of the dropped uniform attention row of MultiHeadAttention(Q, rep(u), rep(u)) (transformer.py:259).
+ * rg_seq_wsum: out[b,h,:] = sum_q s[b*L+q,h] * x[b,q,:]  (backward of that stage). */
+int rg_cross_drop_scale(const int64_t* enc_ids, int64_t pad_value, float* s, int B, int L, int H, float drop_p,
+                        unsigned long long seed, void* stream);
+int rg_seq_wsum(const void* x, const float* s, void* out, int B, int L, int H, int N, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

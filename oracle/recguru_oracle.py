@@ -17,6 +17,15 @@ import math
 
 import torch
 
+# Train-mode dropout for the CPU-baseline timing only (bench.py cpu_baseline); parity tests keep 0 = eval mode.
+DROPOUT = 0.0       # transformer blocks + positional encoding (config_auto4rec.py:225 -> 0.5)
+DROPOUT_D = 0.0     # discriminator (tools/utils.py:44,47,50 -> 0.2)
+
+
+def _drop(x, p):
+    return torch.nn.functional.dropout(x, p, training=True) if p > 0 else x
+
+
 LAMBDA = 0.1        # GURU/gan_training.py:21
 CRITIC_ITERS = 5    # GURU/gan_training.py:22
 LN_EPS = 1e-8       # GURU/Transformer/transformer.py:142,177
@@ -40,7 +49,7 @@ def embed_pe(table, pe, ids, rowmask):
     """(E[ids] + pe[:L]) * mask[..., None]; PE is added BEFORE masking (quirk Q6).
     GURU/Transformer/transformer.py:104-106, GURU/AutoEnc4Rec_cross.py:98-99."""
     L = ids.shape[1]
-    return (table[ids] + pe[:L].unsqueeze(0)) * rowmask.unsqueeze(2)
+    return _drop((table[ids] + pe[:L].unsqueeze(0)) * rowmask.unsqueeze(2), DROPOUT)
 
 
 def layer_norm(x, g, b, eps=LN_EPS):
@@ -75,7 +84,7 @@ def mha(p, pre, xq, xkv, masked, n_heads, d_k=32):
     v = (xkv @ p[pre + "WV.weight"].T + p[pre + "WV.bias"]).view(B, Lk, n_heads, d_k).transpose(1, 2)
     s = (q @ k.transpose(-1, -2)) / math.sqrt(d_k)
     s = s.masked_fill(masked.unsqueeze(1), MASK_FILL)
-    a = torch.softmax(s, dim=-1)
+    a = _drop(torch.softmax(s, dim=-1), DROPOUT)
     ctx = (a @ v).transpose(1, 2).reshape(B, Lq, n_heads * d_k)
     out = ctx @ p[pre + "linear.weight"].T + p[pre + "linear.bias"]
     return layer_norm(out + xq, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
@@ -92,8 +101,8 @@ def mha_cross_collapsed(p, pre, xq, u):
 
 def ffn(p, pre, x):
     """l1 -> (dropout) -> GELU -> l2 -> (dropout) -> +res -> LN.  transformer.py:179-188 (Q4)."""
-    h = gelu_tanh(x @ p[pre + "l1.weight"].T + p[pre + "l1.bias"])
-    o = h @ p[pre + "l2.weight"].T + p[pre + "l2.bias"]
+    h = gelu_tanh(_drop(x @ p[pre + "l1.weight"].T + p[pre + "l1.bias"], DROPOUT))
+    o = _drop(h @ p[pre + "l2.weight"].T + p[pre + "l2.bias"], DROPOUT)
     return layer_norm(o + x, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
 
 
@@ -307,9 +316,9 @@ def myrec_bpr_logits(p, cfg, enc_in, dec_in, dec_out_ids, n_items, fix_enc=False
 # ----------------------------------------------------------------------------------------------
 def discriminator(p, x, pre="main."):
     """Discriminator.forward in eval mode (no dropout).  tools/utils.py:41-57."""
-    h = torch.relu(x @ p[pre + "0.weight"].T + p[pre + "0.bias"])
-    h = torch.relu(h @ p[pre + "3.weight"].T + p[pre + "3.bias"])
-    h = torch.relu(h @ p[pre + "6.weight"].T + p[pre + "6.bias"])
+    h = _drop(torch.relu(x @ p[pre + "0.weight"].T + p[pre + "0.bias"]), DROPOUT_D)
+    h = _drop(torch.relu(h @ p[pre + "3.weight"].T + p[pre + "3.bias"]), DROPOUT_D)
+    h = _drop(torch.relu(h @ p[pre + "6.weight"].T + p[pre + "6.bias"]), DROPOUT_D)
     return (h @ p[pre + "9.weight"].T + p[pre + "9.bias"]).view(-1)
 
 

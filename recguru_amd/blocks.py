@@ -48,11 +48,8 @@ class ScheduledOptim(object):
         self._optimizer.step()
 
 
-def _check_dropout(p, where):
-    if p is not None and p > 0:
-        raise NotImplementedError(
-            "%s: dropout_rate=%g -- the HIP path currently implements the deterministic "
-            "(dropout 0 / eval) arithmetic only; pass --dropout 0 (see DESIGN.md)" % (where, p))
+def _rate(p):
+    return float(p) if p else 0.0
 
 
 class PositionalEncoding(nn.Module):
@@ -70,6 +67,9 @@ class PositionalEncoding(nn.Module):
 
     def table(self):
         return self.pe[0]
+
+    def drop_p(self):
+        return _rate(self.dropout_rate) if self.training else 0.0
 
 
 class MultiHeadAttention(nn.Module):
@@ -115,15 +115,18 @@ class EncoderLayer(nn.Module):
         self.enc_self_attn = MultiHeadAttention(d_model, d_k, d_v, n_heads, device, dropout)
         self.pos_ffn = PositionWiseFeedForwardNet(d_model, d_ff, dropout)
 
+    def drop_p(self):
+        return _rate(self.pos_ffn.dropout_rate) if self.training else 0.0
+
     def forward(self, x, key_ids, pad_value, rowmask, causal=False):
         return ops.EncoderLayerFn.apply(x, key_ids, rowmask, int(pad_value), bool(causal),
-                                        self.enc_self_attn.n_heads,
+                                        self.enc_self_attn.n_heads, self.drop_p(),
                                         *self.enc_self_attn.self_params(), *self.pos_ffn.params())
 
     def forward_last(self, x, key_ids, pad_value, rowmask):
         """Row L-1 of forward() only -> [B, d] (all the hot path ever reads of the last layer)."""
         return ops.EncoderLastLayerFn.apply(x, key_ids, rowmask, int(pad_value), self.enc_self_attn.n_heads,
-                                            *self.enc_self_attn.self_params(), *self.pos_ffn.params())
+                                            self.drop_p(), *self.enc_self_attn.self_params(), *self.pos_ffn.params())
 
 
 class DecoderLayer(nn.Module):
@@ -133,8 +136,9 @@ class DecoderLayer(nn.Module):
         self.dec_enc_attn = MultiHeadAttention(d_model, d_k, d_v, n_heads, device, dropout)
         self.pos_ffn = PositionWiseFeedForwardNet(d_model, d_ff, dropout)
 
-    def forward(self, x, u, dec_ids, rowmask):
-        return ops.DecoderLayerFn.apply(x, u, dec_ids, rowmask, self.dec_self_attn.n_heads,
+    def forward(self, x, u, dec_ids, enc_ids, rowmask):
+        p = _rate(self.pos_ffn.dropout_rate) if self.training else 0.0
+        return ops.DecoderLayerFn.apply(x, u, dec_ids, enc_ids, rowmask, self.dec_self_attn.n_heads, p,
                                         *self.dec_self_attn.self_params(), *self.dec_enc_attn.cross_params(),
                                         *self.pos_ffn.params())
 
@@ -145,7 +149,6 @@ class EncoderM(nn.Module):
 
     def __init__(self, d_model, d_ff, d_k, d_v, n_heads, n_layers, pad_index, device, dropout):
         super(EncoderM, self).__init__()
-        _check_dropout(dropout, "EncoderM")
         self.device = device
         self.pad_index = pad_index
         self.layers = nn.ModuleList([EncoderLayer(d_model, d_ff, d_k, d_v, n_heads, device, dropout)
@@ -169,13 +172,14 @@ class DecoderM(nn.Module):
 
     def __init__(self, d_model, d_ff, d_k, d_v, n_heads, n_layers, pad_index, device, dropout):
         super(DecoderM, self).__init__()
-        _check_dropout(dropout, "DecoderM")
         self.pad_index = pad_index
         self.device = device
         self.layers = nn.ModuleList([DecoderLayer(d_model, d_ff, d_k, d_v, n_heads, device, dropout)
                                      for _ in range(n_layers)])
 
-    def forward(self, x, u, dec_ids, pad_m):
+    def forward(self, x, u, dec_ids, enc_ids, pad_m):
+        """enc_ids: the encoder input ids; their (== 0) positions are the masked keys of the
+        decoder-encoder attention (AutoEnc4Rec_cross.py:134) -- only needed when dropout is active."""
         for layer in self.layers:
-            x = layer(x, u, dec_ids, pad_m)
+            x = layer(x, u, dec_ids, enc_ids, pad_m)
         return x

@@ -163,12 +163,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
     sum += __shfl_xor(sum, 32);
     const float inv = __builtin_amdgcn_rcpf(sum);
     if (drop.thresh) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
-      const unsigned long long base = (((unsigned long long)b * a.H + h) * L + min(q, L - 1)) * L;
+      const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lp4(L) + 4u * lg;
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt)
         if (kt < nkt) {
+          float k4[4];
+          rg_keep4(drop, base + kt * 16, k4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] *= rg_keep(drop, base + kt * 16 + 4 * lg + r);
+          for (int r = 0; r < 4; ++r) s[kt][r] *= k4[r];
         }
     }
     ASTAMP(2);
@@ -238,7 +240,8 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
   T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const DropCfg gdrop = make_drop(a.drop_p, a.seed);
-  const unsigned long long gbase = ((unsigned long long)b * a.H + h) * L;
+  const unsigned int gbase = ((unsigned int)b * a.H + h) * L;
+  const unsigned int glp4 = rg_lp4(L);
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -302,7 +305,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
           // fully masked row: lse = -1e9 + log L rounds to -1e9 in f32, the row is uniform 1/L (Q3)
           const float lq = lse_s[min(q, LPK - 1)];
           float pv = (q < L && key < L) ? (lq < -5e8f ? 1.f / (float)L : __expf(sc - lq)) : 0.f;
-          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * L + min(key, L - 1)) : 1.f;
+          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * glp4 + key) : 1.f;
           p[u][r] = pv * ks;
           ds[u][r] = masked ? 0.f : pv * (dp[r] * ks - dl_s[q]) * a.scale;
         }
@@ -361,7 +364,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
           const int key = ks * 32 + u * 16 + 4 * lg + r;
           const bool masked = (key >= L) || kpad[key] || (a.causal && key > q);
           const float pv = (q < L && key < L && !masked) ? __expf(sv[r] * a.scale - lse_q) : 0.f;
-          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * L + min(key, L - 1)) : 1.f;
+          const float ks = gdrop.thresh ? rg_keep(gdrop, (gbase + min(q, L - 1)) * glp4 + key) : 1.f;
           ds[u][r] = pv * (dp[r] * ks - dl_q) * a.scale;
         }
       }
@@ -417,7 +420,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const float c2 = a.scale * 1.4426950408889634f;
   const DropCfg drop = make_drop(a.drop_p, a.seed);
-  const unsigned long long dbase = ((unsigned long long)b * a.H + h) * L;
+  const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
+  const unsigned int lp4 = rg_lp4(L);
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -478,7 +482,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
           float sc = sv[r] + kb;                                        // -1e30 / -inf where replaced
           if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
-          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * L + min(key, L - 1)) : 1.f;
+          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * lp4 + key) : 1.f;
           ds[u][r] = pe * (dp[r] * ks - d4[r]) * a.scale;
           p[u][r] = (pe + ((key < L) ? r4[r] : 0.f)) * ks;              // uniform 1/L rows (Q3); dropped map feeds dV
         }
@@ -526,14 +530,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         mma(kf, qf, sv);           // S^T[key][q]
         mma(vf, gf, dp);           // dP^T[key][q]
-        float kb4[4];
+        float kb4[4], ks4[4] = {1.f, 1.f, 1.f, 1.f};
         load4f(kb4, kbias + k0 + 4 * lg);
+        if (drop.thresh) rg_keep4(drop, (dbase + min(q, L - 1)) * lp4 + k0 + 4 * lg, ks4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sc = sv[r] + kb4[r];
           if (CAUSAL) sc = (k0 + r > qrel) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -lse_q));
-          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q, L - 1)) * L + min(k0 + 4 * lg + r, L - 1)) : 1.f;
+          const float ks = ks4[r];
           ds[u][r] = pe * (dp[r] * ks - dl_q) * a.scale;
         }
       }

@@ -35,8 +35,12 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
       if (drop.thresh) {
+        float k0[4], k1[4];
+        const unsigned int base = (unsigned int)tok * (unsigned int)d + (unsigned int)c8;
+        rg_keep4(drop, base, k0);
+        rg_keep4(drop, base + 4u, k1);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] *= rg_keep(drop, (unsigned long long)tok * d + c8 + j);
+        for (int j = 0; j < 4; ++j) { v[j] *= k0[j]; v[4 + j] *= k1[j]; }
       }
     } else {
 #pragma unroll
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
     if (m == 0.f || row == skip_row) continue;
     for (int e = lane; e < d; e += 64) {
       float g = (float)dx[(size_t)tok * d + e] * m;
-      if (drop.thresh) g *= rg_keep(drop, (unsigned long long)tok * d + e);
+      if (drop.thresh) g *= rg_keep(drop, (unsigned int)tok * (unsigned int)d + (unsigned int)e);
       atomicAdd(dE + (size_t)row * d + e, g);
     }
   }
@@ -86,6 +90,8 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
   const T* __restrict__ y = reinterpret_cast<const T*>(a.y);
   T* __restrict__ dz = reinterpret_cast<T*>(a.dz);
+  T* __restrict__ dzd = reinterpret_cast<T*>(a.dz_drop);
+  const DropCfg drop = make_drop(a.drop_p, a.drop_seed);
   const float invn = 1.f / (float)N;
   float gam[8], bet[8], dg[8], db[8];
   load8(gam, a.gamma + c8);
@@ -128,6 +134,15 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
       store8(dz + (size_t)m * a.ld + c8, o8);
+      if (dzd) {
+        float k0[4], k1[4];
+        const unsigned int base = (unsigned int)m * (unsigned int)N + (unsigned int)c8;
+        rg_keep4(drop, base, k0);
+        rg_keep4(drop, base + 4u, k1);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { o8[j] *= k0[j]; o8[4 + j] *= k1[j]; }
+        store8(dzd + (size_t)m * a.ld + c8, o8);
+      }
     }
   }
   // column sums: lanes with the same c8 (RPW of them per wave) -> LDS -> atomics
@@ -220,12 +235,13 @@ __global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ 
 // out[m,n] = coef[m] * w[n] * [aux[m,n] > 0]      (seed of the ReLU-mask chains, tools/utils.py:41-52)
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void outer_posmask_kernel(const float* __restrict__ coef, const float* __restrict__ w,
-                                                                const T* __restrict__ aux, T* __restrict__ out, long long M, int N) {
+                                                                const T* __restrict__ aux, T* __restrict__ out, long long M, int N,
+                                                                float scale) {
   const long long total = M * N;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
     const long long m = i / N;
     const int n = (int)(i - m * N);
-    const float c = coef ? coef[m] : 1.f;
+    const float c = (coef ? coef[m] : 1.f) * scale;
     out[i] = (T)(((float)aux[i] > 0.f) ? c * w[n] : 0.f);
   }
 }
@@ -308,9 +324,61 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict_
   }
 }
 
+// s[b*L+q, h] = sum over live keys of keep(...) / n_live : the row sum of the dropped uniform attention
+// map of the collapsed decoder cross-attention (Q1 + nn.Dropout of transformer.py:126-127)
+__global__ __launch_bounds__(EW_BLOCK) void cross_drop_scale_kernel(const int64_t* __restrict__ ids, int64_t pad, float* __restrict__ s,
+                                                                   int B, int L, int H, DropCfg drop) {
+  const long long total = (long long)B * L * H;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const int h = (int)(i % H);
+    const long long bq = i / H;
+    const int b = (int)(bq / L), q = (int)(bq % L);
+    const int64_t* row = ids + (size_t)b * L;
+    int n = 0;
+    for (int j = 0; j < L; ++j) n += row[j] != pad;
+    const bool all_masked = n == 0;                      // replace-fill: uniform over all L keys
+    const unsigned int base = (((unsigned int)b * H + h) * L + q) * rg_lp4(L);     // attention-map index space
+    float acc = 0.f;
+    for (int j = 0; j < L; ++j)
+      if (all_masked || row[j] != pad) acc += rg_keep(drop, base + j);
+    s[i] = acc / (float)(all_masked ? L : n);
+  }
+}
+
+// out[b,h,:] = sum_q s[b*L+q, h] * x[b,q,:]
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out,
+                                                           int L, int H, int N) {
+  const int b = blockIdx.x / H, h = blockIdx.x % H;
+  for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
+    float acc = 0.f;
+    for (int t = 0; t < L; ++t) acc += s[((size_t)b * L + t) * H + h] * (float)x[((size_t)b * L + t) * N + n];
+    out[((size_t)b * H + h) * N + n] = (T)acc;
+  }
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
+extern "C" int rg_cross_drop_scale(const int64_t* enc_ids, int64_t pad_value, float* s, int B, int L, int H, float drop_p,
+                                   unsigned long long seed, void* stream) {
+  if (B <= 0) return 0;
+  hipLaunchKernelGGL(cross_drop_scale_kernel, dim3(ew_grid((long long)B * L * H, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+                     enc_ids, pad_value, s, B, L, H, make_drop(drop_p, seed));
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int L, int H, int N, int dtype, void* stream) {
+  if (B <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == RG_BF16) hipLaunchKernelGGL(seq_wsum_kernel<__bf16>, dim3(B * H), dim3(EW_BLOCK), 0, st, (const __bf16*)x, s, (__bf16*)out, L, H, N);
+  else if (dtype == RG_F32) hipLaunchKernelGGL(seq_wsum_kernel<float>, dim3(B * H), dim3(EW_BLOCK), 0, st, (const float*)x, s, (float*)out, L, H, N);
+  else return rg_set_error_msg(RG_ERR_INVALID, "seq_wsum: bad dtype");
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
 #define DISPATCH_T(dtype, CALL_BF16, CALL_F32, name)                                     \
   if ((dtype) == RG_BF16) { CALL_BF16; } else if ((dtype) == RG_F32) { CALL_F32; }        \
   else return rg_set_error_msg(RG_ERR_INVALID, name ": bad dtype");                       \
@@ -401,13 +469,14 @@ extern "C" int rg_colsum(const void* x, const void* aux, const float* coef, floa
              "colsum")
 }
 
-extern "C" int rg_outer_posmask(const float* coef, const float* w, const void* aux, void* out, long long M, int N, int dtype, void* stream) {
+extern "C" int rg_outer_posmask(const float* coef, const float* w, const void* aux, void* out, long long M, int N, float scale,
+                                int dtype, void* stream) {
   if (M <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   const int grid = ew_grid(M * N, EW_BLOCK);
   DISPATCH_T(dtype,
-             hipLaunchKernelGGL(outer_posmask_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const __bf16*)aux, (__bf16*)out, M, N),
-             hipLaunchKernelGGL(outer_posmask_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const float*)aux, (float*)out, M, N),
+             hipLaunchKernelGGL(outer_posmask_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const __bf16*)aux, (__bf16*)out, M, N, scale),
+             hipLaunchKernelGGL(outer_posmask_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, coef, w, (const float*)aux, (float*)out, M, N, scale),
              "outer_posmask")
 }
 

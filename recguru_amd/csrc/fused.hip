@@ -202,6 +202,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const int n0 = wave * 32;                 // this wave's 32 output features of every 128-wide block
   const int ntiles = (a.M + FT_M - 1) / FT_M;
   const int nchunk = a.dff / FD;
+  const DropCfg drop1 = make_drop(a.drop_p, a.seed_h1), drop2 = make_drop(a.drop_p, a.seed_out);
 
   // ---- once per workgroup: parameters -> LDS
   for (int i = tid; i < FD; i += 256) {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     }
     regs_to_tile<T>(acc, Ay, n0, li, lg);
     STAMP(2);
-    if (a.o_bcast) {
+    if (a.o_bcast || a.cross_s) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
       if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, m0, a.M, tid); }
 #pragma unroll
@@ -276,7 +277,18 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           float o4[4], y4[4];
-          load4f(o4, a.o_bcast + (size_t)(m / a.L) * FD + n0 + ct * 16 + 4 * lg);
+          if (a.cross_s) {      // dropout: o = bo + sum_h s[m,h] * oh[b,h,:]
+            load4f(o4, a.cross_bo + n0 + ct * 16 + 4 * lg);
+            for (int hh = 0; hh < a.H; ++hh) {
+              float w4[4];
+              const float sv = a.cross_s[(size_t)m * a.H + hh];
+              load4f(w4, a.cross_oh + ((size_t)(m / a.L) * a.H + hh) * FD + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o4[r] += sv * w4[r];
+            }
+          } else {
+            load4f(o4, a.o_bcast + (size_t)(m / a.L) * FD + n0 + ct * 16 + 4 * lg);
+          }
           load4t(y4, Ay + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);     // the ROUNDED y1, as the unfused path sees it
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[r];
@@ -292,7 +304,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       regs_to_tile<T>(acc, Ay, n0, li, lg);
     }
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
-    if (a.o_bcast ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, a.o_bcast ? y2save : ysave, FD, 0, m0, a.M, tid);
+    {
+      const bool cross = a.o_bcast || a.cross_s;
+      if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, cross ? y2save : ysave, FD, 0, m0, a.M, tid);
+    }
     STAMP(3);
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
     f32x4 acc2[2][4];
@@ -306,6 +321,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
+      if (drop1.thresh) {       // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float k4[4];
+            rg_keep4(drop1, rb + ct * 16, k4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ct][rt][r] *= k4[r];
+          }
+        }
+      }
       if (h1save) regs_to_tile<T>(acc, Ah, n0, li, lg);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -330,6 +358,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           load_frag(cpre[i], ctx + (size_t)(next_tile * FT_M + r) * FD + c8);
           load_frag(xpre[i], x + (size_t)(next_tile * FT_M + r) * FD + c8);
         } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
+      }
+    }
+    if (drop2.thresh) {         // dropout on the l2 output, before the residual (transformer.py:186-188)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          float k4[4];
+          rg_keep4(drop2, rb + ct * 16, k4);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= k4[r];
+        }
       }
     }
     // ---- + residual y (LDS), LayerNorm 2 on the registers, * rowmask, out via the (free) ctx tile
@@ -373,7 +414,8 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   if (!a || a->M <= 0) return 0;
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
-  if (a->o_bcast && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: o_bcast needs L");
+  if ((a->o_bcast || a->cross_s) && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross stage needs L");
+  if (a->cross_s && (!a->cross_oh || !a->cross_bo || a->H <= 0)) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross_s needs cross_oh, cross_bo, H");
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (a->M + FT_M - 1) / FT_M;
   const int esz = dtype == RG_BF16 ? 2 : 4;

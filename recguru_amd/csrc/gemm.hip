@@ -123,14 +123,25 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
         if (a.epilogue == RG_EPI_RELU) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+          if (a.drop_p > 0.f) {
+            const DropCfg dc = make_drop(a.drop_p, a.drop_seed);
+            float k0[4], k1[4];
+            const unsigned int base = (unsigned int)m * (unsigned int)a.N + (unsigned int)n;   // N % 8 == 0 here
+            rg_keep4(dc, base, k0);
+            rg_keep4(dc, base + 4u, k1);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] *= k0[j]; v[4 + j] *= k1[j]; }
+          }
         } else if (a.epilogue != RG_EPI_NONE) {
           float x[8];
           load8(x, aux + (size_t)m * a.ldaux + n);
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
-            if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] : 0.f;
-            else if (a.epilogue == RG_EPI_GELU_GRAD) v[j] *= gelu_grad_t<Precise<T>::value>(x[j]);
-            else v[j] += x[j];
+            if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] * (a.epi_scale > 0.f ? a.epi_scale : 1.f) : 0.f;
+            else if (a.epilogue == RG_EPI_GELU_GRAD) {
+              v[j] *= gelu_grad_t<Precise<T>::value>(x[j]);
+              if (a.epi_nonzero_scale > 0.f) v[j] = x[j] != 0.f ? v[j] * a.epi_nonzero_scale : 0.f;
+            } else v[j] += x[j];
           }
         }
         if (a.c_is_f32) store8(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n, v);
@@ -139,8 +150,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
         for (int j = 0; j < 8 && n + j < a.N; ++j) {
           float y = v[j];
           switch (a.epilogue) {
-            case RG_EPI_RELU: y = fmaxf(y, 0.f); break;
-            case RG_EPI_MUL_POSMASK: y = ((float)aux[(size_t)m * a.ldaux + n + j] > 0.f) ? y : 0.f; break;
+            case RG_EPI_RELU:
+              y = fmaxf(y, 0.f);
+              if (a.drop_p > 0.f) y *= rg_keep(make_drop(a.drop_p, a.drop_seed), (unsigned int)m * (unsigned int)a.N + (unsigned int)(n + j));
+              break;
+            case RG_EPI_MUL_POSMASK:
+              y = ((float)aux[(size_t)m * a.ldaux + n + j] > 0.f) ? y * (a.epi_scale > 0.f ? a.epi_scale : 1.f) : 0.f;
+              break;
             case RG_EPI_GELU_GRAD: y *= gelu_grad_f((float)aux[(size_t)m * a.ldaux + n + j]); break;
             case RG_EPI_ADD: y += (float)aux[(size_t)m * a.ldaux + n + j]; break;
             default: break;

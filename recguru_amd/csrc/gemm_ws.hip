@@ -129,9 +129,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
                 for (int j = 0; j < 8; ++j) x[j] = (float)axf[i].v[j];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                  if (a.epilogue == RG_EPI_GELU_GRAD) v[j] *= gelu_grad_t<false>(x[j]);
-                  else if (a.epilogue == RG_EPI_ADD) v[j] += x[j];
-                  else if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] : 0.f;
+                  if (a.epilogue == RG_EPI_GELU_GRAD) {
+                    v[j] *= gelu_grad_t<false>(x[j]);
+                    if (a.epi_nonzero_scale > 0.f) v[j] = x[j] != 0.f ? v[j] * a.epi_nonzero_scale : 0.f;
+                  } else if (a.epilogue == RG_EPI_ADD) v[j] += x[j];
+                  else if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] * (a.epi_scale > 0.f ? a.epi_scale : 1.f) : 0.f;
                   else v[j] = fmaxf(v[j], 0.f);
                 }
                 store8(C + off, v);
@@ -159,6 +161,7 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s) {
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
   if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 1;
+  if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 1;   // dropout-after-ReLU lives in the generic kernel
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 1;
   if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 1;
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 1;

@@ -164,26 +164,43 @@ template <> struct Precise<__bf16> { static constexpr bool value = false; };
 // so the backward kernels regenerate exactly the forward's mask (nn.Dropout semantics: element kept
 // with probability 1-p and scaled by 1/(1-p); only the random stream differs from torch's Philox).
 struct DropCfg {
-  unsigned long long seed;
-  unsigned int thresh;       // drop iff hash < thresh  (thresh = p * 2^32); 0 = dropout off
+  unsigned int seed;         // folded 64-bit call seed
+  unsigned int thresh;       // drop iff 16-bit field < thresh  (thresh = p * 65536); 0 = dropout off
   float inv_keep;            // 1 / (1 - p)
 };
-__device__ __forceinline__ unsigned int rg_hash(unsigned long long seed, unsigned long long idx) {
-  unsigned long long z = idx + seed * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;      // splitmix64 finaliser
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  return (unsigned int)((z ^ (z >> 31)) >> 32);
+// Element idx (a 32-bit, wrapping index in a per-site index space) is decided by the (idx & 1)-th 16-bit
+// half of hash(idx >> 1): one lowbias32 hash (2 multiplies) serves two consecutive elements, and
+// rg_keep4 (base % 4 == 0) covers the 4 consecutive elements of an accumulator register with 2 hashes.
+__device__ __forceinline__ unsigned int rg_hash(unsigned int seed, unsigned int x) {
+  x ^= seed;
+  x ^= x >> 16; x *= 0x21f0aaadu;
+  x ^= x >> 15; x *= 0x735a2d97u;
+  x ^= x >> 15;
+  return x;
 }
-__device__ __forceinline__ float rg_keep(const DropCfg& c, unsigned long long idx) {
-  return (c.thresh != 0u && rg_hash(c.seed, idx) < c.thresh) ? 0.f : c.inv_keep;
+__device__ __forceinline__ float rg_keep(const DropCfg& c, unsigned int idx) {
+  const unsigned int h = rg_hash(c.seed, idx >> 1);
+  const unsigned int field = (idx & 1u) ? (h >> 16) : (h & 0xFFFFu);
+  return field < c.thresh ? 0.f : c.inv_keep;
+}
+__device__ __forceinline__ void rg_keep4(const DropCfg& c, unsigned int base, float (&k)[4]) {
+  const unsigned int h0 = rg_hash(c.seed, base >> 1), h1 = rg_hash(c.seed, (base >> 1) + 1u);
+  k[0] = (h0 & 0xFFFFu) < c.thresh ? 0.f : c.inv_keep;
+  k[1] = (h0 >> 16) < c.thresh ? 0.f : c.inv_keep;
+  k[2] = (h1 & 0xFFFFu) < c.thresh ? 0.f : c.inv_keep;
+  k[3] = (h1 >> 16) < c.thresh ? 0.f : c.inv_keep;
 }
 __host__ __device__ inline DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg c;
-  c.seed = seed;
-  c.thresh = p > 0.f ? (unsigned int)((double)p * 4294967296.0) : 0u;
+  unsigned int s = (unsigned int)seed * 0x9E3779B1u ^ ((unsigned int)(seed >> 32) * 0x85EBCA77u + 0x165667B1u);
+  s ^= s >> 15; s *= 0x2c1b3c6du; s ^= s >> 12;
+  c.seed = s;
+  c.thresh = p > 0.f ? (unsigned int)((double)p * 65536.0 + 0.5) : 0u;
   c.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
   return c;
 }
+// attention-map index space: ((b*H + h)*L + q) * LP4 + key with LP4 = L rounded up to a multiple of 4
+__host__ __device__ inline unsigned int rg_lp4(int L) { return (unsigned int)((L + 3) & ~3); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release
 // fence, for which hipcc drains vmcnt(0) whenever a global store is outstanding -- and loads share that

@@ -25,7 +25,8 @@ class GemmNtArgs(ctypes.Structure):
     _fields_ = [("A", c_p), ("lda", c_i), ("W", c_p), ("ldw", c_i), ("bias", c_p), ("C", c_p), ("ldc", c_i),
                 ("c_is_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("prologue", c_i), ("epilogue", c_i),
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
-                ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i)]
+                ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
+                ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -51,7 +52,9 @@ class PostAttnArgs(ctypes.Structure):
                 ("W1", c_p), ("b1", c_p), ("W2", c_p), ("b2", c_p), ("g2", c_p), ("be2", c_p),
                 ("rowmask", c_p), ("out", c_p),
                 ("y_save", c_p), ("rstd1", c_p), ("y2_save", c_p), ("rstd_c", c_p), ("h1_save", c_p), ("rstd2", c_p),
-                ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f)]
+                ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f),
+                ("drop_p", c_f), ("seed_h1", c_u64), ("seed_out", c_u64),
+                ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i)]
 
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
@@ -59,14 +62,16 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
-           "rg_attn_lastq_fwd", "rg_attn_lastq_bwd"]
+           "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
+           "rg_cross_drop_scale", "rg_seq_wsum"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
 
 class LnBwdArgs(ctypes.Structure):
     _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
-                ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i)]
+                ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i),
+                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64)]
 
 
 class ItemLossArgs(ctypes.Structure):
@@ -119,7 +124,8 @@ def _rowmajor(t):
 
 
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
-            gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0):
+            gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
+            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N]."""
     M, K = A.shape
     N = W.shape[0]
@@ -131,7 +137,8 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
-                   _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate)
+                   _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
+                   drop_p, drop_seed)
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
     return out
 
@@ -196,14 +203,17 @@ def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     return dE
 
 
-def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta):
-    """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place."""
+def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0):
+    """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place.
+    With drop_p > 0 also returns dz * dropmask/(1-p) (backward of a dropout feeding the LN input)."""
     M, N = dy.shape
     assert dy.is_contiguous() and y.is_contiguous() and dy.dtype == y.dtype
     dz = torch.empty_like(dy)
-    a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N)
+    dzd = torch.empty_like(dy) if drop_p > 0 else None
+    a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N,
+                  _p(dzd), drop_p, drop_seed)
     _check(lib().rg_ln_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_ln_bwd")
-    return dz
+    return (dz, dzd) if drop_p > 0 else dz
 
 
 def bcast_add_ln(x, o, gamma, beta, L, eps=1e-8):
@@ -231,12 +241,30 @@ def colsum(x, out, aux=None, scale=1.0, coef=None):
     return out
 
 
-def outer_posmask(coef, w, aux):
+def outer_posmask(coef, w, aux, scale=1.0):
     M, N = aux.shape
     assert aux.is_contiguous() and w.dtype == torch.float32 and w.numel() == N
     out = torch.empty_like(aux)
-    _check(lib().rg_outer_posmask(_vp(coef), _vp(w), _vp(aux), _vp(out), c_ll(M), N, dt_of(aux), _stream()),
-           "rg_outer_posmask")
+    _check(lib().rg_outer_posmask(_vp(coef), _vp(w), _vp(aux), _vp(out), c_ll(M), N, c_f(scale), dt_of(aux),
+                                  _stream()), "rg_outer_posmask")
+    return out
+
+
+def cross_drop_scale(enc_ids, pad_value, H, drop_p, seed):
+    """[B*L, H] f32 row sums of the dropped uniform cross-attention map."""
+    B, L = enc_ids.shape
+    assert enc_ids.dtype == torch.int64 and enc_ids.is_contiguous()
+    s = torch.empty(B * L, H, device=enc_ids.device, dtype=torch.float32)
+    _check(lib().rg_cross_drop_scale(_vp(enc_ids), c_l(int(pad_value)), _vp(s), B, L, H, c_f(drop_p), c_u64(seed),
+                                     _stream()), "rg_cross_drop_scale")
+    return s
+
+
+def seq_wsum(x, s, B, L, H):
+    N = x.shape[-1]
+    assert x.is_contiguous() and s.is_contiguous()
+    out = torch.empty(B, H, N, device=x.device, dtype=x.dtype)
+    _check(lib().rg_seq_wsum(_vp(x), _vp(s), _vp(out), B, L, H, N, dt_of(x), _stream()), "rg_seq_wsum")
     return out
 
 
@@ -326,8 +354,10 @@ def post_attn_supported(d, P, dff):
     return d == 128 and P == 128 and dff % 128 == 0 and dff > 0
 
 
-def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8):
-    """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta).
+def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,
+                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None):
+    """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta);
+    under dropout cross = (None, gamma, beta) and cross_drop = (s [M,H], oh [B,H,d] f32, bo [d], H).
     Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
     M, P = ctx.shape
     d = x.shape[1]
@@ -344,10 +374,11 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
             sv["y2"] = torch.empty(M, d, device=dev, dtype=ctx.dtype)
             sv["rstd_c"] = torch.empty(M, device=dev, dtype=torch.float32)
     o, gc, bec = cross if cross is not None else (None, None, None)
+    cs, coh, cbo, cH = cross_drop if cross_drop is not None else (None, None, None, 0)
     a = PostAttnArgs(_p(ctx), _p(x), _p(Wo), _p(bo), _p(g1), _p(be1), _p(o), _p(gc), _p(bec), L,
                      _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
                      _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
-                     _p(sv.get("rstd2")), M, d, P, dff, eps)
+                     _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH)
     _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 
@@ -429,7 +460,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
-          "gp_penalty", "sum_into", "adam", "cast"]
+          "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 
 def start_profile():

@@ -50,14 +50,16 @@ class Discriminator(nn.Module):
             nn.Linear(mid_dim, mid_dim * 2), nn.ReLU(True), nn.Dropout(p=0.2),
             nn.Linear(mid_dim * 2, mid_dim), nn.ReLU(True), nn.Dropout(p=0.2),
             nn.Linear(mid_dim, out_dim))
-        self.hip_dropout = 0.0   # the HIP path evaluates the deterministic (eval) arithmetic
 
     def params(self):
         m = self.main
         return (m[0].weight, m[0].bias, m[3].weight, m[3].bias, m[6].weight, m[6].bias, m[9].weight, m[9].bias)
 
+    def drop_p(self):
+        return 0.2 if self.training else 0.0        # nn.Dropout(p=0.2), tools/utils.py:44,47,50
+
     def forward(self, inputs):
-        return ops.DiscriminatorFn.apply(inputs, *self.params())
+        return ops.DiscriminatorFn.apply(inputs, self.drop_p(), *self.params())
 
 
 class MyAuto4Rec_c(nn.Module):
@@ -107,7 +109,7 @@ class MyAuto4Rec_c(nn.Module):
 
     def _embed(self, ids, domain, mask):
         emb, pos = self._emb(domain)
-        return ops.embed_pe(emb.weight, pos.table(), ids, mask)
+        return ops.embed_pe(emb.weight, pos.table(), ids, mask, drop_p=pos.drop_p())
 
     def _encoder(self, domain):
         if self.enc_share:
@@ -130,7 +132,7 @@ class MyAuto4Rec_c(nn.Module):
         if detach_enc:
             u = u.detach()
         x = self._embed(dec_inputs, domain, d_mask)
-        return stack(x, u.contiguous(), dec_inputs, d_mask)
+        return stack(x, u.contiguous(), dec_inputs, enc_inputs, d_mask)
 
     def get_dec_out(self, enc_inputs, dec_inputs, domain="a", mask=None):
         """AutoEnc4Rec_cross.py:117-147: decoder pad mask comes from enc_inputs (quirk Q5)."""
@@ -187,7 +189,8 @@ class MyAuto4Rec(nn.Module):
 
     def _embed(self, ids, mask):
         # padding_idx row receives no gradient (AutoEnc4Rec.py:153)
-        return ops.embed_pe(self.src_emb.weight, self.pos_emb.table(), ids, mask, skip_row=self.pad_index)
+        return ops.embed_pe(self.src_emb.weight, self.pos_emb.table(), ids, mask, skip_row=self.pad_index,
+                            drop_p=self.pos_emb.drop_p())
 
     def get_seq_embed(self, enc_inputs, last_only=False):
         """AutoEnc4Rec.py:175-184: real pad id for both the row mask and the key mask."""
@@ -201,7 +204,7 @@ class MyAuto4Rec(nn.Module):
             u = u.detach()
         mask = _f32_mask(dec_inputs, self.pad_index)
         x = self._embed(dec_inputs, mask)
-        return stack(x, u.contiguous(), dec_inputs, mask)
+        return stack(x, u.contiguous(), dec_inputs, enc_inputs, mask)
 
     def get_dec_out(self, enc_inputs, dec_inputs):
         """AutoEnc4Rec.py:186-204: decoder pad mask from dec_inputs."""

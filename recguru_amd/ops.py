@@ -79,51 +79,90 @@ def _z(n, like):
 
 
 # ------------------------------------------------------------------------------------------------
-# K1: embedding + positional encoding + mask
+# dropout seeds: every forward call draws fresh 64-bit seeds (masks are a stateless hash of seed and
+# element index inside the kernels) and its backward reuses them.
+# ------------------------------------------------------------------------------------------------
+_SEED = {"base": 0x5EED, "ctr": 0}
+
+
+def manual_seed(seed, rank=0):
+    """Re-seed the dropout stream (independent streams per data-parallel rank)."""
+    _SEED["base"] = (int(seed) * 1000003 + int(rank) * 7919 + 1) & 0xFFFFFFFF
+    _SEED["ctr"] = 0
+
+
+def _draw():
+    _SEED["ctr"] += 1
+    return ((_SEED["base"] << 32) | (_SEED["ctr"] & 0xFFFFFFFF)) & 0x7FFFFFFFFFFFFFFF
+
+
+def _inv_keep(p):
+    return 1.0 / (1.0 - p) if p > 0 else 0.0
+
+
+# ------------------------------------------------------------------------------------------------
+# K1: embedding + positional encoding + mask (+ dropout)
 # ------------------------------------------------------------------------------------------------
 class EmbedPE(torch.autograd.Function):
-    """nn.Embedding lookup + PositionalEncoding.forward (transformer.py:104-106): (E[ids]+pe)*mask."""
+    """nn.Embedding lookup + PositionalEncoding.forward (transformer.py:104-106): dropout((E[ids]+pe)*mask)."""
 
     @staticmethod
-    def forward(ctx, table, pe, ids, mask, skip_row):
+    def forward(ctx, table, pe, ids, mask, skip_row, drop_p):
         B, L = ids.shape
         ids = ids.contiguous()
         mask = mask.reshape(-1).contiguous()
-        out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L)
+        seed = _draw() if drop_p > 0 else 0
+        out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L, drop_p, seed)
         ctx.save_for_backward(ids, mask)
-        ctx.shape = table.shape
-        ctx.skip_row = skip_row
+        ctx.meta = (table.shape, skip_row, drop_p, seed)
         return out.view(B, L, -1)
 
     @staticmethod
     def backward(ctx, dx):
         ids, mask = ctx.saved_tensors
-        dE = torch.zeros(ctx.shape, device=dx.device, dtype=torch.float32)
-        hip.embed_scatter_bwd(dx.contiguous().view(-1, dx.shape[-1]), ids, mask, dE, ctx.skip_row)
-        return dE, None, None, None, None
+        shape, skip_row, drop_p, seed = ctx.meta
+        dE = torch.zeros(shape, device=dx.device, dtype=torch.float32)
+        hip.embed_scatter_bwd(dx.contiguous().view(-1, dx.shape[-1]), ids, mask, dE, skip_row, drop_p, seed)
+        return dE, None, None, None, None, None
 
 
-def embed_pe(table, pe, ids, mask, skip_row=-1):
-    return EmbedPE.apply(table, pe, ids, mask, skip_row)
+def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
+    return EmbedPE.apply(table, pe, ids, mask, skip_row, float(drop_p))
 
 
 # ------------------------------------------------------------------------------------------------
 # attention / FFN building blocks (plain functions over explicit tensors; used by the layer Functions)
 # ------------------------------------------------------------------------------------------------
-def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad):
-    """MultiHeadAttention.forward (transformer.py:151-161): returns y and what backward needs."""
+def _fusable(x2, Wo, W1):
+    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
+
+
+def _need_fused_for_dropout(drop_p, x2, Wo, W1):
+    if drop_p > 0 and not _fusable(x2, Wo, W1):
+        raise NotImplementedError("dropout > 0 is implemented on the fused block path only "
+                                  "(d_model == n_heads*32 == 128, d_ff % 128 == 0); got d=%d P=%d d_ff=%d"
+                                  % (x2.shape[1], Wo.shape[1], W1.shape[0]))
+
+
+def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0):
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
     qkv = hip.gemm_nt(x2, wqkv, bqkv)
-    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad)
+    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed)
+    return qkv, ctx_, lse
+
+
+def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad):
+    """MultiHeadAttention.forward (transformer.py:151-161), unfused (any width): returns y and what backward needs."""
+    qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
     y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
                     gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
     return y, (qkv, ctx_, lse, rstd)
 
 
-def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, Wk, Wv, Wo, g, be):
-    """Backward of the block above.  Returns dx and the parameter gradients in declaration order."""
+def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, Wk, Wv, Wo, g, be, drop_p=0.0, seed=0):
+    """Backward of the attention block.  Returns dx and the parameter gradients in declaration order."""
     qkv, ctx_, lse, rstd = saved
     d = x2.shape[1]
     P = Wo.shape[1]
@@ -132,7 +171,8 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, W
     dWo, dbo = torch.zeros(d, P, device=dy.device), _z(d, dy)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo)
     dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
-    dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H)
+    dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
+                        drop_p=drop_p, seed=seed)
     dqkv2 = dqkv.view(B * L, 3 * P)
     dWqkv, dbqkv = torch.zeros(3 * P, d, device=dy.device), _z(3 * P, dy)
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
@@ -143,7 +183,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, W
 
 
 def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
-    """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539."""
+    """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539, unfused."""
     h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
     rstd = torch.empty(y.shape[0], device=y.device, dtype=torch.float32)
     out = hip.gemm_nt(h1, shadow(W2), b2.detach(), prologue=hip.PRO_GELU, epilogue=hip.EPI_RESID_LN, aux=y,
@@ -151,48 +191,45 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
     return out, (h1, rstd)
 
 
-def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be):
+def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be, drop_p=0.0, seed_h1=0, seed_out=0):
+    """Backward of the FFN block.  Under dropout h1 holds the DROPPED pre-activation (zeros where dropped),
+    the l2-output mask is regenerated from seed_out and the h1 mask is read back from h1 != 0."""
     h1, rstd = saved
     d, dff = W2.shape
     dg, dbe = _z(d, dout), _z(d, dout)
-    dz = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
+    if drop_p > 0:
+        dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out)
+    else:
+        dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
     dW2, db2 = torch.zeros(d, dff, device=dout.device), _z(d, dout)
-    hip.gemm_tn(dz, h1, dW2, db2, prologue_x=hip.PRO_GELU)
-    dh1 = hip.gemm_nt(dz, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1)
+    hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU)
+    dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
+                      epi_nonzero_scale=_inv_keep(drop_p))
     dW1, db1 = torch.zeros(dff, d, device=dout.device), _z(dff, dout)
     hip.gemm_tn(dh1, y, dW1, db1)
     dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
     return dy, (dW1, db1, dW2, db2, dg, dbe)
 
 
-def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad):
-    wqkv = shadow_cat((Wq, Wk, Wv))
-    bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
-    qkv = hip.gemm_nt(x2, wqkv, bqkv)
-    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad)
-    return qkv, ctx_, lse
-
-
-def _fusable(x2, Wo, W1):
-    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
-
-
 class EncoderLayerFn(torch.autograd.Function):
     """EncoderLayer.forward + `* pad_mask` (transformer.py:202-207,:592-594)."""
 
     @staticmethod
-    def forward(ctx, x, key_ids, rowmask, pad_value, causal, H,
+    def forward(ctx, x, key_ids, rowmask, pad_value, causal, H, drop_p,
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
         need = any(ctx.needs_input_grad)
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
+        _need_fused_for_dropout(drop_p, x2, Wo, W1)
+        seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         if _fusable(x2, Wo, W1):
-            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need)
+            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
+                                           drop_p, seeds[0])
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rowmask, save=need, eps=LN_EPS)
+                                        rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
@@ -200,19 +237,20 @@ class EncoderLayerFn(torch.autograd.Function):
             out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf, Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
-            ctx.meta = (B, L, pad_value, causal, H)
+            ctx.meta = (B, L, pad_value, causal, H, drop_p, seeds)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
         (x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2,
          Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
-        B, L, pad_value, causal, H = ctx.meta
+        B, L, pad_value, causal, H, drop_p, seeds = ctx.meta
         d = x2.shape[1]
-        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, W1, W2, g2, be2)
+        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, W1, W2, g2, be2,
+                                drop_p, seeds[1], seeds[2])
         dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
-                                 Wq, Wk, Wv, Wo, g1, be1)
-        return (dx.view(B, L, d), None, None, None, None, None) + ga + gf
+                                 Wq, Wk, Wv, Wo, g1, be1, drop_p, seeds[0])
+        return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
 class EncoderLastLayerFn(torch.autograd.Function):
@@ -224,7 +262,7 @@ class EncoderLastLayerFn(torch.autograd.Function):
     sequence.  Output and gradients equal row L-1 of EncoderLayerFn."""
 
     @staticmethod
-    def forward(ctx, x, key_ids, rowmask, pad_value, H,
+    def forward(ctx, x, key_ids, rowmask, pad_value, H, drop_p,
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
         need = any(ctx.needs_input_grad)
@@ -232,13 +270,15 @@ class EncoderLastLayerFn(torch.autograd.Function):
         key_ids = key_ids.contiguous()
         rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
         x_last = x[:, -1, :].contiguous()
+        _need_fused_for_dropout(drop_p, x_last, Wo, W1)
+        seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), torch.cat([bk.detach(), bv.detach()]))
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
-        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H)
+        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0])
         if _fusable(x_last, Wo, W1):
             out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rm_last, save=need, eps=LN_EPS)
+                                        rm_last, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
             if need:
                 y, rstd1, sf = sv["y"], sv["rstd1"], (sv["h1"], sv["rstd2"])
         else:
@@ -249,24 +289,24 @@ class EncoderLastLayerFn(torch.autograd.Function):
         if need:
             ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf,
                                   Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
-            ctx.meta = (B, L, pad_value, H)
+            ctx.meta = (B, L, pad_value, H, drop_p, seeds)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2,
          Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
-        B, L, pad_value, H = ctx.meta
+        B, L, pad_value, H, drop_p, seeds = ctx.meta
         d = x2.shape[1]
         P = Wo.shape[1]
         dev = dout.device
-        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, W1, W2, g2, be2)
+        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, W1, W2, g2, be2, drop_p, seeds[1], seeds[2])
         dg1, dbe1 = _z(d, dout), _z(d, dout)
         dz = hip.ln_bwd(dy, y, rstd1, g1.detach(), be1.detach(), None, dg1, dbe1)
         dWo, dbo = torch.zeros(d, P, device=dev), _z(d, dout)
         hip.gemm_tn(dz, c_last, dWo, dbo)
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
-        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H)
+        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0])
         dkv2 = dkv.view(B * L, 2 * P)
         dWq, dbq = torch.zeros(P, d, device=dev), _z(P, dout)
         hip.gemm_tn(dq_last, x_last, dWq, dbq)
@@ -275,16 +315,19 @@ class EncoderLastLayerFn(torch.autograd.Function):
         dx = hip.gemm_nt(dkv2, shadow_cat((Wk, Wv), transpose=True)).view(B, L, d)
         dx_last = hip.gemm_nt(dq_last, shadow(Wq, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
         dx[:, -1, :] += dx_last
-        return ((dx, None, None, None, None, dWq, dbq, dWkv[:P], dbkv[:P], dWkv[P:], dbkv[P:], dWo, dbo, dg1, dbe1) + gf)
+        return ((dx, None, None, None, None, None, dWq, dbq, dWkv[:P], dbkv[:P], dWkv[P:], dbkv[P:], dWo, dbo, dg1, dbe1)
+                + gf)
 
 
 class DecoderLayerFn(torch.autograd.Function):
     """DecoderLayer.forward + `* pad_m` (transformer.py:257-261,:533-539) with the decoder-encoder
     attention in its collapsed form (quirk Q1): K/V are L copies of u = enc_out[:, -1], so
-    context = WV u + bV for every query and WQ/WK of that block are dead (exactly-zero gradients)."""
+    context = WV u + bV for every query and WQ/WK of that block are dead (exactly-zero gradients).
+    Under dropout the attention-map dropout of that block leaves context_h = s[b,h,q] * (WV u + bV)_h,
+    with s the row sum of the dropped uniform map over the live keys of enc_ids (cross_drop_scale)."""
 
     @staticmethod
-    def forward(ctx, x, u, key_ids, rowmask, H,
+    def forward(ctx, x, u, key_ids, enc_ids, rowmask, H, drop_p,
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1,
                 cWv, cbv, cWo, cbo, cg, cbe,
                 W1, b1, W2, b2, g2, be2):
@@ -294,13 +337,27 @@ class DecoderLayerFn(torch.autograd.Function):
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
         u = u.contiguous()
+        _need_fused_for_dropout(drop_p, x2, Wo, W1)
+        seeds = (_draw(), _draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0, 0)
+        P = cWv.shape[0]
         c = hip.gemm_nt(u, shadow(cWv), cbv.detach())                        # [B, P]
-        o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)          # [B, d] f32
+        s_cross = None
+        if drop_p > 0:
+            s_cross = hip.cross_drop_scale(enc_ids.contiguous(), 0, H, drop_p, seeds[3])     # [B*L, H]
+            woS = shadow(cWo)
+            oh = torch.empty(B, H, d, device=x.device, dtype=torch.float32)
+            for hh in range(H):
+                hip.gemm_nt(c[:, hh * 32:(hh + 1) * 32], woS[:, hh * 32:(hh + 1) * 32], None, out=oh[:, hh, :])
+            cross_kw = dict(cross=(None, cg.detach(), cbe.detach()), cross_drop=(s_cross, oh, cbo.detach(), H))
+        else:
+            o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)      # [B, d] f32
+            cross_kw = dict(cross=(o, cg.detach(), cbe.detach()))
         if _fusable(x2, Wo, W1):
-            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need)
+            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0])
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rowmask, save=need, cross=(o, cg.detach(), cbe.detach()), L=L, eps=LN_EPS)
+                                        rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
+                                        seed_out=seeds[2], **cross_kw)
             if need:
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
@@ -309,31 +366,46 @@ class DecoderLayerFn(torch.autograd.Function):
             y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
             out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
+            extra = (s_cross,) if s_cross is not None else ()
             ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf,
-                                  Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2)
-            ctx.meta = (B, L, H)
+                                  Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2, *extra)
+            ctx.meta = (B, L, H, drop_p, seeds)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
+        B, L, H, drop_p, seeds = ctx.meta
+        sav = ctx.saved_tensors
         (x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2,
-         Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2) = ctx.saved_tensors
-        B, L, H = ctx.meta
+         Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2) = sav[:29]
+        s_cross = sav[29] if len(sav) > 29 else None
         d = x2.shape[1]
         P = cWv.shape[0]
-        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, W1, W2, g2, be2)
+        dev = dout.device
+        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, W1, W2, g2, be2,
+                                 drop_p, seeds[1], seeds[2])
         dcg, dcbe = _z(d, dout), _z(d, dout)
         dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), None, dcg, dcbe)   # residual: dz == dy1
-        do = hip.seq_sum(dy1, B, L)                                                     # [B, d] tier dtype
-        dcWo, dcbo = torch.zeros(d, P, device=dout.device), _z(d, dout)
-        hip.gemm_tn(do, c, dcWo, dcbo)
-        dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                               # [B, P]
-        dcWv, dcbv = torch.zeros(P, d, device=dout.device), _z(P, dout)
+        dcWo, dcbo = torch.zeros(d, P, device=dev), _z(d, dout)
+        if s_cross is None:
+            do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype
+            hip.gemm_tn(do, c, dcWo, dcbo)
+            dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                            # [B, P]
+        else:
+            doh = hip.seq_wsum(dy1, s_cross, B, L, H)                                    # [B, H, d]
+            hip.colsum(dy1, dcbo)
+            woT = shadow(cWo, transpose=True)                                            # [P, d]
+            dc = torch.empty(B, P, device=dev, dtype=c.dtype)
+            for hh in range(H):
+                blk = slice(hh * 32, (hh + 1) * 32)
+                hip.gemm_tn(doh[:, hh, :], c[:, blk], dcWo[:, blk])
+                hip.gemm_nt(doh[:, hh, :], woT[blk, :], out=dc[:, blk])
+        dcWv, dcbv = torch.zeros(P, d, device=dev), _z(P, dout)
         hip.gemm_tn(dc, u, dcWv, dcbv)
-        du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                               # [B, d]
+        du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
         dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
-                                 Wq, Wk, Wv, Wo, g1, be1)
-        return ((dx.view(B, L, d), du, None, None, None) + ga + (dcWv, dcbv, dcWo, dcbo, dcg, dcbe) + gf)
+                                 Wq, Wk, Wv, Wo, g1, be1, drop_p, seeds[0])
+        return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (dcWv, dcbv, dcWo, dcbo, dcg, dcbe) + gf)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -376,36 +448,42 @@ def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1):
 # ------------------------------------------------------------------------------------------------
 # K9-K11: discriminator MLP and the W-GAN gradient penalty
 # ------------------------------------------------------------------------------------------------
-def _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4):
-    h1 = hip.gemm_nt(x, shadow(W1), b1.detach(), epilogue=hip.EPI_RELU)
-    h2 = hip.gemm_nt(h1, shadow(W2), b2.detach(), epilogue=hip.EPI_RELU)
-    h3 = hip.gemm_nt(h2, shadow(W3), b3.detach(), epilogue=hip.EPI_RELU)
+def _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4, drop_p=0.0, seeds=(0, 0, 0)):
+    """Linear-ReLU-Dropout x3 + Linear.  The stored activations are the DROPPED ones, so `h > 0` is the
+    combined ReLU-and-kept mask the backward chains need."""
+    kw = lambda i: dict(epilogue=hip.EPI_RELU, drop_p=drop_p, drop_seed=seeds[i])
+    h1 = hip.gemm_nt(x, shadow(W1), b1.detach(), **kw(0))
+    h2 = hip.gemm_nt(h1, shadow(W2), b2.detach(), **kw(1))
+    h3 = hip.gemm_nt(h2, shadow(W3), b3.detach(), **kw(2))
     out = hip.gemm_nt(h3, shadow(W4), b4.detach(), out_f32=True)
     return h1, h2, h3, out.view(-1)
 
 
 class DiscriminatorFn(torch.autograd.Function):
-    """Discriminator.forward in eval mode (tools/utils.py:41-57) -> [B] f32."""
+    """Discriminator.forward (tools/utils.py:41-57) -> [B] f32; drop_p = 0.2 in train mode, 0 in eval."""
 
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, W3, b3, W4, b4):
+    def forward(ctx, x, drop_p, W1, b1, W2, b2, W3, b3, W4, b4):
         x = x.contiguous()
-        h1, h2, h3, out = _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4)
+        seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
+        h1, h2, h3, out = _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4, drop_p, seeds)
         ctx.save_for_backward(x, h1, h2, h3, W1, W2, W3, W4)
+        ctx.drop_p = drop_p
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, h1, h2, h3, W1, W2, W3, W4 = ctx.saved_tensors
-        need_w = ctx.needs_input_grad[1]
+        need_w = ctx.needs_input_grad[2]
+        ik = _inv_keep(ctx.drop_p)
         dout = dout.to(torch.float32).contiguous()
         dev = x.device
-        e3 = hip.outer_posmask(dout, W4.detach().view(-1), h3)
-        e2 = hip.gemm_nt(e3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
-        e1 = hip.gemm_nt(e2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        e3 = hip.outer_posmask(dout, W4.detach().view(-1), h3, scale=ik if ik > 0 else 1.0)
+        e2 = hip.gemm_nt(e3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2, epi_scale=ik)
+        e1 = hip.gemm_nt(e2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1, epi_scale=ik)
         dx = hip.gemm_nt(e1, shadow(W1, transpose=True)) if ctx.needs_input_grad[0] else None
         if not need_w:
-            return (dx,) + (None,) * 8
+            return (dx, None) + (None,) * 8
         dW4 = torch.zeros(W4.shape, device=dev)
         hip.colsum(h3, dW4.view(-1), coef=dout)
         db4 = torch.zeros(1, device=dev)
@@ -416,34 +494,38 @@ class DiscriminatorFn(torch.autograd.Function):
         hip.gemm_tn(e2, h1, dW2, db2)
         dW1, db1 = torch.zeros(W1.shape, device=dev), _z(W1.shape[0], x)
         hip.gemm_tn(e1, x, dW1, db1)
-        return dx, dW1, db1, dW2, db2, dW3, db3, dW4, db4
+        return dx, None, dW1, db1, dW2, db2, dW3, db3, dW4, db4
 
 
 class GradientPenaltyFn(torch.autograd.Function):
     """calc_gradient_penalty (gan_training.py:38-55) with its double backward in closed form
     (SURVEY Q13): forward returns lambda*mean((||dD/dxhat|| - 1)^2) and already holds dGP/dW_i;
-    GP has no bias gradient and real/fake are treated as constants (they are detached at :408,:427)."""
+    GP has no bias gradient and real/fake are treated as constants (they are detached at :408,:427).
+    With dropout the masks m_i are relu-mask * drop-mask / (1-p) (netD stays in train mode there)."""
 
     @staticmethod
-    def forward(ctx, real, fake, alpha, W1, b1, W2, b2, W3, b3, W4, b4):
+    def forward(ctx, real, fake, alpha, drop_p, W1, b1, W2, b2, W3, b3, W4, b4):
         dev = real.device
+        ik = _inv_keep(drop_p)
+        sc = ik if ik > 0 else 1.0
+        seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         xh = hip.interpolate(alpha.reshape(-1).to(torch.float32).contiguous(), real.contiguous(), fake.contiguous())
-        h1, h2, h3, _ = _disc_fwd(xh, W1, b1, W2, b2, W3, b3, W4, b4)
-        u3 = hip.outer_posmask(None, W4.detach().view(-1), h3)
-        u2 = hip.gemm_nt(u3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
-        u1 = hip.gemm_nt(u2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        h1, h2, h3, _ = _disc_fwd(xh, W1, b1, W2, b2, W3, b3, W4, b4, drop_p, seeds)
+        u3 = hip.outer_posmask(None, W4.detach().view(-1), h3, scale=sc)
+        u2 = hip.gemm_nt(u3, shadow(W3, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h2, epi_scale=ik)
+        u1 = hip.gemm_nt(u2, shadow(W2, transpose=True), epilogue=hip.EPI_MUL_POSMASK, aux=h1, epi_scale=ik)
         g = hip.gemm_nt(u1, shadow(W1, transpose=True), out_f32=True)
         gp = torch.zeros(1, device=dev)
         dg = hip.gp_penalty(g, gp, GP_LAMBDA, xh.dtype)
         dW1 = torch.zeros(W1.shape, device=dev)
         hip.gemm_tn(u1, dg, dW1)
-        e1 = hip.gemm_nt(dg, shadow(W1), epilogue=hip.EPI_MUL_POSMASK, aux=h1)
+        e1 = hip.gemm_nt(dg, shadow(W1), epilogue=hip.EPI_MUL_POSMASK, aux=h1, epi_scale=ik)
         dW2 = torch.zeros(W2.shape, device=dev)
         hip.gemm_tn(u2, e1, dW2)
-        e2 = hip.gemm_nt(e1, shadow(W2), epilogue=hip.EPI_MUL_POSMASK, aux=h2)
+        e2 = hip.gemm_nt(e1, shadow(W2), epilogue=hip.EPI_MUL_POSMASK, aux=h2, epi_scale=ik)
         dW3 = torch.zeros(W3.shape, device=dev)
         hip.gemm_tn(u3, e2, dW3)
-        e3 = hip.gemm_nt(e2, shadow(W3), epilogue=hip.EPI_MUL_POSMASK, aux=h3)
+        e3 = hip.gemm_nt(e2, shadow(W3), epilogue=hip.EPI_MUL_POSMASK, aux=h3, epi_scale=ik)
         dW4 = torch.zeros(W4.shape, device=dev)
         hip.colsum(e3, dW4.view(-1))
         ctx.save_for_backward(dW1, dW2, dW3, dW4)
@@ -452,4 +534,4 @@ class GradientPenaltyFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gout):
         dW1, dW2, dW3, dW4 = ctx.saved_tensors
-        return (None, None, None, dW1 * gout, None, dW2 * gout, None, dW3 * gout, None, dW4 * gout, None)
+        return (None, None, None, None, dW1 * gout, None, dW2 * gout, None, dW3 * gout, None, dW4 * gout, None)

@@ -44,6 +44,7 @@ def build_cross(z, device="cuda"):
     assert all(k.endswith(".pe") for k in missing.missing_keys) and not missing.unexpected_keys
     D = Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32)
     D.load_state_dict(state_of(z, "D"))
+    D.eval()                       # golden vectors were captured with netD.eval() (no Dropout(0.2))
     return param, G.to(device), D.to(device)
 
 

@@ -132,9 +132,14 @@ def test_noam_schedule_and_state_dict_layout():
     assert list(Discriminator(param.d_model, 1, param.dis_dim).state_dict().keys()) == [str(k) for k in z["D.keys"]]
 
 
-def test_dropout_is_rejected_loudly():
+def test_dropout_flag_reaches_the_modules():
+    """Train mode uses param.dropout_rate (0.2 in the discriminator), eval mode none -- like nn.Dropout."""
     from recguru_amd.config import get_param
-    from recguru_amd.models import MyAuto4Rec_c
-    a = make_args(32, 1, 3, 12, 50, 50, 1, 4, dropout=0.5)
-    with pytest.raises(NotImplementedError, match="dropout"):
-        MyAuto4Rec_c("cpu", get_param(a, make_dirs=False))
+    from recguru_amd.models import Discriminator, MyAuto4Rec_c
+    a = make_args(128, 4, 3, 12, 50, 50, 1, 4, dropout=0.5)
+    G = MyAuto4Rec_c("cpu", get_param(a, make_dirs=False))
+    D = Discriminator(128, 1, 640)
+    assert G.training and G.encoder.layers[0].drop_p() == 0.5 and G.pos_emb_a.drop_p() == 0.5 and D.drop_p() == 0.2
+    G.eval()
+    D.eval()
+    assert G.encoder.layers[0].drop_p() == 0.0 and G.pos_emb_a.drop_p() == 0.0 and D.drop_p() == 0.0

@@ -132,7 +132,7 @@ def test_critic_losses_grads_step(name):
     np.testing.assert_allclose(float(dis_loss), float(z["dis_loss"]), rtol=1e-3, atol=1e-5)
     dis_loss.backward()
     alpha = torch.as_tensor(z["alpha"]).cuda()
-    gp = ops.GradientPenaltyFn.apply(ae, be, alpha, *D.params())
+    gp = ops.GradientPenaltyFn.apply(ae, be, alpha, 0.0, *D.params())
     np.testing.assert_allclose(float(gp), float(z["gp"]), rtol=1e-3, atol=1e-6)
     gp.backward()
     check_grads(D, z, "gradD_critic.", rtol=2e-3, skip=())
