@@ -61,7 +61,21 @@ template <> struct VStage<float> {
 // (Q3).  Only the reported lse maps the sentinel back to the reference's -1e9.
 #define MASK_BIG (-1e30f)
 
-template <typename T, int NKT, bool CAUSAL>
+// One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
+// rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
+// computed once per head instead of once per lane and element.  Layout [word][query].
+template <int NW, int LPK>
+__device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, const DropCfg& drop, int b, int h, int H, int L, int tid) {
+  const unsigned int nw = rg_lpad(L) >> 5;
+  const unsigned int wbase = ((unsigned int)b * H + h) * L * nw;
+  for (int i = tid; i < NW * LPK; i += 256) {
+    const int w = i / LPK, row = i - w * LPK;
+    dmask[i] = (row < L && (unsigned int)w < nw) ? rg_hash(drop.seed, wbase + (unsigned int)row * nw + w) : 0u;
+  }
+}
+
+// DM: dropout mode -- 0 none, 1 p == 0.5 (bit table in LDS, AND masks), 2 generic p (16-bit hash fields)
+template <typename T, int NKT, bool CAUSAL, int DM>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -75,6 +89,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
   __shared__ __align__(16) T Ks[LPK * LDK];
   __shared__ __align__(16) T Vs[VELEMS];
   __shared__ __align__(16) float kbias[LPK];
+  constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
+  __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -83,7 +99,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
   const int nqt = (L + 15) / 16;
-  const DropCfg drop = make_drop(a.drop_p, a.seed);
+  DropCfg drop = make_drop(a.drop_p, a.seed);
+  if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
+  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
 
   // first Q fragment in flight during staging
   Frag<T> qnext;
@@ -161,16 +179,28 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
       }
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
-    const float inv = __builtin_amdgcn_rcpf(sum);
-    if (drop.thresh) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
-      const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lp4(L) + 4u * lg;
+    float inv = __builtin_amdgcn_rcpf(sum);
+    if constexpr (DM == 1) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
+      inv *= drop.inv_keep;                 // dropped entries are ANDed to zero, the 1/(1-p) rides on the normaliser
 #pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
+      for (int kt = 0; kt < NKT; kt += 2)
         if (kt < nkt) {
-          float k4[4];
-          rg_keep4(drop, base + kt * 16, k4);
+          const unsigned int w = dmask[(kt >> 1) * LPK + q] >> (4 * lg);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[kt][r] *= k4[r];
+          for (int r = 0; r < 4; ++r) {
+            s[kt][r] = rg_and(s[kt][r], rg_bitmask(w, r));
+            if (kt + 1 < NKT) s[kt + 1][r] = rg_and(s[kt + 1][r], rg_bitmask(w, 16 + r));
+          }
+        }
+    } else if constexpr (DM == 2) {
+      const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lpad(L) + 4u * lg;
+#pragma unroll
+      for (int kt = 0; kt < NKT; kt += 2)       // NKT is even; rows start on a hash-word boundary
+        if (kt < nkt) {
+          float k0[4], k1[4];
+          rg_keep4_pair(drop, base + kt * 16, k0, k1);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { s[kt][r] *= k0[r]; if (kt + 1 < NKT) s[kt + 1][r] *= k1[r]; }
         }
     }
     ASTAMP(2);
@@ -241,7 +271,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const DropCfg gdrop = make_drop(a.drop_p, a.seed);
   const unsigned int gbase = ((unsigned int)b * a.H + h) * L;
-  const unsigned int glp4 = rg_lp4(L);
+  const unsigned int glp4 = rg_lpad(L);
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -395,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // and the products are oriented so that dK^T / dV^T / dQ^T land with 4 consecutive features per
 // lane: gradients leave as packed 8-byte stores.
 // ------------------------------------------------------------------------------------------------
-template <int NKT, bool CAUSAL>
+template <int NKT, bool CAUSAL, int DM>
 __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
   typedef __bf16 T;
   constexpr int LPK = NKT * 16;
@@ -408,6 +438,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   __shared__ __align__(16) float dl_s[LPK];     // delta = rowsum(dO * O)
   __shared__ __align__(16) float rowp_s[LPK];   // 1/L for fully masked rows, else 0
   __shared__ __align__(16) float kbias[LPK];
+  constexpr int NW = (NKT + 1) / 2;
+  __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query] dropout bits (p == 0.5 mode), see fill_dmask
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -419,9 +451,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const float c2 = a.scale * 1.4426950408889634f;
-  const DropCfg drop = make_drop(a.drop_p, a.seed);
+  DropCfg drop = make_drop(a.drop_p, a.seed);
+  if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
-  const unsigned int lp4 = rg_lp4(L);
+  const unsigned int lp4 = rg_lpad(L);
+  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
@@ -436,13 +470,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr;
     *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr;
     *reinterpret_cast<Frag<T>*>(Vs + row * LDR + c8) = vr;
-    *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr;
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) d += (float)gr.v[j] * (float)orow.v[j];
     d += __shfl_xor(d, 1);
     d += __shfl_xor(d, 2);
     if ((c & 3) == 0) dl_s[row] = d;
+    if constexpr (DM == 1) {      // p == 0.5 mode: the 1/(1-p) = 2 rides (exactly) on the staged dO, masks are ANDs
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gr.v[j] = (T)((float)gr.v[j] * drop.inv_keep);
+    }
+    *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr;
   }
   for (int r = tid; r < LPK; r += 256) {
     const float lse = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
@@ -477,14 +515,32 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         load4f(l4, lse2_s + q0 + 4 * lg);
         load4f(d4, dl_s + q0 + 4 * lg);
         load4f(r4, rowp_s + q0 + 4 * lg);
+        float ks4[4] = {1.f, 1.f, 1.f, 1.f};
+        unsigned int km4[4] = {~0u, ~0u, ~0u, ~0u};
+        if constexpr (DM == 1) {        // dO is pre-scaled by 1/(1-p): a dropped entry is an AND with 0
+          const uint4 w4 = *reinterpret_cast<const uint4*>(dmask + (key >> 5) * LPK + q0 + 4 * lg);
+          km4[0] = rg_bitmask(w4.x >> (key & 31), 0); km4[1] = rg_bitmask(w4.y >> (key & 31), 0);
+          km4[2] = rg_bitmask(w4.z >> (key & 31), 0); km4[3] = rg_bitmask(w4.w >> (key & 31), 0);
+        } else if constexpr (DM == 2) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) ks4[r] = rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * lp4 + key);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sc = sv[r] + kb;                                        // -1e30 / -inf where replaced
           if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
-          const float ks = drop.thresh ? rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * lp4 + key) : 1.f;
-          ds[u][r] = pe * (dp[r] * ks - d4[r]) * a.scale;
-          p[u][r] = (pe + ((key < L) ? r4[r] : 0.f)) * ks;              // uniform 1/L rows (Q3); dropped map feeds dV
+          const float pu = pe + ((key < L) ? r4[r] : 0.f);              // uniform 1/L rows (Q3)
+          if constexpr (DM == 1) {
+            ds[u][r] = pe * (rg_and(dp[r], km4[r]) - d4[r]) * a.scale;
+            p[u][r] = rg_and(pu, km4[r]);                                // the dropped map feeds dV
+          } else if constexpr (DM == 2) {
+            ds[u][r] = pe * (dp[r] * ks4[r] - d4[r]) * a.scale;
+            p[u][r] = pu * ks4[r];
+          } else {
+            ds[u][r] = pe * (dp[r] - d4[r]) * a.scale;
+            p[u][r] = pu;
+          }
         }
       }
       Frag<T> pf, dsf;
@@ -521,6 +577,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     for (int ks = 0; ks < nt / 2; ++ks) {
       f32x4 ds[2];
+      float kd[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
+      unsigned int km[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
+      if constexpr (DM == 1) {
+        const unsigned int w = dmask[ks * LPK + q] >> (4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { km[0][r] = rg_bitmask(w, r); km[1][r] = rg_bitmask(w, 16 + r); }
+      } else if constexpr (DM == 2) {
+        rg_keep4_pair(drop, (dbase + min(q, L - 1)) * lp4 + ks * 32 + 4 * lg, kd[0], kd[1]);
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int k0 = ks * 32 + u * 16;
@@ -530,16 +595,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
         mma(kf, qf, sv);           // S^T[key][q]
         mma(vf, gf, dp);           // dP^T[key][q]
-        float kb4[4], ks4[4] = {1.f, 1.f, 1.f, 1.f};
+        float kb4[4];
         load4f(kb4, kbias + k0 + 4 * lg);
-        if (drop.thresh) rg_keep4(drop, (dbase + min(q, L - 1)) * lp4 + k0 + 4 * lg, ks4);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float sc = sv[r] + kb4[r];
           if (CAUSAL) sc = (k0 + r > qrel) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -lse_q));
-          const float ks = ks4[r];
-          ds[u][r] = pe * (dp[r] * ks - dl_q) * a.scale;
+          if constexpr (DM == 1) ds[u][r] = pe * (rg_and(dp[r], km[u][r]) - dl_q) * a.scale;
+          else if constexpr (DM == 2) ds[u][r] = pe * (dp[r] * kd[u][r] - dl_q) * a.scale;
+          else ds[u][r] = pe * (dp[r] - dl_q) * a.scale;
         }
       }
       Frag<T> dsf;
@@ -565,10 +630,17 @@ template <typename T>
 static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
   dim3 grid(a.B * a.H), block(256);
-#define RG_FWD(N)                                                                          \
-  do {                                                                                     \
-    if (a.causal) hipLaunchKernelGGL((attn_fwd_kernel<T, N, true>), grid, block, 0, s, a); \
-    else hipLaunchKernelGGL((attn_fwd_kernel<T, N, false>), grid, block, 0, s, a);         \
+  const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+#define RG_FWD2(N, C)                                                                              \
+  do {                                                                                             \
+    if (dm == 0) hipLaunchKernelGGL((attn_fwd_kernel<T, N, C, 0>), grid, block, 0, s, a);          \
+    else if (dm == 1) hipLaunchKernelGGL((attn_fwd_kernel<T, N, C, 1>), grid, block, 0, s, a);     \
+    else hipLaunchKernelGGL((attn_fwd_kernel<T, N, C, 2>), grid, block, 0, s, a);                  \
+  } while (0)
+#define RG_FWD(N)                       \
+  do {                                  \
+    if (a.causal) RG_FWD2(N, true);     \
+    else RG_FWD2(N, false);             \
   } while (0)
   if (nkt <= 2) RG_FWD(2);
   else if (nkt <= 4) RG_FWD(4);
@@ -578,6 +650,7 @@ static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   else if (nkt <= 26) RG_FWD(26);
   else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: L > 416 not supported yet");
 #undef RG_FWD
+#undef RG_FWD2
   RG_CHECK_LAUNCH();
   return 0;
 }
@@ -586,10 +659,17 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
   dim3 grid(a.B * a.H), block(256);
   if constexpr (sizeof(T) == 2) {
-#define RG_BWD16(N)                                                                             \
-  do {                                                                                          \
-    if (a.causal) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, true>), grid, block, 0, s, a);    \
-    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, false>), grid, block, 0, s, a);            \
+    const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+#define RG_BWD16_2(N, C)                                                                              \
+  do {                                                                                                \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0>), grid, block, 0, s, a);           \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2>), grid, block, 0, s, a);                   \
+  } while (0)
+#define RG_BWD16(N)                        \
+  do {                                     \
+    if (a.causal) RG_BWD16_2(N, true);     \
+    else RG_BWD16_2(N, false);             \
   } while (0)
     if (nkt <= 2) RG_BWD16(2);
     else if (nkt <= 4) RG_BWD16(4);
@@ -599,6 +679,7 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
     else if (nkt <= 26) RG_BWD16(26);
     else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 not supported yet");
 #undef RG_BWD16
+#undef RG_BWD16_2
   } else {
 #define RG_BWD(N) hipLaunchKernelGGL((attn_bwd_kernel<T, N>), grid, block, 0, s, a)
     if (nkt <= 2) RG_BWD(2);

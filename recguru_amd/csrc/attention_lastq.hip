@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict
   for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
-  const unsigned int dbase = (((unsigned int)b * H + h) * L + (L - 1)) * rg_lp4(L);   // same index space as the full kernel
+  const unsigned int dbase = (((unsigned int)b * H + h) * L + (L - 1)) * rg_lpad(L);   // same index space as the full kernel
   if (drop.thresh) {
 #pragma unroll
     for (int i = 0; i < MAXKPL; ++i) s[i] *= rg_keep(drop, dbase + lane + 64 * i);
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict
   const int wg = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (wg >= B * H) return;
   const int b = wg / H, h = wg % H, P = H * DK;
-  const unsigned int dbase = (((unsigned int)b * H + h) * L + (L - 1)) * rg_lp4(L);
+  const unsigned int dbase = (((unsigned int)b * H + h) * L + (L - 1)) * rg_lpad(L);
   float q[32], g[32];
   load_row32(q, qlast + (size_t)b * P + h * DK);
   load_row32(g, dctx + (size_t)b * P + h * DK);

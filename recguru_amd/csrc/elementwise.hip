@@ -35,12 +35,10 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
       if (drop.thresh) {
-        float k0[4], k1[4];
-        const unsigned int base = (unsigned int)tok * (unsigned int)d + (unsigned int)c8;
-        rg_keep4(drop, base, k0);
-        rg_keep4(drop, base + 4u, k1);
+        float k8[8];
+        rg_keep8(drop, (unsigned int)tok * (unsigned int)d + (unsigned int)c8, k8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] *= k0[j]; v[4 + j] *= k1[j]; }
+        for (int j = 0; j < 8; ++j) v[j] *= k8[j];
       }
     } else {
 #pragma unroll
@@ -135,12 +133,10 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
       for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
       store8(dz + (size_t)m * a.ld + c8, o8);
       if (dzd) {
-        float k0[4], k1[4];
-        const unsigned int base = (unsigned int)m * (unsigned int)N + (unsigned int)c8;
-        rg_keep4(drop, base, k0);
-        rg_keep4(drop, base + 4u, k1);
+        float k8[8];
+        rg_keep8(drop, (unsigned int)m * (unsigned int)N + (unsigned int)c8, k8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { o8[j] *= k0[j]; o8[4 + j] *= k1[j]; }
+        for (int j = 0; j < 8; ++j) o8[j] *= k8[j];
         store8(dzd + (size_t)m * a.ld + c8, o8);
       }
     }
@@ -325,35 +321,87 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict_
 }
 
 // s[b*L+q, h] = sum over live keys of keep(...) / n_live : the row sum of the dropped uniform attention
-// map of the collapsed decoder cross-attention (Q1 + nn.Dropout of transformer.py:126-127)
+// map of the collapsed decoder cross-attention (Q1 + nn.Dropout of transformer.py:126-127).
+// One workgroup per sequence: the live-key set becomes a bit vector in LDS; in the p == 0.5 mode a row
+// sum is popcount(hash word & live word) over the row's L/32 words.
 __global__ __launch_bounds__(EW_BLOCK) void cross_drop_scale_kernel(const int64_t* __restrict__ ids, int64_t pad, float* __restrict__ s,
                                                                    int B, int L, int H, DropCfg drop) {
-  const long long total = (long long)B * L * H;
-  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
-    const int h = (int)(i % H);
-    const long long bq = i / H;
-    const int b = (int)(bq / L), q = (int)(bq % L);
-    const int64_t* row = ids + (size_t)b * L;
-    int n = 0;
-    for (int j = 0; j < L; ++j) n += row[j] != pad;
-    const bool all_masked = n == 0;                      // replace-fill: uniform over all L keys
-    const unsigned int base = (((unsigned int)b * H + h) * L + q) * rg_lp4(L);     // attention-map index space
+  __shared__ unsigned int live[64];        // L <= 2048
+  __shared__ int nlive_s;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const unsigned int nw = rg_lpad(L) >> 5;
+  if (tid < 64) live[tid] = 0u;
+  if (tid == 0) nlive_s = 0;
+  __syncthreads();
+  for (int j = tid; j < L; j += EW_BLOCK)
+    if (ids[(size_t)b * L + j] != pad) { atomicOr(&live[j >> 5], 1u << (j & 31)); atomicAdd(&nlive_s, 1); }
+  __syncthreads();
+  const int n = nlive_s;
+  const bool all_masked = n == 0;                        // replace-fill: uniform over all L keys
+  if (all_masked) {
+    __syncthreads();
+    for (int j = tid; j < L; j += EW_BLOCK) atomicOr(&live[j >> 5], 1u << (j & 31));
+    __syncthreads();
+  }
+  const float inv_n = 1.f / (float)(all_masked ? L : n);
+  for (int i = tid; i < L * H; i += EW_BLOCK) {
+    const int q = i / H, h = i - q * H;
+    const unsigned int row = ((unsigned int)b * H + h) * L + q;                     // attention-map index space
     float acc = 0.f;
-    for (int j = 0; j < L; ++j)
-      if (all_masked || row[j] != pad) acc += rg_keep(drop, base + j);
-    s[i] = acc / (float)(all_masked ? L : n);
+    if (drop.onebit) {
+      int cnt = 0;
+      for (unsigned int w = 0; w < nw; ++w) cnt += __popc(rg_hash(drop.seed, row * nw + w) & live[w]);
+      acc = (float)cnt * drop.inv_keep;
+    } else {
+      for (int j = 0; j < L; ++j)
+        if ((live[j >> 5] >> (j & 31)) & 1u) acc += rg_keep(drop, row * (nw << 5) + j);
+    }
+    s[((size_t)b * L + q) * H + h] = acc * inv_n;
   }
 }
 
-// out[b,h,:] = sum_q s[b*L+q, h] * x[b,q,:]
-template <typename T>
+// out[b,h,:] = sum_q s[b*L+q, h] * x[b,q,:]     (one workgroup per sequence, x read once for all heads)
+template <typename T, int MAXH>
 __global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict__ x, const float* __restrict__ s, T* __restrict__ out,
                                                            int L, int H, int N) {
-  const int b = blockIdx.x / H, h = blockIdx.x % H;
-  for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
-    float acc = 0.f;
-    for (int t = 0; t < L; ++t) acc += s[((size_t)b * L + t) * H + h] * (float)x[((size_t)b * L + t) * N + n];
-    out[((size_t)b * H + h) * N + n] = (T)acc;
+  extern __shared__ float sw_smem[];       // s[b] : L*H floats, then the [rows][H][N] partials
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tpr = N >> 2, rows = EW_BLOCK / tpr;       // threads per row (4 columns each), rows in flight
+  float* sl = sw_smem;
+  float* part = sw_smem + L * H;
+  for (int i = tid; i < L * H; i += EW_BLOCK) sl[i] = s[(size_t)b * L * H + i];
+  __syncthreads();
+  const int c4 = (tid % tpr) * 4, r0 = tid / tpr;
+  float acc[MAXH][4];
+#pragma unroll
+  for (int h = 0; h < MAXH; ++h)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[h][j] = 0.f;
+  if (r0 < rows)
+    for (int t = r0; t < L; t += rows) {
+      float v[4];
+      load4t(v, x + ((size_t)b * L + t) * N + c4);
+#pragma unroll
+      for (int h = 0; h < MAXH; ++h)
+        if (h < H) {
+          const float w = sl[t * H + h];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[h][j] += w * v[j];
+        }
+    }
+  if (r0 < rows) {
+#pragma unroll
+    for (int h = 0; h < MAXH; ++h)
+      if (h < H) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) part[((size_t)r0 * H + h) * N + c4 + j] = acc[h][j];
+      }
+  }
+  __syncthreads();
+  for (int i = tid; i < H * N; i += EW_BLOCK) {
+    float t = 0.f;
+    for (int r = 0; r < rows; ++r) t += part[(size_t)r * H * N + i];
+    out[(size_t)b * H * N + i] = (T)t;
   }
 }
 
@@ -363,7 +411,8 @@ __global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict_
 extern "C" int rg_cross_drop_scale(const int64_t* enc_ids, int64_t pad_value, float* s, int B, int L, int H, float drop_p,
                                    unsigned long long seed, void* stream) {
   if (B <= 0) return 0;
-  hipLaunchKernelGGL(cross_drop_scale_kernel, dim3(ew_grid((long long)B * L * H, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream,
+  if (L > 2048) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "cross_drop_scale: L > 2048");
+  hipLaunchKernelGGL(cross_drop_scale_kernel, dim3(B), dim3(EW_BLOCK), 0, (hipStream_t)stream,
                      enc_ids, pad_value, s, B, L, H, make_drop(drop_p, seed));
   RG_CHECK_LAUNCH();
   return 0;
@@ -372,8 +421,13 @@ extern "C" int rg_cross_drop_scale(const int64_t* enc_ids, int64_t pad_value, fl
 extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int L, int H, int N, int dtype, void* stream) {
   if (B <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (dtype == RG_BF16) hipLaunchKernelGGL(seq_wsum_kernel<__bf16>, dim3(B * H), dim3(EW_BLOCK), 0, st, (const __bf16*)x, s, (__bf16*)out, L, H, N);
-  else if (dtype == RG_F32) hipLaunchKernelGGL(seq_wsum_kernel<float>, dim3(B * H), dim3(EW_BLOCK), 0, st, (const float*)x, s, (float*)out, L, H, N);
+  const int tpr = N >> 2;
+  if ((N & 3) || tpr < 1 || tpr > EW_BLOCK || (EW_BLOCK % tpr) || H > 8)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "seq_wsum: needs N/4 a divisor of the block size and H <= 8");
+  const size_t smem = ((size_t)L * H + (size_t)(EW_BLOCK / tpr) * H * N) * sizeof(float);
+  if (smem > 64 * 1024) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "seq_wsum: L*H + rows*H*N floats exceed 64 KB of LDS");
+  if (dtype == RG_BF16) hipLaunchKernelGGL((seq_wsum_kernel<__bf16, 8>), dim3(B), dim3(EW_BLOCK), smem, st, (const __bf16*)x, s, (__bf16*)out, L, H, N);
+  else if (dtype == RG_F32) hipLaunchKernelGGL((seq_wsum_kernel<float, 8>), dim3(B), dim3(EW_BLOCK), smem, st, (const float*)x, s, (float*)out, L, H, N);
   else return rg_set_error_msg(RG_ERR_INVALID, "seq_wsum: bad dtype");
   RG_CHECK_LAUNCH();
   return 0;

@@ -66,14 +66,6 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][4], const float* __rest
   }
 }
 
-// 4 consecutive elements of a tile row -> float[4]
-__device__ __forceinline__ void load4t(float* o, const float* p) { load4f(o, p); }
-__device__ __forceinline__ void load4t(float* o, const __bf16* p) {
-  const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p);
-#pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = (float)a[j];
-}
-
 // LayerNorm on the accumulator registers.  Lane (li, lg) of wave w holds, for token rt*16+li, the 8
 // features w*32 + ct*16 + 4*lg + r: row statistics = in-lane sum, 2 shuffles across lg, then a
 // [64 tokens x 4 waves] exchange through LDS.  Two-pass (mean, then centred second moment) like
@@ -169,7 +161,8 @@ __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __res
 #define STAMP(i)
 #endif
 
-template <typename T>
+// DM: dropout mode -- 0 none, 1 p == 0.5 (one hash bit per element), 2 generic p (16-bit hash fields)
+template <typename T, int DM>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -202,7 +195,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const int n0 = wave * 32;                 // this wave's 32 output features of every 128-wide block
   const int ntiles = (a.M + FT_M - 1) / FT_M;
   const int nchunk = a.dff / FD;
-  const DropCfg drop1 = make_drop(a.drop_p, a.seed_h1), drop2 = make_drop(a.drop_p, a.seed_out);
+  DropCfg drop1 = make_drop(a.drop_p, a.seed_h1), drop2 = make_drop(a.drop_p, a.seed_out);
+  if constexpr (DM == 2) { drop1.onebit = 0u; drop2.onebit = 0u; }
 
   // ---- once per workgroup: parameters -> LDS
   for (int i = tid; i < FD; i += 256) {
@@ -312,6 +306,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
     f32x4 acc2[2][4];
     init_acc(acc2, p_b2, n0, lg);
+#pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
       load_wset(wq, W2, a.dff, n0, ch * FD, li, lg);    // needed after the GELU below
       init_acc(acc, p_b1 + ch * FD, n0, lg);
@@ -321,16 +316,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
-      if (drop1.thresh) {       // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
+      if constexpr (DM != 0) {  // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
+          if constexpr (DM == 1) {       // rb & 31 == 4*lg: both feature tiles of this lane sit in one hash word
+            const unsigned int w = rg_hash(drop1.seed, rb >> 5) >> (4 * lg);
 #pragma unroll
-          for (int ct = 0; ct < 2; ++ct) {
-            float k4[4];
-            rg_keep4(drop1, rb + ct * 16, k4);
+            for (int r = 0; r < 4; ++r) {
+              acc[0][rt][r] = rg_and(acc[0][rt][r], rg_bitmask(w, r)) * drop1.inv_keep;
+              acc[1][rt][r] = rg_and(acc[1][rt][r], rg_bitmask(w, 16 + r)) * drop1.inv_keep;
+            }
+          } else {
+            float k0[4], k1[4];
+            rg_keep4_pair(drop1, rb, k0, k1);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) acc[ct][rt][r] *= k4[r];
+            for (int r = 0; r < 4; ++r) { acc[0][rt][r] *= k0[r]; acc[1][rt][r] *= k1[r]; }
           }
         }
       }
@@ -360,16 +361,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
         } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
       }
     }
-    if (drop2.thresh) {         // dropout on the l2 output, before the residual (transformer.py:186-188)
+    if constexpr (DM != 0) {    // dropout on the l2 output, before the residual (transformer.py:186-188)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
+        if constexpr (DM == 1) {
+          const unsigned int w = rg_hash(drop2.seed, rb >> 5) >> (4 * lg);
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          float k4[4];
-          rg_keep4(drop2, rb + ct * 16, k4);
+          for (int r = 0; r < 4; ++r) {
+            acc2[0][rt][r] = rg_and(acc2[0][rt][r], rg_bitmask(w, r)) * drop2.inv_keep;
+            acc2[1][rt][r] = rg_and(acc2[1][rt][r], rg_bitmask(w, 16 + r)) * drop2.inv_keep;
+          }
+        } else {
+          float k0[4], k1[4];
+          rg_keep4_pair(drop2, rb, k0, k1);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= k4[r];
+          for (int r = 0; r < 4; ++r) { acc2[0][rt][r] *= k0[r]; acc2[1][rt][r] *= k1[r]; }
         }
       }
     }
@@ -424,13 +431,23 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   const int per_cu = (160 * 1024) / smem;
   int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
   if (grid > ntiles) grid = ntiles;
-  if (dtype == RG_BF16) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(post_attn_fwd_kernel<__bf16>, dim3(grid), dim3(256), smem, s, *a);
-  } else if (dtype == RG_F32) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL(post_attn_fwd_kernel<float>, dim3(grid), dim3(256), smem, s, *a);
-  } else return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: bad dtype");
+  const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
+#define RG_PA(T, DM)                                                                                                      \
+  do {                                                                                                                    \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM>), dim3(grid), dim3(256), smem, s, *a);                                \
+  } while (0)
+#define RG_PA_T(T)                   \
+  do {                               \
+    if (dm == 0) RG_PA(T, 0);        \
+    else if (dm == 1) RG_PA(T, 1);   \
+    else RG_PA(T, 2);                \
+  } while (0)
+  if (dtype == RG_BF16) RG_PA_T(__bf16);
+  else if (dtype == RG_F32) RG_PA_T(float);
+  else return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: bad dtype");
+#undef RG_PA_T
+#undef RG_PA
   RG_CHECK_LAUNCH();
   return 0;
 }

@@ -125,12 +125,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
           for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
           if (a.drop_p > 0.f) {
             const DropCfg dc = make_drop(a.drop_p, a.drop_seed);
-            float k0[4], k1[4];
-            const unsigned int base = (unsigned int)m * (unsigned int)a.N + (unsigned int)n;   // N % 8 == 0 here
-            rg_keep4(dc, base, k0);
-            rg_keep4(dc, base + 4u, k1);
+            float k8[8];
+            rg_keep8(dc, (unsigned int)m * (unsigned int)a.N + (unsigned int)n, k8);   // N % 8 == 0 here
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { v[j] *= k0[j]; v[4 + j] *= k1[j]; }
+            for (int j = 0; j < 8; ++j) v[j] *= k8[j];
           }
         } else if (a.epilogue != RG_EPI_NONE) {
           float x[8];

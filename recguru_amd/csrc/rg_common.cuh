@@ -157,6 +157,14 @@ __device__ __forceinline__ float gelu_grad_t(float x) {
 }
 __device__ __forceinline__ float gelu_f(float x) { return gelu_t<true>(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<true>(x); }
+// 4 consecutive elements -> float[4]
+__device__ __forceinline__ void load4t(float* o, const float* p) { load4f(o, p); }
+__device__ __forceinline__ void load4t(float* o, const __bf16* p) {
+  const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (float)a[j];
+}
+
 template <typename T> struct Precise { static constexpr bool value = true; };
 template <> struct Precise<__bf16> { static constexpr bool value = false; };
 
@@ -165,12 +173,15 @@ template <> struct Precise<__bf16> { static constexpr bool value = false; };
 // with probability 1-p and scaled by 1/(1-p); only the random stream differs from torch's Philox).
 struct DropCfg {
   unsigned int seed;         // folded 64-bit call seed
-  unsigned int thresh;       // drop iff 16-bit field < thresh  (thresh = p * 65536); 0 = dropout off
+  unsigned int thresh;       // 16-bit mode: drop iff field < thresh (= p * 65536); 0 = dropout off
   float inv_keep;            // 1 / (1 - p)
+  unsigned int onebit;       // p == 0.5 exactly: one hash BIT per element (32 elements per hash)
 };
-// Element idx (a 32-bit, wrapping index in a per-site index space) is decided by the (idx & 1)-th 16-bit
-// half of hash(idx >> 1): one lowbias32 hash (2 multiplies) serves two consecutive elements, and
-// rg_keep4 (base % 4 == 0) covers the 4 consecutive elements of an accumulator register with 2 hashes.
+// Element idx (a 32-bit, wrapping index in a per-site index space) is decided
+//   * p == 0.5 : by bit (idx & 31) of hash(idx >> 5) -- a 2-multiply lowbias32 hash serves 32 elements,
+//   * otherwise: by the (idx & 1)-th 16-bit half of hash(idx >> 1) compared with p * 65536.
+// The group helpers (rg_keep4 / rg_keep8 / rg_keep4_pair) return the same decisions as rg_keep()
+// element by element; they only share the hash words.
 __device__ __forceinline__ unsigned int rg_hash(unsigned int seed, unsigned int x) {
   x ^= seed;
   x ^= x >> 16; x *= 0x21f0aaadu;
@@ -178,17 +189,52 @@ __device__ __forceinline__ unsigned int rg_hash(unsigned int seed, unsigned int 
   x ^= x >> 15;
   return x;
 }
+__device__ __forceinline__ float rg_bit(const DropCfg& c, unsigned int w, int j) { return (w >> j) & 1u ? c.inv_keep : 0.f; }
+// bit j of w as an AND mask (all ones = keep) and its use on a float: 2 VALU ops per element, scale applied elsewhere
+__device__ __forceinline__ unsigned int rg_bitmask(unsigned int w, int j) { return (unsigned int)__builtin_amdgcn_sbfe((int)w, j, 1); }
+__device__ __forceinline__ float rg_and(float x, unsigned int m) { return __uint_as_float(__float_as_uint(x) & m); }
+__device__ __forceinline__ float rg_field(const DropCfg& c, unsigned int f16) { return f16 < c.thresh ? 0.f : c.inv_keep; }
 __device__ __forceinline__ float rg_keep(const DropCfg& c, unsigned int idx) {
+  if (c.onebit) return (rg_hash(c.seed, idx >> 5) >> (idx & 31u)) & 1u ? c.inv_keep : 0.f;
   const unsigned int h = rg_hash(c.seed, idx >> 1);
-  const unsigned int field = (idx & 1u) ? (h >> 16) : (h & 0xFFFFu);
-  return field < c.thresh ? 0.f : c.inv_keep;
+  return rg_field(c, (idx & 1u) ? (h >> 16) : (h & 0xFFFFu));
 }
+// base % 4 == 0
 __device__ __forceinline__ void rg_keep4(const DropCfg& c, unsigned int base, float (&k)[4]) {
-  const unsigned int h0 = rg_hash(c.seed, base >> 1), h1 = rg_hash(c.seed, (base >> 1) + 1u);
-  k[0] = (h0 & 0xFFFFu) < c.thresh ? 0.f : c.inv_keep;
-  k[1] = (h0 >> 16) < c.thresh ? 0.f : c.inv_keep;
-  k[2] = (h1 & 0xFFFFu) < c.thresh ? 0.f : c.inv_keep;
-  k[3] = (h1 >> 16) < c.thresh ? 0.f : c.inv_keep;
+  if (c.onebit) {
+    const unsigned int w = rg_hash(c.seed, base >> 5) >> (base & 31u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = rg_bit(c, w, j);
+  } else {
+    const unsigned int h0 = rg_hash(c.seed, base >> 1), h1 = rg_hash(c.seed, (base >> 1) + 1u);
+    k[0] = rg_field(c, h0 & 0xFFFFu); k[1] = rg_field(c, h0 >> 16);
+    k[2] = rg_field(c, h1 & 0xFFFFu); k[3] = rg_field(c, h1 >> 16);
+  }
+}
+// base % 8 == 0
+__device__ __forceinline__ void rg_keep8(const DropCfg& c, unsigned int base, float (&k)[8]) {
+  if (c.onebit) {
+    const unsigned int w = rg_hash(c.seed, base >> 5) >> (base & 31u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) k[j] = rg_bit(c, w, j);
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned int h = rg_hash(c.seed, (base >> 1) + j);
+      k[2 * j] = rg_field(c, h & 0xFFFFu); k[2 * j + 1] = rg_field(c, h >> 16);
+    }
+  }
+}
+// elements base..base+3 and base+16..base+19, base % 4 == 0 and (base & 31) < 16 (both groups in one hash word)
+__device__ __forceinline__ void rg_keep4_pair(const DropCfg& c, unsigned int base, float (&k0)[4], float (&k1)[4]) {
+  if (c.onebit) {
+    const unsigned int w = rg_hash(c.seed, base >> 5) >> (base & 31u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { k0[j] = rg_bit(c, w, j); k1[j] = rg_bit(c, w, 16 + j); }
+  } else {
+    rg_keep4(c, base, k0);
+    rg_keep4(c, base + 16u, k1);
+  }
 }
 __host__ __device__ inline DropCfg make_drop(float p, unsigned long long seed) {
   DropCfg c;
@@ -197,10 +243,12 @@ __host__ __device__ inline DropCfg make_drop(float p, unsigned long long seed) {
   c.seed = s;
   c.thresh = p > 0.f ? (unsigned int)((double)p * 65536.0 + 0.5) : 0u;
   c.inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  c.onebit = p == 0.5f ? 1u : 0u;
   return c;
 }
-// attention-map index space: ((b*H + h)*L + q) * LP4 + key with LP4 = L rounded up to a multiple of 4
-__host__ __device__ inline unsigned int rg_lp4(int L) { return (unsigned int)((L + 3) & ~3); }
+// attention-map index space: ((b*H + h)*L + q) * LPAD + key, LPAD = L rounded up to a multiple of 32
+// (a row starts on a hash-word boundary)
+__host__ __device__ inline unsigned int rg_lpad(int L) { return (unsigned int)((L + 31) & ~31); }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release
 // fence, for which hipcc drains vmcnt(0) whenever a global store is outstanding -- and loads share that

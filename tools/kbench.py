@@ -59,6 +59,10 @@ def main():
         2.0 * M * (d * P + 2 * d * dff), M * 3 * d * es)
     rec("FUSED post-attn (train, saves)", timeit(lambda: hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, rm, save=True), n=10),
         2.0 * M * (d * P + 2 * d * dff), M * (4 * d + dff) * es)
+    rec("FUSED post-attn (train, p=0.5)", timeit(lambda: hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, rm, save=True, drop_p=0.5, seed_h1=1, seed_out=2), n=10),
+        2.0 * M * (d * P + 2 * d * dff), M * (4 * d + dff) * es)
+    rec("FUSED post-attn (train, p=0.3)", timeit(lambda: hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, rm, save=True, drop_p=0.3, seed_h1=1, seed_out=2), n=10),
+        2.0 * M * (d * P + 2 * d * dff), M * (4 * d + dff) * es)
     dW = torch.zeros(dff, d, device=dev)
     cs = torch.zeros(dff, device=dev)
     rec("tn dW1   N1=512 N2=128", timeit(lambda: hip.gemm_tn(h1, x, dW, cs)), 2.0 * M * dff * d, M * (d + dff) * es)
@@ -72,6 +76,11 @@ def main():
     rec("attn fwd full", timeit(lambda: hip.attn_fwd(q3, ids, 0, False, H)), 4.0 * B * H * L * L * 32, M * 4 * P * es)
     dctx = r(B, L, P)
     rec("attn bwd", timeit(lambda: hip.attn_bwd(q3, dctx, c3, lse, ids, 0, True, H), n=5), 10.0 * B * H * L * L * 32, M * 8 * P * es)
+    rec("attn fwd full p=0.5", timeit(lambda: hip.attn_fwd(q3, ids, 0, False, H, drop_p=0.5, seed=3)), 4.0 * B * H * L * L * 32, M * 4 * P * es)
+    rec("attn fwd full p=0.3", timeit(lambda: hip.attn_fwd(q3, ids, 0, False, H, drop_p=0.3, seed=3)), 4.0 * B * H * L * L * 32, M * 4 * P * es)
+    rec("attn bwd full", timeit(lambda: hip.attn_bwd(q3, dctx, c3, lse, ids, 0, False, H), n=5), 10.0 * B * H * L * L * 32, M * 8 * P * es)
+    rec("attn bwd full p=0.5", timeit(lambda: hip.attn_bwd(q3, dctx, c3, lse, ids, 0, False, H, drop_p=0.5, seed=3), n=5), 10.0 * B * H * L * L * 32, M * 8 * P * es)
+    rec("attn bwd full p=0.3", timeit(lambda: hip.attn_bwd(q3, dctx, c3, lse, ids, 0, False, H, drop_p=0.3, seed=3), n=5), 10.0 * B * H * L * L * 32, M * 8 * P * es)
     dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
     rec("ln_bwd", timeit(lambda: hip.ln_bwd(x, x, rstd, g, be, rm, dg, db)), 0, M * 3 * d * es)
     print("%-32s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
