@@ -59,7 +59,7 @@ template <> struct VStage<float> {
 // -inf beyond L.  s + (-1e30) == -1e30 exactly in f32, so every replaced score is the same value --
 // the "replace-fill" semantics of masked_fill_(-1e9): a fully masked row is uniform over all L keys
 // (Q3).  Only the reported lse maps the sentinel back to the reference's -1e9.
-#define MASK_BIG (-1e30f)
+#define MASK_BIG (-0x1p100f)   // ~ -1.27e30; a power of two so that MASK_BIG * c is exact for any float c
 
 // One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
 // rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
@@ -75,8 +75,10 @@ __device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, con
 }
 
 // DM: dropout mode -- 0 none, 1 p == 0.5 (bit table in LDS, AND masks), 2 generic p (16-bit hash fields)
+// (256, 2): a register budget of 256 makes hipcc select the VGPR form of the MFMAs; with the default budget
+// of 512 it parks every score accumulator in AGPRs and copies it out and back (~6 v_accvgpr moves per score).
 template <typename T, int NKT, bool CAUSAL, int DM>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0__ = __builtin_amdgcn_s_memtime();
@@ -111,19 +113,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
     else frag_zero(qnext);
   }
   // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
-  for (int c = tid; c < LPK * 4; c += 256) {
-    const int key = c >> 2, c8 = (c & 3) * 8;
-    Frag<T> kr, vr;
-    if (key < L) {
-      load_frag(kr, qkv + (size_t)key * ld + P + h * DK + c8);
-      load_frag(vr, qkv + (size_t)key * ld + 2 * P + h * DK + c8);
-    } else { frag_zero(kr); frag_zero(vr); }
-    *reinterpret_cast<Frag<T>*>(Ks + key * LDK + c8) = kr;
-    if (VT) {
+  // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
+  // per thread, not one per chunk (the rolled copy loop spent as long staging as computing)
+  constexpr int NCH = (LPK * 4 + 255) / 256;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Vs[(c8 + j) * LDV + key] = vr.v[j];
-    } else {
-      *reinterpret_cast<Frag<T>*>(Vs + key * LDV + c8) = vr;
+  for (int i0 = 0; i0 < NCH; i0 += 4) {
+    Frag<T> kr[4], vr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * (i0 + i), key = c >> 2, c8 = (c & 3) * 8;
+      const int kc = min(key, L - 1);                 // clamped address, zeroed below: no branch between the loads
+      if (i0 + i < NCH) {
+        load_frag(kr[i], qkv + (size_t)kc * ld + P + h * DK + c8);
+        load_frag(vr[i], qkv + (size_t)kc * ld + 2 * P + h * DK + c8);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int key = (tid + 256 * (i0 + i)) >> 2;
+      if (i0 + i >= NCH || key >= L) { frag_zero(kr[i]); frag_zero(vr[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * (i0 + i), key = c >> 2, c8 = (c & 3) * 8;
+      if (i0 + i < NCH && c < LPK * 4) {
+        *reinterpret_cast<Frag<T>*>(Ks + key * LDK + c8) = kr[i];
+        if (VT) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) Vs[(c8 + j) * LDV + key] = vr[i].v[j];
+        } else {
+          *reinterpret_cast<Frag<T>*>(Vs + key * LDV + c8) = vr[i];
+        }
+      }
     }
   }
   for (int key = tid; key < LPK; key += 256)
@@ -151,37 +172,38 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
         load_frag(kf, Ks + (kt * 16 + li) * LDK + 8 * lg);
         float kb[4];
         load4f(kb, kbias + kt * 16 + 4 * lg);
-        s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        s[kt] = (f32x4){kb[0], kb[1], kb[2], kb[3]};     // the key bias rides in the accumulator: -2^100 + x == -2^100
         mma(kf, qf, s[kt]);
+        if (CAUSAL) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[kt][r] + kb[r];
-          if (CAUSAL) v = (kt * 16 + r > qrel) ? fminf(v, MASK_BIG) : v;     // keeps -inf beyond L
-          s[kt][r] = v;
-          mx = fmaxf(mx, v);
+          for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + r > qrel) ? fminf(s[kt][r], MASK_BIG) : s[kt][r];     // keeps -inf beyond L
         }
+        mx = fmaxf(fmaxf(mx, s[kt][0]), s[kt][1]);
+        mx = fmaxf(fmaxf(mx, s[kt][2]), s[kt][3]);
       }
     }
     ASTAMP(1);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
+    // exp2(s*c2 - mx*c2) as ONE fma: for a fully masked row every s and mx are the sentinel -2^100, whose products
+    // with c2 are exact, so the argument is exactly 0 (uniform row, Q3) -- no cancellation residue.
+    const float nmx = -mx * c2;
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
       if (kt < nkt) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          // (s - mx) first: exact 0 for the -1e30 sentinel rows (an fma against -mx*c2 would leave a ~1e22 residual)
-          const float p = __builtin_amdgcn_exp2f((s[kt][r] - mx) * c2);
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, nmx));
           s[kt][r] = p;
-          sum += p;
+          if constexpr (DM != 0) sum += p;      // DM == 0: the row sum comes out of the MFMA below
         }
       }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    float inv = __builtin_amdgcn_rcpf(sum);
+    if constexpr (DM != 0) {
+      sum += __shfl_xor(sum, 16);
+      sum += __shfl_xor(sum, 32);
+    }
     if constexpr (DM == 1) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
-      inv *= drop.inv_keep;                 // dropped entries are ANDed to zero, the 1/(1-p) rides on the normaliser
 #pragma unroll
       for (int kt = 0; kt < NKT; kt += 2)
         if (kt < nkt) {
@@ -206,6 +228,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
     ASTAMP(2);
 
     f32x4 o[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};
+    Frag<T> ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
 #pragma unroll
     for (int ks = 0; ks < NKT / 2; ++ks)
       if (2 * ks < nkt) {
@@ -217,7 +243,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
           VStage<T>::frag(vf, Vs, LDV, ks * 32, dt * 16, li, lg);
           mma(vf, pf, o[dt]);
         }
+        // row sums of P as a third product against a ones tile: every accumulator row of a lane is the
+        // complete sum over the keys (no per-element adds, no cross-lane reduction), and it is the sum of
+        // exactly the (rounded) P that multiplies V
+        if constexpr (DM == 0) mma(ones, pf, osum);
       }
+    if constexpr (DM == 0) sum = osum[0];
+    float inv = __builtin_amdgcn_rcpf(sum);
+    if constexpr (DM == 1) inv *= drop.inv_keep;       // dropped entries were ANDed to zero, the 1/(1-p) rides on the normaliser
     ASTAMP(3);
     if (q < L) {
       T* __restrict__ ctx = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
@@ -235,8 +268,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(rg_attn_args a) {
     ASTAMP(4);
   }
 #ifdef RG_STAMP
-  if (a.lse != nullptr && blockIdx.x < 1024 && lane == 0) {   // diagnostic build: lse doubles as the stamp buffer
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.lse) + (size_t)(blockIdx.x * 4 + wave) * 8;
+  if (a.lse != nullptr && blockIdx.x >= 8192 && blockIdx.x < 9216 && lane == 0) {   // diagnostic build: lse doubles as the stamp buffer (steady-state window)
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.lse) + (size_t)((blockIdx.x - 8192) * 4 + wave) * 8;
     for (int i = 0; i < 8; ++i) dbg[i] = tacc[i];
   }
 #endif
@@ -457,30 +490,48 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const unsigned int lp4 = rg_lpad(L);
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
 
-  for (int c = tid; c < LPK * 4; c += 256) {
-    const int row = c >> 2, c8 = (c & 3) * 8;
-    Frag<T> qr, kr, vr, gr, orow;
-    if (row < L) {
-      load_frag(qr, qkv + (size_t)row * ld + h * DK + c8);
-      load_frag(kr, qkv + (size_t)row * ld + P + h * DK + c8);
-      load_frag(vr, qkv + (size_t)row * ld + 2 * P + h * DK + c8);
-      load_frag(gr, dO + (size_t)row * P + c8);
-      load_frag(orow, O + (size_t)row * P + c8);
-    } else { frag_zero(qr); frag_zero(kr); frag_zero(vr); frag_zero(gr); frag_zero(orow); }
-    *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr;
-    *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr;
-    *reinterpret_cast<Frag<T>*>(Vs + row * LDR + c8) = vr;
-    float d = 0.f;
+  // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
+  constexpr int NCH = (LPK * 4 + 255) / 256;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d += (float)gr.v[j] * (float)orow.v[j];
-    d += __shfl_xor(d, 1);
-    d += __shfl_xor(d, 2);
-    if ((c & 3) == 0) dl_s[row] = d;
-    if constexpr (DM == 1) {      // p == 0.5 mode: the 1/(1-p) = 2 rides (exactly) on the staged dO, masks are ANDs
+  for (int i0 = 0; i0 < NCH; i0 += 4) {
+    Frag<T> qr[4], kr[4], vr[4], gr[4], orow[4];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) gr.v[j] = (T)((float)gr.v[j] * drop.inv_keep);
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+      const int rc = min(row, L - 1);                 // clamped address, zeroed below: no branch between the loads
+      if (i0 + i < NCH) {
+        load_frag(qr[i], qkv + (size_t)rc * ld + h * DK + c8);
+        load_frag(kr[i], qkv + (size_t)rc * ld + P + h * DK + c8);
+        load_frag(vr[i], qkv + (size_t)rc * ld + 2 * P + h * DK + c8);
+        load_frag(gr[i], dO + (size_t)rc * P + c8);
+        load_frag(orow[i], O + (size_t)rc * P + c8);
+      }
     }
-    *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid + 256 * (i0 + i)) >> 2;
+      if (i0 + i >= NCH || row >= L) { frag_zero(qr[i]); frag_zero(kr[i]); frag_zero(vr[i]); frag_zero(gr[i]); frag_zero(orow[i]); }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+      if (i0 + i < NCH && c < LPK * 4) {
+        *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr[i];
+        *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr[i];
+        *reinterpret_cast<Frag<T>*>(Vs + row * LDR + c8) = vr[i];
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += (float)gr[i].v[j] * (float)orow[i].v[j];
+        d += __shfl_xor(d, 1);
+        d += __shfl_xor(d, 2);
+        if ((c & 3) == 0) dl_s[row] = d;
+        if constexpr (DM == 1) {      // p == 0.5 mode: the 1/(1-p) = 2 rides (exactly) on the staged dO, masks are ANDs
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gr[i].v[j] = (T)((float)gr[i].v[j] * drop.inv_keep);
+        }
+        *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr[i];
+      }
+    }
   }
   for (int r = tid; r < LPK; r += 256) {
     const float lse = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
@@ -508,7 +559,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         Frag<T> qf, gf;
         load_frag(qf, Qs + (q0 + li) * LDR + 8 * lg);
         load_frag(gf, Gs + (q0 + li) * LDR + 8 * lg);
-        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        f32x4 sv = (f32x4){kb, kb, kb, kb}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};     // key bias rides in the accumulator
         mma(qf, kf, sv);
         mma(gf, vf, dp);
         float l4[4], d4[4], r4[4];
@@ -527,18 +578,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = sv[r] + kb;                                        // -1e30 / -inf where replaced
+          float sc = sv[r];                                             // -2^100 / -inf where replaced
           if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
           const float pu = pe + ((key < L) ? r4[r] : 0.f);              // uniform 1/L rows (Q3)
           if constexpr (DM == 1) {
-            ds[u][r] = pe * (rg_and(dp[r], km4[r]) - d4[r]) * a.scale;
+            ds[u][r] = pe * (rg_and(dp[r], km4[r]) - d4[r]);          // the 1/sqrt(d_k) is applied to dK / dQ on the way out
             p[u][r] = rg_and(pu, km4[r]);                                // the dropped map feeds dV
           } else if constexpr (DM == 2) {
-            ds[u][r] = pe * (dp[r] * ks4[r] - d4[r]) * a.scale;
+            ds[u][r] = pe * (dp[r] * ks4[r] - d4[r]);
             p[u][r] = pu * ks4[r];
           } else {
-            ds[u][r] = pe * (dp[r] - d4[r]) * a.scale;
+            ds[u][r] = pe * (dp[r] - d4[r]);
             p[u][r] = pu;
           }
         }
@@ -558,7 +609,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     if (key < L) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        float v[4] = {dkt[dt][0], dkt[dt][1], dkt[dt][2], dkt[dt][3]};
+        float v[4] = {dkt[dt][0] * a.scale, dkt[dt][1] * a.scale, dkt[dt][2] * a.scale, dkt[dt][3] * a.scale};
         float w[4] = {dvt[dt][0], dvt[dt][1], dvt[dt][2], dvt[dt][3]};
         store4(dqkv + (size_t)key * ld + P + h * DK + dt * 16 + 4 * lg, v);
         store4(dqkv + (size_t)key * ld + 2 * P + h * DK + dt * 16 + 4 * lg, w);
@@ -592,19 +643,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         Frag<T> kf, vf;
         load_frag(kf, Ks + (k0 + li) * LDR + 8 * lg);
         load_frag(vf, Vs + (k0 + li) * LDR + 8 * lg);
-        f32x4 sv = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-        mma(kf, qf, sv);           // S^T[key][q]
-        mma(vf, gf, dp);           // dP^T[key][q]
         float kb4[4];
         load4f(kb4, kbias + k0 + 4 * lg);
+        f32x4 sv = (f32x4){kb4[0], kb4[1], kb4[2], kb4[3]}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mma(kf, qf, sv);           // S^T[key][q] + key bias
+        mma(vf, gf, dp);           // dP^T[key][q]
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = sv[r] + kb4[r];
+          float sc = sv[r];
           if (CAUSAL) sc = (k0 + r > qrel) ? fminf(sc, MASK_BIG) : sc;
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -lse_q));
-          if constexpr (DM == 1) ds[u][r] = pe * (rg_and(dp[r], km[u][r]) - dl_q) * a.scale;
-          else if constexpr (DM == 2) ds[u][r] = pe * (dp[r] * kd[u][r] - dl_q) * a.scale;
-          else ds[u][r] = pe * (dp[r] - dl_q) * a.scale;
+          if constexpr (DM == 1) ds[u][r] = pe * (rg_and(dp[r], km[u][r]) - dl_q);
+          else if constexpr (DM == 2) ds[u][r] = pe * (dp[r] * kd[u][r] - dl_q);
+          else ds[u][r] = pe * (dp[r] - dl_q);
         }
       }
       Frag<T> dsf;
@@ -619,7 +670,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     if (q < L) {
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        float v[4] = {dqt[dt][0], dqt[dt][1], dqt[dt][2], dqt[dt][3]};
+        float v[4] = {dqt[dt][0] * a.scale, dqt[dt][1] * a.scale, dqt[dt][2] * a.scale, dqt[dt][3] * a.scale};
         store4(dqkv + (size_t)q * ld + h * DK + dt * 16 + 4 * lg, v);
       }
     }
