@@ -75,6 +75,12 @@ typedef struct {
   int use_tr;                 /* bf16: 1 = ds_read_tr16_b64 fragments, 0 = scalar LDS reads */
 } rg_gemm_tn_args;
 int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
+/* Plan queries (no launch): the name of the kernel rg_gemm_nt / rg_gemm_tn would run for these arguments --
+ * "gemm_ws_kernel<K/128,N/128>" (persistent weight-stationary), "gemm_nt_kernel<dtype,NTW>" (generic tiles),
+ * "gemm_tn_big_kernel<N1,N2>" or "gemm_tn_kernel<dtype>" -- written NUL-terminated into name[cap].  Used by the
+ * host-side profiler so that per-kernel times match rocprofv3's kernel names. */
+int rg_gemm_nt_plan(const rg_gemm_nt_args* args /* host */, int dtype, char* name, int cap);
+int rg_gemm_tn_plan(const rg_gemm_tn_args* args /* host */, int dtype, char* name, int cap);
 
 
 /* ---- attention core (d_k = d_v = 32) --------------------------------------------------------------

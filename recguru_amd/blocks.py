@@ -119,13 +119,13 @@ class EncoderLayer(nn.Module):
         return _rate(self.pos_ffn.dropout_rate) if self.training else 0.0
 
     def forward(self, x, key_ids, pad_value, rowmask, causal=False):
-        return ops.EncoderLayerFn.apply(x, key_ids, rowmask, int(pad_value), bool(causal),
+        return ops.EncoderLayerFn.run(x, key_ids, rowmask, int(pad_value), bool(causal),
                                         self.enc_self_attn.n_heads, self.drop_p(),
                                         *self.enc_self_attn.self_params(), *self.pos_ffn.params())
 
     def forward_last(self, x, key_ids, pad_value, rowmask):
         """Row L-1 of forward() only -> [B, d] (all the hot path ever reads of the last layer)."""
-        return ops.EncoderLastLayerFn.apply(x, key_ids, rowmask, int(pad_value), self.enc_self_attn.n_heads,
+        return ops.EncoderLastLayerFn.run(x, key_ids, rowmask, int(pad_value), self.enc_self_attn.n_heads,
                                             self.drop_p(), *self.enc_self_attn.self_params(), *self.pos_ffn.params())
 
 
@@ -138,7 +138,7 @@ class DecoderLayer(nn.Module):
 
     def forward(self, x, u, dec_ids, enc_ids, rowmask):
         p = _rate(self.pos_ffn.dropout_rate) if self.training else 0.0
-        return ops.DecoderLayerFn.apply(x, u, dec_ids, enc_ids, rowmask, self.dec_self_attn.n_heads, p,
+        return ops.DecoderLayerFn.run(x, u, dec_ids, enc_ids, rowmask, self.dec_self_attn.n_heads, p,
                                         *self.dec_self_attn.self_params(), *self.dec_enc_attn.cross_params(),
                                         *self.pos_ffn.params())
 

@@ -8,6 +8,7 @@
 // columns, so each weight element is fetched exactly once per workgroup, straight from L2 into its
 // B fragment (torch Linear weights are [out,in] = [N][K]: 8 consecutive k are 16 contiguous bytes).
 // The residual+LayerNorm epilogue needs whole rows and therefore a tile that spans N.
+#include <stdio.h>
 #include "rg_common.cuh"
 #include "../../include/recguru_hip.h"
 
@@ -203,10 +204,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
   }
 }
 
+static int nt_ntw(const rg_gemm_nt_args& a) {
+  return (a.epilogue == RG_EPI_RESID_LN) ? (a.N <= 64 ? 1 : (a.N <= 128 ? 2 : 4)) : (a.N <= 64 ? 1 : 2);
+}
+
 template <typename T>
 static int launch_nt(const rg_gemm_nt_args& a, hipStream_t s) {
-  const int ntw = (a.epilogue == RG_EPI_RESID_LN) ? (a.N <= 64 ? 1 : (a.N <= 128 ? 2 : 4))
-                                                   : (a.N <= 64 ? 1 : 2);
+  const int ntw = nt_ntw(a);
   const int tn = 64 * ntw;
   dim3 grid((a.M + TM - 1) / TM, (a.N + tn - 1) / tn);
   if (a.epilogue == RG_EPI_RESID_LN && grid.y != 1)
@@ -219,6 +223,17 @@ static int launch_nt(const rg_gemm_nt_args& a, hipStream_t s) {
 }
 
 int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s);   // gemm_ws.hip
+int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype);
+
+// Name of the kernel rg_gemm_nt() launches for these arguments (no launch): lets a profiler attribute time to
+// the persistent weight-stationary kernels and the generic tile kernel separately.
+extern "C" int rg_gemm_nt_plan(const rg_gemm_nt_args* a, int dtype, char* name, int cap) {
+  if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt_plan: null argument");
+  const int ws = (a->debug_ablate & 16) ? 0 : rg_gemm_ws_select(a, dtype);
+  if (ws) snprintf(name, cap, "gemm_ws_kernel<%d,%d>", ws / 10, ws % 10);
+  else snprintf(name, cap, "gemm_nt_kernel<%s,%d>", dtype == RG_BF16 ? "bf16" : "f32", nt_ntw(*a));
+  return 0;
+}
 
 extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0 || a->N <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: empty problem");
@@ -349,6 +364,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(rg_gemm_tn_args a) {
 }
 
 int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s);   // gemm_tn_big.hip
+int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype);
+
+extern "C" int rg_gemm_tn_plan(const rg_gemm_tn_args* a, int dtype, char* name, int cap) {
+  if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_plan: null argument");
+  if (a->splits == 0 && rg_gemm_tn_big_select(a, dtype)) snprintf(name, cap, "gemm_tn_big_kernel<%d,%d>", a->N1, a->N2);
+  else snprintf(name, cap, "gemm_tn_kernel<%s>", dtype == RG_BF16 ? "bf16" : "f32");
+  return 0;
+}
 
 extern "C" int rg_gemm_tn(const rg_gemm_tn_args* a, int dtype, void* stream) {
   if (!a || a->T <= 0 || a->N1 <= 0 || a->N2 <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: empty problem");

@@ -148,9 +148,15 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   return 0;
 }
 
+// 1 if an instantiation takes this problem
+int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
+  if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7)) return 0;
+  return (a->N2 == 128 && (a->N1 == 512 || a->N1 == 384 || a->N1 == 256 || a->N1 == 128)) || (a->N1 == 128 && a->N2 == 512);
+}
+
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
-  if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7)) return 1;
+  if (!rg_gemm_tn_big_select(a, dtype)) return 1;
   if (a->N1 == 512 && a->N2 == 128) return launch_big<512, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 512) return launch_big<128, 512>(*a, s);
   if (a->N1 == 384 && a->N2 == 128) return launch_big<384, 128>(*a, s);

@@ -158,13 +158,21 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s) {
   return 0;
 }
 
+// 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
+int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
+  if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 0;
+  if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;   // dropout-after-ReLU lives in the generic kernel
+  if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
+  if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
+  if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
+  const int nkc = a->K / 128, ncb = a->N / 128;
+  if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;
+  return 0;
+}
+
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
 int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
-  if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 1;
-  if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 1;   // dropout-after-ReLU lives in the generic kernel
-  if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 1;
-  if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 1;
-  if (a->epilogue != RG_EPI_NONE && !a->aux) return 1;
+  if (!rg_gemm_ws_select(a, dtype)) return 1;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if (nkc == 1 && ncb == 1) return launch_ws<1, 1>(*a, s);
   if (nkc == 1 && ncb == 2) return launch_ws<1, 2>(*a, s);

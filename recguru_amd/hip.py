@@ -63,7 +63,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum"]
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -139,6 +139,8 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
                    drop_p, drop_seed)
+    if _PROF is not None:
+        _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
     return out
 
@@ -154,6 +156,8 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
         return dW
     a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
                    prologue_x, scale, splits, use_tr)
+    if _PROF is not None:
+        _note_plan(lib().rg_gemm_tn_plan, a, dt_of(Y))
     _check(lib().rg_gemm_tn(ctypes.byref(a), dt_of(Y), _stream()), "rg_gemm_tn")
     return dW
 
@@ -405,6 +409,15 @@ class Profiler(object):
 
 _PROF = None
 _ORIG = {}
+_PLAN_NAME = None
+
+
+def _note_plan(fn, args, dtype):
+    """Ask the library which kernel it will launch for these GEMM arguments (profiling only)."""
+    global _PLAN_NAME
+    buf = ctypes.create_string_buffer(64)
+    _check(fn(ctypes.byref(args), dtype, buf, 64), "rg_gemm_plan")
+    _PLAN_NAME = buf.value.decode()
 
 
 def _esize(t):
@@ -479,9 +492,13 @@ def start_profile():
                 kname, fl = "item_loss_bwd_kernel", fl * 2
             elif name == "item_loss_fwd":
                 kname = "item_loss_fwd_kernel"
+            global _PLAN_NAME
+            _PLAN_NAME = None
             e0.record()
             out = fn(*a, **k)
             e1.record()
+            if _PLAN_NAME is not None:      # GEMMs: the kernel the library actually picked
+                kname = _PLAN_NAME
             _PROF.records.append((kname, fl, by, e0, e1))
             return out
         return timed

@@ -59,7 +59,7 @@ class Discriminator(nn.Module):
         return 0.2 if self.training else 0.0        # nn.Dropout(p=0.2), tools/utils.py:44,47,50
 
     def forward(self, inputs):
-        return ops.DiscriminatorFn.apply(inputs, self.drop_p(), *self.params())
+        return ops.DiscriminatorFn.run(inputs, self.drop_p(), *self.params())
 
 
 class MyAuto4Rec_c(nn.Module):

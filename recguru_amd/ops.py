@@ -103,7 +103,30 @@ def _inv_keep(p):
 # ------------------------------------------------------------------------------------------------
 # K1: embedding + positional encoding + mask (+ dropout)
 # ------------------------------------------------------------------------------------------------
-class EmbedPE(torch.autograd.Function):
+_GRAD_MODE = True
+
+
+class _Fn(torch.autograd.Function):
+    """autograd.Function whose forward can see the CALLER's grad mode.  Inside forward() autograd is always off
+    and ctx.needs_input_grad only mirrors the inputs' requires_grad flags (parameters: always True), so a layer run
+    under torch.no_grad() -- the critic's encoder passes -- would still save every activation for a backward that
+    never comes (1 GB of HBM writes per layer at the bench shape).  run() records torch.is_grad_enabled() first."""
+
+    @classmethod
+    def run(cls, *args):
+        global _GRAD_MODE
+        prev, _GRAD_MODE = _GRAD_MODE, torch.is_grad_enabled()
+        try:
+            return cls.apply(*args)
+        finally:
+            _GRAD_MODE = prev
+
+
+def _needs_grad(ctx):
+    return _GRAD_MODE and any(ctx.needs_input_grad)
+
+
+class EmbedPE(_Fn):
     """nn.Embedding lookup + PositionalEncoding.forward (transformer.py:104-106): dropout((E[ids]+pe)*mask)."""
 
     @staticmethod
@@ -127,7 +150,7 @@ class EmbedPE(torch.autograd.Function):
 
 
 def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
-    return EmbedPE.apply(table, pe, ids, mask, skip_row, float(drop_p))
+    return EmbedPE.run(table, pe, ids, mask, skip_row, float(drop_p))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -211,14 +234,14 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be, drop_p=0.0, seed
     return dy, (dW1, db1, dW2, db2, dg, dbe)
 
 
-class EncoderLayerFn(torch.autograd.Function):
+class EncoderLayerFn(_Fn):
     """EncoderLayer.forward + `* pad_mask` (transformer.py:202-207,:592-594)."""
 
     @staticmethod
     def forward(ctx, x, key_ids, rowmask, pad_value, causal, H, drop_p,
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
-        need = any(ctx.needs_input_grad)
+        need = _needs_grad(ctx)
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
@@ -253,7 +276,7 @@ class EncoderLayerFn(torch.autograd.Function):
         return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
-class EncoderLastLayerFn(torch.autograd.Function):
+class EncoderLastLayerFn(_Fn):
     """Last EncoderLayer evaluated for position L-1 only -> [B, d].
 
     Every consumer of EncoderM's output reads enc_outputs[:, -1, :] (AutoEnc4Rec_cross.py:122,154;
@@ -265,7 +288,7 @@ class EncoderLastLayerFn(torch.autograd.Function):
     def forward(ctx, x, key_ids, rowmask, pad_value, H, drop_p,
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
-        need = any(ctx.needs_input_grad)
+        need = _needs_grad(ctx)
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
@@ -319,7 +342,7 @@ class EncoderLastLayerFn(torch.autograd.Function):
                 + gf)
 
 
-class DecoderLayerFn(torch.autograd.Function):
+class DecoderLayerFn(_Fn):
     """DecoderLayer.forward + `* pad_m` (transformer.py:257-261,:533-539) with the decoder-encoder
     attention in its collapsed form (quirk Q1): K/V are L copies of u = enc_out[:, -1], so
     context = WV u + bV for every query and WQ/WK of that block are dead (exactly-zero gradients).
@@ -332,7 +355,7 @@ class DecoderLayerFn(torch.autograd.Function):
                 cWv, cbv, cWo, cbo, cg, cbe,
                 W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
-        need = any(ctx.needs_input_grad)
+        need = _needs_grad(ctx)
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
@@ -411,7 +434,7 @@ class DecoderLayerFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 # K7 / K8: sampled-softmax / BPR loss over the item catalogue
 # ------------------------------------------------------------------------------------------------
-class ItemLoss(torch.autograd.Function):
+class ItemLoss(_Fn):
     @staticmethod
     def forward(ctx, h, table, pos, neg, mask, k, mode, skip_row):
         d = h.shape[-1]
@@ -438,11 +461,11 @@ class ItemLoss(torch.autograd.Function):
 
 
 def sampled_softmax_loss(h, table, pos, neg, mask, k, skip_row=-1):
-    return ItemLoss.apply(h, table, pos, neg, mask, k, hip.LOSS_SAMPLED_CE, skip_row)
+    return ItemLoss.run(h, table, pos, neg, mask, k, hip.LOSS_SAMPLED_CE, skip_row)
 
 
 def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1):
-    return ItemLoss.apply(h, table, pos, neg, mask, k, hip.LOSS_BPR, skip_row)
+    return ItemLoss.run(h, table, pos, neg, mask, k, hip.LOSS_BPR, skip_row)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -459,7 +482,7 @@ def _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4, drop_p=0.0, seeds=(0, 0, 0)):
     return h1, h2, h3, out.view(-1)
 
 
-class DiscriminatorFn(torch.autograd.Function):
+class DiscriminatorFn(_Fn):
     """Discriminator.forward (tools/utils.py:41-57) -> [B] f32; drop_p = 0.2 in train mode, 0 in eval."""
 
     @staticmethod
@@ -497,7 +520,7 @@ class DiscriminatorFn(torch.autograd.Function):
         return dx, None, dW1, db1, dW2, db2, dW3, db3, dW4, db4
 
 
-class GradientPenaltyFn(torch.autograd.Function):
+class GradientPenaltyFn(_Fn):
     """calc_gradient_penalty (gan_training.py:38-55) with its double backward in closed form
     (SURVEY Q13): forward returns lambda*mean((||dD/dxhat|| - 1)^2) and already holds dGP/dW_i;
     GP has no bias gradient and real/fake are treated as constants (they are detached at :408,:427).

@@ -110,7 +110,7 @@ def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, device):
     """gan_training.py:38-55.  alpha ~ U[0,1) from the CPU default generator, as there (Q13)."""
     alpha = torch.rand(BATCH_SIZE, 1).to(device)
     D = _unwrap(netD)
-    return ops.GradientPenaltyFn.apply(real_data, fake_data, alpha, D.drop_p(), *D.params())
+    return ops.GradientPenaltyFn.run(real_data, fake_data, alpha, D.drop_p(), *D.params())
 
 
 class _NoDP(object):
