@@ -50,22 +50,75 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
 
 // dE[ids[b,t],:] += dx[b,t,:] * mask[b,t]  -- one wave per token row, 256 contiguous bytes per
 // atomic wave-instruction (the shape the memory-side f32 atomic unit runs at full rate).
-template <typename T>
+// Item popularity is heavy-tailed (the head item of a Zipf(1) catalogue is ~8 % of all tokens), and memory-side
+// atomics onto one row serialise (MI355X_MICROARCH.md, Global float atomics: one row for everybody = 14x slower).
+// So every workgroup keeps ES_SLOTS privately accumulated rows in LDS, claimed first-come by id through a CAS on
+// the slot tag (2 probes): the popular ids show up early and take slots, their later occurrences are LDS adds,
+// and each workgroup sends ONE global add per claimed row at the end.  Ids that find both probes taken go to
+// global memory directly, as before.
+#define ES_SLOTS 64
+#define ES_UNROLL 4          // tokens in flight per wave: the id -> row -> add chain is pure latency otherwise
+template <typename T, int NPL>
 __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __restrict__ dx, const int64_t* __restrict__ ids,
                                                                     const float* __restrict__ mask, float* __restrict__ dE,
                                                                     long long ntok, int d, long long skip_row, DropCfg drop) {
-  const int lane = threadIdx.x & 63;
-  const long long wave = ((long long)blockIdx.x * EW_BLOCK + threadIdx.x) >> 6;
+  extern __shared__ float es_acc[];                       // [ES_SLOTS][d]
+  __shared__ int es_tag[ES_SLOTS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < ES_SLOTS; i += EW_BLOCK) es_tag[i] = -1;
+  for (int i = tid; i < ES_SLOTS * d; i += EW_BLOCK) es_acc[i] = 0.f;
+  __syncthreads();
+  const long long wave = ((long long)blockIdx.x * EW_BLOCK + tid) >> 6;
   const long long nwaves = ((long long)gridDim.x * EW_BLOCK) >> 6;
-  for (long long tok = wave; tok < ntok; tok += nwaves) {
-    const float m = mask[tok];
-    const long long row = ids[tok];
-    if (m == 0.f || row == skip_row) continue;
-    for (int e = lane; e < d; e += 64) {
-      float g = (float)dx[(size_t)tok * d + e] * m;
-      if (drop.thresh) g *= rg_keep(drop, (unsigned int)tok * (unsigned int)d + (unsigned int)e);
-      atomicAdd(dE + (size_t)row * d + e, g);
+  for (long long t0 = wave * ES_UNROLL; t0 < ntok; t0 += nwaves * ES_UNROLL) {
+    float m[ES_UNROLL], g[ES_UNROLL][NPL];
+    long long row[ES_UNROLL];
+#pragma unroll
+    for (int u = 0; u < ES_UNROLL; ++u) {
+      const long long tok = min(t0 + u, ntok - 1);
+      m[u] = (t0 + u < ntok) ? mask[tok] : 0.f;
+      row[u] = ids[tok];
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const int e = lane + 64 * j;
+        g[u][j] = e < d ? (float)dx[(size_t)tok * d + e] : 0.f;
+      }
     }
+#pragma unroll
+    for (int u = 0; u < ES_UNROLL; ++u) {
+      if (m[u] == 0.f || row[u] == skip_row) continue;
+      int slot = -1;
+      if (row[u] >= 0 && row[u] < 0x7fffffffLL) {
+        const unsigned int h = ((unsigned int)row[u] * 2654435761u) >> 26;       // 6 bits
+        int got = -1;
+        if (lane == 0) {
+          int old = atomicCAS(&es_tag[h], -1, (int)row[u]);
+          if (old == -1 || old == (int)row[u]) got = (int)h;
+          else {
+            const unsigned int h2 = h ^ 1u;
+            old = atomicCAS(&es_tag[h2], -1, (int)row[u]);
+            if (old == -1 || old == (int)row[u]) got = (int)h2;
+          }
+        }
+        slot = __builtin_amdgcn_readfirstlane(got);
+      }
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) {
+        const int e = lane + 64 * j;
+        if (e < d) {
+          float v = g[u][j] * m[u];
+          if (drop.thresh) v *= rg_keep(drop, (unsigned int)(t0 + u) * (unsigned int)d + (unsigned int)e);
+          if (slot >= 0) atomicAdd(es_acc + slot * d + e, v);
+          else atomicAdd(dE + (size_t)row[u] * d + e, v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int sl = tid >> 6; sl < ES_SLOTS; sl += EW_BLOCK / 64) {
+    const int row = es_tag[sl];
+    if (row < 0) continue;
+    for (int e = lane; e < d; e += 64) atomicAdd(dE + (size_t)row * d + e, es_acc[sl * d + e]);
   }
 }
 
@@ -456,10 +509,19 @@ extern "C" int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const fl
   const DropCfg drop = make_drop(drop_p, seed);
   if (ntok <= 0) return 0;
   hipStream_t s = (hipStream_t)stream;
-  const int grid = ew_grid(ntok, 4);
-  DISPATCH_T(dtype,
-             hipLaunchKernelGGL(embed_scatter_bwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)dx, ids, mask, dE, ntok, d, skip_row, drop),
-             hipLaunchKernelGGL(embed_scatter_bwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)dx, ids, mask, dE, ntok, d, skip_row, drop),
+  const size_t smem = (size_t)ES_SLOTS * d * sizeof(float);
+  if (d > 256) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_scatter_bwd: d > 256");
+  int grid = ew_grid(ntok, 4 * ES_UNROLL);
+  const int cap = 256 * (d <= 128 ? 4 : 2);                // persistent: few, long-lived workgroups = few flushes per hot row
+  if (grid > cap) grid = cap;
+#define RG_ES(T, NPL) hipLaunchKernelGGL((embed_scatter_bwd_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), smem, s, (const T*)dx, ids, mask, dE, ntok, d, skip_row, drop)
+#define RG_ES_T(T)                   \
+  do {                               \
+    if (d <= 64) RG_ES(T, 1);        \
+    else if (d <= 128) RG_ES(T, 2);  \
+    else RG_ES(T, 4);                \
+  } while (0)
+  DISPATCH_T(dtype, RG_ES_T(__bf16), RG_ES_T(float),
              "embed_scatter_bwd")
 }
 

@@ -83,6 +83,27 @@ def main():
     rec("attn bwd full p=0.3", timeit(lambda: hip.attn_bwd(q3, dctx, c3, lse, ids, 0, False, H, drop_p=0.3, seed=3), n=5), 10.0 * B * H * L * L * 32, M * 8 * P * es)
     dg, db = torch.zeros(d, device=dev), torch.zeros(d, device=dev)
     rec("ln_bwd", timeit(lambda: hip.ln_bwd(x, x, rstd, g, be, rm, dg, db)), 0, M * 3 * d * es)
+    # ---- item-catalogue kernels: Zipf(1) ids over V=100k (head item ~8 % of tokens), lengths U{5..L+20}
+    V, kneg = 100000, 30
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64)
+    zid = (torch.multinomial(w, M, replacement=True) + 1).to(dev)
+    lens = torch.randint(5, L + 21, (B,), device=dev).clamp(max=L)
+    live = (torch.arange(L, device=dev)[None, :] >= (L - lens)[:, None]).float().reshape(-1).contiguous()
+    table = r(V + 2, d)
+    dE = torch.zeros(V + 2, d, device=dev)
+    nlive = float(live.sum())
+    rec("embed_scatter_bwd zipf", timeit(lambda: hip.embed_scatter_bwd(x, zid, live, dE), n=10), 0, nlive * d * (es + 4))
+    uid = torch.randint(1, V + 1, (M,), device=dev)
+    rec("embed_scatter_bwd uniform", timeit(lambda: hip.embed_scatter_bwd(x, uid, live, dE), n=10), 0, nlive * d * (es + 4))
+    pe = torch.zeros(L, d, device=dev)
+    rec("embed_pe_fwd zipf", timeit(lambda: hip.embed_pe_fwd(table, pe, zid, live, L)), 0, M * d * 2 * es + M * 12)
+    neg = torch.randint(1, V + 1, (M, kneg), device=dev)
+    sums, aux = hip.item_loss_fwd(x, table, zid, neg, live, kneg, hip.LOSS_SAMPLED_CE)
+    rec("item_loss_fwd k=30", timeit(lambda: hip.item_loss_fwd(x, table, zid, neg, live, kneg, hip.LOSS_SAMPLED_CE), n=5),
+        2.0 * nlive * (kneg + 1) * d, nlive * (kneg + 2) * d * es)
+    gout = torch.ones(1, device=dev)
+    rec("item_loss_bwd k=30", timeit(lambda: hip.item_loss_bwd(x, table, zid, neg, live, kneg, hip.LOSS_SAMPLED_CE, aux, sums, gout, dE), n=5),
+        4.0 * nlive * (kneg + 1) * d, nlive * (kneg + 1) * d * (es + 4))
     print("%-32s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
     for n, us, tf, gb in rows:
         print("%-32s %10.1f %10.1f %10.1f" % (n, us, tf, gb))
