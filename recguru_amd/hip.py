@@ -488,10 +488,11 @@ def start_profile():
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             kname, fl, by = work(*a, **k) if work else (name + "_kernel", 0.0, 0.0)
-            if name == "item_loss_bwd":
-                kname, fl = "item_loss_bwd_kernel", fl * 2
-            elif name == "item_loss_fwd":
-                kname = "item_loss_fwd_kernel"
+            if name in ("item_loss_fwd", "item_loss_bwd"):      # d = 64/128/256 run the row-group kernels (loss.hip)
+                rows = "_rows" if a[0].shape[1] in (64, 128, 256) else ""
+                kname = "%s%s_kernel" % (name, rows)
+                if name == "item_loss_bwd":
+                    fl = fl * 2
             global _PLAN_NAME
             _PLAN_NAME = None
             e0.record()
