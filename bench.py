@@ -201,6 +201,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
+    t_host = time.perf_counter() - t0          # host time to ENQUEUE the steps (== dt when the host is the bottleneck)
     torch.cuda.synchronize()
     if dp:
         dp.barrier()
@@ -266,7 +267,7 @@ def main():
                        "discriminator_dropout": 0.2 if args.dropout > 0 else 0.0,
                        "sequences_per_step": 12 * B * world, "generator_step_sequences_per_sec":
                            round(2 * B * world * args.steps / dt, 1),
-                       "parallelism": "dp%d" % world,
+                       "parallelism": "dp%d" % world, "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 2),
                        "last_step": dict(zip(("D_cost", "Wasserstein_D", "g_dis", "recon_a", "recon_b"), losses))},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -15,6 +15,7 @@
  */
 #ifndef RECGURU_HIP_H
 #define RECGURU_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 #ifdef __cplusplus
 extern "C" {
@@ -185,6 +186,14 @@ typedef struct {
 } rg_item_loss_args;
 int rg_item_loss_fwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
 int rg_item_loss_bwd(const rg_item_loss_args* args /* host */, int dtype, void* stream);
+/* Same outputs as rg_item_loss_bwd, but the table gradient is built by counting-sorting the (position, item)
+ * pairs into bins of 64 table rows and accumulating each bin in LDS (one flush per bin chunk) instead of one
+ * global atomic row per pair -- the atomic form is bound by the chip-wide float-atomic rate.  table_rows = rows
+ * of the table (V+2).  workspace: caller-owned device scratch of >= rg_item_loss_bwd_binned_workspace() bytes
+ * (returns 0 when the shape is not supported: d not in {64,128,256}, more than 8192 bins, >= 2^31 pairs). */
+size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long table_rows);
+int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long table_rows, void* workspace,
+                            size_t workspace_bytes, int dtype, void* stream);
 
 /* ---- fused post-attention block, forward -------------------------------------------------------------
  * y = LN(ctx.Wo^T + bo + x) [; y = LN(y + o_bcast[b])] ; out = LN(gelu(y.W1^T + b1).W2^T + b2 + y) * rowmask

@@ -206,8 +206,8 @@ __global__ __launch_bounds__(64 * LW) void item_loss_fwd_rows_kernel(rg_item_los
   }
 }
 
-template <typename T, int LPR>
-__global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_loss_args a) {
+template <typename T, int LPR, bool CBUF>
+__global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_loss_args a, float* __restrict__ cbuf) {
   constexpr int G = 64 / LPR;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int gi = lane / LPR, li = lane % LPR;
@@ -227,8 +227,10 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
       const float sg = 1.f / (1.f + __expf(aux));  // sigmoid(-x), BPR only
       float h[8], ht[8];
       load8(h, H + (size_t)t * d + 8 * li);
+      if (!CBUF) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) ht[j] = (float)H[(size_t)t * d + li + LPR * j];
+        for (int j = 0; j < 8; ++j) ht[j] = (float)H[(size_t)t * d + li + LPR * j];
+      }
       const long long pos = a.pos[t];
       for (int i0 = 0; i0 < n; i0 += G * RG_U) {
         long long item[RG_U];
@@ -253,7 +255,9 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
           if (idx >= n) c = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) dh[j] += c * e[u][j];
-          if (idx < n && item[u] != a.skip_row) {
+          if (CBUF) {                       // binned path: the table gradient is built from c by the kernels below
+            if (idx < n && li == 0) cbuf[t * n + idx] = c;
+          } else if (idx < n && item[u] != a.skip_row) {
             float* __restrict__ dst = a.dE + (size_t)item[u] * d + li;
 #pragma unroll
             for (int j = 0; j < 8; ++j) atomicAdd(dst + LPR * j, c * ht[j]);
@@ -276,7 +280,7 @@ static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
   dim3 grid((int)g), block(64 * LW);
 #define RG_R(LPR)                                                                             \
   do {                                                                                        \
-    if (bwd) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, LPR>), grid, block, 0, s, a);   \
+    if (bwd) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, LPR, false>), grid, block, 0, s, a, (float*)nullptr);   \
     else hipLaunchKernelGGL((item_loss_fwd_rows_kernel<T, LPR>), grid, block, 0, s, a);       \
     RG_CHECK_LAUNCH();                                                                        \
     return 0;                                                                                 \
@@ -295,6 +299,272 @@ static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
 #undef RG_L
   RG_CHECK_LAUNCH();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Table gradient without memory-side atomics per (position, item) pair ("binned" backward).
+// The atomic form adds (1+k) rows of d floats per position: 7.4 GB per launch at the bench shape, which runs at
+// the chip-wide float-atomic rate (~1.3 TB/s) whatever the schedule.  Here the backward writes only the scalar
+// c[t, j] = dloss/dlogit; the pairs are then counting-sorted by item BIN (RG_RPB consecutive table rows), and one
+// workgroup per bin chunk accumulates  dE[item] += c * h[t]  in LDS (h rows gathered from L2 / Infinity Cache,
+// 2 bytes per element instead of 4 bytes of atomic per element) and flushes its RG_RPB rows once.
+//   K1 item_loss_bwd_rows_kernel<.., CBUF>   dh, c                       (no atomics)
+//   K2 bin_count_kernel                       pairs per bin (LDS histogram per workgroup)
+//   K3 bin_scan_kernel                        bin offsets, chunk offsets, cursors   (one workgroup)
+//   K4 bin_fill_kernel                        (t, row-in-bin, c) triples grouped by bin
+//   K5 bin_accumulate_kernel                  LDS accumulation per bin chunk, one flush of RG_RPB rows
+// ------------------------------------------------------------------------------------------------
+#define RG_RPB 64            // table rows per bin
+#define RG_RPB_LOG 6
+#define RG_CHUNK 2048        // entries per accumulate work item
+#define RG_MAXBINS 8192
+#define RG_PPW 8192          // (position, item) pairs per workgroup in count / fill
+
+struct BinWs {
+  float* c; int* hist; int* start; int* cursor; int* chunk_start;
+  uint2* ent;        // sorted entries: x = (position << RG_RPB_LOG) | row-in-bin, y = c as bits  (one 8-byte store / load)
+  int nbins;
+};
+
+__device__ __forceinline__ long long pair_item(const rg_item_loss_args& a, long long p, int n) {
+  const long long t = p / n;
+  const int idx = (int)(p - t * n);
+  if (a.mask[t] == 0.f) return -1;
+  const long long item = idx == 0 ? a.pos[t] : a.neg[t * a.k + idx - 1];
+  return item == a.skip_row ? -1 : item;
+}
+
+__global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, BinWs w) {
+  extern __shared__ int lh[];
+  const int n = a.k + 1;
+  const long long npairs = a.ntok * n;
+  for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
+  __syncthreads();
+  const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long item = pair_item(a, p, n);
+    if (item >= 0) atomicAdd(&lh[item >> RG_RPB_LOG], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < w.nbins; i += 256)
+    if (lh[i]) atomicAdd(&w.hist[i], lh[i]);
+}
+
+// one workgroup: start[b] = exclusive prefix of hist, cursor = start, chunk_start = exclusive prefix of ceil(hist/CHUNK)
+__global__ __launch_bounds__(1024) void bin_scan_kernel(BinWs w) {
+  __shared__ int part[1024], partc[1024];
+  const int tid = threadIdx.x;
+  const int per = (w.nbins + 1023) / 1024;
+  const int b0 = tid * per, b1 = min(b0 + per, w.nbins);
+  int s = 0, sc = 0;
+  for (int b = b0; b < b1; ++b) { s += w.hist[b]; sc += (w.hist[b] + RG_CHUNK - 1) / RG_CHUNK; }
+  part[tid] = s; partc[tid] = sc;
+  __syncthreads();
+  if (tid == 0) {
+    int acc = 0, accc = 0;
+    for (int i = 0; i < 1024; ++i) { const int v = part[i], vc = partc[i]; part[i] = acc; partc[i] = accc; acc += v; accc += vc; }
+    w.start[w.nbins] = acc; w.chunk_start[w.nbins] = accc;
+  }
+  __syncthreads();
+  s = part[tid]; sc = partc[tid];
+  for (int b = b0; b < b1; ++b) {
+    w.start[b] = s; w.cursor[b] = s; w.chunk_start[b] = sc;
+    s += w.hist[b]; sc += (w.hist[b] + RG_CHUNK - 1) / RG_CHUNK;
+  }
+}
+
+__global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinWs w) {
+  extern __shared__ int lh[];           // [nbins] counts, then running offsets; [nbins] reserved bases
+  int* base = lh + w.nbins;
+  const int n = a.k + 1;
+  const long long npairs = a.ntok * n;
+  for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
+  __syncthreads();
+  const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long item = pair_item(a, p, n);
+    if (item >= 0) atomicAdd(&lh[item >> RG_RPB_LOG], 1);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < w.nbins; i += 256) {
+    const int cnt = lh[i];
+    base[i] = cnt ? atomicAdd(&w.cursor[i], cnt) : 0;
+    lh[i] = 0;
+  }
+  __syncthreads();
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
+    const long long item = pair_item(a, p, n);
+    if (item < 0) continue;
+    const int b = (int)(item >> RG_RPB_LOG);
+    const int e = base[b] + atomicAdd(&lh[b], 1);
+    w.ent[e] = make_uint2(((unsigned int)(p / n) << RG_RPB_LOG) | (unsigned int)(item & (RG_RPB - 1)), __float_as_uint(w.c[p]));
+  }
+}
+
+// One work item = up to RG_CHUNK entries of one bin.  LDS float atomics run at about one lane per clock per CU on
+// gfx950 (measured: 128 ds_add_f32 lanes per entry made this kernel 14x slower than its gathers), so there are
+// none: the chunk's entries are counting-sorted by row-in-bin inside LDS (integer LDS atomics only), each wave
+// then owns whole rows, sums c * h[t] for a row in registers (LPR lanes per entry, G entries per wave
+// instruction, U per lane group in flight), reduces the G lane groups by shuffles and parks the row in an LDS
+// tile that is flushed once, coalesced, with 256-byte-shaped global atomics.
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a, BinWs w, long long table_rows) {
+  constexpr int G = 64 / LPR, D = LPR * 8, U = 4, EPT = RG_CHUNK / 256;
+  extern __shared__ float sm[];                     // acc [RG_RPB][D] | sorted t [RG_CHUNK] | sorted c [RG_CHUNK]
+  float* acc = sm;
+  int* st = reinterpret_cast<int*>(sm + RG_RPB * D);
+  float* sc = reinterpret_cast<float*>(st + RG_CHUNK);
+  __shared__ int cnt[RG_RPB], rstart[RG_RPB + 1];
+  __shared__ int s_bin, s_lo, s_hi;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const int nchunks = w.chunk_start[w.nbins];
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    if (tid == 0) {
+      int lo = 0, hi = w.nbins;                     // last bin with chunk_start[bin] <= ch
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.chunk_start[mid] <= ch) lo = mid; else hi = mid; }
+      const int bs = w.start[lo], be = w.start[lo + 1];
+      const int e0 = bs + (ch - w.chunk_start[lo]) * RG_CHUNK;
+      s_bin = lo; s_lo = e0; s_hi = min(e0 + RG_CHUNK, be);
+    }
+    if (tid < RG_RPB) cnt[tid] = 0;
+    __syncthreads();
+    const int e0 = s_lo, e1 = s_hi, bin = s_bin;
+    // ---- counting sort of the chunk by row-in-bin
+    int myr[EPT], myp[EPT], myt[EPT];
+    float myc[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+      const int e = e0 + tid + 256 * i;
+      myr[i] = -1;
+      if (e < e1) {
+        const uint2 en = w.ent[e];
+        myr[i] = (int)(en.x & (RG_RPB - 1)); myt[i] = (int)(en.x >> RG_RPB_LOG); myc[i] = __uint_as_float(en.y);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < EPT; ++i)
+      if (myr[i] >= 0) myp[i] = atomicAdd(&cnt[myr[i]], 1);
+    __syncthreads();
+    if (tid < 64) {                                  // RG_RPB == 64: one wave scans the row counts
+      const int v = cnt[tid];
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (tid >= o) incl += up; }
+      rstart[tid] = incl - v;
+      if (tid == 63) rstart[64] = incl;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < EPT; ++i)
+      if (myr[i] >= 0) { const int p = rstart[myr[i]] + myp[i]; st[p] = myt[i]; sc[p] = myc[i]; }
+    __syncthreads();
+    // ---- each wave sums whole rows
+    for (int r = wave; r < RG_RPB; r += 4) {
+      const int lo = rstart[r], hi = rstart[r + 1];
+      float s8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8[j] = 0.f;
+      for (int eb = lo + gi * U; eb < hi; eb += G * U) {
+        int t[U];
+        float c[U], h[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = min(eb + u, hi - 1);
+          t[u] = st[e];
+          c[u] = (eb + u < hi) ? sc[e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] += __shfl_xor(s8[j], o);
+      if (gi == 0) store8(acc + r * D + 8 * li, s8);
+    }
+    __syncthreads();
+    for (int i = tid; i < RG_RPB * D; i += 256) {
+      const long long row = (long long)bin * RG_RPB + i / D;
+      const float v = acc[i];
+      if (row < table_rows && v != 0.f) atomicAdd(a.dE + row * D + (i % D), v);
+    }
+    __syncthreads();
+  }
+}
+
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// bytes of workspace rg_item_loss_bwd_binned needs; 0 if the shape is not supported by the binned path
+extern "C" size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long table_rows) {
+  const long long nbins = (table_rows + RG_RPB - 1) / RG_RPB;
+  const long long npairs = ntok * (k + 1);
+  if (!(d == 64 || d == 128 || d == 256) || nbins > RG_MAXBINS || npairs >= (1LL << 31) || ntok <= 0 ||
+      ntok >= (1LL << (32 - RG_RPB_LOG))) return 0;
+  return align256(npairs * 4) + align256(npairs * 8) + align256((nbins + 1) * 4) * 4;
+}
+
+template <typename T>
+static int launch_binned(const rg_item_loss_args& a, void* ws, size_t ws_bytes, long long table_rows, hipStream_t s) {
+  const int n = a.k + 1;
+  const long long npairs = a.ntok * n;
+  const size_t need = rg_item_loss_bwd_binned_workspace(a.ntok, a.k, a.d, table_rows);
+  if (!need) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_bwd_binned: needs d in {64,128,256}, <= 8192 bins of 64 rows, < 2^31 pairs, < 2^26 positions");
+  if (!ws || ws_bytes < need) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_bwd_binned: workspace too small");
+  BinWs w;
+  w.nbins = (int)((table_rows + RG_RPB - 1) / RG_RPB);
+  char* p = reinterpret_cast<char*>(ws);
+  w.c = reinterpret_cast<float*>(p); p += align256(npairs * 4);
+  w.ent = reinterpret_cast<uint2*>(p); p += align256(npairs * 8);
+  const size_t ib = align256((size_t)(w.nbins + 1) * 4);
+  w.hist = reinterpret_cast<int*>(p); p += ib;
+  w.start = reinterpret_cast<int*>(p); p += ib;
+  w.cursor = reinterpret_cast<int*>(p); p += ib;
+  w.chunk_start = reinterpret_cast<int*>(p);
+  hipError_t e = hipMemsetAsync(w.hist, 0, ib, s);
+  if (e != hipSuccess) return rg_set_error(e, "item_loss_bwd_binned(memset)");
+  // K1: dh and c
+  long long g = (a.ntok + LW - 1) / LW;
+  if (g > 256 * 32) g = 256 * 32;
+  if (a.d == 64) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 8, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
+  else if (a.d == 128) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 16, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
+  else hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 32, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
+  // K2..K4
+  const int gp = (int)((npairs + RG_PPW - 1) / RG_PPW);
+  hipLaunchKernelGGL(bin_count_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 4, s, a, w);
+  hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, w);
+  hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w.nbins * 8);
+  hipLaunchKernelGGL(bin_fill_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 8, s, a, w);
+  // K5
+  const size_t smem = (size_t)RG_RPB * a.d * 4 + (size_t)RG_CHUNK * 8;
+  const int ga = 256 * (int)(smem <= 40 * 1024 ? 4 : (smem <= 52 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1)));
+#define RG_ACC(LPR)                                                                                                 \
+  do {                                                                                                              \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bin_accumulate_kernel<T, LPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((bin_accumulate_kernel<T, LPR>), dim3(ga), dim3(256), smem, s, a, w, table_rows);             \
+  } while (0)
+  if (a.d == 64) RG_ACC(8);
+  else if (a.d == 128) RG_ACC(16);
+  else RG_ACC(32);
+#undef RG_ACC
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+// Same results as rg_item_loss_bwd (dh, dE += table gradient), table gradient built by counting sort + LDS
+// accumulation instead of one global atomic row per (position, item) pair.  workspace: device memory of at least
+// rg_item_loss_bwd_binned_workspace() bytes, contents undefined on entry and exit.
+extern "C" int rg_item_loss_bwd_binned(const rg_item_loss_args* a, long long table_rows, void* workspace, size_t workspace_bytes,
+                                       int dtype, void* stream) {
+  if (!a || a->ntok <= 0) return 0;
+  if (dtype == RG_BF16) return launch_binned<__bf16>(*a, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_binned<float>(*a, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "item_loss_bwd_binned: bad dtype");
 }
 
 extern "C" int rg_item_loss_fwd(const rg_item_loss_args* a, int dtype, void* stream) {

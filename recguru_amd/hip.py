@@ -63,7 +63,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan"]
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
+           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -324,6 +325,34 @@ def item_loss_fwd(h, table, pos, neg, mask, k, mode):
     return sums, aux
 
 
+_BIN_WS = {}
+
+
+def item_loss_bwd_binned_supported(ntok, k, d, table_rows):
+    fn = lib().rg_item_loss_bwd_binned_workspace
+    fn.restype = ctypes.c_size_t
+    return int(fn(c_ll(ntok), k, d, c_ll(table_rows)))
+
+
+def item_loss_bwd_binned(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_row=-1):
+    """item_loss_bwd with the table gradient built by counting sort + LDS accumulation (loss.hip); the scratch
+    buffer is cached per device and grows on demand."""
+    ntok, d = h.shape
+    need = item_loss_bwd_binned_supported(ntok, k, d, table.shape[0])
+    if not need:
+        raise RuntimeError("item_loss_bwd_binned: unsupported shape (d=%d, rows=%d, k=%d)" % (d, table.shape[0], k))
+    ws = _BIN_WS.get(h.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=h.device, dtype=torch.uint8)
+        _BIN_WS[h.device] = ws
+    dh = torch.empty_like(h)
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(aux), _p(sums), _p(gout), _p(dh), _p(dE), ntok,
+                     d, k, mode, skip_row)
+    _check(lib().rg_item_loss_bwd_binned(ctypes.byref(a), c_ll(table.shape[0]), _vp(ws), ctypes.c_size_t(need),
+                                         dt_of(h), _stream()), "rg_item_loss_bwd_binned")
+    return dh
+
+
 def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_row=-1):
     ntok, d = h.shape
     dh = torch.empty_like(h)
@@ -472,7 +501,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

@@ -79,6 +79,95 @@ def _z(n, like):
 
 
 # ------------------------------------------------------------------------------------------------
+# Parameter gradients are accumulated IN PLACE: the weight-gradient kernels (gemm_tn, colsum, ln_bwd, the
+# scatter-adds) all compute dW += ..., so a backward writes straight into p.grad and hands autograd None
+# for that input -- no zero-filled temporary per use, no accumulation add per use (463 fills + 221 adds per
+# iteration at the bench shape).  Buffers survive zero_grad (release_grads() parks them on the parameter and
+# zeroes them in a few multi-tensor launches), p.grad is None again until a backward touches the parameter,
+# which keeps torch.optim.Adam's "skip parameters without gradient" behaviour.
+# ------------------------------------------------------------------------------------------------
+def _direct(p):
+    return p.is_leaf and p.requires_grad and p.dtype == torch.float32
+
+
+def _adopt(p):
+    """Make p.grad a zeroed (or already accumulating) f32 buffer and return it."""
+    if p.grad is None:
+        buf = getattr(p, "_rg_gbuf", None)
+        if buf is None or buf.shape != p.shape:
+            buf = torch.zeros(p.shape, device=p.device, dtype=torch.float32)
+        elif not getattr(p, "_rg_gclean", False):
+            buf.zero_()
+        p._rg_gbuf, p._rg_gclean = buf, False
+        p.grad = buf
+    return p.grad
+
+
+def _gt(p):
+    """(buffer to accumulate p's gradient into, value to hand back to autograd)."""
+    if _direct(p):
+        return _adopt(p), None
+    z = torch.zeros(p.shape, device=p.device, dtype=torch.float32)
+    return z, z
+
+
+def _gt_cat(ps):
+    """Same for parameters whose gradient is produced as ONE row-concatenated matrix (the fused QKV weight):
+    their .grad tensors are row slices of a shared base buffer.  Returns (base, [value for autograd per p])."""
+    rows = [p.shape[0] for p in ps]
+    shape = (sum(rows),) + tuple(ps[0].shape[1:])
+    if all(_direct(p) for p in ps):
+        base = getattr(ps[0], "_rg_gbase", None)
+        ok = base is not None and tuple(base.shape) == shape and all(getattr(p, "_rg_gbase", None) is base for p in ps)
+        if all(p.grad is None for p in ps):
+            if not ok:
+                base = torch.zeros(shape, device=ps[0].device, dtype=torch.float32)
+            elif not all(getattr(p, "_rg_gclean", False) for p in ps):
+                base.zero_()
+            off = 0
+            for p, r in zip(ps, rows):
+                p._rg_gbase, p._rg_gbuf, p._rg_gclean = base, base[off:off + r], False
+                p.grad = p._rg_gbuf
+                off += r
+            return base, [None] * len(ps)
+        if ok:
+            off, same = 0, True
+            for p, r in zip(ps, rows):
+                same = same and p.grad is not None and p.grad.data_ptr() == base[off:off + r].data_ptr()
+                off += r
+            if same:
+                return base, [None] * len(ps)
+    z = torch.zeros(shape, device=ps[0].device, dtype=torch.float32)
+    out, off = [], 0
+    for r in rows:
+        out.append(z[off:off + r])
+        off += r
+    return z, out
+
+
+def release_grads(params):
+    """zero_grad(set_to_none=True) that keeps the buffers: p.grad becomes None, the buffers are zeroed with a few
+    multi-tensor launches and re-adopted by the next backward that touches the parameter."""
+    bufs = {}
+    for p in params:
+        g = p.grad
+        if g is None:
+            continue
+        base = getattr(p, "_rg_gbase", None)
+        if base is not None and getattr(p, "_rg_gbuf", None) is not None and g.data_ptr() == p._rg_gbuf.data_ptr():
+            bufs[id(base)] = base
+        else:
+            p._rg_gbase = None
+            p._rg_gbuf = g if g.dtype == torch.float32 and g.shape == p.shape else None
+            if p._rg_gbuf is not None:
+                bufs[id(g)] = g
+        p._rg_gclean = True
+        p.grad = None
+    if bufs:
+        torch._foreach_zero_(list(bufs.values()))
+
+
+# ------------------------------------------------------------------------------------------------
 # dropout seeds: every forward call draws fresh 64-bit seeds (masks are a stateless hash of seed and
 # element index inside the kernels) and its backward reuses them.
 # ------------------------------------------------------------------------------------------------
@@ -137,16 +226,17 @@ class EmbedPE(_Fn):
         seed = _draw() if drop_p > 0 else 0
         out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L, drop_p, seed)
         ctx.save_for_backward(ids, mask)
-        ctx.meta = (table.shape, skip_row, drop_p, seed)
+        ctx.table = table
+        ctx.meta = (skip_row, drop_p, seed)
         return out.view(B, L, -1)
 
     @staticmethod
     def backward(ctx, dx):
         ids, mask = ctx.saved_tensors
-        shape, skip_row, drop_p, seed = ctx.meta
-        dE = torch.zeros(shape, device=dx.device, dtype=torch.float32)
+        skip_row, drop_p, seed = ctx.meta
+        dE, ret = _gt(ctx.table)
         hip.embed_scatter_bwd(dx.contiguous().view(-1, dx.shape[-1]), ids, mask, dE, skip_row, drop_p, seed)
-        return dE, None, None, None, None, None
+        return ret, None, None, None, None, None
 
 
 def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
@@ -184,25 +274,25 @@ def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv,
     return y, (qkv, ctx_, lse, rstd)
 
 
-def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, Wq, Wk, Wv, Wo, g, be, drop_p=0.0, seed=0):
-    """Backward of the attention block.  Returns dx and the parameter gradients in declaration order."""
+def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, drop_p=0.0, seed=0):
+    """Backward of the attention block; prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be).  Returns dx and, in that
+    order, what autograd gets for each parameter (None where the gradient went straight into p.grad)."""
+    Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be = prm
     qkv, ctx_, lse, rstd = saved
     d = x2.shape[1]
     P = Wo.shape[1]
-    dg, dbe = _z(d, dy), _z(d, dy)
+    (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), None, dg, dbe)
-    dWo, dbo = torch.zeros(d, P, device=dy.device), _z(d, dy)
+    (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo)
     dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
     dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
                         drop_p=drop_p, seed=seed)
     dqkv2 = dqkv.view(B * L, 3 * P)
-    dWqkv, dbqkv = torch.zeros(3 * P, d, device=dy.device), _z(3 * P, dy)
+    (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
     dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz)
-    dWq, dWk, dWv = dWqkv[:P], dWqkv[P:2 * P], dWqkv[2 * P:]
-    dbq, dbk, dbv = dbqkv[:P], dbqkv[P:2 * P], dbqkv[2 * P:]
-    return dx, (dWq, dbq, dWk, dbk, dWv, dbv, dWo, dbo, dg, dbe)
+    return dx, (rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg, rbe)
 
 
 def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
@@ -214,24 +304,26 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
     return out, (h1, rstd)
 
 
-def _ffn_block_bwd(dout, y, out, saved, rowmask, W1, W2, g, be, drop_p=0.0, seed_h1=0, seed_out=0):
-    """Backward of the FFN block.  Under dropout h1 holds the DROPPED pre-activation (zeros where dropped),
-    the l2-output mask is regenerated from seed_out and the h1 mask is read back from h1 != 0."""
+def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, seed_out=0):
+    """Backward of the FFN block; prm = (W1, b1, W2, b2, g, be).  Under dropout h1 holds the DROPPED
+    pre-activation (zeros where dropped), the l2-output mask is regenerated from seed_out and the h1 mask is read
+    back from h1 != 0."""
+    W1, b1, W2, b2, g, be = prm
     h1, rstd = saved
     d, dff = W2.shape
-    dg, dbe = _z(d, dout), _z(d, dout)
+    (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     if drop_p > 0:
         dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out)
     else:
         dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
-    dW2, db2 = torch.zeros(d, dff, device=dout.device), _z(d, dout)
+    (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
                       epi_nonzero_scale=_inv_keep(drop_p))
-    dW1, db1 = torch.zeros(dff, d, device=dout.device), _z(dff, dout)
+    (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
     hip.gemm_tn(dh1, y, dW1, db1)
     dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
-    return dy, (dW1, db1, dW2, db2, dg, dbe)
+    return dy, (rW1, rb1, rW2, rb2, rg, rbe)
 
 
 class EncoderLayerFn(_Fn):
@@ -259,20 +351,20 @@ class EncoderLayerFn(_Fn):
             y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
             out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
-            ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf, Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
+            ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
+            ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, pad_value, causal, H, drop_p, seeds)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
-        (x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2,
-         Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
+        x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2 = ctx.saved_tensors
         B, L, pad_value, causal, H, drop_p, seeds = ctx.meta
         d = x2.shape[1]
-        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, W1, W2, g2, be2,
+        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, ctx.prm[10:],
                                 drop_p, seeds[1], seeds[2])
         dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
-                                 Wq, Wk, Wv, Wo, g1, be1, drop_p, seeds[0])
+                                 ctx.prm[:10], drop_p, seeds[0])
         return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
@@ -310,35 +402,33 @@ class EncoderLastLayerFn(_Fn):
                             gamma=g1.detach(), beta=be1.detach(), rstd_out=rstd1, eps=LN_EPS)
             out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2)
         if need:
-            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf,
-                                  Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2)
+            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf)
+            ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, pad_value, H, drop_p, seeds)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        (x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2,
-         Wq, Wk, Wv, Wo, g1, be1, W1, W2, g2, be2) = ctx.saved_tensors
+        x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2 = ctx.saved_tensors
+        Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1 = ctx.prm[:10]
         B, L, pad_value, H, drop_p, seeds = ctx.meta
         d = x2.shape[1]
         P = Wo.shape[1]
-        dev = dout.device
-        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, W1, W2, g2, be2, drop_p, seeds[1], seeds[2])
-        dg1, dbe1 = _z(d, dout), _z(d, dout)
+        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, ctx.prm[10:], drop_p, seeds[1], seeds[2])
+        (dg1, rg1), (dbe1, rbe1) = _gt(g1), _gt(be1)
         dz = hip.ln_bwd(dy, y, rstd1, g1.detach(), be1.detach(), None, dg1, dbe1)
-        dWo, dbo = torch.zeros(d, P, device=dev), _z(d, dout)
+        (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
         hip.gemm_tn(dz, c_last, dWo, dbo)
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
         dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0])
         dkv2 = dkv.view(B * L, 2 * P)
-        dWq, dbq = torch.zeros(P, d, device=dev), _z(P, dout)
-        hip.gemm_tn(dq_last, x_last, dWq, dbq)
-        dWkv, dbkv = torch.zeros(2 * P, d, device=dev), _z(2 * P, dout)
-        hip.gemm_tn(dkv2, x2, dWkv, dbkv)
+        (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))    # same shared base as the full layer
+        hip.gemm_tn(dq_last, x_last, dWqkv[:P], dbqkv[:P])
+        hip.gemm_tn(dkv2, x2, dWqkv[P:], dbqkv[P:])
         dx = hip.gemm_nt(dkv2, shadow_cat((Wk, Wv), transpose=True)).view(B, L, d)
         dx_last = hip.gemm_nt(dq_last, shadow(Wq, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
         dx[:, -1, :] += dx_last
-        return ((dx, None, None, None, None, None, dWq, dbq, dWkv[:P], dbkv[:P], dWkv[P:], dbkv[P:], dWo, dbo, dg1, dbe1)
+        return ((dx, None, None, None, None, None, rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg1, rbe1)
                 + gf)
 
 
@@ -390,8 +480,8 @@ class DecoderLayerFn(_Fn):
             out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
         if need:
             extra = (s_cross,) if s_cross is not None else ()
-            ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf,
-                                  Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2, *extra)
+            ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf, *extra)
+            ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, cWv, cbv, cWo, cbo, cg, cbe, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, H, drop_p, seeds)
         return out.view(B, L, d)
 
@@ -399,17 +489,17 @@ class DecoderLayerFn(_Fn):
     def backward(ctx, dout):
         B, L, H, drop_p, seeds = ctx.meta
         sav = ctx.saved_tensors
-        (x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2,
-         Wq, Wk, Wv, Wo, g1, be1, cWv, cWo, cg, cbe, W1, W2, g2, be2) = sav[:29]
-        s_cross = sav[29] if len(sav) > 29 else None
+        x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2 = sav[:15]
+        s_cross = sav[15] if len(sav) > 15 else None
+        cWv, cbv, cWo, cbo, cg, cbe = ctx.prm[10:16]
         d = x2.shape[1]
         P = cWv.shape[0]
         dev = dout.device
-        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, W1, W2, g2, be2,
+        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, ctx.prm[16:],
                                  drop_p, seeds[1], seeds[2])
-        dcg, dcbe = _z(d, dout), _z(d, dout)
+        (dcg, rcg), (dcbe, rcbe) = _gt(cg), _gt(cbe)
         dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), None, dcg, dcbe)   # residual: dz == dy1
-        dcWo, dcbo = torch.zeros(d, P, device=dev), _z(d, dout)
+        (dcWo, rcWo), (dcbo, rcbo) = _gt(cWo), _gt(cbo)
         if s_cross is None:
             do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype
             hip.gemm_tn(do, c, dcWo, dcbo)
@@ -423,12 +513,12 @@ class DecoderLayerFn(_Fn):
                 blk = slice(hh * 32, (hh + 1) * 32)
                 hip.gemm_tn(doh[:, hh, :], c[:, blk], dcWo[:, blk])
                 hip.gemm_nt(doh[:, hh, :], woT[blk, :], out=dc[:, blk])
-        dcWv, dcbv = torch.zeros(P, d, device=dev), _z(P, dout)
+        (dcWv, rcWv), (dcbv, rcbv) = _gt(cWv), _gt(cbv)
         hip.gemm_tn(dc, u, dcWv, dcbv)
         du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
         dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
-                                 Wq, Wk, Wv, Wo, g1, be1, drop_p, seeds[0])
-        return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (dcWv, dcbv, dcWo, dcbo, dcg, dcbe) + gf)
+                                 ctx.prm[:10], drop_p, seeds[0])
+        return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -446,18 +536,24 @@ class ItemLoss(_Fn):
         sums, aux = hip.item_loss_fwd(h2, tab, pos, neg, mask, k, mode)
         if _DP is not None and _DP.world > 1:
             _DP.global_count(sums[1:2])          # Q12: sum(l*m) / GLOBAL sum(m); grads are SUM-reduced
-        ctx.save_for_backward(h2, pos, neg, mask, aux, sums, table)
+        ctx.save_for_backward(h2, pos, neg, mask, aux, sums)
+        ctx.table = table
         ctx.meta = (k, mode, skip_row, h.shape)
         return sums[0] / sums[1]
 
     @staticmethod
     def backward(ctx, gout):
-        h2, pos, neg, mask, aux, sums, table = ctx.saved_tensors
+        h2, pos, neg, mask, aux, sums = ctx.saved_tensors
+        table = ctx.table
         k, mode, skip_row, shape = ctx.meta
-        dE = torch.zeros(table.shape, device=h2.device, dtype=torch.float32)
+        dE, ret = _gt(table)
         g1 = gout.reshape(1).to(torch.float32).contiguous()
-        dh = hip.item_loss_bwd(h2, shadow(table), pos, neg, mask, k, mode, aux, sums, g1, dE, skip_row)
-        return dh.view(shape), dE, None, None, None, None, None, None
+        # large batches: counting-sort + LDS accumulation of the table gradient (the atomic form is bound by the
+        # chip-wide float-atomic rate); small ones: one atomic row per (position, item) pair
+        binned = h2.shape[0] >= 65536 and hip.item_loss_bwd_binned_supported(h2.shape[0], k, h2.shape[1], table.shape[0])
+        fn = hip.item_loss_bwd_binned if binned else hip.item_loss_bwd
+        dh = fn(h2, shadow(table), pos, neg, mask, k, mode, aux, sums, g1, dE, skip_row)
+        return dh.view(shape), ret, None, None, None, None, None, None
 
 
 def sampled_softmax_loss(h, table, pos, neg, mask, k, skip_row=-1):
@@ -490,13 +586,15 @@ class DiscriminatorFn(_Fn):
         x = x.contiguous()
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         h1, h2, h3, out = _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4, drop_p, seeds)
-        ctx.save_for_backward(x, h1, h2, h3, W1, W2, W3, W4)
+        ctx.save_for_backward(x, h1, h2, h3)
+        ctx.prm = (W1, b1, W2, b2, W3, b3, W4, b4)
         ctx.drop_p = drop_p
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x, h1, h2, h3, W1, W2, W3, W4 = ctx.saved_tensors
+        x, h1, h2, h3 = ctx.saved_tensors
+        W1, b1, W2, b2, W3, b3, W4, b4 = ctx.prm
         need_w = ctx.needs_input_grad[2]
         ik = _inv_keep(ctx.drop_p)
         dout = dout.to(torch.float32).contiguous()
@@ -507,17 +605,16 @@ class DiscriminatorFn(_Fn):
         dx = hip.gemm_nt(e1, shadow(W1, transpose=True)) if ctx.needs_input_grad[0] else None
         if not need_w:
             return (dx, None) + (None,) * 8
-        dW4 = torch.zeros(W4.shape, device=dev)
+        (dW4, rW4), (db4, rb4) = _gt(W4), _gt(b4)
         hip.colsum(h3, dW4.view(-1), coef=dout)
-        db4 = torch.zeros(1, device=dev)
         hip.sum_into(dout, db4)
-        dW3, db3 = torch.zeros(W3.shape, device=dev), _z(W3.shape[0], x)
+        (dW3, rW3), (db3, rb3) = _gt(W3), _gt(b3)
         hip.gemm_tn(e3, h2, dW3, db3)
-        dW2, db2 = torch.zeros(W2.shape, device=dev), _z(W2.shape[0], x)
+        (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
         hip.gemm_tn(e2, h1, dW2, db2)
-        dW1, db1 = torch.zeros(W1.shape, device=dev), _z(W1.shape[0], x)
+        (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
         hip.gemm_tn(e1, x, dW1, db1)
-        return dx, None, dW1, db1, dW2, db2, dW3, db3, dW4, db4
+        return dx, None, rW1, rb1, rW2, rb2, rW3, rb3, rW4, rb4
 
 
 class GradientPenaltyFn(_Fn):

@@ -13,12 +13,16 @@ class Adam(object):
         self.state = {}
 
     def zero_grad(self, set_to_none=True):
+        """p.grad = None for every parameter (so step() skips what the next backward does not touch), but the
+        gradient buffers are kept, zeroed in a few multi-tensor launches and re-adopted by the in-place
+        accumulating backward (ops.release_grads)."""
         for g in self.param_groups:
-            for p in g["params"]:
-                if set_to_none:
-                    p.grad = None
-                elif p.grad is not None:
-                    p.grad.zero_()
+            if set_to_none:
+                ops.release_grads(g["params"])
+            else:
+                for p in g["params"]:
+                    if p.grad is not None:
+                        p.grad.zero_()
 
     @torch.no_grad()
     def step(self):

@@ -317,6 +317,33 @@ def test_item_loss(dt, d, k, mode):
     t = dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-3)
     torch.testing.assert_close(dh.float(), hf.grad, **t)
     torch.testing.assert_close(dE, tf.grad, **t)
+    if hip.item_loss_bwd_binned_supported(ntok, k, d, V + 2):       # counting-sort path: same dh, same table gradient
+        dE2 = torch.zeros(V + 2, d, device="cuda")
+        dh2 = hip.item_loss_bwd_binned(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE2)
+        torch.testing.assert_close(dh2.float(), dh.float(), rtol=0, atol=0)
+        torch.testing.assert_close(dE2, dE, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("V,ntok,k", [(1000, 5000, 30), (70000, 20000, 7)])
+def test_item_loss_bwd_binned_large(V, ntok, k):
+    """Many bins, several chunks per bin, skewed positives, a skip row: binned == atomic table gradient."""
+    from recguru_amd import hip
+    d, dt = 128, torch.bfloat16
+    g0 = torch.Generator().manual_seed(V)
+    h = rnd(ntok, d, dt=dt, scale=0.3, seed=1)
+    table = rnd(V + 2, d, dt=dt, seed=2)
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64)
+    pos = (torch.multinomial(w, ntok, replacement=True, generator=g0) + 1).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.3).float().cuda()
+    sums, aux = hip.item_loss_fwd(h, table, pos, neg, mask, k, 0)
+    gout = torch.full((1,), 0.9, device="cuda")
+    dE1, dE2 = torch.zeros(V + 2, d, device="cuda"), torch.zeros(V + 2, d, device="cuda")
+    dh1 = hip.item_loss_bwd(h, table, pos, neg, mask, k, 0, aux, sums, gout, dE1, skip_row=1)
+    dh2 = hip.item_loss_bwd_binned(h, table, pos, neg, mask, k, 0, aux, sums, gout, dE2, skip_row=1)
+    torch.testing.assert_close(dh2.float(), dh1.float(), rtol=0, atol=0)
+    assert float(dE1[1].abs().max()) == 0.0 and float(dE2[1].abs().max()) == 0.0
+    torch.testing.assert_close(dE2, dE1, rtol=1e-4, atol=1e-6)
 
 
 @pytest.mark.parametrize("dt", DTYPES)

@@ -104,6 +104,8 @@ def main():
     gout = torch.ones(1, device=dev)
     rec("item_loss_bwd k=30", timeit(lambda: hip.item_loss_bwd(x, table, zid, neg, live, kneg, hip.LOSS_SAMPLED_CE, aux, sums, gout, dE), n=5),
         4.0 * nlive * (kneg + 1) * d, nlive * (kneg + 1) * d * (es + 4))
+    rec("item_loss_bwd binned k=30", timeit(lambda: hip.item_loss_bwd_binned(x, table, zid, neg, live, kneg, hip.LOSS_SAMPLED_CE, aux, sums, gout, dE), n=5),
+        4.0 * nlive * (kneg + 1) * d, nlive * (kneg + 1) * d * (es + es))
     print("%-32s %10s %10s %10s" % ("kernel", "us", "TFLOP/s", "GB/s"))
     for n, us, tf, gb in rows:
         print("%-32s %10.1f %10.1f %10.1f" % (n, us, tf, gb))
