@@ -52,6 +52,7 @@ def pmc_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--no_overlap", action="store_true", help="critic encoder passes on the main stream (debug A/B)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="users per domain per GPU per draw")
@@ -97,17 +98,15 @@ def build(args, device, rank, world):
     return param, G, D, opt_g, opt_d, loaders
 
 
-def make_step(param, G, D, opt_g, opt_d, loaders, device, dp):
+def make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args):
     from recguru_amd import training as T
     a_iter, b_iter = T._Cycler(loaders[0]), T._Cycler(loaders[1])
     g_params = list(G.parameters())
     ndp = dp or T._NoDP()
 
     def step():
-        for _ in range(T.CRITIC_ITERS):
-            in_a = a_iter.next(device)[0]
-            in_b = b_iter.next(device)[0]
-            d_cost, w_d = T.critic_iteration(G, D, in_a, in_b, opt_d, param, device, ndp)
+        batches = [(a_iter.next(device)[0], b_iter.next(device)[0]) for _ in range(T.CRITIC_ITERS)]
+        d_cost, w_d = T.critic_phase(G, D, batches, opt_d, param, device, ndp, overlap=not args.no_overlap)
         ba = a_iter.next(device)
         bb = b_iter.next(device)
         g_dis, lra, lrb = T.generator_iteration(G, D, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param, device, ndp,
@@ -191,7 +190,7 @@ def main():
     ops.set_data_parallel(dp)
     ops.manual_seed(0, rank)                  # independent dropout streams per rank
     param, G, D, opt_g, opt_d, loaders = build(args, device, rank, world)
-    step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp)
+    step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args)
 
     for _ in range(args.warmup):
         out = step()

@@ -166,11 +166,16 @@ def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True,
     return losses
 
 
-def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp):
-    """One critic update (gan_training.py:399-449): two no-grad encoder passes, W-loss, GP, Adam(D)."""
+def critic_embed(netG, in_seq_a, in_seq_b, param, device):
+    """The two no-grad encoder passes of a critic update (gan_training.py:399-411)."""
     with torch.no_grad():
         ae = get_user_embed(netG, in_seq_a, "a", param, device, param.pad_index)
         be = get_user_embed(netG, in_seq_b, "b", param, device, param.pad_index)
+    return ae, be
+
+
+def critic_update(netD, ae, be, opt_d, device, dp):
+    """W-loss, gradient penalty and Adam(D) of a critic update (gan_training.py:412-449)."""
     opt_d.zero_grad()
     D_real = netD(ae)
     D_fake = netD(be)
@@ -184,6 +189,55 @@ def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp):
     dp.sync_grads(list(netD.parameters()))
     opt_d.step()
     return D_cost, Wasserstein_D
+
+
+def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp):
+    """One critic update (gan_training.py:399-449): two no-grad encoder passes, W-loss, GP, Adam(D)."""
+    ae, be = critic_embed(netG, in_seq_a, in_seq_b, param, device)
+    return critic_update(netD, ae, be, opt_d, device, dp)
+
+
+_SIDE = {}
+
+
+def critic_phase(netG, netD, batches, opt_d, param, device, dp, overlap=True):
+    """The CRITIC_ITERS critic updates of one phase-2 iteration (gan_training.py:397-449) over `batches` =
+    [(in_seq_a, in_seq_b), ...].  The encoder does not change between critic updates, so the user embeddings of
+    update i+1 do not depend on update i: they are computed on a second HIP stream while the discriminator /
+    gradient-penalty / Adam(D) kernels of update i -- a hundred launches over [B, <=1280] matrices that fill a
+    fraction of the 256 CUs -- run on the main stream.  Same arithmetic as calling critic_iteration in a loop; the
+    dropout seeds are drawn in a different (still deterministic) order."""
+    if not (overlap and torch.cuda.is_available() and len(batches) > 1):
+        out = None
+        for in_a, in_b in batches:
+            out = critic_iteration(netG, netD, in_a, in_b, opt_d, param, device, dp)
+        return out
+    main = torch.cuda.current_stream()
+    side = _SIDE.get(main.device)
+    if side is None:
+        side = _SIDE[main.device] = torch.cuda.Stream(device=main.device)
+    side.wait_stream(main)                       # parameters (and their operand shadows) of the last generator step
+
+    def embed(i):
+        with torch.cuda.stream(side):
+            ae, be = critic_embed(netG, batches[i][0], batches[i][1], param, device)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return ae, be, ev
+
+    nxt = embed(0)
+    out = None
+    for i in range(len(batches)):
+        ae, be, ev = nxt
+        if i + 1 < len(batches):
+            nxt = embed(i + 1)                   # enqueued before update i: runs beside it
+        main.wait_event(ev)
+        ae.record_stream(main)
+        be.record_stream(main)
+        out = critic_update(netD, ae, be, opt_d, device, dp)
+    side.wait_stream(main)                       # nothing of this phase outlives it on the side stream
+    main.wait_stream(side)
+    return out
 
 
 def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, g_params=None):
@@ -242,10 +296,8 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
         if iteration < int(iterations * 0.6):                                   # phase 2
             for p in netD.parameters():
                 p.requires_grad = True
-            for _ in range(CRITIC_ITERS):
-                in_seq_a = a_iter.next(device)[0]
-                in_seq_b = b_iter.next(device)[0]
-                D_cost, Wasserstein_D = critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp)
+            batches = [(a_iter.next(device)[0], b_iter.next(device)[0]) for _ in range(CRITIC_ITERS)]
+            D_cost, Wasserstein_D = critic_phase(netG, netD, batches, opt_d, param, device, dp)
             ba = a_iter.next(device)
             bb = b_iter.next(device)
             g_dis, lra, lrb = generator_iteration(netG, netD, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param,

@@ -22,8 +22,8 @@ for _ in range(3):
 torch.cuda.synchronize()
 t = dbg.view(-1, 12).double()
 t = t[t.sum(1) > 0]
-names = ["stage ctx+x issue+bar", "oproj mma+W1 issue+bar", "acc->Z+bar", "LN1+bar", "wq issue+mma1", "bar(ch>0)", "gelu+Ag write",
-         "bar", "mma2", "ctx prefetch+bar+acc->Z+bar", "LN2+bar", "-"]
+names = ["0 stage ctx+x -> LDS + bar", "1 oproj mma + resid", "2 LN1 + y -> LDS", "3 (cross) + bar + ysave", "4 W2 issue + mma1 (x4)",
+         "5 bar ch>0 (x4)", "6 drop+gelu+g -> LDS (x4)", "7 bar (x4)", "8 mma2 (x4)", "9 prefetch+LN2+out -> LDS", "10 bar+store+bar", "-"]
 tot = t.sum(1).mean()
 print("waves sampled", t.shape[0], "mean cycles per wave", tot.item(), "per tile", tot.item() / (M / 64 / (t.shape[0] / 4)))
 for i, n in enumerate(names):
