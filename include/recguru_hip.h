@@ -162,6 +162,15 @@ int rg_sum(const float* x, float* out, long long n, float scale, void* stream); 
  * step counts from 1.  shadow (optional): operand-tier copy refreshed in the same pass. */
 int rg_adam(float* p, const float* g, float* m, float* v, void* shadow, int shadow_dtype, long long n, float lr,
             float beta1, float beta2, float eps, int step, void* stream);
+/* Multi-tensor Adam: ONE launch for a whole optimizer step.  segs is a DEVICE array; block i updates segment i
+ * (callers split large tensors into chunks, e.g. 64K elements).  Same arithmetic as rg_adam with
+ * step_lr = lr / (1 - beta1^t) and inv_bc2_sqrt = 1 / sqrt(1 - beta2^t) of the parameter's own step count t. */
+typedef struct {
+  float* p; const float* g; float* m; float* v;
+  long long n;
+  float step_lr; float inv_bc2_sqrt;
+} rg_adam_seg;
+int rg_adam_multi(const rg_adam_seg* segs /* device */, int nsegs, float beta1, float beta2, float eps, void* stream);
 int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
 
 /* ---- K7/K8: fused gather-dot-loss over the item catalogue --------------------------------------

@@ -352,6 +352,42 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_kernel(float* __restrict__ p, c
   }
 }
 
+// Multi-tensor form: one launch updates every (chunk of a) parameter listed in a device-resident segment table
+// (222 per-tensor launches of ~5 us each per optimizer step otherwise).  Block b owns segs[b]; the per-parameter
+// bias corrections (step counts may differ between parameters: torch skips parameters without gradient) ride in
+// the segment.
+__global__ __launch_bounds__(EW_BLOCK) void adam_multi_kernel(const rg_adam_seg* __restrict__ segs, float b1, float b2, float eps) {
+  const rg_adam_seg sg = segs[blockIdx.x];
+  float* __restrict__ p = sg.p;
+  const float* __restrict__ g = sg.g;
+  float* __restrict__ m = sg.m;
+  float* __restrict__ v = sg.v;
+  const long long n4 = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) ? 0 : (sg.n >> 2);
+  for (long long i = threadIdx.x; i < n4; i += EW_BLOCK) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+      pp[j] = pp[j] - sg.step_lr * (mm[j] / (sqrtf(vv[j]) * sg.inv_bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  }
+  for (long long i = (n4 << 2) + threadIdx.x; i < sg.n; i += EW_BLOCK) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - sg.step_lr * (mi / (sqrtf(vi) * sg.inv_bc2_sqrt + eps));
+  }
+}
+
 // dst[c,r] (or dst[r,c]) = (T) src[r,c]
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict__ src, T* __restrict__ dst, int R, int C, int transpose) {
@@ -635,6 +671,14 @@ extern "C" int rg_adam(float* p, const float* g, float* m, float* v, void* shado
     hipLaunchKernelGGL(adam_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, p, g, m, v, (__bf16*)shadow, n, lr, beta1, beta2, eps, bc1, bc2s);
   else
     hipLaunchKernelGGL(adam_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, p, g, m, v, (float*)nullptr, n, lr, beta1, beta2, eps, bc1, bc2s);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_adam_multi(const rg_adam_seg* segs_device, int nsegs, float beta1, float beta2, float eps, void* stream) {
+  if (nsegs <= 0) return 0;
+  if (!segs_device) return rg_set_error_msg(RG_ERR_INVALID, "adam_multi: null segment table");
+  hipLaunchKernelGGL(adam_multi_kernel, dim3(nsegs), dim3(EW_BLOCK), 0, (hipStream_t)stream, segs_device, beta1, beta2, eps);
   RG_CHECK_LAUNCH();
   return 0;
 }

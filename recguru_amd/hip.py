@@ -64,7 +64,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
-           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned"]
+           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -303,6 +303,16 @@ def adam(p, g, m, v, shadow, lr, beta1, beta2, eps, step):
                          c_f(beta2), c_f(eps), int(step), _stream()), "rg_adam")
 
 
+ADAM_CHUNK = 1 << 16
+# numpy mirror of rg_adam_seg (48 bytes: 4 pointers, n, 2 floats)
+ADAM_SEG_DTYPE = [("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("step_lr", "<f4"), ("inv_bc2_sqrt", "<f4")]
+
+
+def adam_multi(seg_table_dev, nsegs, beta1, beta2, eps):
+    """seg_table_dev: uint8 CUDA tensor holding nsegs rg_adam_seg records."""
+    _check(lib().rg_adam_multi(_vp(seg_table_dev), int(nsegs), c_f(beta1), c_f(beta2), c_f(eps), _stream()), "rg_adam_multi")
+
+
 def cast(src, dtype, transpose=False):
     """f32 [R,C] -> dtype [R,C] or [C,R]."""
     assert src.dtype == torch.float32 and src.is_contiguous()
@@ -501,7 +511,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["adam_multi", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

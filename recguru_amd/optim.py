@@ -11,6 +11,7 @@ class Adam(object):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
         self.param_groups = [{"params": [p for p in params], "lr": lr, "betas": tuple(betas), "eps": eps}]
         self.state = {}
+        self._tables = {}
 
     def zero_grad(self, set_to_none=True):
         """p.grad = None for every parameter (so step() skips what the next backward does not touch), but the
@@ -26,8 +27,12 @@ class Adam(object):
 
     @torch.no_grad()
     def step(self):
-        for g in self.param_groups:
+        """One rg_adam_multi launch per parameter group: a device-resident segment table lists (chunks of) the
+        parameters that have a gradient; the pointer columns are rebuilt only when that set changes."""
+        import numpy as np
+        for gi, g in enumerate(self.param_groups):
             b1, b2 = g["betas"]
+            live = []
             for p in g["params"]:
                 if p.grad is None:
                     continue
@@ -36,6 +41,29 @@ class Adam(object):
                     st = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
                     self.state[p] = st
                 st["step"] += 1
-                grad = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
-                hip.adam(p.data, grad, st["exp_avg"], st["exp_avg_sq"], None, g["lr"], b1, b2, g["eps"], st["step"])
+                if not p.grad.is_contiguous():
+                    p.grad = p.grad.contiguous()
+                live.append((p, st))
+            if not live:
+                continue
+            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in live)
+            cache = self._tables.get(gi)
+            if cache is None or cache["key"] != key:
+                rows, owner = [], []
+                for i, (p, st) in enumerate(live):
+                    n = p.numel()
+                    for off in range(0, n, hip.ADAM_CHUNK):
+                        rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
+                                     st["exp_avg_sq"].data_ptr() + 4 * off, min(hip.ADAM_CHUNK, n - off), 0.0, 0.0))
+                        owner.append(i)
+                cache = {"key": key, "tbl": np.array(rows, dtype=hip.ADAM_SEG_DTYPE), "owner": np.array(owner)}
+                self._tables[gi] = cache
+            steps = np.array([st["step"] for _, st in live], dtype=np.float64)
+            tbl = cache["tbl"]
+            tbl["step_lr"] = (g["lr"] / (1.0 - b1 ** steps))[cache["owner"]]
+            tbl["inv_bc2_sqrt"] = (1.0 / np.sqrt(1.0 - b2 ** steps))[cache["owner"]]
+            dev = live[0][0].device
+            tdev = torch.from_numpy(tbl.view(np.uint8).copy()).to(dev, non_blocking=True)
+            hip.adam_multi(tdev, len(tbl), b1, b2, g["eps"])
+            for p, _ in live:
                 ops.bump(p)
