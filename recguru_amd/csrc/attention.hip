@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 // scores: dS = 0 there, exactly like masked_fill_ in the reference.
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NKT>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(rg_attn_bwd_args a) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
   constexpr int LPK = NKT * 16;
   constexpr int LDT = LPK + 8;        // transposed images [32][LPK]
   __shared__ __align__(16) T Qt[DK * LDT];

@@ -17,7 +17,7 @@
 #define APAD 8
 
 template <typename T, int NTW>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(rg_gemm_nt_args a) {
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   constexpr int TN = 64 * NTW;
   constexpr int LDA = KC + APAD;
   constexpr int A_BYTES = TM * LDA * (int)sizeof(T);
@@ -288,7 +288,7 @@ __device__ __forceinline__ void load_frag_tr(Frag<__bf16>& f, const __bf16* tile
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(rg_gemm_tn_args a) {
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(rg_gemm_tn_args a) {
   constexpr int LD = 64 + TPAD;
   __shared__ __align__(16) T Ys[TT * LD];
   __shared__ __align__(16) T Xs[TT * LD];
