@@ -204,6 +204,22 @@ size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long
 int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long table_rows, void* workspace,
                             size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- ranking evaluation -------------------------------------------------------------
+ * gan_training.py:58-87 (get_scores) + the double argsort of evaluation_2 (:129-132), fused: per user b the
+ * scores h[b].E[target[b]] and h[b].E[cand[b,j]] (scores[b,0] = target, optional) and rank[b] = number of
+ * candidates scoring strictly higher than the target (= the reference's 0-based rank when scores are distinct).
+ * d in {64, 128, 256}; h and table in the operand dtype. */
+typedef struct {
+  const void* h;             /* [B, d] last recommender-decoder state */
+  const void* table;         /* [rows, d] item embeddings */
+  const int64_t* target;     /* [B] */
+  const int64_t* cand;       /* [B, C] */
+  float* scores;             /* [B, 1 + C] or NULL */
+  int* rank;                 /* [B] or NULL */
+  int B, d, C;
+} rg_rank_args;
+int rg_rank_scores(const rg_rank_args* args /* host */, int dtype, void* stream);
+
 /* ---- fused post-attention block, forward -------------------------------------------------------------
  * y = LN(ctx.Wo^T + bo + x) [; y = LN(y + o_bcast[b])] ; out = LN(gelu(y.W1^T + b1).W2^T + b2 + y) * rowmask
  * = MultiHeadAttention tail (Transformer/transformer.py:160-161) [+ collapsed dec_enc_attn, :259, Q1]

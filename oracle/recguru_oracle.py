@@ -15,6 +15,8 @@ All citations are paths relative to /root/reference/.
 """
 import math
 
+import numpy as np
+
 import torch
 
 # Train-mode dropout for the CPU-baseline timing only (bench.py cpu_baseline); parity tests keep 0 = eval mode.
@@ -464,3 +466,31 @@ def generator_step(pG, pD, cfg, batch_a, batch_b, opt_g, collapsed=False):
     lb.backward()
     opt_g.step()
     return g_dis.detach(), la.detach(), lb.detach()
+
+
+# ----------------------------------------------------------------------------------------------
+# ranking evaluation  
+# ----------------------------------------------------------------------------------------------
+def get_scores(p, cfg, enc_in, dec_in, target, n_items, domain, candidate_size, collapsed=False):
+    """gan_training.py:58-87 (sas=False, single device): score of the held-out target and of `candidate_size`
+    sampled negatives against the LAST recommender-decoder state -> [B, 1 + candidate_size], column 0 = target.
+    get_pad_mask(dec_in) is the encoder mask handed to recommend_forward (:62)."""
+    enc_mask = nonpad(dec_in, cfg.pad_index)
+    h = cross_get_dec_out(p, cfg, enc_in, dec_in, domain, enc_mask, collapsed,
+                          dec_prefix="recommend_%s." % domain, d_mask_from="dec", detach_enc=True)[:, -1, :]
+    emb = p["src_emb_%s.weight" % domain]
+    cand = torch.cat([emb[target].view(-1, 1, cfg.d_model), emb[n_items].view(-1, candidate_size, cfg.d_model)], 1)
+    return torch.matmul(h.unsqueeze(1), cand.transpose(1, 2)).squeeze(1)
+
+
+def ranks_from_scores(scores):
+    """evaluation_2, gan_training.py:129-132: position of column 0 in the descending order of each row."""
+    return torch.argsort(torch.argsort(-scores, dim=1), dim=1)[:, 0]
+
+
+def metrics_at_k(ranks, k):
+    """tools/metrics.py:26-68 over a list of 0-based ranks: (hit@k, NDCG@k, MRR@k), each a batch mean."""
+    r = np.asarray(ranks, dtype=np.float64)
+    hit = r < k
+    return (float(hit.mean()), float(np.where(hit, 1.0 / np.log2(r + 2.0), 0.0).mean()),
+            float(np.where(hit, 1.0 / (r + 1.0), 0.0).mean()))

@@ -567,6 +567,89 @@ extern "C" int rg_item_loss_bwd_binned(const rg_item_loss_args* a, long long tab
   return rg_set_error_msg(RG_ERR_INVALID, "item_loss_bwd_binned: bad dtype");
 }
 
+// ------------------------------------------------------------------------------------------------
+// Ranking evaluation (gan_training.py:58-87 get_scores + the double argsort of evaluation_2 :129-132):
+// per user, the score of the held-out target and of C sampled candidates against the last recommender-decoder
+// state, and the 0-based rank of the target = number of candidates scoring strictly higher (ties: the reference's
+// unstable argsort leaves their order unspecified).  One wave per user, row-group gathers as in the loss kernels;
+// the [B, C, d] candidate-embedding tensor, the concatenation and both sorts are never materialised.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int LPR>
+__global__ __launch_bounds__(64 * LW) void rank_scores_kernel(rg_rank_args a) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const T* __restrict__ E = reinterpret_cast<const T*>(a.table);
+  const int d = a.d, n = a.C + 1;
+  for (int b = blockIdx.x * LW + wave; b < a.B; b += gridDim.x * LW) {
+    float h[8];
+    load8(h, H + (size_t)b * d + 8 * li);
+    const long long tgt = a.target[b];
+    float s0;
+    {
+      float e[8];
+      load8(e, E + (size_t)tgt * d + 8 * li);
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot += e[j] * h[j];
+      s0 = __shfl(group_sum<LPR>(dot), 0);
+    }
+    if (lane == 0 && a.scores) a.scores[(size_t)b * n] = s0;
+    int higher = 0;
+    for (int i0 = 0; i0 < a.C; i0 += G * RG_U) {
+      long long item[RG_U];
+      float e[RG_U][8];
+#pragma unroll
+      for (int u = 0; u < RG_U; ++u) {
+        const int idx = i0 + u * G + gi;
+        item[u] = idx < a.C ? a.cand[(size_t)b * a.C + idx] : tgt;
+      }
+#pragma unroll
+      for (int u = 0; u < RG_U; ++u) load8(e[u], E + (size_t)item[u] * d + 8 * li);
+#pragma unroll
+      for (int u = 0; u < RG_U; ++u) {
+        const int idx = i0 + u * G + gi;
+        float dot = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dot += e[u][j] * h[j];
+        dot = group_sum<LPR>(dot);
+        if (idx < a.C) {
+          if (li == 0) {
+            higher += dot > s0;
+            if (a.scores) a.scores[(size_t)b * n + 1 + idx] = dot;
+          }
+        }
+      }
+    }
+    higher = (int)wave_sum((float)higher);          // exact below 2^24 candidates
+    if (lane == 0 && a.rank) a.rank[b] = higher;
+  }
+}
+
+extern "C" int rg_rank_scores(const rg_rank_args* a, int dtype, void* stream) {
+  if (!a || a->B <= 0) return 0;
+  if (a->C < 0 || a->C >= (1 << 24)) return rg_set_error_msg(RG_ERR_INVALID, "rank_scores: bad candidate count");
+  if (!(a->d == 64 || a->d == 128 || a->d == 256)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "rank_scores: d must be 64, 128 or 256");
+  hipStream_t s = (hipStream_t)stream;
+  int g = (a->B + LW - 1) / LW;
+  if (g > 256 * 32) g = 256 * 32;
+#define RG_RK(T, LPR) hipLaunchKernelGGL((rank_scores_kernel<T, LPR>), dim3(g), dim3(64 * LW), 0, s, *a)
+#define RG_RK_T(T)                  \
+  do {                              \
+    if (a->d == 64) RG_RK(T, 8);    \
+    else if (a->d == 128) RG_RK(T, 16); \
+    else RG_RK(T, 32);              \
+  } while (0)
+  if (dtype == RG_BF16) RG_RK_T(__bf16);
+  else if (dtype == RG_F32) RG_RK_T(float);
+  else return rg_set_error_msg(RG_ERR_INVALID, "rank_scores: bad dtype");
+#undef RG_RK_T
+#undef RG_RK
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int rg_item_loss_fwd(const rg_item_loss_args* a, int dtype, void* stream) {
   if (!a || a->ntok <= 0) return 0;
   if (dtype == RG_BF16) return launch<__bf16>(*a, false, (hipStream_t)stream);

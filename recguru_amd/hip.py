@@ -64,7 +64,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
-           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi"]
+           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -333,6 +333,24 @@ def item_loss_fwd(h, table, pos, neg, mask, k, mode):
                      mode, -1)
     _check(lib().rg_item_loss_fwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_fwd")
     return sums, aux
+
+
+class RankArgs(ctypes.Structure):
+    _fields_ = [("h", c_p), ("table", c_p), ("target", c_p), ("cand", c_p), ("scores", c_p), ("rank", c_p),
+                ("B", c_i), ("d", c_i), ("C", c_i)]
+
+
+def rank_scores(h, table, target, cand, want_scores=True, want_rank=True):
+    """h [B,d], table [rows,d] (same dtype); target [B], cand [B,C] int64 -> (scores [B,1+C] f32 | None, rank [B] int32 | None)."""
+    B, d = h.shape
+    C = cand.shape[1]
+    assert h.is_contiguous() and table.is_contiguous() and table.dtype == h.dtype
+    assert target.dtype == torch.int64 and cand.dtype == torch.int64 and cand.is_contiguous() and target.numel() == B
+    scores = torch.empty(B, C + 1, device=h.device, dtype=torch.float32) if want_scores else None
+    rank = torch.empty(B, device=h.device, dtype=torch.int32) if want_rank else None
+    a = RankArgs(_p(h), _p(table), _p(target.contiguous()), _p(cand), _p(scores), _p(rank), B, d, C)
+    _check(lib().rg_rank_scores(ctypes.byref(a), dt_of(h), _stream()), "rg_rank_scores")
+    return scores, rank
 
 
 _BIN_WS = {}

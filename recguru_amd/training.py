@@ -115,6 +115,7 @@ def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, device):
 
 class _NoDP(object):
     world = 1
+    rank = 0
 
     def scale_mean(self, loss):
         return loss
@@ -164,6 +165,69 @@ def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True,
             plot.plot(param.result_path + "/%s_a_%s" % (tag, param.date), la)
             plot.plot(param.result_path + "/%s_b_%s" % (tag, param.date), lb)
     return losses
+
+
+def _last_rec_state(model, enc_in, dec_in, domain, param, device):
+    """recommend_forward(...)[:, -1, :] under no_grad: the state every candidate is scored against."""
+    enc_mask = get_pad_mask(dec_in, param.pad_index, device)
+    with torch.no_grad():
+        h = _unwrap(model).recommend_forward(enc_in, dec_in, domain, enc_mask)
+    return h[:, -1, :].contiguous()
+
+
+def get_scores(model, enc_in, dec_in, target, n_items, param, sas=False, domain="a", device=None):
+    """gan_training.py:58-87: [B, 1 + candidate_size] scores, column 0 = the held-out target (torch.squeeze'd like
+    the reference).  The candidate gather, concatenation and batched matmul are one HIP kernel."""
+    if sas:
+        raise NotImplementedError("SASRec scoring is outside the hot path")
+    from . import hip
+    m = _unwrap(model)
+    h = _last_rec_state(model, enc_in, dec_in, domain, param, device)
+    cand = n_items.reshape(-1, param.candidate_size).contiguous()
+    scores, _ = hip.rank_scores(h, ops.shadow(m.item_table(domain)), target.reshape(-1), cand, want_rank=False)
+    return torch.squeeze(scores)
+
+
+def evaluation_2(model_train, data_loader, de, param, k_val=None, sas=False, domain="a"):
+    """gan_training.py:90-149: ranks of the validation / test targets among frequency-sampled and random
+    candidates over param.eval_steps batches, then hit / NDCG / MRR @k.  Returns [result_freq, result_rand] with the
+    reference's layout.  The rank is counted in the scoring kernel (no argsort, no score tensor)."""
+    from . import hip, metrics
+    if sas:
+        raise NotImplementedError("SASRec scoring is outside the hot path")
+    if k_val is None:
+        k_val = [1, 5, 10, 20, 30]
+    model_train.eval()
+    m = _unwrap(model_train)
+    names = ("ht_eval", "ndcg_eval", "mrr_eval", "ht_test", "ndcg_test", "mrr_test")
+    result_rand = {str(k): {n: [] for n in names} for k in k_val}
+    result_freq = {str(k): {n: [] for n in names} for k in k_val}
+    ranks = {"eval_f": [], "eval_r": [], "test_f": [], "test_r": []}
+    it = iter(data_loader)
+    for _ in range(param.eval_steps):
+        try:
+            eval_data, test_data, n_items_f, n_items_r = next(it)
+        except StopIteration:
+            it = iter(data_loader)
+            eval_data, test_data, n_items_f, n_items_r = next(it)
+        table = ops.shadow(m.item_table(domain))
+        cf = n_items_f.to(de).reshape(-1, param.candidate_size).contiguous()
+        cr = n_items_r.to(de).reshape(-1, param.candidate_size).contiguous()
+        for tag, data in (("eval", eval_data), ("test", test_data)):
+            enc_in, dec_in, target = data[0].to(de), data[1].to(de), data[2].to(de)
+            h = _last_rec_state(model_train, enc_in, dec_in, domain, param, de)
+            for sfx, cand in (("f", cf), ("r", cr)):
+                _, rk = hip.rank_scores(h, table, target.reshape(-1), cand, want_scores=False)
+                ranks["%s_%s" % (tag, sfx)].append(rk)
+    host = {kk: torch.cat(v).cpu().numpy() for kk, v in ranks.items()}        # one sync for the whole evaluation
+    for k in k_val:
+        for res, sfx in ((result_rand, "r"), (result_freq, "f")):
+            for tag in ("eval", "test"):
+                r = host["%s_%s" % (tag, sfx)]
+                res[str(k)]["ht_" + tag].append(metrics.hit_at_k_batch(r, k))
+                res[str(k)]["ndcg_" + tag].append(metrics.NDCG_at_k_batch(r, k))
+                res[str(k)]["mrr_" + tag].append(metrics.mrr_at_k_batch(r, k))
+    return [result_freq, result_rand]
 
 
 def critic_embed(netG, in_seq_a, in_seq_b, param, device):
@@ -281,8 +345,9 @@ class _Cycler(object):
 
 def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iterations, train_overlap, rec_loaders,
                   test_loaders, domain="a", overlap=True, dp=None, evaluate=None):
-    """Phases 2 and 3 (gan_training.py:353-587).  `evaluate(netG)` (optional) is called at the
-    reference's evaluation points; the ranking evaluation itself is a 'next' row."""
+    """Phases 2 and 3 (gan_training.py:353-587).  At the reference's evaluation points (:569-580) the ranking
+    evaluation (evaluation_2) runs over test_loaders and result_<domain>.pickle is rewritten; `evaluate(netG)`
+    (optional) replaces it."""
     if overlap:
         raise NotImplementedError("overlap=True (MSE on overlapped users) is off in main_2 (gan_training.py:1010)")
     dp = dp or _NoDP()
@@ -292,6 +357,7 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
     rec_task = _Cycler(rec_loaders[0]) if rec_loaders is not None else None
     rec_iter = _Cycler(gan_loader[0] if domain == "a" else gan_loader[1])
     history = []
+    result = [{}, {}]                                                           # [frequency-sampled, random] candidates
     for iteration in range(int(iterations * 1.2)):
         if iteration < int(iterations * 0.6):                                   # phase 2
             for p in netD.parameters():
@@ -321,9 +387,20 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
             dp.sync_grads(g_params)
             opt_final_rec.step()
             plot.plot(param.result_path + "/tuning_recommendation_loss", loss_recommend)
-        if evaluate is not None and iteration > int(iterations * 0.8) and iteration % 30 == 29:
-            netG.eval()
-            evaluate(netG)
+        if iteration > int(iterations * 0.8) and iteration % 30 == 29 and (evaluate is not None or test_loaders is not None):
+            netG.eval()                          # gan_training.py:570-580
+            if evaluate is not None:
+                evaluate(netG)
+            else:
+                result_tmp = evaluation_2(netG, test_loaders, device, param, sas=False, domain=domain)
+                for key in ("1", "5", "10", "20", "30"):
+                    for metric in result_tmp[0][key]:
+                        result[0].setdefault(key, {}).setdefault(metric, []).extend(result_tmp[0][key][metric])
+                        result[1].setdefault(key, {}).setdefault(metric, []).extend(result_tmp[1][key][metric])
+                if dp.rank == 0:
+                    import pickle
+                    with open(os.path.join(param.result_path, "result_%s.pickle" % param.target_domain), "wb") as f:
+                        pickle.dump(result, f)
             netG.train()
     return history
 

@@ -215,3 +215,21 @@ def test_single_domain(name):
     m = O.nonpad(dec_in).view(-1)
     close(O.bpr_loss_sas(pl, nl, m), z["single.loss_bpr_sas"], rtol=1e-5)
     close(O.bpr_loss(pl, nl, m), z["single.loss_bpr"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", CASES)
+@pytest.mark.parametrize("collapsed", [False, True])
+def test_ranking_eval(name, collapsed):
+    """get_scores / double-argsort rank / hit-NDCG-MRR@k against the reference (oracle/gen_golden_eval.py)."""
+    z, cfg, st, bt = load(name)
+    ze = load_case("eval_" + name)
+    cand = int(ze["candidate_size"])
+    for dom in "ab":
+        enc_in, dec_in = bt[dom][0], bt[dom][1]
+        sc = O.get_scores(st["G"], cfg, enc_in, dec_in, torch.as_tensor(ze["target.%s" % dom]),
+                          torch.as_tensor(ze["n_items.%s" % dom]), dom, cand, collapsed=collapsed)
+        close(sc, ze["scores.%s" % dom], rtol=2e-4, atol=2e-5)
+        ranks = O.ranks_from_scores(sc).numpy()
+        assert (ranks == ze["ranks.%s" % dom]).all()
+        for i, k in enumerate((1, 5, 10, 20, 30)):
+            np.testing.assert_allclose(O.metrics_at_k(ranks, k), ze["metrics.%s" % dom][i], rtol=1e-12, atol=0)

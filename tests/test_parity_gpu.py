@@ -256,3 +256,62 @@ def test_last_only_equals_full_encoder(name):
             scale = float(gfull[k].abs().max())
             # WK.bias is structurally gradient-free (softmax invariance): both paths give rounding noise
             torch.testing.assert_close(p.grad, gfull[k], rtol=2e-3, atol=2e-4 * scale + 1e-6, msg=lambda m: k + ": " + m)
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_ranking_eval(name):
+    """get_scores / evaluation_2 against the reference's vectors: scores within the f32-tier
+    tolerance, ranks and hit/NDCG/MRR@k identical."""
+    from golden_util import load_case
+    from recguru_amd import metrics, ops, training
+    ops.set_compute_dtype(torch.float32)
+    z = load_case(name)
+    ze = load_case("eval_" + name)
+    param, G, D = build_cross(z)
+    G.eval()
+    bt = batches(z, "cuda")
+    param.candidate_size = int(ze["candidate_size"])
+    for dom in "ab":
+        enc_in, dec_in = bt[dom][0], bt[dom][1]
+        target = torch.as_tensor(ze["target.%s" % dom]).cuda()
+        cand = torch.as_tensor(ze["n_items.%s" % dom]).cuda()
+        sc = training.get_scores(G, enc_in, dec_in, target, cand, param, False, dom, "cuda")
+        np.testing.assert_allclose(sc.cpu().numpy(), ze["scores.%s" % dom], rtol=1e-3, atol=2e-5)
+        # evaluation_2 over a one-batch "loader": validation == test batch here, freq == random candidates.
+        # An all-pad user (golden case2, domain b) has a zero decoder state: every score ties at 0 and the reference's
+        # unstable argsort ranks the target arbitrarily -- such rows are left out of the rank comparison.
+        gs = ze["scores.%s" % dom]
+        keep = np.flatnonzero(~np.all(gs == gs[:, :1], axis=1))
+        assert len(keep) >= gs.shape[0] - 1
+        ki = torch.as_tensor(keep).cuda()
+        param.eval_steps = 1
+        data = (enc_in[ki], dec_in[ki], target[ki])
+        loader = [(data, data, cand[ki], cand[ki])]
+        res = training.evaluation_2(G, loader, "cuda", param, domain=dom)
+        from oracle import recguru_oracle as O      # metrics_at_k is pinned to tools/metrics.py by the CPU suite
+        for i, k in enumerate((1, 5, 10, 20, 30)):
+            exp = O.metrics_at_k(ze["ranks.%s" % dom][keep], k)
+            if len(keep) == gs.shape[0]:
+                np.testing.assert_allclose(exp, ze["metrics.%s" % dom][i], rtol=1e-12, atol=0)
+            for res_x in res:
+                got = (res_x[str(k)]["ht_eval"][0], res_x[str(k)]["ndcg_eval"][0], res_x[str(k)]["mrr_eval"][0])
+                np.testing.assert_allclose(got, exp, rtol=1e-12, atol=0)
+                assert res_x[str(k)]["ht_test"][0] == res_x[str(k)]["ht_eval"][0]
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("d,C", [(64, 19), (128, 199), (256, 1000)])
+def test_rank_scores_kernel(d, C):
+    from recguru_amd import hip
+    B, V = 37, 500
+    g0 = torch.Generator().manual_seed(C)
+    for dt in (torch.float32, torch.bfloat16):
+        h = (torch.randn(B, d, generator=g0) * 0.3).to(dt).cuda()
+        table = torch.randn(V + 2, d, generator=g0).to(dt).cuda()
+        target = torch.randint(1, V + 1, (B,), generator=g0).cuda()
+        cand = torch.randint(1, V + 1, (B, C), generator=g0).cuda()
+        sc, rk = hip.rank_scores(h, table, target, cand)
+        ref = torch.einsum("bd,bcd->bc", h.float(), torch.cat([table[target][:, None], table[cand]], 1).float())
+        tol = dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+        torch.testing.assert_close(sc, ref, **tol)
+        assert torch.equal(rk.long(), (sc[:, 1:] > sc[:, :1]).sum(1))       # rank = candidates strictly above the target
