@@ -52,6 +52,9 @@ def pmc_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--device_sampler", action="store_true",
+                    help="loaders included: assemble every batch and draw fresh negatives on the GPU (recguru_amd.sampler) "
+                         "instead of iterating pre-staged tensors")
     ap.add_argument("--no_overlap", action="store_true", help="critic encoder passes on the main stream (debug A/B)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
@@ -93,8 +96,16 @@ def build(args, device, rank, world):
     n_users = args.batch * args.batches_per_domain * world
     loaders = []
     for i, seed in enumerate((1, 2)):
-        dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed)
-        loaders.append(synthetic.TensorLoader(dom, args.batch, device, rank=rank, world=world))
+        if args.device_sampler:
+            # loaders INCLUDED in the step: batches assembled and fresh negatives drawn on the GPU for every draw
+            from recguru_amd import sampler
+            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed)
+            dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
+            loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
+                                                args.seq_len * args.n_negs, seed=seed, shuffle=False, rank=rank, world=world))
+        else:
+            dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed)
+            loaders.append(synthetic.TensorLoader(dom, args.batch, device, rank=rank, world=world))
     return param, G, D, opt_g, opt_d, loaders
 
 
@@ -258,7 +269,7 @@ def main():
             "metric": "user-sequences/sec (AE+GAN step)", "value": round(12 * B * world * args.steps / dt, 1),
             "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (", batches assembled + negatives sampled on device each draw" if args.device_sampler else ""),
             "config": {"workload": "cross-domain RecGURU AE+GAN phase-2 iteration (5 critic + 1 generator update), "
                                    "two %d-item domains" % args.items,
                        "per_gpu_batch": B, "seq_len": args.seq_len, "d_model": args.d_model, "n_head": args.n_head,

@@ -204,6 +204,24 @@ size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long
 int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long table_rows, void* workspace,
                             size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- input side: batch assembly and negative sampling on the device ------------------
+ * Users are CSR rows: items[offsets[u] .. offsets[u+1]) is user u's chronological item sequence, and
+ * excl[excl_off[u] .. excl_off[u+1]) its SORTED, UNIQUE exclusion set (ids in 1..V).  `users` [B] picks the batch.
+ * rg_assemble_batch = seq_padding (GURU/data/data_loader.py:25-36) for B users: enc_in [B,L_enc] = left-padded last
+ *   L_enc-1 items + eos; dec_in / dec_out [B,L_dec] = the last L_dec entries of [0,0]+enc_in[:-2] / [0,0]+enc_in[1:-1].
+ * rg_sample_negatives = pickle_loader.__getitem__'s torch.multinomial(weights, n, replacement=True) with weights
+ *   uniform over 1..V and zero on the exclusion set (data_loader.py:298-314): out [B,n]; exact uniform over the
+ *   allowed items (the u-th allowed item by binary search, no rejection), counter-based hash of (seed, draw index).
+ * rg_sample_negatives_alias = the frequency^0.75-weighted variant (:251-254): Walker alias table over slots ids
+ *   (prob [slots] f32, alias [slots] int32), excluded draws rejected. */
+int rg_assemble_batch(const int64_t* items, const int64_t* offsets, const int64_t* users, int B, int L_enc, int L_dec,
+                      int64_t eos, int64_t* enc_in, int64_t* dec_in, int64_t* dec_out, void* stream);
+int rg_sample_negatives(const int64_t* excl, const int64_t* excl_off, const int64_t* users, int B, int n, int64_t V,
+                        unsigned long long seed, int64_t* out, void* stream);
+int rg_sample_negatives_alias(const float* prob, const int* alias, int64_t slots, const int64_t* excl,
+                              const int64_t* excl_off, const int64_t* users, int B, int n, int64_t V,
+                              unsigned long long seed, int64_t* out, void* stream);
+
 /* ---- ranking evaluation -------------------------------------------------------------
  * gan_training.py:58-87 (get_scores) + the double argsort of evaluation_2 (:129-132), fused: per user b the
  * scores h[b].E[target[b]] and h[b].E[cand[b,j]] (scores[b,0] = target, optional) and rank[b] = number of

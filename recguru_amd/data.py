@@ -57,6 +57,25 @@ def domain_from_pickles(files, L, eos, V, k, seed=0, wf=None):
             "val": np.asarray(val, dtype=np.int64), "test": np.asarray(test, dtype=np.int64)}
 
 
+def device_loader_gen(files, param, num_n, domain="a", device="cuda", rank=0, world=1, seed=0, wf=None, batch_size=None,
+                      eval_n=False, rec=False, exclude_val=False):
+    """dataloader_gen on the device: the pickles' users go to the GPU as CSR rows once; every batch
+    is assembled (seq_padding) and gets FRESH negatives (enc_maxlen * num_n per user, or candidate_size with eval_n)
+    by two kernel launches -- recguru_amd.sampler."""
+    from .sampler import DeviceDomain, DeviceLoader
+    eos = param.vocab_size_a if domain == "a" else param.vocab_size_b
+    seqs, val, test = [], [], []
+    for fn in files:
+        d = load_pickle(fn)
+        seqs.extend(d["seq"])
+        val.extend(d["val"])
+        test.extend(d["test"])
+    dom = DeviceDomain(seqs, val, test, eos - 1, device, exclude_val=exclude_val, wf=wf)
+    n_neg = param.candidate_size if eval_n else param.enc_maxlen * num_n
+    return DeviceLoader(dom, batch_size or param.batch_size, param.enc_maxlen, param.rec_maxlen if rec else param.enc_maxlen,
+                        eos, n_neg, seed=seed, shuffle=True, rank=rank, world=world)
+
+
 def dataloader_gen(files, param, num_n, domain="a", device=None, rank=0, world=1, seed=0, wf=None, batch_size=None):
     """Counterpart of Dataloader.dataloader_gen(train=True) (data/data_loader.py:455-483)."""
     eos = param.vocab_size_a if domain == "a" else param.vocab_size_b

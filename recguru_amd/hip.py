@@ -64,7 +64,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
-           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores"]
+           "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
+           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -351,6 +352,40 @@ def rank_scores(h, table, target, cand, want_scores=True, want_rank=True):
     a = RankArgs(_p(h), _p(table), _p(target.contiguous()), _p(cand), _p(scores), _p(rank), B, d, C)
     _check(lib().rg_rank_scores(ctypes.byref(a), dt_of(h), _stream()), "rg_rank_scores")
     return scores, rank
+
+
+def _i64(t):
+    assert t.dtype == torch.int64 and t.is_contiguous() and t.is_cuda
+    return _vp(t)
+
+
+def assemble_batch(items, offsets, users, L_enc, L_dec, eos):
+    """seq_padding for a batch of CSR users -> (enc_in [B,L_enc], dec_in [B,L_dec], dec_out [B,L_dec]) int64."""
+    B = users.numel()
+    dev = users.device
+    enc_in = torch.empty(B, L_enc, device=dev, dtype=torch.int64)
+    dec_in = torch.empty(B, L_dec, device=dev, dtype=torch.int64)
+    dec_out = torch.empty(B, L_dec, device=dev, dtype=torch.int64)
+    _check(lib().rg_assemble_batch(_i64(items), _i64(offsets), _i64(users), B, int(L_enc), int(L_dec), c_ll(int(eos)),
+                                   _vp(enc_in), _vp(dec_in), _vp(dec_out), _stream()), "rg_assemble_batch")
+    return enc_in, dec_in, dec_out
+
+
+def sample_negatives(excl, excl_off, users, n, V, seed, alias=None):
+    """[B, n] negatives with replacement over 1..V minus each user's sorted exclusion set; alias = (prob f32, alias i32)
+    switches to the frequency-weighted draw."""
+    B = users.numel()
+    out = torch.empty(B, n, device=users.device, dtype=torch.int64)
+    if alias is None:
+        _check(lib().rg_sample_negatives(_i64(excl), _i64(excl_off), _i64(users), B, int(n), c_ll(int(V)), c_u64(int(seed)),
+                                         _vp(out), _stream()), "rg_sample_negatives")
+    else:
+        prob, al = alias
+        assert prob.dtype == torch.float32 and al.dtype == torch.int32 and prob.numel() == al.numel()
+        _check(lib().rg_sample_negatives_alias(_vp(prob), _vp(al), c_ll(prob.numel()), _i64(excl), _i64(excl_off), _i64(users), B,
+                                               int(n), c_ll(int(V)), c_u64(int(seed)), _vp(out), _stream()),
+               "rg_sample_negatives_alias")
+    return out
 
 
 _BIN_WS = {}

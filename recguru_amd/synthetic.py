@@ -28,8 +28,8 @@ def pad_sequences(seqs, L, eos):
     return enc, dec_in, dec_out
 
 
-def make_domain(n_users, V, L, k, seed, zipf_s=1.0):
-    """Returns dict of int64 arrays: enc_in/dec_in/dec_out [n,L], n_items [n,L*k], val/test [n]."""
+def make_users(n_users, V, L, seed, zipf_s=1.0):
+    """Raw users: (seqs [list of int64 arrays], val [n], test [n]) -- Zipf popularity, lengths U{5..L+20}."""
     rng = np.random.default_rng(seed)
     pop = 1.0 / np.arange(1, V + 1, dtype=np.float64) ** zipf_s
     cdf = np.cumsum(pop / pop.sum())
@@ -42,6 +42,12 @@ def make_domain(n_users, V, L, k, seed, zipf_s=1.0):
         items[1:][rep] = items[1:][rep] % V + 1
         seqs.append(items[:-2])
         val[i], test[i] = items[-2], items[-1]
+    return seqs, val, test, rng
+
+
+def make_domain(n_users, V, L, k, seed, zipf_s=1.0):
+    """Returns dict of int64 arrays: enc_in/dec_in/dec_out [n,L], n_items [n,L*k], val/test [n]."""
+    seqs, val, test, rng = make_users(n_users, V, L, seed, zipf_s)
     enc, dec_in, dec_out = pad_sequences(seqs, L, V + 1)
     neg = rng.integers(1, V + 1, size=(n_users, L * k))
     for i in range(n_users):                                # rejection against the user's own items
