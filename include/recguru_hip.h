@@ -204,6 +204,15 @@ size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long
 int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long table_rows, void* workspace,
                             size_t workspace_bytes, int dtype, void* stream);
 
+/* ---- dropout pieces of the block paths that are not fused (widths other than d_model = 128) ---------------
+ * rg_dropout: x [M,N] *= keep(seed, m*N + c) / (1-p) in place (nn.Dropout; the mask is a stateless hash, the same
+ *   index space as the fused kernel and rg_ln_bwd's dz_drop, so backward kernels regenerate it from the seed).
+ * rg_cross_rows: out [M,N] f32 = bo + sum_h s[m,h] * oh[m/L,h,:] -- the collapsed cross-attention output per row
+ *   under attention-map dropout (s from rg_cross_drop_scale). */
+int rg_dropout(void* x, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream);
+int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N,
+                  void* stream);
+
 /* ---- input side: batch assembly and negative sampling on the device ------------------
  * Users are CSR rows: items[offsets[u] .. offsets[u+1]) is user u's chronological item sequence, and
  * excl[excl_off[u] .. excl_off[u+1]) its SORTED, UNIQUE exclusion set (ids in 1..V).  `users` [B] picks the batch.

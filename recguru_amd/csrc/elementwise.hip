@@ -494,6 +494,45 @@ __global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict_
   }
 }
 
+// x[m, c] *= keep(m*N + c) in place: nn.Dropout for the block paths that are not fused (any width); same index
+// space as the fused kernel / ln_bwd's dz_drop, so a backward regenerates the mask from the seed.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void dropout_kernel(T* __restrict__ x, long long M, int N, DropCfg drop) {
+  const int n8 = N >> 3;
+  if ((N & 7) == 0) {
+    const long long total = M * n8;
+    for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+      const long long m = i / n8;
+      const int c8 = (int)(i - m * n8) * 8;
+      float v[8], k8[8];
+      load8(v, x + (size_t)m * N + c8);
+      rg_keep8(drop, (unsigned int)m * (unsigned int)N + (unsigned int)c8, k8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= k8[j];
+      store8(x + (size_t)m * N + c8, v);
+    }
+  } else {
+    const long long total = M * N;
+    for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK)
+      x[i] = (T)((float)x[i] * rg_keep(drop, (unsigned int)i));
+  }
+}
+
+// o[m, :] = bo + sum_h s[m, h] * oh[m / L, h, :]  : the collapsed decoder cross-attention output per ROW under
+// attention-map dropout (what the fused kernel forms in registers), for the unfused block path.
+__global__ __launch_bounds__(EW_BLOCK) void cross_rows_kernel(const float* __restrict__ s, const float* __restrict__ oh,
+                                                             const float* __restrict__ bo, float* __restrict__ out, long long M, int L,
+                                                             int H, int N) {
+  const long long total = M * N;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const long long m = i / N;
+    const int n = (int)(i - m * N);
+    float acc = bo[n];
+    for (int h = 0; h < H; ++h) acc += s[m * H + h] * oh[((m / L) * H + h) * N + n];
+    out[i] = acc;
+  }
+}
+
 // ================================================================================================
 // C ABI
 // ================================================================================================
@@ -526,6 +565,24 @@ extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int 
   if ((dtype) == RG_BF16) { CALL_BF16; } else if ((dtype) == RG_F32) { CALL_F32; }        \
   else return rg_set_error_msg(RG_ERR_INVALID, name ": bad dtype");                       \
   RG_CHECK_LAUNCH(); return 0;
+
+extern "C" int rg_dropout(void* x, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  if (M <= 0 || N <= 0 || drop_p <= 0.f) return 0;
+  const DropCfg drop = make_drop(drop_p, seed);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(M * ((N & 7) ? N : (N >> 3)), EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (__bf16*)x, M, N, drop),
+             hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (float*)x, M, N, drop),
+             "dropout")
+}
+
+extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N, void* stream) {
+  if (M <= 0) return 0;
+  hipLaunchKernelGGL(cross_rows_kernel, dim3(ew_grid(M * N, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, s, oh, bo, out, M, L, H, N);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
                                long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {

@@ -65,7 +65,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
-           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias"]
+           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -230,6 +230,23 @@ def bcast_add_ln(x, o, gamma, beta, L, eps=1e-8):
     _check(lib().rg_bcast_add_ln(_vp(x), _vp(o), _vp(gamma), _vp(beta), _vp(y), _vp(rstd), c_ll(M), L, N,
                                  c_f(eps), dt_of(x), _stream()), "rg_bcast_add_ln")
     return y, rstd
+
+
+def dropout_(x, drop_p, seed):
+    """In-place nn.Dropout on a contiguous [M, N] matrix (mask = hash(seed, m*N + c))."""
+    assert x.is_contiguous() and x.dim() == 2
+    _check(lib().rg_dropout(_vp(x), c_ll(x.shape[0]), x.shape[1], c_f(drop_p), c_u64(seed), dt_of(x), _stream()), "rg_dropout")
+    return x
+
+
+def cross_rows(s, oh, bo, L):
+    """s [M,H], oh [B,H,N] f32, bo [N] -> [M,N] f32 = bo + sum_h s[m,h] * oh[m//L,h,:]."""
+    M, H = s.shape
+    N = oh.shape[2]
+    assert s.dtype == torch.float32 and oh.dtype == torch.float32 and s.is_contiguous() and oh.is_contiguous()
+    out = torch.empty(M, N, device=s.device, dtype=torch.float32)
+    _check(lib().rg_cross_rows(_vp(s), _vp(oh), _vp(bo), _vp(out), c_ll(M), L, H, N, _stream()), "rg_cross_rows")
+    return out
 
 
 def seq_sum(x, B, L):
@@ -564,7 +581,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["adam_multi", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["dropout_", "cross_rows", "adam_multi", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

@@ -250,13 +250,6 @@ def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
 
 
-def _need_fused_for_dropout(drop_p, x2, Wo, W1):
-    if drop_p > 0 and not _fusable(x2, Wo, W1):
-        raise NotImplementedError("dropout > 0 is implemented on the fused block path only "
-                                  "(d_model == n_heads*32 == 128, d_ff % 128 == 0); got d=%d P=%d d_ff=%d"
-                                  % (x2.shape[1], Wo.shape[1], W1.shape[0]))
-
-
 def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0):
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
@@ -265,9 +258,10 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     return qkv, ctx_, lse
 
 
-def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad):
+def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad,
+                    drop_p=0.0, seed=0):
     """MultiHeadAttention.forward (transformer.py:151-161), unfused (any width): returns y and what backward needs."""
-    qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad)
+    qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p, seed)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
     y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
                     gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
@@ -295,9 +289,19 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     return dx, (rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg, rbe)
 
 
-def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be):
-    """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539, unfused."""
+def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, seed_out=0):
+    """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539, unfused (any
+    width).  With dropout: l1 -> dropout -> GELU -> l2 -> dropout -> + y -> LayerNorm, the two dropouts as in-place
+    passes over the GEMM outputs (h1 keeps the DROPPED pre-activation, as the fused kernel saves it)."""
     h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
+    if drop_p > 0:
+        hip.dropout_(h1, drop_p, seed_h1)
+        l2 = hip.gemm_nt(h1, shadow(W2), b2.detach(), prologue=hip.PRO_GELU, out_f32=True)
+        hip.dropout_(l2, drop_p, seed_out)
+        out, rstd = hip.bcast_add_ln(y, l2, g.detach(), be.detach(), 1, LN_EPS)       # L = 1: a per-row addend
+        if rowmask is not None:
+            out = out * rowmask.to(out.dtype).unsqueeze(1)
+        return out, (h1, rstd)
     rstd = torch.empty(y.shape[0], device=y.device, dtype=torch.float32)
     out = hip.gemm_nt(h1, shadow(W2), b2.detach(), prologue=hip.PRO_GELU, epilogue=hip.EPI_RESID_LN, aux=y,
                       gamma=g.detach(), beta=be.detach(), rowmask=rowmask, rstd_out=rstd, eps=LN_EPS)
@@ -337,7 +341,6 @@ class EncoderLayerFn(_Fn):
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
-        _need_fused_for_dropout(drop_p, x2, Wo, W1)
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
@@ -348,8 +351,9 @@ class EncoderLayerFn(_Fn):
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
-            y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
-            out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2)
+            y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
+                                    drop_p, seeds[0])
+            out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
@@ -385,7 +389,6 @@ class EncoderLastLayerFn(_Fn):
         key_ids = key_ids.contiguous()
         rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
         x_last = x[:, -1, :].contiguous()
-        _need_fused_for_dropout(drop_p, x_last, Wo, W1)
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), torch.cat([bk.detach(), bv.detach()]))
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
@@ -400,7 +403,7 @@ class EncoderLastLayerFn(_Fn):
             rstd1 = torch.empty(B, device=x.device, dtype=torch.float32)
             y = hip.gemm_nt(c_last, shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x_last,
                             gamma=g1.detach(), beta=be1.detach(), rstd_out=rstd1, eps=LN_EPS)
-            out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2)
+            out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
             ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
@@ -450,7 +453,6 @@ class DecoderLayerFn(_Fn):
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
         u = u.contiguous()
-        _need_fused_for_dropout(drop_p, x2, Wo, W1)
         seeds = (_draw(), _draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0, 0)
         P = cWv.shape[0]
         c = hip.gemm_nt(u, shadow(cWv), cbv.detach())                        # [B, P]
@@ -475,9 +477,14 @@ class DecoderLayerFn(_Fn):
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
-            y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need)
-            y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
-            out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2)
+            y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
+                                     drop_p, seeds[0])
+            if drop_p > 0:          # per-row cross-attention output under attention-map dropout
+                o_rows = hip.cross_rows(s_cross, oh, cbo.detach(), L)
+                y2, rstd_c = hip.bcast_add_ln(y1, o_rows, cg.detach(), cbe.detach(), 1, LN_EPS)
+            else:
+                y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
+            out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
             extra = (s_cross,) if s_cross is not None else ()
             ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf, *extra)

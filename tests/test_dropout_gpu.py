@@ -51,11 +51,13 @@ def _ids(B, L):
     return ids.cuda()
 
 
-def test_encoder_layer_dropout_grad_consistency():
+@pytest.mark.parametrize("d,H,dff,p", [(128, 4, 128, 0.5), (64, 2, 96, 0.5), (64, 2, 96, 0.3)])
+def test_encoder_layer_dropout_grad_consistency(d, H, dff, p):
+    """d = 128: the fused post-attention kernel; d = 64: the unfused block path (GEMMs + in-place dropout passes)."""
     from recguru_amd.blocks import EncoderLayer
     torch.manual_seed(0)
-    B, L, d, H = 2, 16, 128, 4
-    layer = EncoderLayer(d, 128, 32, 32, H, "cuda", 0.5).cuda()
+    B, L = 2, 16
+    layer = EncoderLayer(d, dff, 32, 32, H, "cuda", p).cuda()
     ids = _ids(B, L)
     mask = (ids != 0).float()
     x = torch.randn(B, L, d, device="cuda", requires_grad=True)
@@ -89,11 +91,12 @@ def test_encoder_layer_dropout_grad_consistency():
     _dir_check(f2, ps, seed=13, names=["x", "WV", "Wo", "W1", "b2", "ln2.gamma", "WQ"])
 
 
-def test_decoder_layer_dropout_grad_consistency():
+@pytest.mark.parametrize("d,H,dff", [(128, 4, 128), (64, 2, 96)])
+def test_decoder_layer_dropout_grad_consistency(d, H, dff):
     from recguru_amd.blocks import DecoderLayer
     torch.manual_seed(1)
-    B, L, d, H = 2, 16, 128, 4
-    layer = DecoderLayer(d, 128, 32, 32, H, "cuda", 0.5).cuda()
+    B, L = 2, 16
+    layer = DecoderLayer(d, dff, 32, 32, H, "cuda", 0.5).cuda()
     dec_ids = _ids(B, L)
     enc_ids = _ids(B, L)
     enc_ids[1, :] = 0                                   # a sequence whose cross keys are all masked (Q3)
@@ -203,8 +206,10 @@ def test_discriminator_and_gp_dropout_exact_vs_autograd_with_same_masks():
             assert g_gp[k] is None                       # GP has no bias gradient
 
 
-def test_training_step_with_dropout_runs_and_learns():
-    """A few phase-1 steps with the reference's dropout 0.5 on the C2 block shape: finite and decreasing."""
+@pytest.mark.parametrize("d,H", [(128, 4), (64, 2)])
+def test_training_step_with_dropout_runs_and_learns(d, H):
+    """A few phase-1 steps with the reference's dropout 0.5 on the C2 block shape (fused kernel) and on the C1 width
+    (hidden 64: unfused block path): finite and decreasing."""
     import argparse
     from recguru_amd import ops, synthetic, training as T
     from recguru_amd.blocks import ScheduledOptim
@@ -215,10 +220,10 @@ def test_training_step_with_dropout_runs_and_learns():
     ops.set_compute_dtype(torch.bfloat16)
     torch.manual_seed(0)
     L, V, k, B = 24, 300, 5, 64
-    param = get_param(make_args(128, 4, k, L, V, V, 1, B, dropout=0.5), make_dirs=False)
+    param = get_param(make_args(d, H, k, L, V, V, 1, B, dropout=0.5), make_dirs=False)
     G = MyAuto4Rec_c("cuda", param).cuda()
     loaders = [synthetic.TensorLoader(synthetic.make_domain(2 * B, V, L, k, seed=s), B, "cuda") for s in (1, 2)]
-    opt = ScheduledOptim(Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-9), 1.0, 128, 30)
+    opt = ScheduledOptim(Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-9), 1.0, d, 30)
     ops.manual_seed(3)
     losses = T.train_recon_x(G, opt, 40, loaders, param, "cuda", loss_type="s_soft", opt_type="schedule", log_every=0)
     la = [float(a) for a, b in losses]
