@@ -93,19 +93,22 @@ def build(args, device, rank, world):
         D.eval()
     opt_g = optim.Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:128
     opt_d = optim.Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:134
-    n_users = args.batch * args.batches_per_domain * world
+    # every rank synthesises ITS OWN shard of users (seeded by rank): same per-GPU work and the same statistics as
+    # sharding one big stream rank::world, without each of the N processes building all N shards on the host
+    n_users = args.batch * args.batches_per_domain
     loaders = []
     for i, seed in enumerate((1, 2)):
+        seed = seed + 1000 * rank
         if args.device_sampler:
             # loaders INCLUDED in the step: batches assembled and fresh negatives drawn on the GPU for every draw
             from recguru_amd import sampler
             seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed)
             dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
             loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
-                                                args.seq_len * args.n_negs, seed=seed, shuffle=False, rank=rank, world=world))
+                                                args.seq_len * args.n_negs, seed=seed, shuffle=False))
         else:
             dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed)
-            loaders.append(synthetic.TensorLoader(dom, args.batch, device, rank=rank, world=world))
+            loaders.append(synthetic.TensorLoader(dom, args.batch, device))
     return param, G, D, opt_g, opt_d, loaders
 
 
@@ -223,6 +226,8 @@ def main():
     losses = [float(x) for x in out]
 
     roof = None
+    if not args.no_roofline and rank != 0:
+        step()                          # the instrumented repetition contains collectives: every rank takes part
     if not args.no_roofline and rank == 0:
         prof = hip.start_profile()
         step()
