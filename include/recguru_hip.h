@@ -96,6 +96,9 @@ typedef struct {
   int B, L, H, dk;
   float scale;                /* 1/sqrt(d_k), transformer.py:120 */
   float drop_p; unsigned long long seed;   /* attention-probability dropout, transformer.py:126-127 */
+  /* optional [B*L] f32: rows with rowmask == 0 are the padded positions whose layer output the caller multiplies by
+   * the pad mask (transformer.py:594 / :539) -- a 16-query tile made only of such rows is skipped (ctx rows = 0). */
+  const float* rowmask;
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
 
@@ -106,6 +109,7 @@ typedef struct {
   int B, L, H, dk;
   float scale;
   float drop_p; unsigned long long seed;   /* must equal the forward's */
+  const float* rowmask;       /* optional, as in the forward: dctx of those rows is zero, their tiles are skipped */
 } rg_attn_bwd_args;
 int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream);
 

@@ -61,6 +61,22 @@ template <> struct VStage<float> {
 // (Q3).  Only the reported lse maps the sentinel back to the reference's -1e9.
 #define MASK_BIG (-0x1p100f)   // ~ -1.27e30; a power of two so that MASK_BIG * c is exact for any float c
 
+// qlive[t] = 1 iff the 16-query tile t of sequence b holds a row with rowmask != 0 (all 1 without a rowmask).  One
+// coalesced load per row and a ballot per wave; visible after the caller's next LDS barrier.
+template <int NT16>
+__device__ __forceinline__ void fill_qlive(int* __restrict__ qlive, const float* __restrict__ rowmask, int b, int L, int tid) {
+  const int lane = tid & 63;
+  for (int r0 = 0; r0 < NT16 * 16; r0 += 256) {
+    const int r = r0 + tid;
+    const float v = rowmask ? (r < L ? rowmask[(size_t)b * L + r] : 0.f) : 1.f;
+    const unsigned long long m = __ballot(v != 0.f);
+    if (lane < 4) {
+      const int t = (r0 + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
+      if (t < NT16) qlive[t] = ((m >> (16 * lane)) & 0xFFFFull) != 0ull;
+    }
+  }
+}
+
 // One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
 // rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
 // computed once per head instead of once per lane and element.  Layout [word][query].
@@ -93,6 +109,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   __shared__ __align__(16) float kbias[LPK];
   constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
+  __shared__ int qlive[NKT];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -104,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   DropCfg drop = make_drop(a.drop_p, a.seed);
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
+  fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
 
   // first Q fragment in flight during staging
   Frag<T> qnext;
@@ -162,6 +180,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       const int q2 = (qt + 4) * 16 + li;
       if (q2 < L) load_frag(qnext, qkv + (size_t)q2 * ld + h * DK + 8 * lg);
       else frag_zero(qnext);
+    }
+    {
+      // a tile of padded positions only: the layer multiplies these rows by the pad mask, nothing downstream reads
+      // their context -- skip the tile (rows written as zeros so that saved activations stay finite)
+      if (!qlive[qt]) {
+        if (q < L) {
+          T* __restrict__ ctxz = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
+          const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+          store4(ctxz + 4 * lg, z4);
+          store4(ctxz + 16 + 4 * lg, z4);
+#ifndef RG_STAMP
+          if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = 0.f;
+#endif
+        }
+        continue;
+      }
     }
     f32x4 s[NKT];
     float mx = -INFINITY;
@@ -473,6 +507,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   __shared__ __align__(16) float kbias[LPK];
   constexpr int NW = (NKT + 1) / 2;
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query] dropout bits (p == 0.5 mode), see fill_dmask
+  __shared__ int qlive[NKT];                    // 16-query tile has a row with rowmask != 0 (all 1 without a rowmask)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -489,6 +524,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
   const unsigned int lp4 = rg_lpad(L);
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
+  fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
 
   // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
   constexpr int NCH = (LPK * 4 + 255) / 256;
@@ -552,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     f32x4 dkt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     for (int qs = 0; qs < nt / 2; ++qs) {
+      if (!(qlive[2 * qs] | qlive[2 * qs + 1])) continue;   // padded query rows only: dO = 0 there, nothing to add to dK / dV
       f32x4 p[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -626,7 +663,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     const float lse_q = lse2_s[q], dl_q = dl_s[q];
     const int qrel = q - 4 * lg;
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    for (int ks = 0; ks < nt / 2; ++ks) {
+    for (int ks = 0; ks < (qlive[qt] ? nt / 2 : 0); ++ks) {      // padded query tile: dQ rows stay 0
       f32x4 ds[2];
       float kd[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
       unsigned int km[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};

@@ -154,6 +154,18 @@ __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __res
   }
 }
 
+// rows m0.. of a row-major HBM matrix <- 0 (64 x 128 block at column col0), coalesced 16-byte stores
+template <typename T>
+__device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col0, int m0, int M, int tid) {
+  Frag<T> z;
+  frag_zero(z);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+    if (m0 + r < M) *reinterpret_cast<Frag<T>*>(dst + (size_t)(m0 + r) * ld + col0 + c8) = z;
+  }
+}
+
 #ifdef RG_STAMP
 #define STAMP(i) do { unsigned long long t1__ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
     tacc[i] += t1__ - t0__; t0__ = t1__; } while (0)
@@ -234,6 +246,33 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     for (int rt = 0; rt < 4; ++rt) {
       const int m = m0 + rt * 16 + li;
       rm4[rt] = (a.rowmask && m < a.M) ? a.rowmask[m] : 1.f;
+    }
+    if (a.rowmask && __ballot(rm4[0] != 0.f || rm4[1] != 0.f || rm4[2] != 0.f || rm4[3] != 0.f) == 0ull) {
+      // 64 padded positions: the block's output is out * rowmask = 0 whatever the arithmetic gives, and no gradient
+      // comes back through these rows -- write the zeros (and finite placeholders for what backward reads) and move on
+      zero_to_hbm<T>(out, FD, 0, m0, a.M, tid);
+      const bool cross = a.o_bcast || a.cross_s;
+      if (ysave) zero_to_hbm<T>(ysave, FD, 0, m0, a.M, tid);
+      if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, m0, a.M, tid);
+      if (h1save)
+        for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, m0, a.M, tid);
+      if (tid < FT_M && m0 + tid < a.M) {
+        if (a.rstd1) a.rstd1[m0 + tid] = 0.f;
+        if (a.rstd2) a.rstd2[m0 + tid] = 0.f;
+        if (a.rstd_c) a.rstd_c[m0 + tid] = 0.f;
+      }
+      lds_barrier();                                    // the staged ctx / x tile of this iteration is dropped
+      if (next_tile < ntiles) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+          if (next_tile * FT_M + r < a.M) {
+            load_frag(cpre[i], ctx + (size_t)(next_tile * FT_M + r) * FD + c8);
+            load_frag(xpre[i], x + (size_t)(next_tile * FT_M + r) * FD + c8);
+          } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
+        }
+      }
+      continue;
     }
     lds_barrier();
     STAMP(0);

@@ -37,13 +37,13 @@ class GemmTnArgs(ctypes.Structure):
 
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
-                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64)]
+                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p)]
 
 
 class AttnBwdArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("dctx", c_p), ("ctx", c_p), ("lse", c_p), ("key_ids", c_p), ("pad_value", c_l),
                 ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f),
-                ("drop_p", c_f), ("seed", c_u64)]
+                ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p)]
 
 
 class PostAttnArgs(ctypes.Structure):
@@ -164,24 +164,24 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     return dW
 
 
-def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0):
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None):
     """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32)."""
     B, L, P3 = qkv.shape
     assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed)
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask))
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 
 
-def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0):
+def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None):
     B, L, _ = qkv.shape
     assert dctx.is_contiguous() and ctx.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty_like(qkv)
     a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
-                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed)
+                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask))
     _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
     return dqkv
 

@@ -250,25 +250,30 @@ def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
 
 
-def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0):
+def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0,
+                  rowmask=None):
+    """rowmask [B*L]: the pad mask the layer output is multiplied by -- query tiles made of padded positions only are
+    skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
     qkv = hip.gemm_nt(x2, wqkv, bqkv)
-    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed)
+    ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
+                             rowmask=rowmask)
     return qkv, ctx_, lse
 
 
 def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad,
-                    drop_p=0.0, seed=0):
+                    drop_p=0.0, seed=0, rowmask=None):
     """MultiHeadAttention.forward (transformer.py:151-161), unfused (any width): returns y and what backward needs."""
-    qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p, seed)
+    qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p, seed,
+                                   rowmask)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
     y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
                     gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
     return y, (qkv, ctx_, lse, rstd)
 
 
-def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, drop_p=0.0, seed=0):
+def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, drop_p=0.0, seed=0, rowmask=None):
     """Backward of the attention block; prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be).  Returns dx and, in that
     order, what autograd gets for each parameter (None where the gradient went straight into p.grad)."""
     Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be = prm
@@ -281,7 +286,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo)
     dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
     dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
-                        drop_p=drop_p, seed=seed)
+                        drop_p=drop_p, seed=seed, rowmask=rowmask)
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
@@ -344,7 +349,7 @@ class EncoderLayerFn(_Fn):
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
-                                           drop_p, seeds[0])
+                                           drop_p, seeds[0], rowmask)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
@@ -352,7 +357,7 @@ class EncoderLayerFn(_Fn):
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
             y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
-                                    drop_p, seeds[0])
+                                    drop_p, seeds[0], rowmask)
             out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
@@ -368,7 +373,7 @@ class EncoderLayerFn(_Fn):
         dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, ctx.prm[10:],
                                 drop_p, seeds[1], seeds[2])
         dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
-                                 ctx.prm[:10], drop_p, seeds[0])
+                                 ctx.prm[:10], drop_p, seeds[0], rowmask)
         return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
@@ -468,7 +473,8 @@ class DecoderLayerFn(_Fn):
             o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)      # [B, d] f32
             cross_kw = dict(cross=(o, cg.detach(), cbe.detach()))
         if _fusable(x2, Wo, W1):
-            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0])
+            qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
+                                           rowmask)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
@@ -478,7 +484,7 @@ class DecoderLayerFn(_Fn):
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
             y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
-                                     drop_p, seeds[0])
+                                     drop_p, seeds[0], rowmask)
             if drop_p > 0:          # per-row cross-attention output under attention-map dropout
                 o_rows = hip.cross_rows(s_cross, oh, cbo.detach(), L)
                 y2, rstd_c = hip.bcast_add_ln(y1, o_rows, cg.detach(), cbe.detach(), 1, LN_EPS)
@@ -524,7 +530,7 @@ class DecoderLayerFn(_Fn):
         hip.gemm_tn(dc, u, dcWv, dcbv)
         du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
         dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
-                                 ctx.prm[:10], drop_p, seeds[0])
+                                 ctx.prm[:10], drop_p, seeds[0], rowmask)
         return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
 
 
