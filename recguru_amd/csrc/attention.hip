@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  int b, h;
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
@@ -329,7 +330,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  int b, h;
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
@@ -511,7 +513,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  int b, h;
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
@@ -717,7 +720,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 template <typename T>
 static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
-  dim3 grid(a.B * a.H), block(256);
+  dim3 grid(rg_head_grid(a.B, a.H)), block(256);
   const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
 #define RG_FWD2(N, C)                                                                              \
   do {                                                                                             \
@@ -745,7 +748,7 @@ static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
 template <typename T>
 static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
-  dim3 grid(a.B * a.H), block(256);
+  dim3 grid(rg_head_grid(a.B, a.H)), block(256);
   if constexpr (sizeof(T) == 2) {
     const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
 #define RG_BWD16_2(N, C)                                                                              \

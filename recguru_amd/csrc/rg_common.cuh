@@ -250,6 +250,25 @@ __host__ __device__ inline DropCfg make_drop(float p, unsigned long long seed) {
 // (a row starts on a hash-word boundary)
 __host__ __device__ inline unsigned int rg_lpad(int L) { return (unsigned int)((L + 31) & ~31); }
 
+// XCD-aware (b, h) assignment for one-workgroup-per-head kernels.  Workgroups are dealt round-robin to the 8 XCDs,
+// each with its own L2; heads 2p and 2p+1 of a sequence share every 128-byte line of the [.., H*32] bf16 rows
+// (64 bytes each), so with blockIdx = b*H + h the two halves of every line are fetched by two different L2s
+// (rocprofv3 FETCH_SIZE: 2x the algorithmic bytes).  Here consecutive ROUNDS of the same XCD (blockIdx and
+// blockIdx + 8) take the two heads of a pair, so the second one hits the lines the first brought in.  Only speed
+// depends on the dispatch order.  Returns false for the padding blocks of the grid (rg_head_grid).
+__device__ __forceinline__ bool rg_head_of_block(int bid, int B, int H, int& b, int& h) {
+  const int hp = (H + 1) >> 1;
+  const int xcd = bid & 7, rnd = bid >> 3;
+  const int slot = (rnd >> 1) * 8 + xcd;
+  b = slot / hp;
+  h = 2 * (slot - b * hp) + (rnd & 1);
+  return b < B && h < H;
+}
+static inline int rg_head_grid(int B, int H) {
+  const int slots = B * ((H + 1) >> 1);
+  return ((slots + 7) / 8) * 16;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a workgroup-scope release
 // fence, for which hipcc drains vmcnt(0) whenever a global store is outstanding -- and loads share that
 // counter, so every software-prefetched global load would be waited for at every barrier.
