@@ -272,8 +272,16 @@ typedef struct {
    * cross_oh [M/L, H, d] f32 (per-head output projections) and cross_bo [d] instead of o_bcast. */
   float drop_p; unsigned long long seed_h1; unsigned long long seed_out;
   const float* cross_s; const float* cross_oh; const float* cross_bo; int H;
+  /* optional, forward without saves only: the list of live 16-row tiles from rg_live_tiles.  Padded row tiles are
+   * then compacted away -- a work tile is 4 consecutive LIST entries instead of 64 consecutive rows -- and the rows of
+   * the padded tiles are written as zeros. */
+  const int* live16;
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
+/* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their
+ * indices ascending; the remaining (padded) tiles are listed from the far end backwards (list[nt], list[nt-1], ..);
+ * list[1+nt ..] is scratch (the per-tile flags).  rowmask must be 16-byte aligned. */
+int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream);
 
 /* ---- single-query attention for the last encoder layer --------------------------------------------
  * Only enc_outputs[:, -1, :] is consumed on the hot path (AutoEnc4Rec_cross.py:122,154;

@@ -494,6 +494,51 @@ __global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict_
   }
 }
 
+// Live-tile list in two launches.  (1) flags, fully parallel: flag[t] = any(rowmask[16t..16t+15] != 0).  (2) one
+// workgroup compacts: list[0] = number of live tiles, list[1 + i] = index of the i-th live one (ascending), and the dead
+// ones from the far end backwards (list[nt - j] = j-th dead tile).  The flags live in list[1 + nt ..] (scratch).
+__global__ __launch_bounds__(EW_BLOCK) void live_flags_kernel(const float* __restrict__ rowmask, long long M, int* __restrict__ flags) {
+  const long long nt = (M + 15) >> 4;
+  for (long long t = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * EW_BLOCK) {
+    int live = 0;
+    if (16 * t + 16 <= M) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 v = reinterpret_cast<const float4*>(rowmask + 16 * t)[j];
+        live |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+      }
+    } else {
+      for (long long r = 16 * t; r < M; ++r) live |= rowmask[r] != 0.f;
+    }
+    flags[t] = live;
+  }
+}
+
+__global__ __launch_bounds__(1024) void live_compact_kernel(long long nt, int* __restrict__ list) {
+  __shared__ int part[1024];
+  const int* __restrict__ flags = list + 1 + nt;
+  const int tid = threadIdx.x;
+  const long long per = (nt + 1023) / 1024;
+  const long long t0 = min((long long)tid * per, nt), t1 = min(t0 + per, nt);
+  int cnt = 0;
+  for (long long t = t0; t < t1; ++t) cnt += flags[t];
+  part[tid] = cnt;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan
+    const int v = tid >= o ? part[tid - o] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int pos = part[tid] - cnt;                            // live tiles before this thread's run
+  long long dpos = t0 - pos;                            // dead tiles before it
+  if (tid == 1023) list[0] = part[1023];
+  for (long long t = t0; t < t1; ++t) {
+    if (flags[t]) list[1 + pos++] = (int)t;
+    else list[nt - dpos++] = (int)t;
+  }
+}
+
 // x[m, c] *= keep(m*N + c) in place: nn.Dropout for the block paths that are not fused (any width); same index
 // space as the fused kernel / ln_bwd's dz_drop, so a backward regenerates the mask from the seed.
 template <typename T>
@@ -565,6 +610,15 @@ extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int 
   if ((dtype) == RG_BF16) { CALL_BF16; } else if ((dtype) == RG_F32) { CALL_F32; }        \
   else return rg_set_error_msg(RG_ERR_INVALID, name ": bad dtype");                       \
   RG_CHECK_LAUNCH(); return 0;
+
+extern "C" int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream) {
+  if (M <= 0) return 0;
+  const long long nt = (M + 15) >> 4;
+  hipLaunchKernelGGL(live_flags_kernel, dim3(ew_grid(nt, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rowmask, M, list + 1 + nt);
+  hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nt, list);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
 
 extern "C" int rg_dropout(void* x, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream) {
   if (M <= 0 || N <= 0 || drop_p <= 0.f) return 0;

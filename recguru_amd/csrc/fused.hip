@@ -143,26 +143,29 @@ __device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restri
     }
 }
 
-// cooperative, coalesced copy of a [64 x 128] LDS tile to rows m0.. of a row-major HBM matrix
+// A work tile is 4 row tiles of 16 consecutive rows each, at rows mb[0..3] (mb[rt] >= M marks an absent one): the 64
+// rows of a plain tile (mb[rt] = m0 + 16 rt), or the next 4 LIVE row tiles of the workgroup's range when padded row
+// tiles are compacted away.  Thread tid stages chunk i of the tile = row 16 i + (tid >> 4), columns 8 (tid & 15)..
+// cooperative, coalesced copy of a [64 x 128] LDS tile to its rows of a row-major HBM matrix
 template <typename T>
-__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, int m0, int M, int tid) {
+__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[4], int M, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-    if (m0 + r < M)
-      *reinterpret_cast<Frag<T>*>(dst + (size_t)(m0 + r) * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + r * FLD + c8);
+    const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
+    if (m < M)
+      *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + r * FLD + c8);
   }
 }
 
-// rows m0.. of a row-major HBM matrix <- 0 (64 x 128 block at column col0), coalesced 16-byte stores
+// the tile's rows of a row-major HBM matrix <- 0 (128 columns from col0), coalesced 16-byte stores
 template <typename T>
-__device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col0, int m0, int M, int tid) {
+__device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col0, const int (&mb)[4], int M, int tid) {
   Frag<T> z;
   frag_zero(z);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-    if (m0 + r < M) *reinterpret_cast<Frag<T>*>(dst + (size_t)(m0 + r) * ld + col0 + c8) = z;
+    const int c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
+    if (m < M) *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = z;
   }
 }
 
@@ -219,21 +222,43 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 
   WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
   Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
-  int tile = blockIdx.x;
-  if (tile < ntiles) {
-    load_wset(wp, Wo, FD, n0, 0, li, lg);
+
+  // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16,
+  // forward without saves): 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
+  // work tile is 64 live-ish rows wherever the padding sits).
+  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
+  int cur = (int)blockIdx.x;
+  auto next_group = [&](int (&g)[4]) -> bool {
+    if (cur >= nwork) return false;
+    if (!a.live16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
+    } else {
+      const int nlive = a.live16[0];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = 4 * cur + rt < nlive ? a.live16[1 + 4 * cur + rt] * 16 : a.M;
+    }
+    cur += gridDim.x;
+    return true;
+  };
+  auto prefetch_rows = [&](const int (&g)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      if (tile * FT_M + r < a.M) {
-        load_frag(cpre[i], ctx + (size_t)(tile * FT_M + r) * FD + c8);
-        load_frag(xpre[i], x + (size_t)(tile * FT_M + r) * FD + c8);
+      const int c8 = (tid & 15) * 8, m = g[i] + (tid >> 4);
+      if (m < a.M) {
+        load_frag(cpre[i], ctx + (size_t)m * FD + c8);
+        load_frag(xpre[i], x + (size_t)m * FD + c8);
       } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
     }
+  };
+  int mb[4], mbn[4];
+  bool have = next_group(mb);
+  if (have) {
+    load_wset(wp, Wo, FD, n0, 0, li, lg);
+    prefetch_rows(mb);
   }
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * FT_M;
-    const int next_tile = tile + gridDim.x;
+  for (; have;) {
+    const bool have_next = next_group(mbn);
     // ---- ctx and x tiles: registers -> LDS (x parks in the g-chunk buffer, free until the FFN)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -244,34 +269,28 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     float rm4[4];
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
-      const int m = m0 + rt * 16 + li;
+      const int m = mb[rt] + li;
       rm4[rt] = (a.rowmask && m < a.M) ? a.rowmask[m] : 1.f;
     }
-    if (a.rowmask && __ballot(rm4[0] != 0.f || rm4[1] != 0.f || rm4[2] != 0.f || rm4[3] != 0.f) == 0ull) {
+    if (a.rowmask && !a.live16 && __ballot(rm4[0] != 0.f || rm4[1] != 0.f || rm4[2] != 0.f || rm4[3] != 0.f) == 0ull) {
       // 64 padded positions: the block's output is out * rowmask = 0 whatever the arithmetic gives, and no gradient
       // comes back through these rows -- write the zeros (and finite placeholders for what backward reads) and move on
-      zero_to_hbm<T>(out, FD, 0, m0, a.M, tid);
+      zero_to_hbm<T>(out, FD, 0, mb, a.M, tid);
       const bool cross = a.o_bcast || a.cross_s;
-      if (ysave) zero_to_hbm<T>(ysave, FD, 0, m0, a.M, tid);
-      if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, m0, a.M, tid);
+      if (ysave) zero_to_hbm<T>(ysave, FD, 0, mb, a.M, tid);
+      if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, mb, a.M, tid);
       if (h1save)
-        for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, m0, a.M, tid);
-      if (tid < FT_M && m0 + tid < a.M) {
-        if (a.rstd1) a.rstd1[m0 + tid] = 0.f;
-        if (a.rstd2) a.rstd2[m0 + tid] = 0.f;
-        if (a.rstd_c) a.rstd_c[m0 + tid] = 0.f;
+        for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, mb, a.M, tid);
+      if (tid < FT_M && mb[0] + tid < a.M) {            // plain tiles only: 64 consecutive rows
+        if (a.rstd1) a.rstd1[mb[0] + tid] = 0.f;
+        if (a.rstd2) a.rstd2[mb[0] + tid] = 0.f;
+        if (a.rstd_c) a.rstd_c[mb[0] + tid] = 0.f;
       }
       lds_barrier();                                    // the staged ctx / x tile of this iteration is dropped
-      if (next_tile < ntiles) {
+      if (have_next) prefetch_rows(mbn);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-          if (next_tile * FT_M + r < a.M) {
-            load_frag(cpre[i], ctx + (size_t)(next_tile * FT_M + r) * FD + c8);
-            load_frag(xpre[i], x + (size_t)(next_tile * FT_M + r) * FD + c8);
-          } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
-        }
-      }
+      for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+      have = have_next;
       continue;
     }
     lds_barrier();
@@ -297,16 +316,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     if (a.rstd1 && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
-        if (m0 + rt * 16 + li < a.M) a.rstd1[m0 + rt * 16 + li] = rstd[rt];
+        if (mb[rt] + li < a.M) a.rstd1[mb[rt] + li] = rstd[rt];
     }
     regs_to_tile<T>(acc, Ay, n0, li, lg);
     STAMP(2);
     if (a.o_bcast || a.cross_s) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
-      if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, m0, a.M, tid); }
+      if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, mb, a.M, tid); }
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const int m = min(m0 + rt * 16 + li, a.M - 1);
+        const int m = min(mb[rt] + li, a.M - 1);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) {
           float o4[4], y4[4];
@@ -332,14 +351,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       if (a.rstd_c && wave == 0 && lg == 0) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-          if (m0 + rt * 16 + li < a.M) a.rstd_c[m0 + rt * 16 + li] = rstd[rt];
+          if (mb[rt] + li < a.M) a.rstd_c[mb[rt] + li] = rstd[rt];
       }
       regs_to_tile<T>(acc, Ay, n0, li, lg);
     }
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
     {
       const bool cross = a.o_bcast || a.cross_s;
-      if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, cross ? y2save : ysave, FD, 0, m0, a.M, tid);
+      if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, cross ? y2save : ysave, FD, 0, mb, a.M, tid);
     }
     STAMP(3);
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
@@ -351,14 +370,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       init_acc(acc, p_b1 + ch * FD, n0, lg);
       mma_wset<T>(acc, wp, Ay, li, lg);                 // h1 chunk = y . W1[chunk]^T + b1
       if (ch + 1 < nchunk) load_wset(wp, W1, FD, (ch + 1) * FD + n0, 0, li, lg);
-      else if (next_tile < ntiles) load_wset(wp, Wo, FD, n0, 0, li, lg);
+      else if (have_next) load_wset(wp, Wo, FD, n0, 0, li, lg);
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
       if constexpr (DM != 0) {  // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
-          const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
+          const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
           if constexpr (DM == 1) {       // rb & 31 == 4*lg: both feature tiles of this lane sit in one hash word
             const unsigned int w = rg_hash(drop1.seed, rb >> 5) >> (4 * lg);
 #pragma unroll
@@ -385,25 +404,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       STAMP(6);
       lds_barrier();
       STAMP(7);
-      if (h1save) tile_to_hbm<T>(Ah, h1save, a.dff, ch * FD, m0, a.M, tid);
+      if (h1save) tile_to_hbm<T>(Ah, h1save, a.dff, ch * FD, mb, a.M, tid);
       mma_wset<T>(acc2, wq, Ag, li, lg);                // out += g . W2[:, chunk]^T
       STAMP(8);
     }
     // prefetch the next tile's ctx / x rows while the second LayerNorm runs
-    if (next_tile < ntiles) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-        if (next_tile * FT_M + r < a.M) {
-          load_frag(cpre[i], ctx + (size_t)(next_tile * FT_M + r) * FD + c8);
-          load_frag(xpre[i], x + (size_t)(next_tile * FT_M + r) * FD + c8);
-        } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
-      }
-    }
+    if (have_next) prefetch_rows(mbn);
     if constexpr (DM != 0) {    // dropout on the l2 output, before the residual (transformer.py:186-188)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
-        const unsigned int rb = (unsigned int)(m0 + rt * 16 + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
+        const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
         if constexpr (DM == 1) {
           const unsigned int w = rg_hash(drop2.seed, rb >> 5) >> (4 * lg);
 #pragma unroll
@@ -433,7 +443,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     if (a.rstd2 && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
-        if (m0 + rt * 16 + li < a.M) a.rstd2[m0 + rt * 16 + li] = rstd[rt];
+        if (mb[rt] + li < a.M) a.rstd2[mb[rt] + li] = rstd[rt];
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -444,9 +454,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     regs_to_tile<T>(acc2, Actx, n0, li, lg);
     STAMP(9);
     lds_barrier();
-    tile_to_hbm<T>(Actx, out, FD, 0, m0, a.M, tid);
+    tile_to_hbm<T>(Actx, out, FD, 0, mb, a.M, tid);
     lds_barrier();                                      // before the next tile overwrites Actx / Ag / Ay
     STAMP(10);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+    have = have_next;
+  }
+  if (a.live16) {
+    // the padded row tiles (listed from the far end of live16): out rows = 0, 4 row tiles per step
+    const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
+    for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
+      int md[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
+      zero_to_hbm<T>(out, FD, 0, md, a.M, tid);
+    }
   }
 #ifdef RG_STAMP
   if (a.rstd_c == nullptr && a.o_bcast == nullptr && a.y2_save != nullptr && (tid & 63) == 0) {

@@ -54,7 +54,7 @@ class PostAttnArgs(ctypes.Structure):
                 ("y_save", c_p), ("rstd1", c_p), ("y2_save", c_p), ("rstd_c", c_p), ("h1_save", c_p), ("rstd2", c_p),
                 ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f),
                 ("drop_p", c_f), ("seed_h1", c_u64), ("seed_out", c_u64),
-                ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i)]
+                ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i), ("live16", c_p)]
 
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
@@ -65,7 +65,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
-           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows"]
+           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles"]
 LOSS_SAMPLED_CE, LOSS_BPR = 0, 1
 c_ll = ctypes.c_longlong
 
@@ -467,8 +467,26 @@ def post_attn_supported(d, P, dff):
     return d == 128 and P == 128 and dff % 128 == 0 and dff > 0
 
 
+_LIVE = {}
+
+
+def live_tiles(rowmask, M):
+    """int32 [1 + ceil(M/16)]: count, then the indices of the 16-row tiles holding a row with rowmask != 0.  Cached for
+    the last few masks (every layer of a forward pass uses the same one)."""
+    key = (rowmask.data_ptr(), rowmask._version, M)
+    hit = _LIVE.get(key)
+    if hit is not None and hit[0] is rowmask:
+        return hit[1]
+    flags = torch.empty(1 + 2 * ((M + 15) // 16), device=rowmask.device, dtype=torch.int32)
+    _check(lib().rg_live_tiles(_vp(rowmask), c_ll(M), _vp(flags), _stream()), "rg_live_tiles")
+    if len(_LIVE) > 8:
+        _LIVE.clear()
+    _LIVE[key] = (rowmask, flags)
+    return flags
+
+
 def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,
-                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None):
+                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True):
     """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta);
     under dropout cross = (None, gamma, beta) and cross_drop = (s [M,H], oh [B,H,d] f32, bo [d], H).
     Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
@@ -476,6 +494,11 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     d = x.shape[1]
     dff = W1.shape[0]
     dev = ctx.device
+    # forward without saves under a pad mask: padded 16-row tiles are compacted away inside the kernel (their rows
+    # of `out` are written as zeros, which is what out * rowmask gives there)
+    live16 = None
+    if rowmask is not None and not save and M >= 4096 and compact:
+        live16 = live_tiles(rowmask, M)
     out = torch.empty(M, d, device=dev, dtype=ctx.dtype)
     sv = {}
     if save:
@@ -491,7 +514,8 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     a = PostAttnArgs(_p(ctx), _p(x), _p(Wo), _p(bo), _p(g1), _p(be1), _p(o), _p(gc), _p(bec), L,
                      _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
                      _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
-                     _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH)
+                     _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH,
+                     _p(live16))
     _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 

@@ -551,3 +551,28 @@ def test_attn_dropout_consistency(dt, causal):
         ((a @ v_)[:, -1, :] * dctx[:, -1, :].float()).sum().backward()
         torch.testing.assert_close(dq.float(), x.grad[:, -1, :P], **t)
         torch.testing.assert_close(dkv.float(), x.grad[:, :, P:], **t)
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_post_attn_live_tile_compaction(drop_p):
+    """Forward without saves under a pad mask: compacting the padded 16-row tiles away gives bit-identical rows for
+    the live positions and zeros for the padded ones."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    B, L, d, dff = 40, 120, 128, 256
+    M = B * L
+    g0 = torch.Generator().manual_seed(7)
+    lens = torch.randint(0, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = 0, L                                  # an all-pad and a full sequence
+    mask = (torch.arange(L)[None, :] >= (L - lens)[:, None]).float().reshape(-1).cuda().contiguous()
+    ctx, x = rnd(M, d, dt=dt, seed=1), rnd(M, d, dt=dt, seed=2)
+    x = x * mask[:, None].to(dt)
+    wo, w1, w2 = rnd(d, d, dt=dt, seed=3), rnd(dff, d, dt=dt, seed=4), rnd(d, dff, dt=dt, seed=5)
+    f32 = torch.float32
+    bo, b1, b2 = rnd(d, dt=f32, seed=6), rnd(dff, dt=f32, seed=7), rnd(d, dt=f32, seed=8)
+    g, be = 1 + 0.1 * rnd(d, dt=f32, seed=9), 0.1 * rnd(d, dt=f32, seed=10)
+    kw = dict(drop_p=drop_p, seed_h1=11, seed_out=12)
+    a, _ = hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, mask, compact=True, **kw)
+    b, _ = hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, mask, compact=False, **kw)
+    assert torch.equal(a, b)
+    assert float(a[mask == 0].abs().max()) == 0.0
