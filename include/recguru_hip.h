@@ -272,9 +272,9 @@ typedef struct {
    * cross_oh [M/L, H, d] f32 (per-head output projections) and cross_bo [d] instead of o_bcast. */
   float drop_p; unsigned long long seed_h1; unsigned long long seed_out;
   const float* cross_s; const float* cross_oh; const float* cross_bo; int H;
-  /* optional, forward without saves only: the list of live 16-row tiles from rg_live_tiles.  Padded row tiles are
-   * then compacted away -- a work tile is 4 consecutive LIST entries instead of 64 consecutive rows -- and the rows of
-   * the padded tiles are written as zeros. */
+  /* optional: the list of live 16-row tiles from rg_live_tiles.  Padded row tiles are then compacted away -- a work
+   * tile is 4 consecutive LIST entries instead of 64 consecutive rows -- and the rows of the padded tiles are written
+   * as zeros (out, y_save, y2_save, h1_save, rstd*). */
   const int* live16;
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);

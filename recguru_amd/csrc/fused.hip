@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
   Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
 
-  // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16,
-  // forward without saves): 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
+  // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16):
+  // 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
   // work tile is 64 live-ish rows wherever the padding sits).
   const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
   int cur = (int)blockIdx.x;
@@ -462,13 +462,27 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     have = have_next;
   }
   if (a.live16) {
-    // the padded row tiles (listed from the far end of live16): out rows = 0, 4 row tiles per step
+    // the padded row tiles (listed from the far end of live16): out rows = 0 -- and zeros / finite placeholders in
+    // everything a backward pass reads --, 4 row tiles per step
     const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
+    const bool cross = a.o_bcast || a.cross_s;
     for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
       int md[4];
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
       zero_to_hbm<T>(out, FD, 0, md, a.M, tid);
+      if (ysave) zero_to_hbm<T>(ysave, FD, 0, md, a.M, tid);
+      if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, md, a.M, tid);
+      if (h1save)
+        for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, md, a.M, tid);
+      if (tid < FT_M) {
+        const int m = md[tid >> 4] + (tid & 15);
+        if (m < a.M) {
+          if (a.rstd1) a.rstd1[m] = 0.f;
+          if (a.rstd2) a.rstd2[m] = 0.f;
+          if (a.rstd_c) a.rstd_c[m] = 0.f;
+        }
+      }
     }
   }
 #ifdef RG_STAMP

@@ -468,6 +468,7 @@ def post_attn_supported(d, P, dff):
 
 
 _LIVE = {}
+COMPACT_MIN_ROWS = 4096       # below this the padded-tile compaction of the fused block is not worth its two small launches
 
 
 def live_tiles(rowmask, M):
@@ -494,10 +495,10 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     d = x.shape[1]
     dff = W1.shape[0]
     dev = ctx.device
-    # forward without saves under a pad mask: padded 16-row tiles are compacted away inside the kernel (their rows
-    # of `out` are written as zeros, which is what out * rowmask gives there)
+    # under a pad mask the padded 16-row tiles are compacted away inside the kernel: their rows of `out` (and of the
+    # saved activations) are written as zeros, which is what out * rowmask gives there
     live16 = None
-    if rowmask is not None and not save and M >= 4096 and compact:
+    if rowmask is not None and M >= COMPACT_MIN_ROWS and compact:
         live16 = live_tiles(rowmask, M)
     out = torch.empty(M, d, device=dev, dtype=ctx.dtype)
     sv = {}

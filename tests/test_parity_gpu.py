@@ -315,3 +315,34 @@ def test_rank_scores_kernel(d, C):
         tol = dict(rtol=1e-5, atol=1e-5) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
         torch.testing.assert_close(sc, ref, **tol)
         assert torch.equal(rk.long(), (sc[:, 1:] > sc[:, :1]).sum(1))       # rank = candidates strictly above the target
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_padded_tile_compaction_is_invisible(name):
+    """The fused block with the padded 16-row tiles compacted away (forced on at the golden sizes) gives the golden
+    reconstruction loss and gradients, and the same results as the uncompacted path."""
+    from recguru_amd import hip, training as T
+    z = load_case(name)
+    res = {}
+    old = hip.COMPACT_MIN_ROWS
+    for mode, thr in (("compact", 0), ("plain", 1 << 30)):
+        hip.COMPACT_MIN_ROWS = thr
+        try:
+            param, G, D = build_cross(z)
+            bt = batches(z, "cuda")
+            B, L = bt["a"][0].shape
+            tot = 0.0
+            for dom in "ab":
+                mask = T.get_pad_mask(bt[dom][2], 0, "cuda")
+                l = T.loss_ae(G, *bt[dom], True, B, L, param, mask, "cuda", domain=dom)
+                l.backward()
+                np.testing.assert_allclose(float(l.detach()), float(z["loss_ae.%s" % dom]), rtol=1e-3, atol=1e-5)
+                tot += float(l.detach())
+            res[mode] = (tot, {k: p.grad.detach().clone() for k, p in G.named_parameters() if p.grad is not None})
+            check_grads(G, z, "gradG_recon.")
+        finally:
+            hip.COMPACT_MIN_ROWS = old
+    # equal up to the arrival order of f32 atomics (loss sums, weight-gradient flushes, table scatter-adds)
+    np.testing.assert_allclose(res["compact"][0], res["plain"][0], rtol=1e-6)
+    for k, g in res["plain"][1].items():
+        torch.testing.assert_close(res["compact"][1][k], g, rtol=1e-5, atol=1e-7, msg=k)
