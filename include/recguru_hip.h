@@ -61,6 +61,9 @@ typedef struct {
   float epi_nonzero_scale;    /* GELU_GRAD: also multiply by (aux != 0 ? this : 0) -- backward of the
                                  dropout that precedes GELU (transformer.py:182-184), aux = dropped h1 */
   float drop_p; unsigned long long drop_seed;   /* RELU: C = dropout(relu(.)), tools/utils.py:43-44 */
+  const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): rows of the other tiles are not read and
+                                 their rows of C are written as zeros; honoured by the weight-stationary kernel, ignored
+                                 (every row computed) by the generic one */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 
@@ -74,6 +77,8 @@ typedef struct {
   float scale;
   int splits;                 /* token splits (0 = auto) */
   int use_tr;                 /* bf16: 1 = ds_read_tr16_b64 fragments, 0 = scalar LDS reads */
+  const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): only those rows are summed (the others
+                                 carry zero Y); honoured by the big-shape kernel, ignored (all rows summed) otherwise */
 } rg_gemm_tn_args;
 int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
 /* Plan queries (no launch): the name of the kernel rg_gemm_nt / rg_gemm_tn would run for these arguments --

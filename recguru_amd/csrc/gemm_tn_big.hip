@@ -44,7 +44,9 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const int m1 = SPLIT1 ? wave * MT * 16 : 0;
   const int m2 = SPLIT1 ? 0 : wave * NT * 16;
-  const int nchunks = (a.T + TB_T - 1) / TB_T;
+  // a.live16 (optional): the list of live 16-row tiles (rg_live_tiles) -- a chunk is then 2 consecutive LIST entries
+  // instead of 32 consecutive tokens; rows of padded tiles carry zero upstream gradient and are never read
+  const int nchunks = a.live16 ? (a.live16[0] + 1) >> 1 : (a.T + TB_T - 1) / TB_T;
   const int per = (nchunks + gridDim.x - 1) / gridDim.x;
   const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
@@ -61,13 +63,19 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   frag_fill(ones, 1.f);
   Frag<T> py[PY], px[PX];
   auto prefetch = [&](int chunk) {
-    const int t0 = chunk * TB_T;
+    int b0 = chunk * TB_T, b1 = chunk * TB_T + 16;      // first rows of the chunk's two 16-row halves
+    if (a.live16) {
+      const int nl = a.live16[0];
+      b0 = a.live16[1 + 2 * chunk] * 16;
+      b1 = 2 * chunk + 1 < nl ? a.live16[2 + 2 * chunk] * 16 : a.T;
+    }
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
       const int c = tid + 512 * i;
       if (c < CY) {
         const int r = c / (N1 / 8), c8 = (c % (N1 / 8)) * 8;
-        if (t0 + r < a.T) load_frag(py[i], Y + (size_t)(t0 + r) * a.ldy + c8);
+        const int t = (r < 16 ? b0 : b1 - 16) + r;
+        if (t < a.T) load_frag(py[i], Y + (size_t)t * a.ldy + c8);
         else frag_zero(py[i]);
       }
     }
@@ -76,7 +84,8 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
       const int c = tid + 512 * i;
       if (c < CX) {
         const int r = c / (N2 / 8), c8 = (c % (N2 / 8)) * 8;
-        if (t0 + r < a.T) load_frag(px[i], X + (size_t)(t0 + r) * a.ldx + c8);
+        const int t = (r < 16 ? b0 : b1 - 16) + r;
+        if (t < a.T) load_frag(px[i], X + (size_t)t * a.ldx + c8);
         else frag_zero(px[i]);
       }
     }

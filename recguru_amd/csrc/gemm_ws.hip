@@ -46,21 +46,35 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   __shared__ __align__(16) float bs[NCB * 128];
   for (int i = tid; i < NCB * 128; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;   // visible after the first barrier
 
-  // chunk (tile, kc) -> rows m0.., columns kc*128.. of A ; each thread stages 4 x 16 bytes
+  // A work tile is 4 row tiles of 16 rows at rows mb[0..3] (>= M: absent): 64 consecutive rows, or -- with the list
+  // of live 16-row tiles a.live16 (rg_live_tiles) -- 4 consecutive list entries; rows of the padded tiles are not read
+  // and their rows of C are written as zeros at the end.  Thread tid stages chunk i = row 16 i + (tid >> 4).
+  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
+  auto group = [&](int wt, int (&g)[4]) {
+    if (!a.live16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = wt * WS_M + 16 * rt;
+    } else {
+      const int nl = a.live16[0];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = (wt < nwork && 4 * wt + rt < nl) ? a.live16[1 + 4 * wt + rt] * 16 : a.M;
+    }
+  };
+  // chunk (tile, kc) -> the tile's rows, columns kc*128.. of A ; each thread stages 4 x 16 bytes
   Frag<T> pre[4];
-  auto prefetch = [&](int tile, int kc) {
+  auto prefetch = [&](const int (&g)[4], int kc) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      const int m = tile * WS_M + r;
+      const int c8 = (tid & 15) * 8, m = g[i] + (tid >> 4);
       if (m < a.M) load_frag(pre[i], A + (size_t)m * a.lda + kc * 128 + c8);
       else frag_zero(pre[i]);
     }
   };
   int tile = blockIdx.x;
-  if (tile < ntiles) prefetch(tile, 0);
-  for (; tile < ntiles; tile += gridDim.x) {
-    const int m0 = tile * WS_M;
+  int mb[4], mbn[4];
+  if (tile < nwork) { group(tile, mb); prefetch(mb, 0); }
+  for (; tile < nwork; tile += gridDim.x) {
+    group(tile + (int)gridDim.x, mbn);
     f32x4 acc[2][4];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {
@@ -70,8 +84,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
         const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
         *reinterpret_cast<Frag<T>*>(As + r * WS_LD + c8) = pre[i];
       }
-      if (kc + 1 < NKC) prefetch(tile, kc + 1);
-      else if (tile + (int)gridDim.x < ntiles) prefetch(tile + gridDim.x, 0);
+      if (kc + 1 < NKC) prefetch(mb, kc + 1);
+      else if (tile + (int)gridDim.x < nwork) prefetch(mbn, 0);
       lds_barrier();
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
@@ -79,8 +93,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
         if (kc == NKC - 1 && a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-            const int m = m0 + r;
+            const int c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
             if (m < a.M) load_frag(axf[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
             else frag_zero(axf[i]);
           }
@@ -116,8 +129,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
           lds_barrier();
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-            const int m = m0 + r;
+            const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8;
+            const int m = mb[i] + (tid >> 4);
             if (m < a.M) {
               const size_t off = (size_t)m * a.ldc + cb * 128 + c8;
               if (a.epilogue == RG_EPI_NONE) {
@@ -144,6 +157,25 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
         }
       }
       if (NKC > 1 || true) lds_barrier();                 // As / Cs are rewritten by the next chunk / tile
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+  }
+  if (a.live16) {                                         // rows of the padded tiles: C = 0
+    const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
+    Frag<T> z;
+    frag_zero(z);
+    for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (j + i < ndead) {
+          const int m = a.live16[nrt - (j + i)] * 16 + (tid >> 4);
+          if (m < a.M) {
+            for (int cb = 0; cb < NCB; ++cb)
+              *reinterpret_cast<Frag<T>*>(C + (size_t)m * a.ldc + cb * 128 + (tid & 15) * 8) = z;
+          }
+        }
+      }
     }
   }
 }

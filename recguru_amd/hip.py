@@ -26,13 +26,13 @@ class GemmNtArgs(ctypes.Structure):
                 ("c_is_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("prologue", c_i), ("epilogue", c_i),
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
-                ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64)]
+                ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p)]
 
 
 class GemmTnArgs(ctypes.Structure):
     _fields_ = [("Y", c_p), ("ldy", c_i), ("X", c_p), ("ldx", c_i), ("dW", c_p), ("lddw", c_i), ("colsum", c_p),
                 ("T", c_i), ("N1", c_i), ("N2", c_i), ("prologue_x", c_i), ("scale", c_f), ("splits", c_i),
-                ("use_tr", c_i)]
+                ("use_tr", c_i), ("live16", c_p)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -127,7 +127,7 @@ def _rowmajor(t):
 
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
             gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
-            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0):
+            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N]."""
     M, K = A.shape
     N = W.shape[0]
@@ -140,14 +140,14 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed)
+                   drop_p, drop_seed, _p(live))
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
     return out
 
 
-def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1):
+def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None):
     """dW[N1,N2] += Y[T,N1].T @ pro(X[T,N2]) (f32, accumulated); colsum[N1] += Y.sum(0)."""
     T, N1 = Y.shape
     N2 = X.shape[1]
@@ -157,7 +157,7 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     if T == 0:
         return dW
     a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
-                   prologue_x, scale, splits, use_tr)
+                   prologue_x, scale, splits, use_tr, _p(live))
     if _PROF is not None:
         _note_plan(lib().rg_gemm_tn_plan, a, dt_of(Y))
     _check(lib().rg_gemm_tn(ctypes.byref(a), dt_of(Y), _stream()), "rg_gemm_tn")

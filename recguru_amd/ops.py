@@ -78,6 +78,13 @@ def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
 
+def _live(rowmask, M):
+    """List of live 16-row tiles for the big token-level GEMMs of a backward pass (None: process every row)."""
+    if rowmask is None or M < hip.COMPACT_MIN_ROWS or _COMPUTE != torch.bfloat16:
+        return None
+    return hip.live_tiles(rowmask, M)
+
+
 # ------------------------------------------------------------------------------------------------
 # Parameter gradients are accumulated IN PLACE: the weight-gradient kernels (gemm_tn, colsum, ln_bwd, the
 # scatter-adds) all compute dW += ..., so a backward writes straight into p.grad and hands autograd None
@@ -282,9 +289,10 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     P = Wo.shape[1]
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), None, dg, dbe)
+    live = _live(rowmask, dy.shape[0])
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
-    hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo)
-    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
+    hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
+    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live)
     dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
                         drop_p=drop_p, seed=seed, rowmask=rowmask)
     dqkv2 = dqkv.view(B * L, 3 * P)
@@ -320,18 +328,19 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     W1, b1, W2, b2, g, be = prm
     h1, rstd = saved
     d, dff = W2.shape
+    live = _live(rowmask, dout.shape[0])           # padded 16-row tiles: zero upstream gradient, skipped by the GEMMs
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     if drop_p > 0:
         dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out)
     else:
         dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
-    hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU)
+    hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
-                      epi_nonzero_scale=_inv_keep(drop_p))
+                      epi_nonzero_scale=_inv_keep(drop_p), live=live)
     (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
-    hip.gemm_tn(dh1, y, dW1, db1)
-    dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
+    hip.gemm_tn(dh1, y, dW1, db1, live=live)
+    dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dy, (rW1, rb1, rW2, rb2, rg, rbe)
 
 

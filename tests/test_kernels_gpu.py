@@ -576,3 +576,54 @@ def test_post_attn_live_tile_compaction(drop_p):
     b, _ = hip.post_attn_fwd(ctx, x, wo, bo, g, be, w1, b1, w2, b2, g, be, mask, compact=False, **kw)
     assert torch.equal(a, b)
     assert float(a[mask == 0].abs().max()) == 0.0
+
+
+def _pad_mask(B, L, seed):
+    g0 = torch.Generator().manual_seed(seed)
+    lens = torch.randint(0, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = 0, L
+    return (torch.arange(L)[None, :] >= (L - lens)[:, None]).float().reshape(-1).cuda().contiguous()
+
+
+@pytest.mark.parametrize("K,N,epi", [(128, 512, "gelu_grad"), (512, 128, "add"), (128, 128, "none"), (384, 128, "add")])
+def test_gemm_ws_live_tile_list(K, N, epi):
+    """Weight-stationary GEMM over the list of live 16-row tiles == over every row, when the padded rows carry zeros."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    B, L = 75, 120
+    M = B * L
+    mask = _pad_mask(B, L, K + N)
+    live = hip.live_tiles(mask, M)
+    A = rnd(M, K, dt=dt, seed=1) * mask[:, None].to(dt)
+    W = rnd(N, K, dt=dt, seed=2, scale=0.1)
+    aux = rnd(M, N, dt=dt, seed=3) * mask[:, None].to(dt)
+    kw = {"gelu_grad": dict(epilogue=hip.EPI_GELU_GRAD, aux=aux), "add": dict(epilogue=hip.EPI_ADD, aux=aux), "none": {}}[epi]
+    full = hip.gemm_nt(A, W, **kw)
+    part = hip.gemm_nt(A, W, live=live, **kw)
+    assert torch.equal(part[mask != 0], full[mask != 0])
+    assert float(part[mask == 0].abs().max()) == 0.0
+    assert float(full[mask == 0].abs().max()) == 0.0          # zero inputs give zero outputs: nothing was lost
+
+
+@pytest.mark.parametrize("N1,N2,gelu", [(128, 512, True), (512, 128, False), (128, 128, False)])
+def test_gemm_tn_big_live_tile_list(N1, N2, gelu):
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    B, L = 75, 120
+    T = B * L
+    mask = _pad_mask(B, L, N1 + N2)
+    live = hip.live_tiles(mask, T)
+    Y = rnd(T, N1, dt=dt, seed=1) * mask[:, None].to(dt)
+    X = rnd(T, N2, dt=dt, seed=2)                              # garbage-like (non-zero) on the padded rows
+    kw = dict(prologue_x=hip.PRO_GELU) if gelu else {}
+    cs1, cs2 = torch.zeros(N1, device="cuda"), torch.zeros(N1, device="cuda")
+    full = hip.gemm_tn(Y, X, None, cs1, **kw)
+    part = hip.gemm_tn(Y, X, None, cs2, live=live, **kw)
+    torch.testing.assert_close(part, full, rtol=1e-5, atol=1e-4)
+    torch.testing.assert_close(cs2, cs1, rtol=1e-5, atol=1e-4)
+    Xn = X.clone()
+    pad16 = torch.nn.functional.pad(mask, (0, (-T) % 16))
+    dead_tile = (pad16.view(-1, 16).sum(1) == 0).repeat_interleave(16)[:T]
+    Xn[dead_tile] = float("nan")                               # rows of fully padded 16-row tiles are really never read
+    part2 = hip.gemm_tn(Y, Xn, None, None, live=live, **kw)
+    assert torch.isfinite(part2).all()
