@@ -288,7 +288,8 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     d = x2.shape[1]
     P = Wo.shape[1]
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
-    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), None, dg, dbe)
+    # rowmask here only lets the kernel skip the padded rows (their dy is already zero; the mask values are 0 / 1)
+    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
     live = _live(rowmask, dy.shape[0])
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
@@ -298,7 +299,9 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
-    dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz)
+    # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
+    # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
+    dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dx, (rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg, rbe)
 
 
@@ -520,7 +523,7 @@ class DecoderLayerFn(_Fn):
         dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, ctx.prm[16:],
                                  drop_p, seeds[1], seeds[2])
         (dcg, rcg), (dcbe, rcbe) = _gt(cg), _gt(cbe)
-        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), None, dcg, dcbe)   # residual: dz == dy1
+        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), rowmask, dcg, dcbe)   # residual: dz == dy1
         (dcWo, rcWo), (dcbo, rcbo) = _gt(cWo), _gt(cbo)
         if s_cross is None:
             do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype

@@ -52,3 +52,36 @@ def test_cross_model_vs_oracle(d, H, L, N, k):
         assert n >= 20
     finally:
         ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.5])
+def test_live_tile_lists_end_to_end(dropout):
+    """bf16 tier at a size where the list-driven kernels engage (M = B*L >= 8192): a reconstruction step with the
+    padded 16-row tiles compacted away / skipped everywhere gives the same loss and gradients as without (up to the
+    arrival order of f32 atomics)."""
+    from recguru_amd import hip, ops, synthetic, training as T
+    from recguru_amd.config import get_param
+    from recguru_amd.models import MyAuto4Rec_c
+    d, H, L, N, k, V, B = 128, 4, 200, 2, 3, 500, 48
+    dom = synthetic.make_domain(B, V, L, k, seed=3)
+    res = {}
+    old = hip.COMPACT_MIN_ROWS
+    for mode, thr in (("lists", 0), ("plain", 1 << 30)):
+        hip.COMPACT_MIN_ROWS = thr
+        try:
+            torch.manual_seed(1)
+            param = get_param(make_args(d, H, k, L, V, V, N, B, dropout=dropout), make_dirs=False)
+            G = MyAuto4Rec_c("cuda", param).to(torch.float32).cuda()
+            cb = tuple(torch.as_tensor(dom[n]).cuda() for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+            ops.manual_seed(5)
+            mask = T.get_pad_mask(cb[2], 0, "cuda")
+            la = T.loss_ae(G, *cb, True, B, L, param, mask, "cuda", domain="a")
+            la.backward()
+            res[mode] = (float(la.detach()), {kk: p.grad.detach().clone() for kk, p in G.named_parameters() if p.grad is not None})
+        finally:
+            hip.COMPACT_MIN_ROWS = old
+    np.testing.assert_allclose(res["lists"][0], res["plain"][0], rtol=1e-5)
+    assert len(res["plain"][1]) >= 40
+    for kk, g in res["plain"][1].items():
+        scale = float(g.abs().max())
+        torch.testing.assert_close(res["lists"][1][kk], g, rtol=1e-3, atol=1e-6 + 1e-4 * scale, msg=kk)
