@@ -514,28 +514,43 @@ __global__ __launch_bounds__(EW_BLOCK) void live_flags_kernel(const float* __res
   }
 }
 
+#define LIVE_MAXW 8192     // 64-tile words the single compaction workgroup can scan: M <= 8.4 M rows
 __global__ __launch_bounds__(1024) void live_compact_kernel(long long nt, int* __restrict__ list) {
+  __shared__ int woff[LIVE_MAXW];                       // live tiles per 64-tile word, then their exclusive prefix
   __shared__ int part[1024];
   const int* __restrict__ flags = list + 1 + nt;
-  const int tid = threadIdx.x;
-  const long long per = (nt + 1023) / 1024;
-  const long long t0 = min((long long)tid * per, nt), t1 = min(t0 + per, nt);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nwords = (int)((nt + 63) >> 6);
+  for (int w = wave; w < nwords; w += 16) {              // coalesced: one wave, one 64-tile word
+    const long long t = 64ll * w + lane;
+    const unsigned long long m = __ballot(t < nt && flags[t] != 0);
+    if (lane == 0) woff[w] = __popcll(m);
+  }
+  __syncthreads();
+  const int per = (nwords + 1023) / 1024;
+  const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
   int cnt = 0;
-  for (long long t = t0; t < t1; ++t) cnt += flags[t];
+  for (int w = w0; w < w1; ++w) cnt += woff[w];
   part[tid] = cnt;
   __syncthreads();
-  for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan
+  for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the per-thread sums
     const int v = tid >= o ? part[tid - o] : 0;
     __syncthreads();
     part[tid] += v;
     __syncthreads();
   }
-  int pos = part[tid] - cnt;                            // live tiles before this thread's run
-  long long dpos = t0 - pos;                            // dead tiles before it
+  int run = part[tid] - cnt;
+  for (int w = w0; w < w1; ++w) { const int c = woff[w]; woff[w] = run; run += c; }
   if (tid == 1023) list[0] = part[1023];
-  for (long long t = t0; t < t1; ++t) {
-    if (flags[t]) list[1 + pos++] = (int)t;
-    else list[nt - dpos++] = (int)t;
+  __syncthreads();
+  for (int w = wave; w < nwords; w += 16) {
+    const long long t = 64ll * w + lane;
+    const bool in = t < nt;
+    const bool live = in && flags[t] != 0;
+    const unsigned long long m = __ballot(live);
+    const int rank = __popcll(m & ((1ull << lane) - 1ull));             // live tiles of this word before this lane
+    if (live) list[1 + woff[w] + rank] = (int)t;
+    else if (in) list[nt - ((64ll * w - woff[w]) + (lane - rank))] = (int)t;   // j-th dead tile goes to list[nt - j]
   }
 }
 
@@ -614,6 +629,7 @@ extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int 
 extern "C" int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream) {
   if (M <= 0) return 0;
   const long long nt = (M + 15) >> 4;
+  if (((nt + 63) >> 6) > LIVE_MAXW) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "live_tiles: more than 8.4 M rows");
   hipLaunchKernelGGL(live_flags_kernel, dim3(ew_grid(nt, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rowmask, M, list + 1 + nt);
   hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nt, list);
   RG_CHECK_LAUNCH();

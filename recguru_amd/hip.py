@@ -468,7 +468,7 @@ def post_attn_supported(d, P, dff):
 
 
 _LIVE = {}
-COMPACT_MIN_ROWS = 4096       # below this the padded-tile compaction of the fused block is not worth its two small launches
+COMPACT_MIN_ROWS = 16384      # below this the padded-tile lists are not worth their two small launches
 
 
 def live_tiles(rowmask, M):
@@ -480,8 +480,8 @@ def live_tiles(rowmask, M):
         return hit[1]
     flags = torch.empty(1 + 2 * ((M + 15) // 16), device=rowmask.device, dtype=torch.int32)
     _check(lib().rg_live_tiles(_vp(rowmask), c_ll(M), _vp(flags), _stream()), "rg_live_tiles")
-    if len(_LIVE) > 8:
-        _LIVE.clear()
+    if len(_LIVE) >= 32:
+        _LIVE.pop(next(iter(_LIVE)))          # oldest entry out
     _LIVE[key] = (rowmask, flags)
     return flags
 
