@@ -285,7 +285,7 @@ typedef struct {
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 /* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their
  * indices ascending; the remaining (padded) tiles are listed from the far end backwards (list[nt], list[nt-1], ..);
- * list[1+nt ..] is scratch (the per-tile flags).  rowmask must be 16-byte aligned. */
+ * list[1+nt ..] is scratch (the per-tile flags). */
 int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream);
 
 /* ---- single-query attention for the last encoder layer --------------------------------------------

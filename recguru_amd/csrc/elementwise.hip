@@ -501,14 +501,14 @@ __global__ __launch_bounds__(EW_BLOCK) void live_flags_kernel(const float* __res
   const long long nt = (M + 15) >> 4;
   for (long long t = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * EW_BLOCK) {
     int live = 0;
-    if (16 * t + 16 <= M) {
+    if (16 * t + 16 <= M && (reinterpret_cast<uintptr_t>(rowmask) & 15) == 0) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float4 v = reinterpret_cast<const float4*>(rowmask + 16 * t)[j];
         live |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
       }
     } else {
-      for (long long r = 16 * t; r < M; ++r) live |= rowmask[r] != 0.f;
+      for (long long r = 16 * t; r < min(16 * t + 16, M); ++r) live |= rowmask[r] != 0.f;
     }
     flags[t] = live;
   }
