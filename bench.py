@@ -118,9 +118,9 @@ def make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args):
     g_params = list(G.parameters())
     ndp = dp or T._NoDP()
 
-    def step():
+    def step(overlap=True):
         batches = [(a_iter.next(device)[0], b_iter.next(device)[0]) for _ in range(T.CRITIC_ITERS)]
-        d_cost, w_d = T.critic_phase(G, D, batches, opt_d, param, device, ndp, overlap=not args.no_overlap)
+        d_cost, w_d = T.critic_phase(G, D, batches, opt_d, param, device, ndp, overlap=overlap and not args.no_overlap)
         ba = a_iter.next(device)
         bb = b_iter.next(device)
         g_dis, lra, lrb = T.generator_iteration(G, D, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param, device, ndp,
@@ -226,11 +226,13 @@ def main():
     losses = [float(x) for x in out]
 
     roof = None
+    # the instrumented repetition runs on ONE stream (no critic overlap), so that a HIP-event pair brackets its kernel
+    # alone and the per-kernel averages agree with rocprofv3's
     if not args.no_roofline and rank != 0:
-        step()                          # the instrumented repetition contains collectives: every rank takes part
+        step(overlap=False)             # it contains collectives: every rank takes part
     if not args.no_roofline and rank == 0:
         prof = hip.start_profile()
-        step()
+        step(overlap=False)
         agg = hip.stop_profile().summary()
         total_ms = sum(v["ms"] for v in agg.values())
         peak_tf = MFMA_PEAK_TFLOPS[args.dtype]
