@@ -95,3 +95,42 @@ class DeviceLoader(object):
             u = order[i * self.bs:(i + 1) * self.bs]
             yield self.dom.batch(u, self.Le, self.Ld, self.eos, self.n_neg, (self.seed << 20) + self.epoch * self.nb + i)
         self.epoch += 1
+
+
+class DeviceEvalLoader(object):
+    """Evaluation batches in the reference's layout (pickle_loader_eval + test_seq_gen, data_loader.py:39-55,58-150):
+    ((eval_enc_in, eval_dec_in, val), (test_enc_in, test_dec_in, test), n_items_f, n_items_r) with candidate_size
+    frequency-weighted (n_items_f, when the domain has an alias table) and uniform (n_items_r) candidates that exclude
+    the user's items.  The validation input is the sequence, the test input the sequence + [val]."""
+
+    def __init__(self, seqs, val, test, V, device, batch_size, L_enc, L_dec, eos, candidate_size, wf=None, seed=0,
+                 rank=0, world=1):
+        self.eval_dom = DeviceDomain(seqs, val, test, V, device, exclude_val=True, wf=wf)
+        self.test_dom = DeviceDomain([list(s) + [int(v)] for s, v in zip(seqs, val)], val, test, V, device,
+                                     exclude_val=True)
+        self.bs, self.Le, self.Ld, self.eos, self.C, self.seed = batch_size, L_enc, L_dec, eos, candidate_size, int(seed)
+        self.users = torch.arange(rank, len(seqs), world, device=device)
+        self.nb = max(1, self.users.numel() // batch_size)
+        self.epoch = 0
+
+    def __len__(self):
+        return self.nb
+
+    def _inputs(self, dom, u):
+        enc_in, _, _ = hip.assemble_batch(dom.items, dom.offsets, u, self.Le, self.Ld, self.eos)
+        dec_in = torch.cat([torch.zeros_like(enc_in[:, :1]), enc_in[:, :-1]], 1)[:, -self.Ld:].contiguous()   # [0] + enc_in[:-1]
+        return enc_in, dec_in
+
+    def __iter__(self):
+        for i in range(self.nb):
+            u = self.users[i * self.bs:(i + 1) * self.bs].contiguous()
+            if u.numel() == 0:
+                return
+            s = (self.seed << 20) + self.epoch * self.nb + i
+            ev = self._inputs(self.eval_dom, u) + (self.eval_dom.val[u],)
+            te = self._inputs(self.test_dom, u) + (self.eval_dom.test[u],)
+            d = self.eval_dom
+            n_r = hip.sample_negatives(d.excl, d.excl_off, u, self.C, d.V, 2 * s)
+            n_f = hip.sample_negatives(d.excl, d.excl_off, u, self.C, d.V, 2 * s + 1, d.alias) if d.alias is not None else n_r
+            yield ev, te, n_f, n_r
+        self.epoch += 1

@@ -99,3 +99,26 @@ def test_device_loader_shards_and_shapes():
             assert enc.shape == (8, 16) and neg.shape == (8, 48) and enc[:, -1].eq(V + 1).all()
             seen.append(t)
     assert torch.cat(seen).numel() == 64
+
+
+def test_eval_loader_matches_test_seq_gen():
+    """DeviceEvalLoader inputs == the reference's test_seq_gen list arithmetic (data_loader.py:39-55)."""
+    from recguru_amd import sampler
+    rng = np.random.default_rng(4)
+    V, n, Le, Ld, C = 150, 16, 12, 12, 20
+    seqs, val, test = _users(rng, n, V, 20)
+    ld = sampler.DeviceEvalLoader(seqs, val, test, V, "cuda", 8, Le, Ld, V + 1, C)
+    row = 0
+    for (e_enc, e_dec, e_t), (t_enc, t_dec, t_t), nf, nr in ld:
+        for i in range(e_enc.shape[0]):
+            s, sv = list(seqs[row]), list(seqs[row]) + [int(val[row])]
+            def pad(q):
+                return q[-Le + 1:] + [V + 1] if len(q) >= Le else [0] * (Le - len(q) - 1) + q + [V + 1]
+            ee, te = pad(s), pad(sv)
+            assert e_enc[i].tolist() == ee and e_dec[i].tolist() == ([0] + ee[0:-1])[-Ld:]
+            assert t_enc[i].tolist() == te and t_dec[i].tolist() == ([0] + te[0:-1])[-Ld:]
+            assert int(e_t[i]) == int(val[row]) and int(t_t[i]) == int(test[row])
+            own = set(s) | {int(val[row]), int(test[row])}
+            assert not (set(nr[i].tolist()) & own) and nr.shape[1] == C
+            row += 1
+    assert row == 16

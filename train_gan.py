@@ -88,7 +88,16 @@ def main():
         rec_dom = synthetic.make_domain(args.synthetic, (param.vocab_size_a if args.target_domain == "a"
                                                          else param.vocab_size_b) - 1, L, param.n_bpr_neg, seed=3)
         rec_loaders = [mk(rec_dom), mk(rec_dom)]
+        # ranking evaluation at the reference's evaluation points (gan_training.py:569-580)
+        from recguru_amd import sampler
+        Vt = (param.vocab_size_a if args.target_domain == "a" else param.vocab_size_b) - 1
+        seqs, val, test, _ = synthetic.make_users(args.synthetic, Vt, L, seed=1 if args.target_domain == "a" else 2)
+        param.candidate_size = min(param.candidate_size, Vt - L - 3)
+        param.eval_steps = max(1, min(param.eval_steps, args.synthetic // param.batch_size_val))
+        test_loaders = sampler.DeviceEvalLoader(seqs, val, test, Vt, device, param.batch_size_val, L, param.rec_maxlen, Vt + 1,
+                                                param.candidate_size, rank=rank, world=world)
     else:
+        test_loaders = None
         files = Dataloader.discover(param.data_path, param.domain_name_a, param.domain_name_b)
         print("=================\n", files, "\n*****************")
         ae_loaders = [Dataloader.dataloader_gen(files["a"], param, k, "a", device, rank, world),
@@ -105,8 +114,13 @@ def main():
     opt_gen = Adam(enc_model.parameters(), lr=0.0001, betas=(0.5, 0.9))
     netD = Model.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
     opt_dis = Adam(netD.parameters(), lr=0.0001, betas=(0.5, 0.9))
-    hist = gt.main_2(enc_model, opt_rec, netD, opt_gen, opt_dis, param, device, ae_loaders, rec_loaders, None, None,
+    hist = gt.main_2(enc_model, opt_rec, netD, opt_gen, opt_dis, param, device, ae_loaders, rec_loaders, test_loaders, None,
                      dp=dp, phase1_steps=args.phase1_steps)
+    if rank == 0 and test_loaders is not None:
+        res = gt.evaluation_2(enc_model, test_loaders, device, param, domain=args.target_domain)
+        print("final ranking evaluation (random candidates): " + "  ".join(
+            "HR@%s %.4f NDCG@%s %.4f" % (kk, res[1][kk]["ht_test"][0], kk, res[1][kk]["ndcg_test"][0]) for kk in ("5", "10", "20")))
+        enc_model.train()
     if rank == 0:
         log = gt.plot.flush()
         import pickle
