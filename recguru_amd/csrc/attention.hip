@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
   __shared__ int qlive[NKT];
+  __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -123,6 +124,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
+  if (tid == 0) klo_s = L;
 
   // first Q fragment in flight during staging
   Frag<T> qnext;
@@ -166,9 +168,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
     }
   }
-  for (int key = tid; key < LPK; key += 256)
-    kbias[key] = key >= L ? -INFINITY : (a.key_ids[(size_t)b * L + key] == a.pad_value ? MASK_BIG : 0.f);
+  __syncthreads();                    // klo_s initialised
+  for (int key = tid; key < LPK; key += 256) {
+    const bool pad = key < L && a.key_ids[(size_t)b * L + key] == a.pad_value;
+    kbias[key] = key >= L ? -INFINITY : (pad ? MASK_BIG : 0.f);
+    if (CAUSAL && key < L && !pad) atomicMin(&klo_s, key);
+  }
   lds_barrier();
+  const int klo = klo_s;
   ASTAMP(0);
 
   // scores stay RAW dot products; the reference's 1/sqrt(d_k) and log2(e) are folded into the exp2 argument
@@ -198,11 +205,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
         continue;
       }
     }
+    // causal: a key tile that lies entirely in the future of every row of this query tile contributes exact zeros --
+    // unless a row is FULLY masked (no live key at or before it: uniform over all L keys, Q3), which can only happen
+    // for rows before the first live key
+    const int nkq = (CAUSAL && qt * 16 >= klo) ? min(nkt, qt + 1) : nkt;
     f32x4 s[NKT];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt < nkt) {
+      if (kt >= nkq) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt < nkq) {
         Frag<T> kf;
         load_frag(kf, Ks + (kt * 16 + li) * LDK + 8 * lg);
         float kb[4];
@@ -226,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
-      if (kt < nkt) {
+      if (kt < nkq) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, nmx));
@@ -269,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
 #pragma unroll
     for (int ks = 0; ks < NKT / 2; ++ks)
-      if (2 * ks < nkt) {
+      if (2 * ks < nkq) {
         Frag<T> pf;
         acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
 #pragma unroll
@@ -510,6 +522,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   constexpr int NW = (NKT + 1) / 2;
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query] dropout bits (p == 0.5 mode), see fill_dmask
   __shared__ int qlive[NKT];                    // 16-query tile has a row with rowmask != 0 (all 1 without a rowmask)
+  __shared__ int klo_s;                         // first key not replaced by the pad mask (causal tile skipping, see forward)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -528,6 +541,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const unsigned int lp4 = rg_lpad(L);
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
+  if (tid == 0) klo_s = L;
+  __syncthreads();
 
   // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
   constexpr int NCH = (LPK * 4 + 255) / 256;
@@ -577,9 +592,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     const bool full = lse < -5e8f;                  // -1e9 + log L rounds to -1e9: row was uniform 1/L (Q3)
     lse2_s[r] = (r < L && !full) ? lse * 1.4426950408889634f : INFINITY;     // exp2(x - inf) = 0
     rowp_s[r] = (r < L && full) ? 1.f / (float)L : 0.f;
-    kbias[r] = r >= L ? -INFINITY : (a.key_ids[(size_t)b * L + r] == a.pad_value ? MASK_BIG : 0.f);
+    const bool padk = r < L && a.key_ids[(size_t)b * L + r] == a.pad_value;
+    kbias[r] = r >= L ? -INFINITY : (padk ? MASK_BIG : 0.f);
+    if (CAUSAL && r < L && !padk) atomicMin(&klo_s, r);
   }
   lds_barrier();
+  const int klo = klo_s;
 
   // ---------------------------------------------------------------- phase 1: dK^T, dV^T
   for (int kt = wave; kt < nt; kt += 4) {
@@ -592,6 +610,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     for (int qs = 0; qs < nt / 2; ++qs) {
       if (!(qlive[2 * qs] | qlive[2 * qs + 1])) continue;   // padded query rows only: dO = 0 there, nothing to add to dK / dV
+      if (CAUSAL && 2 * qs + 1 < kt && qs * 32 >= klo) continue;   // keys entirely in the future of both query tiles: P = dS = 0
       f32x4 p[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -666,7 +685,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     const float lse_q = lse2_s[q], dl_q = dl_s[q];
     const int qrel = q - 4 * lg;
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    for (int ks = 0; ks < (qlive[qt] ? nt / 2 : 0); ++ks) {      // padded query tile: dQ rows stay 0
+    const int nks = !qlive[qt] ? 0 : ((CAUSAL && qt * 16 >= klo) ? min(nt / 2, qt / 2 + 1) : nt / 2);
+    for (int ks = 0; ks < nks; ++ks) {      // padded query tile: dQ rows stay 0; causal: future key pairs contribute 0
       f32x4 ds[2];
       float kd[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
       unsigned int km[2][4] = {{~0u, ~0u, ~0u, ~0u}, {~0u, ~0u, ~0u, ~0u}};
