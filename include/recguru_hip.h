@@ -281,6 +281,8 @@ typedef struct {
    * tile is 4 consecutive LIST entries instead of 64 consecutive rows -- and the rows of the padded tiles are written
    * as zeros (out, y_save, y2_save, h1_save, rstd*). */
   const int* live16;
+  int skip_dead_saves;   /* with live16: 1 = leave the padded tiles' rows of the *_save / rstd* buffers untouched (every
+                            consumer is list-driven as well), 0 = write zeros / finite placeholders there */
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 /* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their

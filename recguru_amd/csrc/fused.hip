@@ -471,6 +471,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
       zero_to_hbm<T>(out, FD, 0, md, a.M, tid);
+      if (a.skip_dead_saves) continue;      // the backward is list-driven too: it never reads the padded tiles' saves
       if (ysave) zero_to_hbm<T>(ysave, FD, 0, md, a.M, tid);
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, md, a.M, tid);
       if (h1save)

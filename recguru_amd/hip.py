@@ -54,7 +54,8 @@ class PostAttnArgs(ctypes.Structure):
                 ("y_save", c_p), ("rstd1", c_p), ("y2_save", c_p), ("rstd_c", c_p), ("h1_save", c_p), ("rstd2", c_p),
                 ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f),
                 ("drop_p", c_f), ("seed_h1", c_u64), ("seed_out", c_u64),
-                ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i), ("live16", c_p)]
+                ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i), ("live16", c_p),
+                ("skip_dead_saves", c_i)]
 
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
@@ -487,7 +488,7 @@ def live_tiles(rowmask, M):
 
 
 def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,
-                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True):
+                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True, skip_dead_saves=False):
     """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta);
     under dropout cross = (None, gamma, beta) and cross_drop = (s [M,H], oh [B,H,d] f32, bo [d], H).
     Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
@@ -516,7 +517,7 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
                      _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
                      _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
                      _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH,
-                     _p(live16))
+                     _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0)
     _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 

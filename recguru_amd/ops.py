@@ -78,6 +78,13 @@ def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
 
+def _lists_everywhere(W1):
+    """True when every backward consumer of the fused block's saved activations is one of the list-driven kernels
+    (bf16 tier; d_model = 128 is implied by the fused path; d_ff = 512 are the weight-gradient shapes the big kernel
+    has) -- only then may the padded tiles' rows of those buffers stay unwritten."""
+    return _COMPUTE == torch.bfloat16 and W1.shape[0] == 512
+
+
 def _live(rowmask, M):
     """List of live 16-row tiles for the big token-level GEMMs of a backward pass (None: process every row)."""
     if rowmask is None or M < hip.COMPACT_MIN_ROWS or _COMPUTE != torch.bfloat16:
@@ -364,7 +371,8 @@ class EncoderLayerFn(_Fn):
                                            drop_p, seeds[0], rowmask)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
+                                        rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
+                                        skip_dead_saves=_lists_everywhere(W1))
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
@@ -490,7 +498,7 @@ class DecoderLayerFn(_Fn):
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
-                                        seed_out=seeds[2], **cross_kw)
+                                        seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1), **cross_kw)
             if need:
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
