@@ -190,6 +190,7 @@ int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype,
  * Backward: dh fully overwritten; dE ACCUMULATED with gout[0]/sums[1] folded in. */
 #define RG_LOSS_SAMPLED_CE 0
 #define RG_LOSS_BPR 1
+#define RG_LOSS_BPR_SAS 2        /* BPRLoss_sas, tools/lossfunctions.py:79-96 (train_auto.py:26): the two-term form */
 typedef struct {
   const void* h;              /* [ntok,d] dtype : decoder states */
   const void* table;          /* [rows,d] dtype */

@@ -17,6 +17,31 @@
 
 #define LW 4  // waves per block
 
+// BPR forms.  RG_LOSS_BPR (tools/lossfunctions.py:56-72): -log sigmoid(p - nbar), aux = p - nbar.
+// RG_LOSS_BPR_SAS (:79-96): -[log(sigmoid(p) + 1e-24) + log(1 - sigmoid(nbar) + 1e-24)], aux = nbar (p is
+// recomputed by the backward before it needs it; nbar is needed by every negative's coefficient).
+#define RG_SAS_EPS 1e-24f
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ void bpr_value(int mode, float p, float nbar, float& loss, float& aux) {
+  if (mode == RG_LOSS_BPR_SAS) {
+    aux = nbar;
+    loss = -(__logf(sigmoidf_(p) + RG_SAS_EPS) + __logf(1.f - sigmoidf_(nbar) + RG_SAS_EPS));
+  } else {
+    aux = p - nbar;
+    loss = -__logf(sigmoidf_(aux));
+  }
+}
+// d loss / d logit of row idx (0 = positive), before the position weight w; p = the positive's logit (SAS only)
+__device__ __forceinline__ float bpr_coef(int mode, int idx, float aux, float p, int k) {
+  if (mode == RG_LOSS_BPR_SAS) {
+    if (idx == 0) { const float sp = sigmoidf_(p); return -sp * (1.f - sp) / (sp + RG_SAS_EPS); }
+    const float sn = sigmoidf_(aux);
+    return sn * (1.f - sn) / (1.f - sn + RG_SAS_EPS) / (float)k;
+  }
+  const float sg = 1.f / (1.f + __expf(aux));          // sigmoid(-(p - nbar))
+  return idx == 0 ? -sg : sg / (float)k;
+}
+
 template <typename T, int NPL>
 __device__ __forceinline__ float row_dot(const T* __restrict__ row, const float* h, int lane, int d, float* keep) {
   float s = 0.f;
@@ -56,8 +81,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_fwd_kernel(rg_item_loss_arg
     } else {
       float ns = 0.f;
       for (int j = 0; j < k; ++j) ns += row_dot<T, NPL>(E + (size_t)a.neg[t * k + j] * d, h, lane, d, nullptr);
-      aux = l0 - ns / (float)k;
-      loss = -__logf(1.f / (1.f + __expf(-aux)));
+      bpr_value(a.mode, l0, ns / (float)k, loss, aux);
     }
     if (lane == 0 && a.aux_tok) a.aux_tok[t] = aux;
     lsum += loss * m;
@@ -92,13 +116,14 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_kernel(rg_item_loss_arg
       float h[NPL], row[NPL];
 #pragma unroll
       for (int j = 0; j < NPL; ++j) { const int e = lane + 64 * j; h[j] = e < d ? (float)H[(size_t)t * d + e] : 0.f; }
-      const float sg = 1.f / (1.f + __expf(aux));  // sigmoid(-x), BPR only
+      float l0 = 0.f;
       for (int j = -1; j < k; ++j) {
         const long long item = j < 0 ? a.pos[t] : a.neg[t * k + j];
         const float lj = row_dot<T, NPL>(E + (size_t)item * d, h, lane, d, row);
         float c;
+        if (j < 0) l0 = lj;
         if (a.mode == RG_LOSS_SAMPLED_CE) c = (__expf(lj - aux) - (j < 0 ? 1.f : 0.f)) * w;
-        else c = (j < 0 ? -sg : sg / (float)k) * w;
+        else c = bpr_coef(a.mode, j + 1, aux, l0, k) * w;
 #pragma unroll
         for (int q = 0; q < NPL; ++q) {
           const int e = lane + 64 * q;
@@ -189,8 +214,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_fwd_rows_kernel(rg_item_los
     } else {
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1) ns += __shfl_xor(ns, o);
-      aux = l0 - ns / (float)k;
-      loss = -__logf(1.f / (1.f + __expf(-aux)));
+      bpr_value(a.mode, l0, ns / (float)k, loss, aux);
     }
     if (lane == 0 && a.aux_tok) a.aux_tok[t] = aux;
     lsum += loss * m;
@@ -224,7 +248,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
     if (m != 0.f) {
       const float w = m * gs;
       const float aux = a.aux_tok[t];
-      const float sg = 1.f / (1.f + __expf(aux));  // sigmoid(-x), BPR only
+      float l0 = 0.f;                               // the positive's logit (BPR_SAS coefficient of row 0)
       float h[8], ht[8];
       load8(h, H + (size_t)t * d + 8 * li);
       if (!CBUF) {
@@ -250,8 +274,9 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
           for (int j = 0; j < 8; ++j) dot += e[u][j] * h[j];
           dot = group_sum<LPR>(dot);
           float c;
+          if (idx == 0) l0 = dot;
           if (a.mode == RG_LOSS_SAMPLED_CE) c = (__expf(dot - aux) - (idx == 0 ? 1.f : 0.f)) * w;
-          else c = (idx == 0 ? -sg : sg / (float)k) * w;
+          else c = bpr_coef(a.mode, idx, aux, l0, k) * w;
           if (idx >= n) c = 0.f;
 #pragma unroll
           for (int j = 0; j < 8; ++j) dh[j] += c * e[u][j];

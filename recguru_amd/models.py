@@ -33,9 +33,9 @@ class SampledLogits(object):
         """SampledCrossEntropyLoss with label 0 and masked mean (tools/lossfunctions.py:36-49)."""
         return ops.sampled_softmax_loss(self.h, self.table, self.pos, self.neg, mask, self.k, self.skip_row)
 
-    def bpr(self, mask):
-        """BPRLoss (tools/lossfunctions.py:56-72)."""
-        return ops.bpr_loss(self.h, self.table, self.pos, self.neg, mask, self.k, self.skip_row)
+    def bpr(self, mask, sas=False):
+        """BPRLoss (tools/lossfunctions.py:56-72); sas=True: BPRLoss_sas (:79-96), what train_auto.py uses (:26)."""
+        return ops.bpr_loss(self.h, self.table, self.pos, self.neg, mask, self.k, self.skip_row, sas=sas)
 
 
 class Discriminator(nn.Module):

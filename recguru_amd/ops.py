@@ -593,8 +593,9 @@ def sampled_softmax_loss(h, table, pos, neg, mask, k, skip_row=-1):
     return ItemLoss.run(h, table, pos, neg, mask, k, hip.LOSS_SAMPLED_CE, skip_row)
 
 
-def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1):
-    return ItemLoss.run(h, table, pos, neg, mask, k, hip.LOSS_BPR, skip_row)
+def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1, sas=False):
+    """BPRLoss, or with sas=True BPRLoss_sas (tools/lossfunctions.py:56-72 / :79-96)."""
+    return ItemLoss.run(h, table, pos, neg, mask, k, hip.LOSS_BPR_SAS if sas else hip.LOSS_BPR, skip_row)
 
 
 # ------------------------------------------------------------------------------------------------

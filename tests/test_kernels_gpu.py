@@ -288,7 +288,8 @@ def test_adam_and_cast():
 
 
 @pytest.mark.parametrize("dt", DTYPES)
-@pytest.mark.parametrize("d,k,mode", [(64, 3, 0), (128, 30, 0), (256, 7, 0), (32, 5, 1), (128, 5, 1)])
+@pytest.mark.parametrize("d,k,mode", [(64, 3, 0), (128, 30, 0), (256, 7, 0), (32, 5, 1), (128, 5, 1), (128, 5, 2), (32, 4, 2),
+                                      (64, 30, 2)])
 def test_item_loss(dt, d, k, mode):
     from recguru_amd import hip
     ntok, V = 61, 97
@@ -304,8 +305,10 @@ def test_item_loss(dt, d, k, mode):
     ln_ = torch.einsum("td,tkd->tk", hf, tf[neg])
     if mode == 0:
         lt = torch.logsumexp(torch.cat([lp, ln_], 1), 1) - lp[:, 0]
-    else:
+    elif mode == 1:
         lt = -torch.log(torch.sigmoid(lp[:, 0] - ln_.mean(1)))
+    else:                       # BPRLoss_sas, tools/lossfunctions.py:79-96
+        lt = -((torch.sigmoid(lp[:, 0]) + 1e-24).log() + (1 - torch.sigmoid(ln_.mean(1)) + 1e-24).log())
     ref = (lt * mask).sum() / mask.sum()
     (ref * 1.7).backward()
     sums, aux = hip.item_loss_fwd(h, table, pos, neg, mask, k, mode)

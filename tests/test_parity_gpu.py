@@ -204,6 +204,9 @@ def test_single_domain_myrec(name):
     with torch.no_grad():
         bpr = R(enc_in, dec_in, dec_out, nb, recon=False).bpr(m_in)
     np.testing.assert_allclose(float(bpr), float(z["single.loss_bpr"]), rtol=1e-3, atol=1e-5)
+    with torch.no_grad():       # lf.BPRLoss_sas, the loss train_auto.py fine-tunes with (train_auto.py:26)
+        bpr_sas = R(enc_in, dec_in, dec_out, nb, recon=False).bpr(m_in, sas=True)
+    np.testing.assert_allclose(float(bpr_sas), float(z["single.loss_bpr_sas"]), rtol=1e-3, atol=1e-5)
 
 
 @pytest.mark.parametrize("name", CASES)

@@ -102,7 +102,7 @@ def main():
             enc_in, dec_in, dec_out = seqs
             opt2.zero_grad()
             mask = (dec_in != param.pad_index).view(-1).to(torch.float32)
-            loss = model(enc_in, dec_in, dec_out, n_items, recon=False).bpr(mask)
+            loss = model(enc_in, dec_in, dec_out, n_items, recon=False).bpr(mask, sas=True)   # lf.BPRLoss_sas, train_auto.py:26
             loss.backward()
             opt2.step()
             step += 1
