@@ -67,13 +67,15 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][4], const float* __rest
 }
 
 // LayerNorm on the accumulator registers.  Lane (li, lg) of wave w holds, for token rt*16+li, the 8
-// features w*32 + ct*16 + 4*lg + r: row statistics = in-lane sum, 2 shuffles across lg, then a
-// [64 tokens x 4 waves] exchange through LDS.  Two-pass (mean, then centred second moment) like
-// torch's LayerNorm.  On return v holds (v - mean) * rstd * gamma + beta and rstd[rt] the row rstd.
+// features w*32 + ct*16 + 4*lg + r.  Each wave forms the mean and the centred second moment of ITS 32 features of a
+// row (in-lane sums + 2 shuffles across lg each), the four (sum, M2) pairs of a row are exchanged through LDS ONCE and
+// combined exactly (Chan et al.: M2 = sum_w M2_w + 32 * sum_w (mean_w - mean)^2) -- as accurate as torch's two-pass
+// LayerNorm with one workgroup barrier instead of two.  On return v holds (v - mean) * rstd * gamma + beta and
+// rstd[rt] the row rstd.
 __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], const float* __restrict__ gamma_lds,
                                         const float* __restrict__ beta_lds, float* __restrict__ redA, float* __restrict__ redB,
                                         float eps, int n0, int wave, int li, int lg) {
-  float s[4];
+  float s[4], m2[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
     float t = 0.f;
@@ -83,41 +85,33 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], cons
       for (int r = 0; r < 4; ++r) t += v[ct][rt][r];
     t += __shfl_xor(t, 16);
     t += __shfl_xor(t, 32);
-    s[rt] = t;
+    s[rt] = t;                                  // sum over this wave's 32 features
+    const float mw = t * (1.f / 32.f);
+    float q = 0.f;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float dd = v[ct][rt][r] - mw; q += dd * dd; }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    m2[rt] = q;
   }
   if (lg == 0) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) redA[(rt * 16 + li) * 4 + wave] = s[rt];
+    for (int rt = 0; rt < 4; ++rt) { redA[(rt * 16 + li) * 4 + wave] = s[rt]; redB[(rt * 16 + li) * 4 + wave] = m2[rt]; }
   }
   lds_barrier();
   float mean[4];
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt) {
-    float p[4];
+    float p[4], q[4];
     load4f(p, redA + (rt * 16 + li) * 4);
+    load4f(q, redB + (rt * 16 + li) * 4);
     mean[rt] = (p[0] + p[1] + p[2] + p[3]) * (1.f / FD);
-  }
+    float M2 = (q[0] + q[1]) + (q[2] + q[3]);
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    float t = 0.f;
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { v[ct][rt][r] -= mean[rt]; t += v[ct][rt][r] * v[ct][rt][r]; }
-    t += __shfl_xor(t, 16);
-    t += __shfl_xor(t, 32);
-    s[rt] = t;
-  }
-  if (lg == 0) {
-#pragma unroll
-    for (int rt = 0; rt < 4; ++rt) redB[(rt * 16 + li) * 4 + wave] = s[rt];
-  }
-  lds_barrier();
-#pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
-    float p[4];
-    load4f(p, redB + (rt * 16 + li) * 4);
-    rstd[rt] = rsqrtf((p[0] + p[1] + p[2] + p[3]) * (1.f / FD) + eps);
+    for (int w = 0; w < 4; ++w) { const float dm = p[w] * (1.f / 32.f) - mean[rt]; M2 += 32.f * dm * dm; }
+    rstd[rt] = rsqrtf(M2 * (1.f / FD) + eps);
   }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
@@ -127,7 +121,7 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], cons
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[ct][rt][r] = v[ct][rt][r] * rstd[rt] * g[r] + b[r];
+      for (int r = 0; r < 4; ++r) v[ct][rt][r] = (v[ct][rt][r] - mean[rt]) * rstd[rt] * g[r] + b[r];
   }
 }
 
