@@ -62,20 +62,31 @@ template <> struct VStage<float> {
 #define MASK_BIG (-0x1p100f)   // ~ -1.27e30; a power of two so that MASK_BIG * c is exact for any float c
 
 // qlive[t] = 1 iff the 16-query tile t of sequence b holds a row with rowmask != 0 (all 1 without a rowmask).  One
-// coalesced load per row and a ballot per wave; visible after the caller's next LDS barrier.
+// coalesced load per row and a ballot per wave, in two halves so that the caller can put its own global loads
+// between the mask load and its first use; visible after the caller's next LDS barrier.
 template <int NT16>
-__device__ __forceinline__ void fill_qlive(int* __restrict__ qlive, const float* __restrict__ rowmask, int b, int L, int tid) {
-  const int lane = tid & 63;
-  for (int r0 = 0; r0 < NT16 * 16; r0 += 256) {
-    const int r = r0 + tid;
-    const float v = rowmask ? (r < L ? rowmask[(size_t)b * L + r] : 0.f) : 1.f;
-    const unsigned long long m = __ballot(v != 0.f);
-    if (lane < 4) {
-      const int t = (r0 + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
-      if (t < NT16) qlive[t] = ((m >> (16 * lane)) & 0xFFFFull) != 0ull;
+struct QLive {
+  static constexpr int NR = (NT16 * 16 + 255) / 256;
+  float v[NR];
+  __device__ __forceinline__ void load(const float* __restrict__ rowmask, int b, int L, int tid) {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int r = i * 256 + tid;
+      v[i] = rowmask ? (r < L ? rowmask[(size_t)b * L + r] : 0.f) : 1.f;
     }
   }
-}
+  __device__ __forceinline__ void publish(int* __restrict__ qlive, int tid) const {
+    const int lane = tid & 63;
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const unsigned long long m = __ballot(v[i] != 0.f);
+      if (lane < 4) {
+        const int t = (i * 256 + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
+        if (t < NT16) qlive[t] = ((m >> (16 * lane)) & 0xFFFFull) != 0ull;
+      }
+    }
+  }
+};
 
 // One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
 // rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
@@ -109,7 +120,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   __shared__ __align__(16) float kbias[LPK];
   constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
-  __shared__ int qlive[NKT];
   __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -123,15 +133,26 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   DropCfg drop = make_drop(a.drop_p, a.seed);
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
-  fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
   if (tid == 0) klo_s = L;
+  __syncthreads();                    // klo_s initialised (nothing in flight yet: a cheap barrier)
 
-  // first Q fragment in flight during staging
-  Frag<T> qnext;
-  {
-    const int q = wave * 16 + li;
-    if (wave < nqt && q < L) load_frag(qnext, qkv + (size_t)q * ld + h * DK + 8 * lg);
-    else frag_zero(qnext);
+  // This wave's query tiles are wave, wave+4, ...; a tile made of padded positions only is skipped (the layer
+  // multiplies those rows by the pad mask, nothing downstream reads their context).  The wave finds its live tiles
+  // itself -- lane group g of round rd loads the 16 mask values of tile wave + 4 (g + 4 rd), one ballot per round --
+  // with loads issued here, ahead of the K / V staging loads, and consumed after them.
+  constexpr int NRD = (NKT + 15) / 16;             // rounds of 4 tiles per wave
+  float rmw[NRD];
+#pragma unroll
+  for (int rd = 0; rd < NRD; ++rd) {
+    const int t = wave + 4 * (lg + 4 * rd), row = t * 16 + li;
+    rmw[rd] = (t < nqt && row < L) ? (a.rowmask ? a.rowmask[(size_t)b * L + row] : 1.f) : 0.f;
+  }
+  constexpr int NKR = (LPK + 255) / 256;
+  bool padk_r[NKR];                                // key ids: loaded ahead of the staging loads as well
+#pragma unroll
+  for (int i = 0; i < NKR; ++i) {
+    const int key = i * 256 + tid;
+    padk_r[i] = key < L && a.key_ids[(size_t)b * L + key] == a.pad_value;
   }
   // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
   // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
@@ -168,42 +189,46 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
     }
   }
-  __syncthreads();                    // klo_s initialised
-  for (int key = tid; key < LPK; key += 256) {
-    const bool pad = key < L && a.key_ids[(size_t)b * L + key] == a.pad_value;
+#pragma unroll
+  for (int i = 0; i < NKR; ++i) {
+    const int key = i * 256 + tid;
+    if (key >= LPK) break;
+    const bool pad = padk_r[i];
     kbias[key] = key >= L ? -INFINITY : (pad ? MASK_BIG : 0.f);
     if (CAUSAL && key < L && !pad) atomicMin(&klo_s, key);
   }
+  unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
+#pragma unroll
+  for (int rd = 0; rd < NRD; ++rd) {
+    const unsigned long long m = __ballot(rmw[rd] != 0.f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if ((m >> (16 * g)) & 0xFFFFull) wl |= 1u << (g + 4 * rd);
+  }
+  // first live tile's Q fragment: in flight across the barrier
+  Frag<T> qnext;
+  frag_zero(qnext);
+  if (wl) {
+    const int q = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
+    if (q < L) load_frag(qnext, qkv + (size_t)q * ld + h * DK + 8 * lg);
+  }
+  const unsigned int wl0 = wl;
   lds_barrier();
   const int klo = klo_s;
   ASTAMP(0);
 
   // scores stay RAW dot products; the reference's 1/sqrt(d_k) and log2(e) are folded into the exp2 argument
   const float c2 = a.scale * 1.4426950408889634f;
-  for (int qt = wave; qt < nqt; qt += 4) {
+  while (wl) {
+    const int qt = wave + 4 * __builtin_ctz(wl);
+    wl &= wl - 1u;                         // next live tile, if any: its Q fragment is prefetched under this tile's work
     const int q = qt * 16 + li;            // this lane's query (column of S^T)
     const int qrel = q - 4 * lg;           // key (= kt*16 + 4*lg + r) > q  <=>  kt*16 + r > qrel
     const Frag<T> qf = qnext;
-    if (qt + 4 < nqt) {
-      const int q2 = (qt + 4) * 16 + li;
+    if (wl) {
+      const int q2 = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
       if (q2 < L) load_frag(qnext, qkv + (size_t)q2 * ld + h * DK + 8 * lg);
       else frag_zero(qnext);
-    }
-    {
-      // a tile of padded positions only: the layer multiplies these rows by the pad mask, nothing downstream reads
-      // their context -- skip the tile (rows written as zeros so that saved activations stay finite)
-      if (!qlive[qt]) {
-        if (q < L) {
-          T* __restrict__ ctxz = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
-          const float z4[4] = {0.f, 0.f, 0.f, 0.f};
-          store4(ctxz + 4 * lg, z4);
-          store4(ctxz + 16 + 4 * lg, z4);
-#ifndef RG_STAMP
-          if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = 0.f;
-#endif
-        }
-        continue;
-      }
     }
     // causal: a key tile that lies entirely in the future of every row of this query tile contributes exact zeros --
     // unless a row is FULLY masked (no live key at or before it: uniform over all L keys, Q3), which can only happen
@@ -313,6 +338,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #endif
     }
     ASTAMP(4);
+  }
+  // rows of this wave's padded tiles: context = 0 (finite placeholders for a backward that never reads them); last,
+  // so that no load of the loop above waits behind these stores
+  for (int i = 0; wave + 4 * i < nqt; ++i) {
+    if ((wl0 >> i) & 1u) continue;
+    const int q = (wave + 4 * i) * 16 + li;
+    if (q < L) {
+      T* __restrict__ ctxz = reinterpret_cast<T*>(a.ctx) + ((size_t)b * L + q) * P + h * DK;
+      const float z4[4] = {0.f, 0.f, 0.f, 0.f};
+      store4(ctxz + 4 * lg, z4);
+      store4(ctxz + 16 + 4 * lg, z4);
+#ifndef RG_STAMP
+      if (lg == 0 && a.lse) a.lse[((size_t)b * a.H + h) * L + q] = 0.f;
+#endif
+    }
   }
 #ifdef RG_STAMP
   if (a.lse != nullptr && blockIdx.x >= 8192 && blockIdx.x < 9216 && lane == 0) {   // diagnostic build: lse doubles as the stamp buffer (steady-state window)
@@ -540,7 +580,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
   const unsigned int lp4 = rg_lpad(L);
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
-  fill_qlive<NKT>(qlive, a.rowmask, b, L, tid);
+  QLive<NKT> ql;
+  ql.load(a.rowmask, b, L, tid);      // consumed after the staging loads below are in flight
+  float lse_r[QLive<NKT>::NR];        // same for the per-row softmax statistics and key ids
+  bool padk_r[QLive<NKT>::NR];
+#pragma unroll
+  for (int i = 0; i < QLive<NKT>::NR; ++i) {
+    const int r = i * 256 + tid;
+    lse_r[i] = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
+    padk_r[i] = r < L && a.key_ids[(size_t)b * L + r] == a.pad_value;
+  }
   if (tid == 0) klo_s = L;
   __syncthreads();
 
@@ -587,12 +636,16 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
       }
     }
   }
-  for (int r = tid; r < LPK; r += 256) {
-    const float lse = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
+  ql.publish(qlive, tid);
+#pragma unroll
+  for (int i = 0; i < QLive<NKT>::NR; ++i) {
+    const int r = i * 256 + tid;
+    if (r >= LPK) break;
+    const float lse = lse_r[i];
     const bool full = lse < -5e8f;                  // -1e9 + log L rounds to -1e9: row was uniform 1/L (Q3)
     lse2_s[r] = (r < L && !full) ? lse * 1.4426950408889634f : INFINITY;     // exp2(x - inf) = 0
     rowp_s[r] = (r < L && full) ? 1.f / (float)L : 0.f;
-    const bool padk = r < L && a.key_ids[(size_t)b * L + r] == a.pad_value;
+    const bool padk = padk_r[i];
     kbias[r] = r >= L ? -INFINITY : (padk ? MASK_BIG : 0.f);
     if (CAUSAL && r < L && !padk) atomicMin(&klo_s, r);
   }
