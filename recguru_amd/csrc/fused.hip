@@ -25,7 +25,20 @@
 #define FD 128       // d_model == P == chunk width
 #define FPAD 8
 #define FLD (FD + FPAD)
-#define FZLD (FD + 4)
+
+// Activation tiles in LDS are [64 tokens x 128 features].  bf16: rows of exactly 256 B (all 64 banks) with the sixteen
+// 16-byte chunks of a row XOR-swizzled by the row index -- chunk c of row r sits at chunk
+// c ^ (r & 15) -- which makes the B-operand fragment reads (ds_read_b128: lane (li, lg) reads chunk 4 ks + lg of row li)
+// conflict-free under the hardware's 16-lane service groups ({0-3, 12-15, 20-27}, ...: lanes of two lg values land in
+// complementary chunk sets); a padded row (272 B) put two lanes of every group on one bank -- 43 % of the kernel's
+// LDS cycles were bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  f32 (parity tier): padded rows.
+template <typename T> struct Tile {
+  static constexpr int LD = sizeof(T) == 2 ? FD : FLD;          // row pitch in elements
+  static __device__ __forceinline__ int off(int row, int col) {  // col: any element whose 16-byte chunk holds it
+    if constexpr (sizeof(T) == 2) return row * FD + ((((col >> 3) ^ row) & 15) << 3) + (col & 7);
+    else return row * FLD + col;
+  }
+};
 
 // One GEMM step = a set of 8 weight fragments (4 k-steps x 2 feature tiles of this wave), loaded
 // straight from L2 one GEMM ahead of its use (software pipelining: the load of set s+1 is issued
@@ -47,7 +60,7 @@ __device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][4], const WSet<T>& w, c
   for (int ks = 0; ks < 4; ++ks) {
     Frag<T> af[4];                          // the k-step's four token-tile fragments in one LDS burst
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], Act + (rt * 16 + li) * FLD + ks * 32 + 8 * lg);
+    for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], Act + Tile<T>::off(rt * 16 + li, ks * 32 + 8 * lg));
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -133,7 +146,7 @@ __device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restri
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) {
       float t[4] = {v[ct][rt][0], v[ct][rt][1], v[ct][rt][2], v[ct][rt][3]};
-      store4(tile + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg, t);
+      store4(tile + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg), t);
     }
 }
 
@@ -147,7 +160,7 @@ __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __res
   for (int i = 0; i < 4; ++i) {
     const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
     if (m < M)
-      *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + r * FLD + c8);
+      *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
   }
 }
 
@@ -178,7 +191,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   unsigned long long t0__ = __builtin_amdgcn_s_memtime();
 #endif
   // LDS: ctx tile (later: out staging) | x tile (later: g chunk) | y tile | params | row-stat exchange | [h1 chunk]
-  constexpr int ACT_BYTES = FT_M * FLD * (int)sizeof(T);
+  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* Actx = reinterpret_cast<T*>(smem);
   T* Ag = reinterpret_cast<T*>(smem + ACT_BYTES);
@@ -257,8 +270,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      *reinterpret_cast<Frag<T>*>(Actx + r * FLD + c8) = cpre[i];
-      *reinterpret_cast<Frag<T>*>(Ag + r * FLD + c8) = xpre[i];
+      *reinterpret_cast<Frag<T>*>(Actx + Tile<T>::off(r, c8)) = cpre[i];
+      *reinterpret_cast<Frag<T>*>(Ag + Tile<T>::off(r, c8)) = xpre[i];
     }
     float rm4[4];
 #pragma unroll
@@ -300,7 +313,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         float r4[4];
-        load4t(r4, Ag + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);
+        load4t(r4, Ag + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[ct][rt][r] += r4[r];
       }
@@ -335,7 +348,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           } else {
             load4f(o4, a.o_bcast + (size_t)(m / a.L) * FD + n0 + ct * 16 + 4 * lg);
           }
-          load4t(y4, Ay + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);     // the ROUNDED y1, as the unfused path sees it
+          load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[r];
         }
@@ -429,7 +442,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         float r4[4];
-        load4t(r4, Ay + (rt * 16 + li) * FLD + n0 + ct * 16 + 4 * lg);
+        load4t(r4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
       }
@@ -497,7 +510,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (a->M + FT_M - 1) / FT_M;
   const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int act = FT_M * FLD * esz;
+  const int act = FT_M * (dtype == RG_BF16 ? FD : FLD) * esz;
   const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * FT_M * 4 * 4 + (a->h1_save ? act : 0);
   const int per_cu = (160 * 1024) / smem;
   int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
