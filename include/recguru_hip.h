@@ -79,8 +79,15 @@ typedef struct {
   int use_tr;                 /* bf16: 1 = ds_read_tr16_b64 fragments, 0 = scalar LDS reads */
   const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): only those rows are summed (the others
                                  carry zero Y); honoured by the big-shape kernel, ignored (all rows summed) otherwise */
+  float* partials;            /* optional caller-owned device scratch of >= rg_gemm_tn_workspace() bytes: the big-shape kernel
+                                 then writes each workgroup's partial dW with plain coalesced stores and a second launch
+                                 sums them into dW (256 x |dW| of 64-byte-segment float atomics ran at a fraction of the
+                                 memory-side atomic rate and cost more than the GEMM itself).  NULL: atomics.  Must not be
+                                 shared by calls that may run concurrently on different streams. */
 } rg_gemm_tn_args;
 int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
+/* bytes of `partials` scratch rg_gemm_tn can use for these arguments (0: the kernel it would run has no use for it) */
+size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* args /* host */, int dtype);
 /* Plan queries (no launch): the name of the kernel rg_gemm_nt / rg_gemm_tn would run for these arguments --
  * "gemm_ws_kernel<K/128,N/128>" (persistent weight-stationary), "gemm_nt_kernel<dtype,NTW>" (generic tiles),
  * "gemm_tn_big_kernel<N1,N2>" or "gemm_tn_kernel<dtype>" -- written NUL-terminated into name[cap].  Used by the

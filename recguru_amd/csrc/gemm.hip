@@ -366,6 +366,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(rg_gemm_tn_args a) {
 int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s);   // gemm_tn_big.hip
 int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype);
 
+size_t rg_gemm_tn_big_workspace(const rg_gemm_tn_args* a, int dtype);
+
+extern "C" size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* a, int dtype) {
+  if (!a || a->splits != 0) return 0;
+  return rg_gemm_tn_big_workspace(a, dtype);
+}
+
 extern "C" int rg_gemm_tn_plan(const rg_gemm_tn_args* a, int dtype, char* name, int cap) {
   if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_plan: null argument");
   if (a->splits == 0 && rg_gemm_tn_big_select(a, dtype)) snprintf(name, cap, "gemm_tn_big_kernel<%d,%d>", a->N1, a->N2);

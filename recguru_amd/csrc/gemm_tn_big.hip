@@ -3,15 +3,17 @@
 // out-projection -- plus the bias gradient colsum[n1] += sum_t Y[t,n1].
 //
 // One workgroup (8 waves) owns the WHOLE dW tile in its accumulators (<= 128 VGPRs per lane) and
-// walks a contiguous token range in 32-token chunks, so Y and X are read from HBM exactly once in
+// walks a contiguous token range in 64-token chunks, so Y and X are read from HBM exactly once in
 // total (the 64x64-tile kernel in gemm.hip re-reads X N1/64 times and Y N2/64 times).  Chunks are
 // staged row-major in LDS (raw 16-byte copies, next chunk prefetched in registers) and the
 // token-major MFMA fragments come from the transposing LDS read.  The waves split the larger of
-// N1 / N2.  Partial results are combined with f32 atomics (256 workgroups x |dW|, a few MB).
+// N1 / N2.  Partial results: with a.partials each workgroup stores its accumulators register-major (every store
+// instruction = 256 contiguous bytes) and tn_big_reduce_kernel sums the slices into dW; without it, f32 atomics
+// (a 16x16 accumulator register is 4 x 64-byte segments per instruction: 256 x |dW| of those cost more than the GEMM).
 #include "rg_common.cuh"
 #include "../../include/recguru_hip.h"
 
-#define TB_T 32
+#define TB_T 64      // tokens per chunk: two MFMA k-steps per barrier pair and >= 80 KB of loads in flight per CU
 
 // fragment whose 8 slots (g, j) are rows 8g + j of column c0 + (lane & 15) of a row-major LDS tile
 __device__ __forceinline__ void frag_tr16(Frag<__bf16>& f, const __bf16* tile, int ld, int c0, int li, int lg) {
@@ -36,17 +38,18 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   constexpr int LDY = N1 + 8, LDX = N2 + 8;
   constexpr int CY = TB_T * N1 / 8, CX = TB_T * N2 / 8;          // 16-byte chunks per staged tile
   constexpr int PY = (CY + 511) / 512, PX = (CX + 511) / 512;    // per-thread prefetch registers
-  __shared__ __align__(16) T Ys[TB_T * LDY];
-  __shared__ __align__(16) T Xs[TB_T * LDX];
+  extern __shared__ __align__(16) unsigned char smem_tb[];
+  T* Ys = reinterpret_cast<T*>(smem_tb);                // [TB_T][LDY]
+  T* Xs = Ys + TB_T * LDY;                              // [TB_T][LDX]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ Y = reinterpret_cast<const T*>(a.Y);
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const int m1 = SPLIT1 ? wave * MT * 16 : 0;
   const int m2 = SPLIT1 ? 0 : wave * NT * 16;
-  // a.live16 (optional): the list of live 16-row tiles (rg_live_tiles) -- a chunk is then 2 consecutive LIST entries
-  // instead of 32 consecutive tokens; rows of padded tiles carry zero upstream gradient and are never read
-  const int nchunks = a.live16 ? (a.live16[0] + 1) >> 1 : (a.T + TB_T - 1) / TB_T;
+  // a.live16 (optional): the list of live 16-row tiles (rg_live_tiles) -- a chunk is then 4 consecutive LIST entries
+  // instead of 64 consecutive tokens; rows of padded tiles carry zero upstream gradient and are never read
+  const int nchunks = a.live16 ? (a.live16[0] + 3) >> 2 : (a.T + TB_T - 1) / TB_T;
   const int per = (nchunks + gridDim.x - 1) / gridDim.x;
   const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
@@ -62,19 +65,31 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   Frag<T> ones;
   frag_fill(ones, 1.f);
   Frag<T> py[PY], px[PX];
-  auto prefetch = [&](int chunk) {
-    int b0 = chunk * TB_T, b1 = chunk * TB_T + 16;      // first rows of the chunk's two 16-row halves
-    if (a.live16) {
-      const int nl = a.live16[0];
-      b0 = a.live16[1 + 2 * chunk] * 16;
-      b1 = 2 * chunk + 1 < nl ? a.live16[2 + 2 * chunk] * 16 : a.T;
+  // First rows of a chunk's 16-row sub-tiles.  With a live list they are read ONE CHUNK AHEAD of the prefetch that
+  // needs them (list entry -> row address -> data is two dependent memory latencies otherwise, once per chunk), by a
+  // per-lane VECTOR load (lane q & 3 holds entry q) queued behind the chunk's data loads: it has landed by the time
+  // those are stored to LDS, and it does not drain the LDS queue the way a scalar load's lgkmcnt(0) would.
+  // The load is unconditional (clamped index; validity is decided when the value is used): a load under a divergent
+  // condition makes the compiler drain vmcnt(0) right behind it -- and with it the whole data prefetch.
+  const int nlive = a.live16 ? a.live16[0] : 0;
+  const int nt16 = (a.T + 15) >> 4;
+  int nb = 0;
+  auto rows_of = [&](int chunk) {
+    if (a.live16) nb = a.live16[1 + min((TB_T / 16) * chunk + (lane & (TB_T / 16 - 1)), nt16 - 1)];
+  };
+  auto prefetch = [&](int chunk) {                      // expects nb = rows_of(chunk); leaves nb = rows_of(chunk + 1)
+    int bs[TB_T / 16];
+#pragma unroll
+    for (int q = 0; q < TB_T / 16; ++q) {
+      if (a.live16) bs[q] = (TB_T / 16) * chunk + q < nlive ? __builtin_amdgcn_readlane(nb, q) * 16 : a.T;
+      else bs[q] = chunk * TB_T + 16 * q;
     }
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
       const int c = tid + 512 * i;
       if (c < CY) {
         const int r = c / (N1 / 8), c8 = (c % (N1 / 8)) * 8;
-        const int t = (r < 16 ? b0 : b1 - 16) + r;
+        const int t = bs[r >> 4] + (r & 15);
         if (t < a.T) load_frag(py[i], Y + (size_t)t * a.ldy + c8);
         else frag_zero(py[i]);
       }
@@ -84,13 +99,14 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
       const int c = tid + 512 * i;
       if (c < CX) {
         const int r = c / (N2 / 8), c8 = (c % (N2 / 8)) * 8;
-        const int t = (r < 16 ? b0 : b1 - 16) + r;
+        const int t = bs[r >> 4] + (r & 15);
         if (t < a.T) load_frag(px[i], X + (size_t)t * a.ldx + c8);
         else frag_zero(px[i]);
       }
     }
+    rows_of(chunk + 1);
   };
-  if (c_beg < c_end) prefetch(c_beg);
+  if (c_beg < c_end) { rows_of(c_beg); prefetch(c_beg); }
   for (int chunk = c_beg; chunk < c_end; ++chunk) {
 #pragma unroll
     for (int i = 0; i < PY; ++i) {
@@ -117,29 +133,49 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
     }
     if (chunk + 1 < c_end) prefetch(chunk + 1);
     lds_barrier();
-    Frag<T> af[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      frag_tr16(af[i], Ys, LDY, m1 + i * 16, li, lg);
-      if (do_cs) mma(af[i], ones, cs[i]);
-    }
+    for (int k = 0; k < TB_T / 32; ++k) {               // MFMA k-steps of 32 tokens
+      if constexpr (MT <= NT) {                         // hold the shorter side's fragments, stream the longer
+        Frag<T> af[MT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      Frag<T> bf;
-      frag_tr16(bf, Xs, LDX, m2 + j * 16, li, lg);
+        for (int i = 0; i < MT; ++i) {
+          frag_tr16(af[i], Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg);
+          if (do_cs) mma(af[i], ones, cs[i]);
+        }
 #pragma unroll
-      for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+        for (int j = 0; j < NT; ++j) {
+          Frag<T> bf;
+          frag_tr16(bf, Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg);
+#pragma unroll
+          for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+        }
+      } else {
+        Frag<T> bf[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) frag_tr16(bf[j], Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          Frag<T> af;
+          frag_tr16(af, Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg);
+          if (do_cs) mma(af, ones, cs[i]);
+#pragma unroll
+          for (int j = 0; j < NT; ++j) mma(af, bf[j], acc[i][j]);
+        }
+      }
     }
     lds_barrier();
   }
   if (c_beg >= c_end) return;
+  float* __restrict__ part = a.partials ? a.partials + (size_t)blockIdx.x * (N1 * N2) + tid : nullptr;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
+      for (int r = 0; r < 4; ++r) {
+        if (part) part[((i * NT + j) * 4 + r) * 512] = acc[i][j][r];     // element e = slot * 512 + tid of this workgroup's slice
+        else atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
+      }
     if (do_cs && li == 0) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) atomicAdd(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
@@ -147,12 +183,52 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   }
 }
 
+// dW += scale * sum over the active workgroups' slices.  Thread = one element e of the register-major slice layout
+// (coalesced across threads for every slice); blockIdx.y splits the slices so that small dW still fill the chip.
+template <int N1, int N2>
+__global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, int grid1) {
+  constexpr bool SPLIT1 = N1 >= N2;
+  constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;
+  const int nchunks = a.live16 ? (a.live16[0] + 3) >> 2 : (a.T + TB_T - 1) / TB_T;
+  if (nchunks <= 0) return;
+  const int per = (nchunks + grid1 - 1) / grid1;
+  const int nact = (nchunks + per - 1) / per;          // workgroups of the first launch that had a token range
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int b0 = (int)((long long)nact * blockIdx.y / gridDim.y), b1 = (int)((long long)nact * (blockIdx.y + 1) / gridDim.y);
+  const float* __restrict__ p = a.partials + e;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = b0;
+  for (; b + 4 <= b1; b += 4) {
+    s0 += p[(size_t)b * (N1 * N2)];
+    s1 += p[(size_t)(b + 1) * (N1 * N2)];
+    s2 += p[(size_t)(b + 2) * (N1 * N2)];
+    s3 += p[(size_t)(b + 3) * (N1 * N2)];
+  }
+  for (; b < b1; ++b) s0 += p[(size_t)b * (N1 * N2)];
+  const int tid = e & 511, slot = e >> 9, r = slot & 3, j = (slot >> 2) % NT, i = (slot >> 2) / NT;
+  const int wave = tid >> 6, li = tid & 15, lg = (tid >> 4) & 3;
+  constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;
+  const int m1 = SPLIT1 ? wave * MT * 16 : 0, m2 = SPLIT1 ? 0 : wave * NT * 16;
+  atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, ((s0 + s1) + (s2 + s3)) * a.scale);
+}
+
 template <int N1, int N2>
 static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   const int nchunks = (a.T + TB_T - 1) / TB_T;
   int grid = nchunks < 256 ? nchunks : 256;
-  if (a.prologue_x == RG_PRO_GELU) hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, true>), dim3(grid), dim3(512), 0, s, a);
-  else hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, false>), dim3(grid), dim3(512), 0, s, a);
+  const int smem = TB_T * (N1 + 8 + N2 + 8) * 2;
+  if (a.prologue_x == RG_PRO_GELU) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<N1, N2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, true>), dim3(grid), dim3(512), smem, s, a);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<N1, N2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, false>), dim3(grid), dim3(512), smem, s, a);
+  }
+  if (a.partials) {
+    const int gx = N1 * N2 / 256;
+    const int gy = gx >= 256 ? 4 : (gx >= 128 ? 8 : 16);
+    hipLaunchKernelGGL((tn_big_reduce_kernel<N1, N2>), dim3(gx, gy), dim3(256), 0, s, a, grid);
+  }
   RG_CHECK_LAUNCH();
   return 0;
 }
@@ -161,6 +237,12 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
 int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
   if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7)) return 0;
   return (a->N2 == 128 && (a->N1 == 512 || a->N1 == 384 || a->N1 == 256 || a->N1 == 128)) || (a->N1 == 128 && a->N2 == 512);
+}
+
+// bytes of partial-sum scratch the big kernel can use for this problem (0 if it does not take it)
+size_t rg_gemm_tn_big_workspace(const rg_gemm_tn_args* a, int dtype) {
+  if (!rg_gemm_tn_big_select(a, dtype)) return 0;
+  return (size_t)256 * a->N1 * a->N2 * sizeof(float);
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)

@@ -32,7 +32,7 @@ class GemmNtArgs(ctypes.Structure):
 class GemmTnArgs(ctypes.Structure):
     _fields_ = [("Y", c_p), ("ldy", c_i), ("X", c_p), ("ldx", c_i), ("dW", c_p), ("lddw", c_i), ("colsum", c_p),
                 ("T", c_i), ("N1", c_i), ("N2", c_i), ("prologue_x", c_i), ("scale", c_f), ("splits", c_i),
-                ("use_tr", c_i), ("live16", c_p)]
+                ("use_tr", c_i), ("live16", c_p), ("partials", c_p)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -64,7 +64,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan",
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
@@ -148,7 +148,21 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     return out
 
 
-def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None):
+_TN_WS = {}
+
+
+def _tn_workspace(dev, nbytes):
+    """Partial-sum scratch of the weight-gradient GEMM, one buffer per (device, stream): calls on one stream are
+    ordered, calls on different streams (critic phase overlap) must not share it."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _TN_WS.get(key)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
+        _TN_WS[key] = ws
+    return ws
+
+
+def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None, partials=True):
     """dW[N1,N2] += Y[T,N1].T @ pro(X[T,N2]) (f32, accumulated); colsum[N1] += Y.sum(0)."""
     T, N1 = Y.shape
     N2 = X.shape[1]
@@ -158,7 +172,13 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     if T == 0:
         return dW
     a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
-                   prologue_x, scale, splits, use_tr, _p(live))
+                   prologue_x, scale, splits, use_tr, _p(live), None)
+    if partials:
+        fn = lib().rg_gemm_tn_workspace
+        fn.restype = ctypes.c_size_t
+        need = int(fn(ctypes.byref(a), dt_of(Y)))
+        if need:
+            a.partials = _p(_tn_workspace(Y.device, need))
     if _PROF is not None:
         _note_plan(lib().rg_gemm_tn_plan, a, dt_of(Y))
     _check(lib().rg_gemm_tn(ctypes.byref(a), dt_of(Y), _stream()), "rg_gemm_tn")

@@ -1,0 +1,25 @@
+"""The fused post-attention block alone, in its training configuration at the bench shape (pad mask, live-tile list,
+saves, dropout 0.5) -- the target of `rocprofv3 --pmc ...  -- python3 tools/pa_only.py` counter passes."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recguru_amd import hip, synthetic
+B, L, d = 4096, 200, 128
+M = B * L
+dom = synthetic.make_domain(B, 100000, L, 1, seed=1)
+ids = torch.as_tensor(dom["enc_in"]).cuda()
+mask = (ids != 0).float().reshape(-1).contiguous()
+dt = torch.bfloat16
+r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
+x, ctx = r(M, d), r(M, d)
+wo, w1, w2 = r(d, d), r(512, d), r(d, 512)
+z = lambda n: torch.zeros(n, device="cuda")
+g = torch.ones(d, device="cuda")
+mode = sys.argv[1] if len(sys.argv) > 1 else "train"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+for _ in range(n):
+    if mode == "train":
+        hip.post_attn_fwd(ctx, x, wo, z(d), g, z(d), w1, z(512), w2, z(d), g, z(d), mask, save=True, drop_p=0.5, seed_h1=3,
+                          seed_out=4, skip_dead_saves=True)
+    else:
+        hip.post_attn_fwd(ctx, x, wo, z(d), g, z(d), w1, z(512), w2, z(d), g, z(d), mask)
+torch.cuda.synchronize()
