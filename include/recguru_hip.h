@@ -64,6 +64,9 @@ typedef struct {
   const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): rows of the other tiles are not read and
                                  their rows of C are written as zeros; honoured by the weight-stationary kernel, ignored
                                  (every row computed) by the generic one */
+  int skip_dead_fill;         /* with live16: leave the rows of C of the padded tiles UNWRITTEN -- for outputs whose every
+                                 consumer is list- or rowmask-driven (the list-driven GEMMs never read them; rg_attn_bwd takes
+                                 dctx rows with rowmask == 0 as zero) */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 

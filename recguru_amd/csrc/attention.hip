@@ -598,22 +598,29 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 #pragma unroll
   for (int i0 = 0; i0 < NCH; i0 += 4) {
     Frag<T> qr[4], kr[4], vr[4], gr[4], orow[4];
+    float rmr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
       const int rc = min(row, L - 1);                 // clamped address, zeroed below: no branch between the loads
+      rmr[i] = 1.f;
       if (i0 + i < NCH) {
         load_frag(qr[i], qkv + (size_t)rc * ld + h * DK + c8);
         load_frag(kr[i], qkv + (size_t)rc * ld + P + h * DK + c8);
         load_frag(vr[i], qkv + (size_t)rc * ld + 2 * P + h * DK + c8);
         load_frag(gr[i], dO + (size_t)rc * P + c8);
         load_frag(orow[i], O + (size_t)rc * P + c8);
+        if (a.rowmask) rmr[i] = a.rowmask[(size_t)b * L + rc];
       }
     }
+    // dctx rows with rowmask == 0 are zero by contract (rg_attn_bwd_args.rowmask) and are TAKEN as zero whatever the
+    // buffer holds: its producer may leave the rows of padded 16-row tiles unwritten (rg_gemm_nt_args.skip_dead_fill).
+    // The qkv / ctx rows of such positions are real data (a padded position is still a key unless its id is pad_value).
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (tid + 256 * (i0 + i)) >> 2;
       if (i0 + i >= NCH || row >= L) { frag_zero(qr[i]); frag_zero(kr[i]); frag_zero(vr[i]); frag_zero(gr[i]); frag_zero(orow[i]); }
+      else if (rmr[i] == 0.f) frag_zero(gr[i]);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

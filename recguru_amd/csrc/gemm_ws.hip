@@ -161,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
   }
-  if (a.live16) {                                         // rows of the padded tiles: C = 0
+  if (a.live16 && !a.skip_dead_fill) {                    // rows of the padded tiles: C = 0
     const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
     Frag<T> z;
     frag_zero(z);

@@ -26,7 +26,8 @@ class GemmNtArgs(ctypes.Structure):
                 ("c_is_f32", c_i), ("M", c_i), ("N", c_i), ("K", c_i), ("prologue", c_i), ("epilogue", c_i),
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
-                ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p)]
+                ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p),
+                ("skip_dead_fill", c_i)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -126,22 +127,31 @@ def _rowmajor(t):
     return t.stride(0)
 
 
+# test knob: outputs whose padded-tile rows a kernel is allowed to leave unwritten start as NaN, so that any consumer
+# that still reads such a row shows up in the results
+POISON_UNWRITTEN = False
+
+
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
             gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
-            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None):
-    """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N]."""
+            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False):
+    """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N].  live: list of live 16-row tiles
+    (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill
+    (only for outputs whose consumers are all list- or rowmask-driven)."""
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.dtype == A.dtype
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
+        if POISON_UNWRITTEN and live is not None and skip_dead_fill:
+            out.fill_(float("nan"))
     if M == 0:
         return out
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed, _p(live))
+                   drop_p, drop_seed, _p(live), 1 if (live is not None and skip_dead_fill) else 0)
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
@@ -531,6 +541,9 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
         if cross is not None:
             sv["y2"] = torch.empty(M, d, device=dev, dtype=ctx.dtype)
             sv["rstd_c"] = torch.empty(M, device=dev, dtype=torch.float32)
+        if POISON_UNWRITTEN and live16 is not None and skip_dead_saves:
+            for t in sv.values():
+                t.fill_(float("nan"))
     o, gc, bec = cross if cross is not None else (None, None, None)
     cs, coh, cbo, cH = cross_drop if cross_drop is not None else (None, None, None, 0)
     a = PostAttnArgs(_p(ctx), _p(x), _p(Wo), _p(bo), _p(g1), _p(be1), _p(o), _p(gc), _p(bec), L,

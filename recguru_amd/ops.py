@@ -270,6 +270,8 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+    # every row is projected: a padded position is still a KEY unless its id equals pad_value (the reference masks
+    # keys by pad_value and rows by id != 0 -- two different sets), so its K / V rows are real operands
     qkv = hip.gemm_nt(x2, wqkv, bqkv)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
                              rowmask=rowmask)
@@ -300,12 +302,12 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     live = _live(rowmask, dy.shape[0])
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
-    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live)
+    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
     dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
                         drop_p=drop_p, seed=seed, rowmask=rowmask)
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
-    hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)
+    hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)                 # every row: a padded position that is a live key has dK, dV != 0
     # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
     # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
     dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
@@ -347,7 +349,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
-                      epi_nonzero_scale=_inv_keep(drop_p), live=live)
+                      epi_nonzero_scale=_inv_keep(drop_p), live=live, skip_dead_fill=True)   # both consumers list-driven
     (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
     hip.gemm_tn(dh1, y, dW1, db1, live=live)
     dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
