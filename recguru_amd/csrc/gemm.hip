@@ -134,13 +134,22 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
         } else if (a.epilogue != RG_EPI_NONE) {
           float x[8];
           load8(x, aux + (size_t)m * a.ldaux + n);
+          // uniform switch outside the element loops (inside, each element is its own basic block)
+          if (a.epilogue == RG_EPI_MUL_POSMASK) {
+            const float sc = a.epi_scale > 0.f ? a.epi_scale : 1.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] * (a.epi_scale > 0.f ? a.epi_scale : 1.f) : 0.f;
-            else if (a.epilogue == RG_EPI_GELU_GRAD) {
-              v[j] *= gelu_grad_t<Precise<T>::value>(x[j]);
-              if (a.epi_nonzero_scale > 0.f) v[j] = x[j] != 0.f ? v[j] * a.epi_nonzero_scale : 0.f;
-            } else v[j] += x[j];
+            for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] * sc : 0.f;
+          } else if (a.epilogue == RG_EPI_GELU_GRAD) {
+            const float nz = a.epi_nonzero_scale;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_t<Precise<T>::value>(x[j]);
+            if (nz > 0.f) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] = x[j] != 0.f ? v[j] * nz : 0.f;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += x[j];
           }
         }
         if (a.c_is_f32) store8(reinterpret_cast<float*>(a.C) + (size_t)m * a.ldc + n, v);

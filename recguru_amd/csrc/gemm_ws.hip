@@ -64,15 +64,30 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   Frag<T> pre[4];
   auto prefetch = [&](const int (&g)[4], int kc) {
 #pragma unroll
+    for (int i = 0; i < 4; ++i) {      // rows >= M: clamped address, no branch (their results are never stored)
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(pre[i], A + (size_t)m * a.lda + kc * 128 + c8);
+    }
+  };
+  // aux rows (epilogue operand) of the NEXT epilogue step -- the next 128-feature block of this tile, or block 0 of
+  // the next tile -- are loaded a whole step ahead: loaded inside the step they cost one exposed HBM latency per
+  // block (the MFMAs of one block cover a fifth of it)
+  const bool need_aux = a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU;
+  Frag<T> axn[4];
+  auto aux_prefetch = [&](const int (&g)[4], int cb) {
+#pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c8 = (tid & 15) * 8, m = g[i] + (tid >> 4);
-      if (m < a.M) load_frag(pre[i], A + (size_t)m * a.lda + kc * 128 + c8);
-      else frag_zero(pre[i]);
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(axn[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
     }
   };
   int tile = blockIdx.x;
   int mb[4], mbn[4];
-  if (tile < nwork) { group(tile, mb); prefetch(mb, 0); }
+  if (tile < nwork) {
+    group(tile, mb);
+    prefetch(mb, 0);
+    if (need_aux) aux_prefetch(mb, 0);
+  }
   for (; tile < nwork; tile += gridDim.x) {
     group(tile + (int)gridDim.x, mbn);
     f32x4 acc[2][4];
@@ -89,14 +104,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
       lds_barrier();
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
-        Frag<T> axf[4];                                   // aux rows of this block, in flight under the MFMAs
-        if (kc == NKC - 1 && a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) {
+        Frag<T> axf[4];                                   // aux rows of this block (prefetched one step ago)
+        if (kc == NKC - 1 && need_aux) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
-            if (m < a.M) load_frag(axf[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
-            else frag_zero(axf[i]);
-          }
+          for (int i = 0; i < 4; ++i) axf[i] = axn[i];
+          if (cb + 1 < NCB) aux_prefetch(mb, cb + 1);
+          else if (tile + (int)gridDim.x < nwork) aux_prefetch(mbn, 0);
         }
         if (kc == 0) {
 #pragma unroll
@@ -140,14 +153,26 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
                 load8(v, Cs + r * WS_LD + c8);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) x[j] = (float)axf[i].v[j];
+                // the (uniform) epilogue switch sits OUTSIDE the element loops: inside, every element became its own
+                // basic block and the 8 dependent exp / rcp chains of a vector ran one after the other
+                if (a.epilogue == RG_EPI_GELU_GRAD) {
+                  const float nz = a.epi_nonzero_scale;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                  if (a.epilogue == RG_EPI_GELU_GRAD) {
-                    v[j] *= gelu_grad_t<false>(x[j]);
-                    if (a.epi_nonzero_scale > 0.f) v[j] = x[j] != 0.f ? v[j] * a.epi_nonzero_scale : 0.f;
-                  } else if (a.epilogue == RG_EPI_ADD) v[j] += x[j];
-                  else if (a.epilogue == RG_EPI_MUL_POSMASK) v[j] = x[j] > 0.f ? v[j] * (a.epi_scale > 0.f ? a.epi_scale : 1.f) : 0.f;
-                  else v[j] = fmaxf(v[j], 0.f);
+                  for (int j = 0; j < 8; ++j) v[j] *= gelu_grad_t<false>(x[j]);
+                  if (nz > 0.f) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = x[j] != 0.f ? v[j] * nz : 0.f;
+                  }
+                } else if (a.epilogue == RG_EPI_ADD) {
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] += x[j];
+                } else if (a.epilogue == RG_EPI_MUL_POSMASK) {
+                  const float sc = a.epi_scale > 0.f ? a.epi_scale : 1.f;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] * sc : 0.f;
+                } else {
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 store8(C + off, v);
               }
