@@ -151,6 +151,9 @@ typedef struct {
   long long M; int N; int ld;
   void* dz_drop; float drop_p; unsigned long long drop_seed;  /* optional 2nd output dz * dropmask/(1-p):
                                  backward of the dropout on the l2 output (transformer.py:186-187) */
+  const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): only the rows of listed tiles are
+                                 processed; the rows of dz / dz_drop of the other (fully padded) tiles stay UNWRITTEN --
+                                 for callers whose consumers of dz are all list-driven */
 } rg_ln_bwd_args;
 int rg_ln_bwd(const rg_ln_bwd_args* args /* host */, int dtype, void* stream);
 

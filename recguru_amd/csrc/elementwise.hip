@@ -150,7 +150,12 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
   const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
-  for (long long m0 = gw * RPW; m0 < a.M; m0 += nw * RPW) {
+  // work unit = RPW consecutive rows: unit u of the matrix, or -- list-driven -- part (u % (16 / RPW)) of the
+  // u / (16 / RPW)-th live 16-row tile (rows of unlisted tiles are neither read nor written)
+  constexpr int UPT = 16 / RPW;
+  const long long nunits = a.live16 ? (long long)a.live16[0] * UPT : (a.M + RPW - 1) / RPW;
+  for (long long u = gw; u < nunits; u += nw) {
+    const long long m0 = a.live16 ? (long long)a.live16[1 + u / UPT] * 16 + (u % UPT) * RPW : u * RPW;
     const long long m = m0 + rr;
     const bool live = m < a.M;
     const float rm = live ? (a.rowmask ? a.rowmask[m] : 1.f) : 0.f;

@@ -75,7 +75,7 @@ c_ll = ctypes.c_longlong
 class LnBwdArgs(ctypes.Structure):
     _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i),
-                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64)]
+                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p)]
 
 
 class ItemLossArgs(ctypes.Structure):
@@ -240,15 +240,20 @@ def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     return dE
 
 
-def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0):
+def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0, live=None):
     """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place.
-    With drop_p > 0 also returns dz * dropmask/(1-p) (backward of a dropout feeding the LN input)."""
+    With drop_p > 0 also returns dz * dropmask/(1-p) (backward of a dropout feeding the LN input).
+    live: list of live 16-row tiles -- the rows of the other tiles of dz stay UNWRITTEN (list-driven consumers only)."""
     M, N = dy.shape
     assert dy.is_contiguous() and y.is_contiguous() and dy.dtype == y.dtype
     dz = torch.empty_like(dy)
     dzd = torch.empty_like(dy) if drop_p > 0 else None
+    if POISON_UNWRITTEN and live is not None:
+        dz.fill_(float("nan"))
+        if dzd is not None:
+            dzd.fill_(float("nan"))
     a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N,
-                  _p(dzd), drop_p, drop_seed)
+                  _p(dzd), drop_p, drop_seed, _p(live))
     _check(lib().rg_ln_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_ln_bwd")
     return (dz, dzd) if drop_p > 0 else dz
 

@@ -78,16 +78,20 @@ def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
 
-def _lists_everywhere(W1):
+def _lists_everywhere(W1, M):
     """True when every backward consumer of the fused block's saved activations is one of the list-driven kernels
     (bf16 tier; d_model = 128 is implied by the fused path; d_ff = 512 are the weight-gradient shapes the big kernel
-    has) -- only then may the padded tiles' rows of those buffers stay unwritten."""
-    return _COMPUTE == torch.bfloat16 and W1.shape[0] == 512
+    has; M rows enough for those kernels to be selected -- the conditions under which _live() hands the backward a
+    list) -- only then may the padded tiles' rows of those buffers stay unwritten."""
+    return _COMPUTE == torch.bfloat16 and W1.shape[0] == 512 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
 
 
-def _live(rowmask, M):
-    """List of live 16-row tiles for the big token-level GEMMs of a backward pass (None: process every row)."""
-    if rowmask is None or M < hip.COMPACT_MIN_ROWS or _COMPUTE != torch.bfloat16:
+def _live(rowmask, M, shapes_ok=True):
+    """List of live 16-row tiles for the token-level kernels of a backward pass (None: process every row).  Producers
+    leave the padded tiles' rows of dz / dctx / dh1 UNWRITTEN when a list is in use, so a list is handed out only where
+    every consumer honours it: bf16 tier, the shapes the list-driven GEMMs are instantiated for (shapes_ok) and enough
+    rows for them to be selected (rg_gemm_tn_big_select: T >= 8192; rg_gemm_ws_select: M >= 4096)."""
+    if rowmask is None or M < max(hip.COMPACT_MIN_ROWS, 8192) or _COMPUTE != torch.bfloat16 or not shapes_ok:
         return None
     return hip.live_tiles(rowmask, M)
 
@@ -298,8 +302,9 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     P = Wo.shape[1]
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     # rowmask here only lets the kernel skip the padded rows (their dy is already zero; the mask values are 0 / 1)
-    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
-    live = _live(rowmask, dy.shape[0])
+    live = _live(rowmask, dy.shape[0], d == 128 and P == 128)
+    # every consumer of dz below is list-driven: the padded tiles' rows of dz are never written nor read
+    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
     dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
@@ -340,12 +345,12 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     W1, b1, W2, b2, g, be = prm
     h1, rstd = saved
     d, dff = W2.shape
-    live = _live(rowmask, dout.shape[0])           # padded 16-row tiles: zero upstream gradient, skipped by the GEMMs
+    live = _live(rowmask, dout.shape[0], d == 128 and dff == 512)   # padded 16-row tiles: zero upstream gradient, skipped
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     if drop_p > 0:
-        dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out)
+        dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out, live=live)
     else:
-        dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe)
+        dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
@@ -374,7 +379,7 @@ class EncoderLayerFn(_Fn):
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
-                                        skip_dead_saves=_lists_everywhere(W1))
+                                        skip_dead_saves=_lists_everywhere(W1, B * L))
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
@@ -500,7 +505,7 @@ class DecoderLayerFn(_Fn):
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
-                                        seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1), **cross_kw)
+                                        seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1, B * L), **cross_kw)
             if need:
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
