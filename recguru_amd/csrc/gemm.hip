@@ -40,45 +40,49 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kc = 0; kc < a.K; kc += KC) {
-    const int klen = min(KC, a.K - kc);
-    const int ksteps = klen >> 5;
-    // weight fragments for the whole chunk: issued first so they fly while A is staged
-    Frag<T> bf[4][NTW];
+  // K is walked in 128-wide chunks, software-pipelined one chunk deep: while chunk c is in its MFMA phase the weight
+  // fragments and the A rows of chunk c+1 are already on their way into a second set of registers (the un-pipelined
+  // loop paid one exposed L2 / HBM latency per chunk: 10 of them for K = 1280, most of the kernel at M = 4096).
+  const int nk = (a.K + KC - 1) / KC;
+  auto load_chunk = [&](Frag<T> (&w)[4][NTW], Frag<T> (&pre)[4], int ci) {
+    const int kc = ci * KC, klen = min(KC, a.K - kc), ksteps = klen >> 5, cpr = klen >> 3;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
-        const int n = nb0 + j * 16 + li;
-        if (ks < ksteps && n < a.N && !(a.debug_ablate & 8))
-          load_frag(bf[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
-        else
-          frag_zero(bf[ks][j]);
+        const int n = min(nb0 + j * 16 + li, a.N - 1);           // clamped: columns >= N are never stored
+        if (ks < ksteps && !(a.debug_ablate & 8)) load_frag(w[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
+        else frag_zero(w[ks][j]);
       }
-    // stage pro(A[m0:m0+64, kc:kc+klen]) into LDS
-    const int cpr = klen >> 3;  // 8-element chunks per row
-    for (int c = tid; c < TM * cpr; c += 256) {
-      const int r = c / cpr, c8 = (c - r * cpr) * 8;
-      if (a.prologue == RG_PRO_NONE) {
-        // raw 16/32-byte copy, no conversion
-        Frag<T> raw;
-        if (m0 + r < a.M && !(a.debug_ablate & 1)) load_frag(raw, A + (size_t)(m0 + r) * a.lda + kc + c8);
-        else frag_zero(raw);
-        *reinterpret_cast<Frag<T>*>(As + r * LDA + c8) = raw;
-      } else {
-        float v[8];
-        if (m0 + r < a.M) {
-          load8(v, A + (size_t)(m0 + r) * a.lda + kc + c8);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_t<Precise<T>::value>(v[j]);
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = 0.f;
-        }
-        store8(As + r * LDA + c8, v);
+    for (int i = 0; i < 4; ++i) {                                 // 64 rows x (klen / 8) 16-byte chunks over 256 threads
+      const int c = tid + 256 * i;
+      if (c < TM * cpr) {
+        const int r = c / cpr, c8 = (c - r * cpr) * 8;
+        load_frag(pre[i], A + (size_t)min(m0 + r, a.M - 1) * a.lda + kc + c8);   // rows >= M: clamped, never stored
       }
     }
-    __syncthreads();
+  };
+  auto stage_chunk = [&](const Frag<T> (&pre)[4], int ci) {       // registers -> LDS, prologue applied on the way
+    const int klen = min(KC, a.K - ci * KC), cpr = klen >> 3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i;
+      if (c < TM * cpr) {
+        const int r = c / cpr, c8 = (c - r * cpr) * 8;
+        if (a.prologue == RG_PRO_NONE) {
+          *reinterpret_cast<Frag<T>*>(As + r * LDA + c8) = pre[i];
+        } else {
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = gelu_t<Precise<T>::value>((float)pre[i].v[j]);
+          store8(As + r * LDA + c8, v);
+        }
+      }
+    }
+  };
+  auto mma_chunk = [&](const Frag<T> (&w)[4][NTW], int ci) {
+    const int ksteps = min(KC, a.K - ci * KC) >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       if (ks < ksteps && !(a.debug_ablate & 2)) {
@@ -87,11 +91,36 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
           Frag<T> af;
           load_frag(af, As + (rt * 16 + li) * LDA + ks * 32 + 8 * lg);
 #pragma unroll
-          for (int j = 0; j < NTW; ++j) mma(af, bf[ks][j], acc[rt][j]);
+          for (int j = 0; j < NTW; ++j) mma(af, w[ks][j], acc[rt][j]);
         }
       }
     }
+  };
+  Frag<T> w0[4][NTW], p0[4];
+  if constexpr (sizeof(T) == 4) {     // f32 parity tier: fragments are twice as wide, one register set only
+    for (int ci = 0; ci < nk; ++ci) {
+      load_chunk(w0, p0, ci);
+      stage_chunk(p0, ci);
+      __syncthreads();
+      mma_chunk(w0, ci);
+      __syncthreads();
+    }
+  } else {
+  Frag<T> w1[4][NTW], p1[4];
+  load_chunk(w0, p0, 0);
+  for (int ci = 0; ci < nk; ci += 2) {
+    stage_chunk(p0, ci);
     __syncthreads();
+    if (ci + 1 < nk) load_chunk(w1, p1, ci + 1);
+    mma_chunk(w0, ci);
+    __syncthreads();
+    if (ci + 1 >= nk) break;
+    stage_chunk(p1, ci + 1);
+    __syncthreads();
+    if (ci + 2 < nk) load_chunk(w0, p0, ci + 2);
+    mma_chunk(w1, ci + 1);
+    __syncthreads();
+  }
   }
 
   // ------------------------------------------------------------------ epilogue
