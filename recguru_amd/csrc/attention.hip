@@ -68,18 +68,23 @@ template <int NT16>
 struct QLive {
   static constexpr int NR = (NT16 * 16 + 255) / 256;
   float v[NR];
-  __device__ __forceinline__ void load(const float* __restrict__ rowmask, int b, int L, int tid) {
+  bool has_mask;
+  int len;
+  // dummy: any readable float array, read at [0] when there is no rowmask (== rowmask otherwise)
+  __device__ __forceinline__ void load(const float* __restrict__ rowmask, const float* __restrict__ dummy, int b, int L, int tid) {
 #pragma unroll
-    for (int i = 0; i < NR; ++i) {
+    for (int i = 0; i < NR; ++i) {      // unconditional loads from clamped addresses, selected afterwards (no branch, no wait)
       const int r = i * 256 + tid;
-      v[i] = rowmask ? (r < L ? rowmask[(size_t)b * L + r] : 0.f) : 1.f;
+      v[i] = dummy[rowmask ? (size_t)b * L + min(r, L - 1) : 0];      // raw value; interpreted in publish()
     }
+    has_mask = rowmask != nullptr;
+    len = L;
   }
   __device__ __forceinline__ void publish(int* __restrict__ qlive, int tid) const {
     const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const unsigned long long m = __ballot(v[i] != 0.f);
+      const unsigned long long m = __ballot(has_mask ? (i * 256 + tid < len && v[i] != 0.f) : true);
       if (lane < 4) {
         const int t = (i * 256 + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
         if (t < NT16) qlive[t] = ((m >> (16 * lane)) & 0xFFFFull) != 0ull;
@@ -145,14 +150,19 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
   for (int rd = 0; rd < NRD; ++rd) {
     const int t = wave + 4 * (lg + 4 * rd), row = t * 16 + li;
-    rmw[rd] = (t < nqt && row < L) ? (a.rowmask ? a.rowmask[(size_t)b * L + row] : 1.f) : 0.f;
+    // unconditional load from a clamped address (a load under a condition makes hipcc wait for it at the join,
+    // i.e. BEFORE the staging loads below are issued); without a rowmask any readable float stands in
+    const float* __restrict__ rmp = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(a.qkv);
+    const float v = rmp[a.rowmask ? (size_t)b * L + min(row, L - 1) : 0];
+    rmw[rd] = (t < nqt && row < L) ? (a.rowmask ? v : 1.f) : 0.f;
   }
   constexpr int NKR = (LPK + 255) / 256;
   bool padk_r[NKR];                                // key ids: loaded ahead of the staging loads as well
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
     const int key = i * 256 + tid;
-    padk_r[i] = key < L && a.key_ids[(size_t)b * L + key] == a.pad_value;
+    const int64_t kid = a.key_ids[(size_t)b * L + min(key, L - 1)];
+    padk_r[i] = key < L && kid == a.pad_value;
   }
   // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
   // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
@@ -581,14 +591,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const unsigned int lp4 = rg_lpad(L);
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   QLive<NKT> ql;
-  ql.load(a.rowmask, b, L, tid);      // consumed after the staging loads below are in flight
+  const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.lse;
+  ql.load(a.rowmask, rmp, b, L, tid); // consumed after the staging loads below are in flight
   float lse_r[QLive<NKT>::NR];        // same for the per-row softmax statistics and key ids
   bool padk_r[QLive<NKT>::NR];
 #pragma unroll
   for (int i = 0; i < QLive<NKT>::NR; ++i) {
     const int r = i * 256 + tid;
-    lse_r[i] = (r < L) ? a.lse[((size_t)b * a.H + h) * L + r] : 0.f;
-    padk_r[i] = r < L && a.key_ids[(size_t)b * L + r] == a.pad_value;
+    const float lv = a.lse[((size_t)b * a.H + h) * L + min(r, L - 1)];
+    const int64_t kid = a.key_ids[(size_t)b * L + min(r, L - 1)];
+    lse_r[i] = (r < L) ? lv : 0.f;
+    padk_r[i] = r < L && kid == a.pad_value;
   }
   if (tid == 0) klo_s = L;
   __syncthreads();
@@ -610,7 +623,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         load_frag(vr[i], qkv + (size_t)rc * ld + 2 * P + h * DK + c8);
         load_frag(gr[i], dO + (size_t)rc * P + c8);
         load_frag(orow[i], O + (size_t)rc * P + c8);
-        if (a.rowmask) rmr[i] = a.rowmask[(size_t)b * L + rc];
+        const float x = rmp[a.rowmask ? (size_t)b * L + rc : 0];     // unconditional (see QLive::load)
+        rmr[i] = a.rowmask ? x : 1.f;
       }
     }
     // dctx rows with rowmask == 0 are zero by contract (rg_attn_bwd_args.rowmask) and are TAKEN as zero whatever the

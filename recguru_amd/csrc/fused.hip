@@ -236,7 +236,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
   int cur = (int)blockIdx.x;
   auto next_group = [&](int (&g)[4]) -> bool {
-    if (cur >= nwork) return false;
+    if (cur >= nwork) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = a.M;       // absent: prefetch_rows clamps, nothing is stored
+      return false;
+    }
     if (!a.live16) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
@@ -248,14 +252,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     cur += gridDim.x;
     return true;
   };
-  auto prefetch_rows = [&](const int (&g)[4]) {
+  auto prefetch_rows = [&](const int (&g)[4]) {         // rows >= M: clamped address, no branch (never stored)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c8 = (tid & 15) * 8, m = g[i] + (tid >> 4);
-      if (m < a.M) {
-        load_frag(cpre[i], ctx + (size_t)m * FD + c8);
-        load_frag(xpre[i], x + (size_t)m * FD + c8);
-      } else { frag_zero(cpre[i]); frag_zero(xpre[i]); }
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(cpre[i], ctx + (size_t)m * FD + c8);
+      load_frag(xpre[i], x + (size_t)m * FD + c8);
     }
   };
   int mb[4], mbn[4];
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
         if (a.rstd_c) a.rstd_c[mb[0] + tid] = 0.f;
       }
       lds_barrier();                                    // the staged ctx / x tile of this iteration is dropped
-      if (have_next) prefetch_rows(mbn);
+      prefetch_rows(mbn);
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
       have = have_next;
@@ -376,8 +378,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       load_wset(wq, W2, a.dff, n0, ch * FD, li, lg);    // needed after the GELU below
       init_acc(acc, p_b1 + ch * FD, n0, lg);
       mma_wset<T>(acc, wp, Ay, li, lg);                 // h1 chunk = y . W1[chunk]^T + b1
-      if (ch + 1 < nchunk) load_wset(wp, W1, FD, (ch + 1) * FD + n0, 0, li, lg);
-      else if (have_next) load_wset(wp, Wo, FD, n0, 0, li, lg);
+      // next weight set: W1 chunk ch+1, or Wo for the next tile -- ONE unconditional load sequence from a selected
+      // pointer (loads under a branch made hipcc drain vmcnt(0) at the join: the W2 fragments just issued above, i.e.
+      // one exposed L2 latency per chunk; Wo is fetched needlessly after a workgroup's last tile, 32 KB once)
+      load_wset(wp, (ch + 1 < nchunk) ? W1 + (size_t)(ch + 1) * FD * FD : Wo, FD, n0, 0, li, lg);
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
@@ -415,8 +419,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       mma_wset<T>(acc2, wq, Ag, li, lg);                // out += g . W2[:, chunk]^T
       STAMP(8);
     }
-    // prefetch the next tile's ctx / x rows while the second LayerNorm runs
-    if (have_next) prefetch_rows(mbn);
+    // prefetch the next tile's ctx / x rows while the second LayerNorm runs (unconditional: see next_group)
+    prefetch_rows(mbn);
     if constexpr (DM != 0) {    // dropout on the l2 output, before the residual (transformer.py:186-188)
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
