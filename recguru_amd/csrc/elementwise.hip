@@ -71,19 +71,20 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
   const long long wave = ((long long)blockIdx.x * EW_BLOCK + tid) >> 6;
   const long long nwaves = ((long long)gridDim.x * EW_BLOCK) >> 6;
   for (long long t0 = wave * ES_UNROLL; t0 < ntok; t0 += nwaves * ES_UNROLL) {
-    float m[ES_UNROLL], g[ES_UNROLL][NPL];
+    float m[ES_UNROLL];
+    T g[ES_UNROLL][NPL];        // raw: converted where used, so that the loads of all tokens are in flight together
     long long row[ES_UNROLL];
 #pragma unroll
     for (int u = 0; u < ES_UNROLL; ++u) {
       const long long tok = min(t0 + u, ntok - 1);
-      m[u] = (t0 + u < ntok) ? mask[tok] : 0.f;
+      m[u] = mask[tok];
       row[u] = ids[tok];
 #pragma unroll
-      for (int j = 0; j < NPL; ++j) {
-        const int e = lane + 64 * j;
-        g[u][j] = e < d ? (float)dx[(size_t)tok * d + e] : 0.f;
-      }
+      for (int j = 0; j < NPL; ++j) g[u][j] = dx[(size_t)tok * d + min(lane + 64 * j, d - 1)];
     }
+#pragma unroll
+    for (int u = 0; u < ES_UNROLL; ++u)
+      if (t0 + u >= ntok) m[u] = 0.f;
 #pragma unroll
     for (int u = 0; u < ES_UNROLL; ++u) {
       if (m[u] == 0.f || row[u] == skip_row) continue;
@@ -106,7 +107,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
       for (int j = 0; j < NPL; ++j) {
         const int e = lane + 64 * j;
         if (e < d) {
-          float v = g[u][j] * m[u];
+          float v = (float)g[u][j] * m[u];
           if (drop.thresh) v *= rg_keep(drop, (unsigned int)(t0 + u) * (unsigned int)d + (unsigned int)e);
           if (slot >= 0) atomicAdd(es_acc + slot * d + e, v);
           else atomicAdd(dE + (size_t)row[u] * d + e, v);
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   T* __restrict__ dzd = reinterpret_cast<T*>(a.dz_drop);
   const DropCfg drop = make_drop(a.drop_p, a.drop_seed);
   const float invn = 1.f / (float)N;
-  float gam[8], bet[8], dg[8], db[8];
+  float gam[8], bet[8], igam[8], dg[8], db[8];
   load8(gam, a.gamma + c8);
   load8(bet, a.beta + c8);
 #pragma unroll
-  for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; igam[j] = 1.f / gam[j]; }
+  const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.rstd;      // any readable float array stands in
   const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
   // work unit = RPW consecutive rows: unit u of the matrix, or -- list-driven -- part (u % (16 / RPW)) of the
   // u / (16 / RPW)-th live 16-row tile (rows of unlisted tiles are neither read nor written)
@@ -158,18 +160,31 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
     const long long m0 = a.live16 ? (long long)a.live16[1 + u / UPT] * 16 + (u % UPT) * RPW : u * RPW;
     const long long m = m0 + rr;
     const bool live = m < a.M;
-    const float rm = live ? (a.rowmask ? a.rowmask[m] : 1.f) : 0.f;
-    float g[8], xh[8];
-    float s1 = 0.f, s2 = 0.f;
+    const long long mc = live ? m : a.M - 1;
+    float g[8], xh[8], d8[8], y8[8];
+    float s1 = 0.f, s2 = 0.f, rm, rstd_m = 0.f;
+    if (a.live16) {
+      // list-driven: 9 of 10 rows of a live tile are live -- mask, dy, y and rstd are loaded together, unconditionally
+      // (clamped row), instead of mask -> branch -> rows -> rstd as three dependent latencies
+      const float rv = rmp[a.rowmask ? mc : 0];
+      load8(d8, dy + (size_t)mc * a.ld + c8);
+      load8(y8, y + (size_t)mc * a.ld + c8);
+      rstd_m = a.rstd[mc];
+      rm = live ? (a.rowmask ? rv : 1.f) : 0.f;
+    } else {
+      rm = live ? (a.rowmask ? a.rowmask[m] : 1.f) : 0.f;
+      if (rm != 0.f) {                // 43 % of the rows are padding here: their dy / y are not read
+        load8(d8, dy + (size_t)m * a.ld + c8);
+        load8(y8, y + (size_t)m * a.ld + c8);
+        rstd_m = a.rstd[m];
+      }
+    }
     if (rm != 0.f) {
-      float d8[8], y8[8];
-      load8(d8, dy + (size_t)m * a.ld + c8);
-      load8(y8, y + (size_t)m * a.ld + c8);
       const float irm = 1.f / rm;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float d = d8[j] * rm;
-        xh[j] = (y8[j] * irm - bet[j]) / gam[j];
+        xh[j] = (y8[j] * irm - bet[j]) * igam[j];
         g[j] = d * gam[j];
         dg[j] += d * xh[j];
         db[j] += d;
@@ -183,7 +198,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
 #pragma unroll
     for (int o = 1; o < LPR; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
     if (live) {
-      const float rstd = rm != 0.f ? a.rstd[m] : 0.f;
+      const float rstd = rm != 0.f ? rstd_m : 0.f;
       s1 *= invn;
       s2 *= invn;
       float o8[8];

@@ -359,6 +359,26 @@ __device__ __forceinline__ long long pair_item(const rg_item_loss_args& a, long 
   return item == a.skip_row ? -1 : item;
 }
 
+// The items of pairs p, p+256, p+512, p+768 (-1: masked position, skip row, or p >= p1).  Branch-free: clamped
+// indices and ONE id load per pair from a selected pointer, so that the 8 loads of a batch are in flight together
+// (a pair at a time, mask -> id was two dependent latencies per loop iteration).
+#define RG_PB 4
+__device__ __forceinline__ void pair_items4(const rg_item_loss_args& a, long long p, long long p1, int n, long long (&it)[RG_PB]) {
+  float mk[RG_PB];
+#pragma unroll
+  for (int u = 0; u < RG_PB; ++u) {
+    const long long pc = min(p + 256 * u, p1 - 1);
+    const long long t = pc / n;
+    const int idx = (int)(pc - t * n);
+    mk[u] = a.mask[t];
+    const int64_t* __restrict__ src = idx == 0 ? a.pos + t : a.neg + t * a.k + (idx - 1);
+    it[u] = *src;
+  }
+#pragma unroll
+  for (int u = 0; u < RG_PB; ++u)
+    if (p + 256 * u >= p1 || mk[u] == 0.f || it[u] == a.skip_row) it[u] = -1;
+}
+
 __global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, BinWs w) {
   extern __shared__ int lh[];
   const int n = a.k + 1;
@@ -366,9 +386,12 @@ __global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, Bin
   for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
   __syncthreads();
   const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
-  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
-    const long long item = pair_item(a, p, n);
-    if (item >= 0) atomicAdd(&lh[item >> RG_RPB_LOG], 1);
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256 * RG_PB) {
+    long long it[RG_PB];
+    pair_items4(a, p, p1, n, it);
+#pragma unroll
+    for (int u = 0; u < RG_PB; ++u)
+      if (it[u] >= 0) atomicAdd(&lh[it[u] >> RG_RPB_LOG], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < w.nbins; i += 256)
@@ -406,9 +429,12 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
   for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
   __syncthreads();
   const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
-  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
-    const long long item = pair_item(a, p, n);
-    if (item >= 0) atomicAdd(&lh[item >> RG_RPB_LOG], 1);
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256 * RG_PB) {
+    long long it[RG_PB];
+    pair_items4(a, p, p1, n, it);
+#pragma unroll
+    for (int u = 0; u < RG_PB; ++u)
+      if (it[u] >= 0) atomicAdd(&lh[it[u] >> RG_RPB_LOG], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < w.nbins; i += 256) {
@@ -417,12 +443,20 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
     lh[i] = 0;
   }
   __syncthreads();
-  for (long long p = p0 + threadIdx.x; p < p1; p += 256) {
-    const long long item = pair_item(a, p, n);
-    if (item < 0) continue;
-    const int b = (int)(item >> RG_RPB_LOG);
-    const int e = base[b] + atomicAdd(&lh[b], 1);
-    w.ent[e] = make_uint2(((unsigned int)(p / n) << RG_RPB_LOG) | (unsigned int)(item & (RG_RPB - 1)), __float_as_uint(w.c[p]));
+  for (long long p = p0 + threadIdx.x; p < p1; p += 256 * RG_PB) {
+    long long it[RG_PB];
+    float cv[RG_PB];
+    pair_items4(a, p, p1, n, it);
+#pragma unroll
+    for (int u = 0; u < RG_PB; ++u) cv[u] = w.c[min(p + 256 * u, p1 - 1)];
+#pragma unroll
+    for (int u = 0; u < RG_PB; ++u) {
+      if (it[u] < 0) continue;
+      const long long pu = p + 256 * u;
+      const int b = (int)(it[u] >> RG_RPB_LOG);
+      const int e = base[b] + atomicAdd(&lh[b], 1);
+      w.ent[e] = make_uint2(((unsigned int)(pu / n) << RG_RPB_LOG) | (unsigned int)(it[u] & (RG_RPB - 1)), __float_as_uint(cv[u]));
+    }
   }
 }
 
@@ -462,11 +496,10 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
       const int e = e0 + tid + 256 * i;
-      myr[i] = -1;
-      if (e < e1) {
-        const uint2 en = w.ent[e];
-        myr[i] = (int)(en.x & (RG_RPB - 1)); myt[i] = (int)(en.x >> RG_RPB_LOG); myc[i] = __uint_as_float(en.y);
-      }
+      const uint2 en = w.ent[max(min(e, e1 - 1), 0)];       // unconditional (clamped): the 8 loads fly together
+      myr[i] = e < e1 ? (int)(en.x & (RG_RPB - 1)) : -1;
+      myt[i] = (int)(en.x >> RG_RPB_LOG);
+      myc[i] = __uint_as_float(en.y);
     }
 #pragma unroll
     for (int i = 0; i < EPT; ++i)
