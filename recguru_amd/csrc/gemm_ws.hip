@@ -17,7 +17,9 @@
 #define WS_M 64
 #define WS_LD (128 + 8)
 
-template <int NKC, int NCB>
+// AUX: the epilogue reads an aux operand (compile-time: a load under a runtime condition gets a vmcnt(0) at the join,
+// which also drained the next tile's A prefetch -- one exposed HBM latency per tile even for the aux-free GEMMs)
+template <int NKC, int NCB, bool AUX>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   static_assert(NKC == 1 || NCB == 1, "either K or N spans a single 128-wide block");
   typedef __bf16 T;
@@ -72,7 +74,6 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // aux rows (epilogue operand) of the NEXT epilogue step -- the next 128-feature block of this tile, or block 0 of
   // the next tile -- are loaded a whole step ahead: loaded inside the step they cost one exposed HBM latency per
   // block (the MFMAs of one block cover a fifth of it)
-  const bool need_aux = a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU;
   Frag<T> axn[4];
   auto aux_prefetch = [&](const int (&g)[4], int cb) {
 #pragma unroll
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   if (tile < nwork) {
     group(tile, mb);
     prefetch(mb, 0);
-    if (need_aux) aux_prefetch(mb, 0);
+    if constexpr (AUX) aux_prefetch(mb, 0);
   }
   for (; tile < nwork; tile += gridDim.x) {
     group(tile + (int)gridDim.x, mbn);
@@ -99,17 +100,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
         const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
         *reinterpret_cast<Frag<T>*>(As + r * WS_LD + c8) = pre[i];
       }
+      // unconditional (rows of an absent next tile are clamped inside prefetch): loads under a runtime branch get a
+      // vmcnt(0) at the join, which exposed one HBM latency per tile
       if (kc + 1 < NKC) prefetch(mb, kc + 1);
-      else if (tile + (int)gridDim.x < nwork) prefetch(mbn, 0);
+      else prefetch(mbn, 0);
       lds_barrier();
 #pragma unroll
       for (int cb = 0; cb < NCB; ++cb) {
         Frag<T> axf[4];                                   // aux rows of this block (prefetched one step ago)
-        if (kc == NKC - 1 && need_aux) {
+        if constexpr (AUX) if (kc == NKC - 1) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) axf[i] = axn[i];
           if (cb + 1 < NCB) aux_prefetch(mb, cb + 1);
-          else if (tile + (int)gridDim.x < nwork) aux_prefetch(mbn, 0);
+          else aux_prefetch(mbn, 0);
         }
         if (kc == 0) {
 #pragma unroll
@@ -146,8 +149,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             const int m = mb[i] + (tid >> 4);
             if (m < a.M) {
               const size_t off = (size_t)m * a.ldc + cb * 128 + c8;
-              if (a.epilogue == RG_EPI_NONE) {
-                *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
+              if constexpr (!AUX) {
+                if (a.epilogue == RG_EPI_NONE) {
+                  *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
+                } else {              // RG_EPI_RELU
+                  float v[8];
+                  load8(v, Cs + r * WS_LD + c8);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+                  store8(C + off, v);
+                }
               } else {
                 float v[8], x[8];
                 load8(v, Cs + r * WS_LD + c8);
@@ -166,13 +177,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
                 } else if (a.epilogue == RG_EPI_ADD) {
 #pragma unroll
                   for (int j = 0; j < 8; ++j) v[j] += x[j];
-                } else if (a.epilogue == RG_EPI_MUL_POSMASK) {
+                } else {              // RG_EPI_MUL_POSMASK
                   const float sc = a.epi_scale > 0.f ? a.epi_scale : 1.f;
 #pragma unroll
                   for (int j = 0; j < 8; ++j) v[j] = x[j] > 0.f ? v[j] * sc : 0.f;
-                } else {
-#pragma unroll
-                  for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
                 }
                 store8(C + off, v);
               }
@@ -210,7 +218,8 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   int grid = 512;
   if (grid > ntiles) grid = ntiles;
-  hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB>), dim3(grid), dim3(256), 0, s, a);
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, false>), dim3(grid), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
 }
