@@ -556,15 +556,25 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // and the products are oriented so that dK^T / dV^T / dQ^T land with 4 consecutive features per
 // lane: gradients leave as packed 8-byte stores.
 // ------------------------------------------------------------------------------------------------
-template <int NKT, bool CAUSAL, int DM>
+//
+// ONEPASS (L <= 256): dQ is accumulated in the SAME sweep instead of a second one that recomputes S^T, dP^T and the
+// softmax -- the kernel is bound by the VALU (exp2, masks, converts: 14 issue slots per score in phase 1 + 9.5 in
+// phase 2 against 1/4 of an MFMA), not by the matrix pipe.  A wave keeps dQ^T for ALL queries of the head in
+// registers (NKT x 2 accumulator tiles, partial over the wave's key tiles); each 16 x 16 dS tile is written as bf16
+// into the (otherwise unused) pad columns of the wave's own rows of the Q / K tiles and read back with the
+// transposing LDS read as the [key][query] operand of a 16x16x16 MFMA against K^T; the four partial dQ^T are summed
+// through the (by then dead) Q/K/V/dO tiles at the end.
+template <int NKT, bool CAUSAL, int DM, bool ONEPASS>
 __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
+  static_assert(!ONEPASS || NKT >= 8, "the dS scratch tiles need 4 x 32 rows of pad columns");
   typedef __bf16 T;
   constexpr int LPK = NKT * 16;
   constexpr int LDR = DK + 8;
-  __shared__ __align__(16) T Qs[LPK * LDR];
-  __shared__ __align__(16) T Ks[LPK * LDR];
-  __shared__ __align__(16) T Vs[LPK * LDR];
-  __shared__ __align__(16) T Gs[LPK * LDR];     // dO
+  __shared__ __align__(16) T QKVG[4 * LPK * LDR];            // one block: reused as f32 scratch by the ONEPASS reduction
+  T* const Qs = QKVG;
+  T* const Ks = QKVG + LPK * LDR;
+  T* const Vs = QKVG + 2 * LPK * LDR;
+  T* const Gs = QKVG + 3 * LPK * LDR;           // dO
   __shared__ __align__(16) float lse2_s[LPK];   // lse * log2(e)   (+inf marks a fully masked row)
   __shared__ __align__(16) float dl_s[LPK];     // delta = rowsum(dO * O)
   __shared__ __align__(16) float rowp_s[LPK];   // 1/L for fully masked rows, else 0
@@ -673,6 +683,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   lds_barrier();
   const int klo = klo_s;
 
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  f32x4 dq1[ONEPASS ? NKT : 1][2];                  // ONEPASS: this wave's partial dQ^T, all query tiles
+  if constexpr (ONEPASS) {
+#pragma unroll
+    for (int i = 0; i < NKT; ++i) { dq1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  }
   // ---------------------------------------------------------------- phase 1: dK^T, dV^T
   for (int kt = wave; kt < nt; kt += 4) {
     const int key = kt * 16 + li;                   // this lane's key (column of S)
@@ -682,9 +699,15 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     const float kb = kbias[key];
     f32x4 dkt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    for (int qs = 0; qs < nt / 2; ++qs) {
-      if (!(qlive[2 * qs] | qlive[2 * qs + 1])) continue;   // padded query rows only: dO = 0 there, nothing to add to dK / dV
-      if (CAUSAL && 2 * qs + 1 < kt && qs * 32 >= klo) continue;   // keys entirely in the future of both query tiles: P = dS = 0
+    s16x4 ktf16[2];                                 // ONEPASS: K^T of this key tile as the [dk][key] operand (k = 16 keys)
+    if constexpr (ONEPASS) {
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+        ktf16[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Ks + (kt * 16 + 4 * lg + (li >> 2)) * LDR + dt * 16 + 4 * (li & 3)));
+    }
+    auto qstep = [&](const int qs) {
+      if (!(qlive[2 * qs] | qlive[2 * qs + 1])) return;     // padded query rows only: dO = 0 there, nothing to add to dK / dV
+      if (CAUSAL && 2 * qs + 1 < kt && qs * 32 >= klo) return;     // keys entirely in the future of both query tiles: P = dS = 0
       f32x4 p[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -738,6 +761,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         mma(gtf, pf, dvt[dt]);     // dV^T[dv][key] += sum_q dO[q][dv] P[q][key]
         mma(qtf, dsf, dkt[dt]);    // dK^T[dk][key] += sum_q Q[q][dk] dS[q][key]
       }
+      if constexpr (ONEPASS) {
+        // dS[q][key] (accumulator layout: lane = key, registers = 4 queries) -> bf16 -> the wave's scratch tile
+        // T[key][q] in the pad columns (32..39) of ITS rows of Qs (q 0..7) and Ks (q 8..15), one 8-byte store per
+        // lane; the transposing read hands lane (q, lg) the keys 4 lg .. 4 lg + 3 of column q: the [key][q] operand
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          bf16x4_t pk;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) pk[r] = (T)ds[u][r];
+          T* wr = (lg < 2 ? Qs : Ks) + (wave * 32 + u * 16 + li) * LDR + DK + 4 * (lg & 1);
+          *reinterpret_cast<bf16x4_t*>(wr) = pk;
+        }
+        asm volatile("" ::: "memory");              // LDS operations of one wave are executed in order
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int pq = li & 3;
+          const T* rd = (pq < 2 ? Qs : Ks) + (wave * 32 + u * 16 + 4 * lg + (li >> 2)) * LDR + DK + 4 * (pq & 1);
+          const s16x4 dst16 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)rd);
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt)        // dQ^T[dk][q] += sum_key K[key][dk] dS[q][key]
+            dq1[2 * qs + u][dt] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(ktf16[dt], dst16, dq1[2 * qs + u][dt], 0, 0, 0);
+        }
+        asm volatile("" ::: "memory");
+      }
+    };
+    if constexpr (ONEPASS) {
+#pragma unroll
+      for (int qs = 0; qs < NKT / 2; ++qs)
+        if (qs < nt / 2) qstep(qs);
+    } else {
+      for (int qs = 0; qs < nt / 2; ++qs) qstep(qs);
     }
     if (key < L) {
 #pragma unroll
@@ -750,6 +804,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     }
   }
 
+  if constexpr (!ONEPASS) {
   // ---------------------------------------------------------------- phase 2: dQ^T
   for (int qt = wave; qt < nt; qt += 4) {
     const int q = qt * 16 + li;                     // this lane's query (column of S^T)
@@ -809,6 +864,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
       }
     }
   }
+  } else {
+    // ---- ONEPASS: sum the four partial dQ^T through the dead operand tiles, half of the query tiles per round:
+    // every wave parks its tiles ([wave][tile][dt] x 1 KB, lane-major: conflict-free 16-byte accesses), then each wave
+    // sums and stores a quarter of them
+    float* red = reinterpret_cast<float*>(QKVG);
+    constexpr int HT = NKT / 2;                     // tiles per round
+#pragma unroll
+    for (int rnd = 0; rnd < 2; ++rnd) {
+      __syncthreads();                              // round 0: every wave is done with Q / K / V / dO; round 1: readers done
+#pragma unroll
+      for (int i = 0; i < HT; ++i)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          *reinterpret_cast<f32x4*>(red + (((wave * HT + i) * 2 + dt) * 64 + lane) * 4) = dq1[rnd * HT + i][dt];
+      __syncthreads();
+      for (int i = wave; i < HT; i += 4) {
+        const int qt = rnd * HT + i, q = qt * 16 + li;
+        if (qt >= nt || q >= L) continue;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          f32x4 sacc = *reinterpret_cast<const f32x4*>(red + (((0 * HT + i) * 2 + dt) * 64 + lane) * 4);
+#pragma unroll
+          for (int w = 1; w < 4; ++w) sacc += *reinterpret_cast<const f32x4*>(red + (((w * HT + i) * 2 + dt) * 64 + lane) * 4);
+          float v[4] = {sacc[0] * a.scale, sacc[1] * a.scale, sacc[2] * a.scale, sacc[3] * a.scale};
+          store4(dqkv + (size_t)q * ld + h * DK + dt * 16 + 4 * lg, v);
+        }
+      }
+    }
+  }
 }
 
 template <typename T>
@@ -847,9 +931,9 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
     const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
 #define RG_BWD16_2(N, C)                                                                              \
   do {                                                                                                \
-    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0>), grid, block, 0, s, a);           \
-    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1>), grid, block, 0, s, a);      \
-    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2>), grid, block, 0, s, a);                   \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, (N >= 8 && N <= 16)>), grid, block, 0, s, a);           \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1, (N >= 8 && N <= 16)>), grid, block, 0, s, a);      \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2, (N >= 8 && N <= 16)>), grid, block, 0, s, a);                   \
   } while (0)
 #define RG_BWD16(N)                        \
   do {                                     \
