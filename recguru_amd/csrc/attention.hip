@@ -13,6 +13,7 @@
 // Whole key range of one head lives on chip (L <= 16*NKT): S^T = K.Q^T accumulators (key on the
 // register axis, query on the lane) are exponentiated in place and fed straight back as the B
 // operand of O^T = V^T.P^T (rg_common.cuh, stacked-accumulator mapping) -- P never touches LDS.
+#include <stdlib.h>
 #include "rg_common.cuh"
 #include "../../include/recguru_hip.h"
 
@@ -929,9 +930,16 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
   dim3 grid(rg_head_grid(a.B, a.H)), block(256);
   if constexpr (sizeof(T) == 2) {
     const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+    // test hook: RG_ATTN_BWD_TWO_PHASE=1 runs the two-phase (softmax recomputed for dQ) form at every length, so that
+    // tests can hold the one-pass form against it on identical inputs and seeds
+    const bool two_phase = getenv("RG_ATTN_BWD_TWO_PHASE") != nullptr;
 #define RG_BWD16_2(N, C)                                                                              \
   do {                                                                                                \
-    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, (N >= 8 && N <= 16)>), grid, block, 0, s, a);           \
+    if (two_phase) {                                                                                  \
+      if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, false>), grid, block, 0, s, a);    \
+      else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1, false>), grid, block, 0, s, a); \
+      else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2, false>), grid, block, 0, s, a);            \
+    } else if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, (N >= 8 && N <= 16)>), grid, block, 0, s, a);  \
     else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1, (N >= 8 && N <= 16)>), grid, block, 0, s, a);      \
     else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2, (N >= 8 && N <= 16)>), grid, block, 0, s, a);                   \
   } while (0)
