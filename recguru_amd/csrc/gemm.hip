@@ -16,7 +16,9 @@
 #define KC 128
 #define APAD 8
 
-template <typename T, int NTW>
+// FULLK: K is a multiple of 128 -- every chunk is whole, so the prefetch of the next chunk is straight-line code (with
+// run-time chunk lengths each guarded load got a vmcnt(0) at its join and the "prefetch" ran one load at a time)
+template <typename T, int NTW, bool FULLK>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   constexpr int TN = 64 * NTW;
   constexpr int LDA = KC + APAD;
@@ -45,30 +47,31 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   // loop paid one exposed L2 / HBM latency per chunk: 10 of them for K = 1280, most of the kernel at M = 4096).
   const int nk = (a.K + KC - 1) / KC;
   auto load_chunk = [&](Frag<T> (&w)[4][NTW], Frag<T> (&pre)[4], int ci) {
-    const int kc = ci * KC, klen = min(KC, a.K - kc), ksteps = klen >> 5, cpr = klen >> 3;
+    const int kc = ci * KC, klen = FULLK ? KC : min(KC, a.K - kc), ksteps = klen >> 5, cpr = klen >> 3;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
       for (int j = 0; j < NTW; ++j) {
         const int n = min(nb0 + j * 16 + li, a.N - 1);           // clamped: columns >= N are never stored
-        if (ks < ksteps && !(a.debug_ablate & 8)) load_frag(w[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
+        if constexpr (FULLK) load_frag(w[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
+        else if (ks < ksteps && !(a.debug_ablate & 8)) load_frag(w[ks][j], W + (size_t)n * a.ldw + kc + ks * 32 + 8 * lg);
         else frag_zero(w[ks][j]);
       }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {                                 // 64 rows x (klen / 8) 16-byte chunks over 256 threads
       const int c = tid + 256 * i;
-      if (c < TM * cpr) {
+      if (FULLK || c < TM * cpr) {
         const int r = c / cpr, c8 = (c - r * cpr) * 8;
         load_frag(pre[i], A + (size_t)min(m0 + r, a.M - 1) * a.lda + kc + c8);   // rows >= M: clamped, never stored
       }
     }
   };
   auto stage_chunk = [&](const Frag<T> (&pre)[4], int ci) {       // registers -> LDS, prologue applied on the way
-    const int klen = min(KC, a.K - ci * KC), cpr = klen >> 3;
+    const int klen = FULLK ? KC : min(KC, a.K - ci * KC), cpr = klen >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i;
-      if (c < TM * cpr) {
+      if (FULLK || c < TM * cpr) {
         const int r = c / cpr, c8 = (c - r * cpr) * 8;
         if (a.prologue == RG_PRO_NONE) {
           *reinterpret_cast<Frag<T>*>(As + r * LDA + c8) = pre[i];
@@ -82,10 +85,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
     }
   };
   auto mma_chunk = [&](const Frag<T> (&w)[4][NTW], int ci) {
-    const int ksteps = min(KC, a.K - ci * KC) >> 5;
+    const int ksteps = FULLK ? 4 : min(KC, a.K - ci * KC) >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
-      if (ks < ksteps && !(a.debug_ablate & 2)) {
+      if (FULLK || (ks < ksteps && !(a.debug_ablate & 2))) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           Frag<T> af;
@@ -109,15 +112,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   Frag<T> w1[4][NTW], p1[4];
   load_chunk(w0, p0, 0);
   for (int ci = 0; ci < nk; ci += 2) {
+    // the prefetch is UNCONDITIONAL (past the end it re-reads the last chunk): under a condition the compiler cannot
+    // count the loads in flight at the join and waits for all of them before the MFMAs
     stage_chunk(p0, ci);
     __syncthreads();
-    if (ci + 1 < nk) load_chunk(w1, p1, ci + 1);
+    load_chunk(w1, p1, min(ci + 1, nk - 1));
     mma_chunk(w0, ci);
     __syncthreads();
     if (ci + 1 >= nk) break;
     stage_chunk(p1, ci + 1);
     __syncthreads();
-    if (ci + 2 < nk) load_chunk(w0, p0, ci + 2);
+    load_chunk(w0, p0, min(ci + 2, nk - 1));
     mma_chunk(w1, ci + 1);
     __syncthreads();
   }
@@ -129,6 +134,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
   float* Z = reinterpret_cast<float*>(smem);
   const int ncol0 = blockIdx.y * TN;
+  // aux vectors of this thread's epilogue iterations: all loaded here, ahead of the Z staging (inside the epilogue loop
+  // each one was a load -> wait -> compute -> store round trip)
+  constexpr int NEI = TM * (TN / 8) / 256;
+  const bool vec_io = ((a.N & 7) == 0) && ((a.ldc & 7) == 0) && (a.aux == nullptr || (a.ldaux & 7) == 0);
+  const bool aux_vec = vec_io && aux != nullptr && a.epilogue != RG_EPI_RESID_LN && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_NONE;
+  Frag<T> axp[NEI];
+  if (aux_vec) {
+#pragma unroll
+    for (int i = 0; i < NEI; ++i) {
+      const int c = tid + 256 * i, row = c / (TN / 8), c8 = (c - row * (TN / 8)) * 8;
+      const int m = min(m0 + row, a.M - 1), n = min(ncol0 + c8, a.N - 8);
+      load_frag(axp[i], aux + (size_t)m * a.ldaux + n);
+    }
+  }
 #pragma unroll
   for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
@@ -141,8 +160,10 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   __syncthreads();
   if (a.epilogue != RG_EPI_RESID_LN) {
     constexpr int CPR = TN / 8;
-    const bool vec = ((a.N & 7) == 0) && ((a.ldc & 7) == 0) && (a.aux == nullptr || (a.ldaux & 7) == 0);
-    for (int c = tid; c < TM * CPR; c += 256) {
+    const bool vec = vec_io;
+#pragma unroll
+    for (int ei = 0; ei < NEI; ++ei) {
+      const int c = tid + 256 * ei;
       const int row = c / CPR, c8 = (c - row * CPR) * 8;
       const int m = m0 + row, n = ncol0 + c8;
       if (m >= a.M || n >= a.N) continue;
@@ -162,7 +183,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
           }
         } else if (a.epilogue != RG_EPI_NONE) {
           float x[8];
-          load8(x, aux + (size_t)m * a.ldaux + n);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = (float)axp[ei].v[j];
           // uniform switch outside the element loops (inside, each element is its own basic block)
           if (a.epilogue == RG_EPI_MUL_POSMASK) {
             const float sc = a.epi_scale > 0.f ? a.epi_scale : 1.f;
@@ -253,9 +275,16 @@ static int launch_nt(const rg_gemm_nt_args& a, hipStream_t s) {
   dim3 grid((a.M + TM - 1) / TM, (a.N + tn - 1) / tn);
   if (a.epilogue == RG_EPI_RESID_LN && grid.y != 1)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: RESID_LN needs N <= 256");
-  if (ntw == 1) hipLaunchKernelGGL((gemm_nt_kernel<T, 1>), grid, dim3(256), 0, s, a);
-  else if (ntw == 2) hipLaunchKernelGGL((gemm_nt_kernel<T, 2>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_nt_kernel<T, 4>), grid, dim3(256), 0, s, a);
+  const bool fullk = (a.K % KC) == 0 && !(a.debug_ablate & 15);
+#define RG_NT(NTW_)                                                                              \
+  do {                                                                                           \
+    if (fullk) hipLaunchKernelGGL((gemm_nt_kernel<T, NTW_, true>), grid, dim3(256), 0, s, a);   \
+    else hipLaunchKernelGGL((gemm_nt_kernel<T, NTW_, false>), grid, dim3(256), 0, s, a);        \
+  } while (0)
+  if (ntw == 1) RG_NT(1);
+  else if (ntw == 2) RG_NT(2);
+  else RG_NT(4);
+#undef RG_NT
   RG_CHECK_LAUNCH();
   return 0;
 }
