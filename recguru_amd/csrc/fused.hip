@@ -332,28 +332,54 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     if (a.o_bcast || a.cross_s) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
       if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, mb, a.M, tid); }
+      // o rows: the (uniform) dropout / no-dropout switch sits outside the loops and the loads of a row tile are
+      // issued together (inside the loops every (rt, ct, head) was a branch + load + wait: ~30 exposed L2 latencies
+      // per tile, the decoder launches ran at half the rate of the encoder ones)
+      int mrow[4], brow[4];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        const int m = min(mb[rt] + li, a.M - 1);
+      for (int rt = 0; rt < 4; ++rt) { mrow[rt] = min(mb[rt] + li, a.M - 1); brow[rt] = mrow[rt] / a.L; }
+      if (a.cross_s) {          // dropout: o = bo + sum_h s[m,h] * oh[b,h,:]   (H == P / 32 == 4 on this path)
+        float sv[4][4], bo4[2][4];
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct) {
-          float o4[4], y4[4];
-          if (a.cross_s) {      // dropout: o = bo + sum_h s[m,h] * oh[b,h,:]
-            load4f(o4, a.cross_bo + n0 + ct * 16 + 4 * lg);
-            for (int hh = 0; hh < a.H; ++hh) {
-              float w4[4];
-              const float sv = a.cross_s[(size_t)m * a.H + hh];
-              load4f(w4, a.cross_oh + ((size_t)(m / a.L) * a.H + hh) * FD + n0 + ct * 16 + 4 * lg);
+        for (int rt = 0; rt < 4; ++rt) load4f(sv[rt], a.cross_s + (size_t)mrow[rt] * 4);
 #pragma unroll
-              for (int r = 0; r < 4; ++r) o4[r] += sv * w4[r];
+        for (int ct = 0; ct < 2; ++ct) load4f(bo4[ct], a.cross_bo + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          float w4[2][4][4];
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+            for (int hh = 0; hh < 4; ++hh)
+              load4f(w4[ct][hh], a.cross_oh + ((size_t)brow[rt] * 4 + hh) * FD + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float y4[4];
+            load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float o = bo4[ct][r];
+#pragma unroll
+              for (int hh = 0; hh < 4; ++hh) o += sv[rt][hh] * w4[ct][hh][r];
+              acc[ct][rt][r] = y4[r] + o;
             }
-          } else {
-            load4f(o4, a.o_bcast + (size_t)(m / a.L) * FD + n0 + ct * 16 + 4 * lg);
           }
-          load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[r];
         }
+      } else {
+        float o4[4][2][4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) load4f(o4[rt][ct], a.o_bcast + (size_t)brow[rt] * FD + n0 + ct * 16 + 4 * lg);
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            float y4[4];
+            load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[rt][ct][r];
+          }
       }
       lds_barrier();                                    // ysave copy done before the tile is overwritten
       ln_regs(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
@@ -510,7 +536,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
   if ((a->o_bcast || a->cross_s) && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross stage needs L");
-  if (a->cross_s && (!a->cross_oh || !a->cross_bo || a->H <= 0)) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross_s needs cross_oh, cross_bo, H");
+  if (a->cross_s && (!a->cross_oh || !a->cross_bo || a->H != 4)) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross_s needs cross_oh, cross_bo, H == P / 32 == 4");
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (a->M + FT_M - 1) / FT_M;
   const int esz = dtype == RG_BF16 ? 2 : 4;
