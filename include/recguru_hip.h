@@ -154,8 +154,12 @@ typedef struct {
   const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): only the rows of listed tiles are
                                  processed; the rows of dz / dz_drop of the other (fully padded) tiles stay UNWRITTEN --
                                  for callers whose consumers of dz are all list-driven */
+  float* partials;            /* optional caller-owned device scratch of >= rg_ln_bwd_workspace(M, N) bytes: per-block column
+                                 sums go there and a second launch adds them to dgamma / dbeta (instead of one float atomic
+                                 per block and column onto the same 2N addresses).  Not to be shared across streams. */
 } rg_ln_bwd_args;
 int rg_ln_bwd(const rg_ln_bwd_args* args /* host */, int dtype, void* stream);
+size_t rg_ln_bwd_workspace(long long M, int N);
 
 /* ---- collapsed decoder cross-attention (quirk Q1) ---------------------------------------------------
  * MultiHeadAttention(Q=x, K=V=rep(u)) of transformer.py:259 with AutoEnc4Rec_cross.py:122: context is

@@ -7,7 +7,9 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librecguru_hip.so")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
+# -Wno-pass-failed: the L > 224 attention instantiations hold > 80 KB of LDS per workgroup, so their launch-bounds
+# occupancy hint (2 waves per SIMD) cannot be met -- expected, not worth a warning per instantiation
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value", "-Wno-pass-failed"]
 
 
 def _stale(target, sources):

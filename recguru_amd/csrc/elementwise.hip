@@ -156,8 +156,14 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   // u / (16 / RPW)-th live 16-row tile (rows of unlisted tiles are neither read nor written)
   constexpr int UPT = 16 / RPW;
   const long long nunits = a.live16 ? (long long)a.live16[0] * UPT : (a.M + RPW - 1) / RPW;
+  // list mode: the tile id of the NEXT iteration is fetched while this one runs (list entry -> row address -> rows is
+  // two dependent latencies per iteration otherwise)
+  const long long ntl = a.live16 ? (long long)a.live16[0] : 0;
+  int tile_next = (a.live16 && gw < nunits) ? a.live16[1 + gw / UPT] : 0;
   for (long long u = gw; u < nunits; u += nw) {
-    const long long m0 = a.live16 ? (long long)a.live16[1 + u / UPT] * 16 + (u % UPT) * RPW : u * RPW;
+    const int tile_cur = tile_next;
+    if (a.live16) tile_next = a.live16[1 + min((u + nw) / UPT, ntl - 1)];       // unconditional (clamped)
+    const long long m0 = a.live16 ? (long long)tile_cur * 16 + (u % UPT) * RPW : u * RPW;
     const long long m = m0 + rr;
     const bool live = m < a.M;
     const long long mc = live ? m : a.M - 1;
@@ -227,8 +233,30 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
     const float sg = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
     const float sb = red[1][0][n] + red[1][1][n] + red[1][2][n] + red[1][3][n];
-    if (a.dgamma) atomicAdd(a.dgamma + n, sg);
-    if (a.dbeta) atomicAdd(a.dbeta + n, sb);
+    if (a.partials) {           // two-stage column sums: [block][2][N] partials, summed by ln_bwd_reduce_kernel
+      a.partials[((size_t)blockIdx.x * 2 + 0) * N + n] = sg;
+      a.partials[((size_t)blockIdx.x * 2 + 1) * N + n] = sb;
+    } else {
+      if (a.dgamma) atomicAdd(a.dgamma + n, sg);
+      if (a.dbeta) atomicAdd(a.dbeta + n, sb);
+    }
+  }
+}
+
+// dgamma / dbeta += column sums of the per-block partials (4096 blocks x 2N same-address float atomics cost 20-40 us
+// of a 130 us kernel: the memory-side atomic unit serialises adds to one row).  Block b sums rows b, b + grid, ...
+__global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int N,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  for (int c = threadIdx.x; c < 2 * N; c += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    int b = blockIdx.x;
+    for (; b + (int)gridDim.x < nblocks; b += 2 * gridDim.x) {
+      s0 += partials[(size_t)b * 2 * N + c];
+      s1 += partials[(size_t)(b + gridDim.x) * 2 * N + c];
+    }
+    if (b < nblocks) s0 += partials[(size_t)b * 2 * N + c];
+    float* dst = c < N ? dgamma : dbeta;
+    if (dst) atomicAdd(dst + (c < N ? c : c - N), s0 + s1);
   }
 }
 
@@ -716,8 +744,13 @@ static int launch_ln_bwd(const rg_ln_bwd_args& a, hipStream_t s) {
   else if (a.N == 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 16>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
   else if (a.N == 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 32>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
   else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ln_bwd: N must be 32, 64, 128 or 256");
+  if (a.partials && (a.dgamma || a.dbeta))
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(grid < 64 ? grid : 64), dim3(256), 0, s, a.partials, grid, a.N, a.dgamma, a.dbeta);
   RG_CHECK_LAUNCH();
   return 0;
+}
+extern "C" size_t rg_ln_bwd_workspace(long long M, int N) {
+  return (size_t)ew_grid(M, 64) * 2 * N * sizeof(float);
 }
 extern "C" int rg_ln_bwd(const rg_ln_bwd_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;

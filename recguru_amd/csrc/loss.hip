@@ -351,14 +351,6 @@ struct BinWs {
   int nbins;
 };
 
-__device__ __forceinline__ long long pair_item(const rg_item_loss_args& a, long long p, int n) {
-  const long long t = p / n;
-  const int idx = (int)(p - t * n);
-  if (a.mask[t] == 0.f) return -1;
-  const long long item = idx == 0 ? a.pos[t] : a.neg[t * a.k + idx - 1];
-  return item == a.skip_row ? -1 : item;
-}
-
 // The items of pairs p, p+256, p+512, p+768 (-1: masked position, skip row, or p >= p1).  Branch-free: clamped
 // indices and ONE id load per pair from a selected pointer, so that the 8 loads of a batch are in flight together
 // (a pair at a time, mask -> id was two dependent latencies per loop iteration).

@@ -65,7 +65,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace",
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
@@ -75,7 +75,7 @@ c_ll = ctypes.c_longlong
 class LnBwdArgs(ctypes.Structure):
     _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i),
-                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p)]
+                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p), ("partials", c_p)]
 
 
 class ItemLossArgs(ctypes.Structure):
@@ -161,10 +161,10 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
 _TN_WS = {}
 
 
-def _tn_workspace(dev, nbytes):
-    """Partial-sum scratch of the weight-gradient GEMM, one buffer per (device, stream): calls on one stream are
-    ordered, calls on different streams (critic phase overlap) must not share it."""
-    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream)
+def _tn_workspace(dev, nbytes, kind="tn"):
+    """Partial-sum scratch (weight-gradient GEMM, LayerNorm backward column sums), one buffer per (kind, device,
+    stream): calls on one stream are ordered, calls on different streams (critic phase overlap) must not share it."""
+    key = (kind, dev.index, torch.cuda.current_stream(dev).cuda_stream)
     ws = _TN_WS.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, device=dev, dtype=torch.float32)
@@ -252,8 +252,13 @@ def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_se
         dz.fill_(float("nan"))
         if dzd is not None:
             dzd.fill_(float("nan"))
+    ws = None
+    if M >= 4096 and (dgamma is not None or dbeta is not None):      # two-stage column sums (see rg_ln_bwd_args.partials)
+        fn = lib().rg_ln_bwd_workspace
+        fn.restype = ctypes.c_size_t
+        ws = _tn_workspace(dy.device, int(fn(c_ll(M), N)), "ln")
     a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N,
-                  _p(dzd), drop_p, drop_seed, _p(live))
+                  _p(dzd), drop_p, drop_seed, _p(live), _p(ws))
     _check(lib().rg_ln_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_ln_bwd")
     return (dz, dzd) if drop_p > 0 else dz
 
