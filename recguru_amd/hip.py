@@ -515,9 +515,11 @@ COMPACT_MIN_ROWS = 16384      # below this the padded-tile lists are not worth t
 def live_tiles(rowmask, M):
     """int32 [1 + ceil(M/16)]: count, then the indices of the 16-row tiles holding a row with rowmask != 0.  Cached for
     the last few masks (every layer of a forward pass uses the same one)."""
-    key = (rowmask.data_ptr(), rowmask._version, M)
+    # the entry keeps a tensor on the mask's storage alive, so a matching (address, version) IS that storage: views
+    # of one mask made per layer (reshape(-1) returns a new tensor object each time) share the list
+    key = (rowmask.data_ptr(), rowmask._version, M, rowmask.dtype)
     hit = _LIVE.get(key)
-    if hit is not None and hit[0] is rowmask:
+    if hit is not None:
         return hit[1]
     flags = torch.empty(1 + 2 * ((M + 15) // 16), device=rowmask.device, dtype=torch.int32)
     _check(lib().rg_live_tiles(_vp(rowmask), c_ll(M), _vp(flags), _stream()), "rg_live_tiles")
