@@ -154,6 +154,8 @@ typedef struct {
   const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): only the rows of listed tiles are
                                  processed; the rows of dz / dz_drop of the other (fully padded) tiles stay UNWRITTEN --
                                  for callers whose consumers of dz are all list-driven */
+  float* dz_colsum;           /* optional [N] f32 += column sums of dz (the bias gradient of whatever produced the LN input:
+                                 saves a separate pass over dz) */
   float* partials;            /* optional caller-owned device scratch of >= rg_ln_bwd_workspace(M, N) bytes: per-block column
                                  sums go there and a second launch adds them to dgamma / dbeta (instead of one float atomic
                                  per block and column onto the same 2N addresses).  Not to be shared across streams. */

@@ -136,7 +136,7 @@ template <typename T, int LPR>
 __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   constexpr int RPW = 64 / LPR;                 // rows per wave pass
   constexpr int N = LPR * 8;
-  __shared__ float red[2][4][N];
+  __shared__ float red[3][4][N];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rr = lane / LPR, c8 = (lane % LPR) * 8;
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
@@ -150,6 +150,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
   load8(bet, a.beta + c8);
 #pragma unroll
   for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; igam[j] = 1.f / gam[j]; }
+  float dc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};        // column sums of dz (a.dz_colsum)
   const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.rstd;      // any readable float array stands in
   const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
   // work unit = RPW consecutive rows: unit u of the matrix, or -- list-driven -- part (u % (16 / RPW)) of the
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
       s2 *= invn;
       float o8[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
+      for (int j = 0; j < 8; ++j) { o8[j] = rstd * (g[j] - s1 - xh[j] * s2); dc[j] += o8[j]; }
       store8(dz + (size_t)m * a.ld + c8, o8);
       if (dzd) {
         float k8[8];
@@ -224,21 +225,24 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
 #pragma unroll
   for (int o = LPR; o < 64; o <<= 1)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { dg[j] += __shfl_xor(dg[j], o); db[j] += __shfl_xor(db[j], o); }
+    for (int j = 0; j < 8; ++j) { dg[j] += __shfl_xor(dg[j], o); db[j] += __shfl_xor(db[j], o); dc[j] += __shfl_xor(dc[j], o); }
   if (rr == 0) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { red[0][wave][c8 + j] = dg[j]; red[1][wave][c8 + j] = db[j]; }
+    for (int j = 0; j < 8; ++j) { red[0][wave][c8 + j] = dg[j]; red[1][wave][c8 + j] = db[j]; red[2][wave][c8 + j] = dc[j]; }
   }
   __syncthreads();
   for (int n = threadIdx.x; n < N; n += EW_BLOCK) {
     const float sg = red[0][0][n] + red[0][1][n] + red[0][2][n] + red[0][3][n];
     const float sb = red[1][0][n] + red[1][1][n] + red[1][2][n] + red[1][3][n];
-    if (a.partials) {           // two-stage column sums: [block][2][N] partials, summed by ln_bwd_reduce_kernel
-      a.partials[((size_t)blockIdx.x * 2 + 0) * N + n] = sg;
-      a.partials[((size_t)blockIdx.x * 2 + 1) * N + n] = sb;
+    const float sc = red[2][0][n] + red[2][1][n] + red[2][2][n] + red[2][3][n];
+    if (a.partials) {           // two-stage column sums: [block][3][N] partials, summed by ln_bwd_reduce_kernel
+      a.partials[((size_t)blockIdx.x * 3 + 0) * N + n] = sg;
+      a.partials[((size_t)blockIdx.x * 3 + 1) * N + n] = sb;
+      a.partials[((size_t)blockIdx.x * 3 + 2) * N + n] = sc;
     } else {
       if (a.dgamma) atomicAdd(a.dgamma + n, sg);
       if (a.dbeta) atomicAdd(a.dbeta + n, sb);
+      if (a.dz_colsum) atomicAdd(a.dz_colsum + n, sc);
     }
   }
 }
@@ -246,17 +250,19 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
 // dgamma / dbeta += column sums of the per-block partials (4096 blocks x 2N same-address float atomics cost 20-40 us
 // of a 130 us kernel: the memory-side atomic unit serialises adds to one row).  Block b sums rows b, b + grid, ...
 __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restrict__ partials, int nblocks, int N,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  for (int c = threadIdx.x; c < 2 * N; c += 256) {
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ dzsum) {
+  for (int c = threadIdx.x; c < 3 * N; c += 256) {
+    float* dst = c < N ? dgamma : (c < 2 * N ? dbeta : dzsum);
+    if (!dst) continue;
     float s0 = 0.f, s1 = 0.f;
     int b = blockIdx.x;
     for (; b + (int)gridDim.x < nblocks; b += 2 * gridDim.x) {
-      s0 += partials[(size_t)b * 2 * N + c];
-      s1 += partials[(size_t)(b + gridDim.x) * 2 * N + c];
+      s0 += partials[(size_t)b * 3 * N + c];
+      s1 += partials[(size_t)(b + gridDim.x) * 3 * N + c];
     }
-    if (b < nblocks) s0 += partials[(size_t)b * 2 * N + c];
-    float* dst = c < N ? dgamma : dbeta;
-    if (dst) atomicAdd(dst + (c < N ? c : c - N), s0 + s1);
+    if (b < nblocks) s0 += partials[(size_t)b * 3 * N + c];
+    atomicAdd(dst + (c % N), s0 + s1);
   }
 }
 
@@ -744,13 +750,14 @@ static int launch_ln_bwd(const rg_ln_bwd_args& a, hipStream_t s) {
   else if (a.N == 128) hipLaunchKernelGGL((ln_bwd_kernel<T, 16>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
   else if (a.N == 256) hipLaunchKernelGGL((ln_bwd_kernel<T, 32>), dim3(grid), dim3(EW_BLOCK), 0, s, a);
   else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ln_bwd: N must be 32, 64, 128 or 256");
-  if (a.partials && (a.dgamma || a.dbeta))
-    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(grid < 64 ? grid : 64), dim3(256), 0, s, a.partials, grid, a.N, a.dgamma, a.dbeta);
+  if (a.partials && (a.dgamma || a.dbeta || a.dz_colsum))
+    hipLaunchKernelGGL(ln_bwd_reduce_kernel, dim3(grid < 64 ? grid : 64), dim3(256), 0, s, a.partials, grid, a.N, a.dgamma, a.dbeta,
+                       a.dz_colsum);
   RG_CHECK_LAUNCH();
   return 0;
 }
 extern "C" size_t rg_ln_bwd_workspace(long long M, int N) {
-  return (size_t)ew_grid(M, 64) * 2 * N * sizeof(float);
+  return (size_t)ew_grid(M, 64) * 3 * N * sizeof(float);
 }
 extern "C" int rg_ln_bwd(const rg_ln_bwd_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;

@@ -75,7 +75,7 @@ c_ll = ctypes.c_longlong
 class LnBwdArgs(ctypes.Structure):
     _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("dz", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", c_ll), ("N", c_i), ("ld", c_i),
-                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p), ("partials", c_p)]
+                ("dz_drop", c_p), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p), ("dz_colsum", c_p), ("partials", c_p)]
 
 
 class ItemLossArgs(ctypes.Structure):
@@ -240,7 +240,7 @@ def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     return dE
 
 
-def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0, live=None):
+def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0, live=None, dz_colsum=None):
     """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place.
     With drop_p > 0 also returns dz * dropmask/(1-p) (backward of a dropout feeding the LN input).
     live: list of live 16-row tiles -- the rows of the other tiles of dz stay UNWRITTEN (list-driven consumers only)."""
@@ -253,12 +253,12 @@ def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_se
         if dzd is not None:
             dzd.fill_(float("nan"))
     ws = None
-    if M >= 4096 and (dgamma is not None or dbeta is not None):      # two-stage column sums (see rg_ln_bwd_args.partials)
+    if M >= 4096 and (dgamma is not None or dbeta is not None or dz_colsum is not None):   # two-stage column sums
         fn = lib().rg_ln_bwd_workspace
         fn.restype = ctypes.c_size_t
         ws = _tn_workspace(dy.device, int(fn(c_ll(M), N)), "ln")
     a = LnBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(dz), _p(dgamma), _p(dbeta), M, N, N,
-                  _p(dzd), drop_p, drop_seed, _p(live), _p(ws))
+                  _p(dzd), drop_p, drop_seed, _p(live), _p(dz_colsum), _p(ws))
     _check(lib().rg_ln_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_ln_bwd")
     return (dz, dzd) if drop_p > 0 else dz
 

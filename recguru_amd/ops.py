@@ -538,15 +538,17 @@ class DecoderLayerFn(_Fn):
         dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, ctx.prm[16:],
                                  drop_p, seeds[1], seeds[2])
         (dcg, rcg), (dcbe, rcbe) = _gt(cg), _gt(cbe)
-        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), rowmask, dcg, dcbe)   # residual: dz == dy1
         (dcWo, rcWo), (dcbo, rcbo) = _gt(cWo), _gt(cbo)
+        # residual: dz == dy1; under dropout the cross-attention output bias gradient is the column sum of dy1, which
+        # the same kernel accumulates
+        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), rowmask, dcg, dcbe,
+                         dz_colsum=dcbo if s_cross is not None else None)
         if s_cross is None:
             do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype
             hip.gemm_tn(do, c, dcWo, dcbo)
             dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                            # [B, P]
         else:
             doh = hip.seq_wsum(dy1, s_cross, B, L, H)                                    # [B, H, d]
-            hip.colsum(dy1, dcbo)
             woT = shadow(cWo, transpose=True)                                            # [P, d]
             dc = torch.empty(B, P, device=dev, dtype=c.dtype)
             for hh in range(H):
