@@ -200,6 +200,16 @@ typedef struct {
 } rg_adam_seg;
 int rg_adam_multi(const rg_adam_seg* segs /* device */, int nsegs, float beta1, float beta2, float eps, void* stream);
 int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
+/* Multi-tensor cast: ONE launch refreshes every operand-tier weight copy after an optimizer step (136 per-tensor casts
+ * per training iteration otherwise).  Segment s: dst[(r + row_off) * ld + c + col_off] = src[r, c], or with transpose
+ * dst[(c + row_off) * ld + r + col_off] = src[r, c]  (a concatenated copy such as the fused QKV weight is several
+ * segments into one dst).  tiles: DEVICE int2 array, one entry per workgroup = (segment, 32 x 32 tile index). */
+typedef struct {
+  const float* src; void* dst;
+  int R, C, ld, row_off, col_off, transpose;
+} rg_cast_seg;
+int rg_cast_multi(const rg_cast_seg* segs /* device */, const int* tiles /* device, 2 ints per workgroup */, int ntiles,
+                  int dtype, void* stream);
 
 /* ---- K7/K8: fused gather-dot-loss over the item catalogue --------------------------------------
  * mode RG_LOSS_SAMPLED_CE: AutoEnc4Rec_cross.py:201-215 + tools/lossfunctions.py:36-49 (label 0).

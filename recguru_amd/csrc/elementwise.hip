@@ -463,6 +463,28 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict_
   }
 }
 
+// one workgroup = one 32 x 32 tile of one segment (rg_cast_seg), staged through LDS so that both orientations read and
+// write 32 consecutive elements per row
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void cast_multi_kernel(const rg_cast_seg* __restrict__ segs, const int* __restrict__ tiles) {
+  __shared__ float tile[32][33];
+  const rg_cast_seg sg = segs[tiles[2 * blockIdx.x]];
+  const int t = tiles[2 * blockIdx.x + 1];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int tiles_c = (sg.C + 31) / 32;
+  const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+  T* __restrict__ dst = reinterpret_cast<T*>(sg.dst);
+  for (int k = ty; k < 32; k += 8) tile[k][tx] = (r0 + k < sg.R && c0 + tx < sg.C) ? sg.src[(size_t)(r0 + k) * sg.C + c0 + tx] : 0.f;
+  __syncthreads();
+  if (sg.transpose) {
+    for (int k = ty; k < 32; k += 8)
+      if (c0 + k < sg.C && r0 + tx < sg.R) dst[(size_t)(c0 + k + sg.row_off) * sg.ld + r0 + tx + sg.col_off] = (T)tile[tx][k];
+  } else {
+    for (int k = ty; k < 32; k += 8)
+      if (r0 + k < sg.R && c0 + tx < sg.C) dst[(size_t)(r0 + k + sg.row_off) * sg.ld + c0 + tx + sg.col_off] = (T)tile[k][tx];
+  }
+}
+
 // s[b*L+q, h] = sum over live keys of keep(...) / n_live : the row sum of the dropped uniform attention
 // map of the collapsed decoder cross-attention (Q1 + nn.Dropout of transformer.py:126-127).
 // One workgroup per sequence: the live-key set becomes a bit vector in LDS; in the p == 0.5 mode a row
@@ -868,6 +890,16 @@ extern "C" int rg_adam_multi(const rg_adam_seg* segs_device, int nsegs, float be
   hipLaunchKernelGGL(adam_multi_kernel, dim3(nsegs), dim3(EW_BLOCK), 0, (hipStream_t)stream, segs_device, beta1, beta2, eps);
   RG_CHECK_LAUNCH();
   return 0;
+}
+
+extern "C" int rg_cast_multi(const rg_cast_seg* segs, const int* tiles, int ntiles, int dtype, void* stream) {
+  if (ntiles <= 0) return 0;
+  if (!segs || !tiles) return rg_set_error_msg(RG_ERR_INVALID, "cast_multi: null table");
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(cast_multi_kernel<__bf16>, dim3(ntiles), dim3(EW_BLOCK), 0, s, segs, tiles),
+             hipLaunchKernelGGL(cast_multi_kernel<float>, dim3(ntiles), dim3(EW_BLOCK), 0, s, segs, tiles),
+             "cast_multi")
 }
 
 extern "C" int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream) {

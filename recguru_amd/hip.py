@@ -65,7 +65,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace",
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
@@ -370,6 +370,16 @@ ADAM_SEG_DTYPE = [("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", 
 def adam_multi(seg_table_dev, nsegs, beta1, beta2, eps):
     """seg_table_dev: uint8 CUDA tensor holding nsegs rg_adam_seg records."""
     _check(lib().rg_adam_multi(_vp(seg_table_dev), int(nsegs), c_f(beta1), c_f(beta2), c_f(eps), _stream()), "rg_adam_multi")
+
+
+CAST_SEG_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("R", "<i4"), ("C", "<i4"), ("ld", "<i4"), ("row_off", "<i4"),
+                  ("col_off", "<i4"), ("transpose", "<i4")]
+
+
+def cast_multi(seg_table_dev, tiles_dev, ntiles, dtype):
+    """seg_table_dev: uint8 CUDA tensor of rg_cast_seg records; tiles_dev: int32 [ntiles, 2] (segment, tile)."""
+    code = BF16 if dtype == torch.bfloat16 else F32
+    _check(lib().rg_cast_multi(_vp(seg_table_dev), _vp(tiles_dev), int(ntiles), code, _stream()), "rg_cast_multi")
 
 
 def cast(src, dtype, transpose=False):

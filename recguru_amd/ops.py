@@ -7,6 +7,8 @@ set_compute_dtype(): torch.bfloat16 (bf16 MFMA, default) or torch.float32 (exact
 parity tier).  Tier copies ("shadows") of the weights, plain and transposed, are cached per
 parameter version so they are rebuilt only after an optimizer step.
 """
+import weakref
+
 import torch
 
 from . import hip
@@ -57,7 +59,7 @@ def shadow(p, transpose=False):
     ent = _SHADOWS.get(key)
     ver = _ver(p)
     if ent is None or ent[0] != ver:
-        ent = (ver, hip.cast(p.detach(), _COMPUTE, transpose=transpose))
+        ent = (ver, hip.cast(p.detach(), _COMPUTE, transpose=transpose), (weakref.ref(p),))
         _SHADOWS[key] = ent
     return ent[1]
 
@@ -69,9 +71,68 @@ def shadow_cat(ps, transpose=False):
     ent = _SHADOWS.get(key)
     if ent is None or ent[0] != ver:
         w = torch.cat([p.detach() for p in ps], 0).contiguous()
-        ent = (ver, hip.cast(w, _COMPUTE, transpose=transpose) if (transpose or _COMPUTE != torch.float32) else w)
+        ent = (ver, hip.cast(w, _COMPUTE, transpose=transpose) if (transpose or _COMPUTE != torch.float32) else w,
+               tuple(weakref.ref(p) for p in ps))
         _SHADOWS[key] = ent
     return ent[1]
+
+
+_REFRESH_TILES = {}
+
+
+def refresh_shadows(params):
+    """Rebuild every cached shadow that involves one of `params` in ONE launch (rg_cast_multi) -- called by the
+    optimizer right after its update, on the stream the update ran on, so that no forward pass pays a cast launch per
+    weight (136 per training iteration).  Shadows are written into NEW buffers: kernels already queued on another
+    stream keep reading the old ones."""
+    import numpy as np
+    ids = set(id(p) for p in params)
+    todo, dead = [], []
+    for key, ent in _SHADOWS.items():
+        ps = tuple(r() for r in ent[2])
+        if any(p is None for p in ps):
+            dead.append(key)                            # its parameters are gone: drop the copy
+            continue
+        if key[2] != _COMPUTE or not any(id(p) in ids for p in ps) or ps[0].dim() != 2 or not ps[0].is_cuda:
+            continue
+        if ent[0] == (_ver(ps[0]) if len(key) == 3 else tuple(_ver(p) for p in ps)):
+            continue                                    # already current
+        todo.append((key, ps))
+    for key in dead:
+        del _SHADOWS[key]
+    if not todo:
+        return
+    dev = todo[0][1][0].device
+    segs, shapes, outs = [], [], []
+    for key, ps in todo:
+        transpose = key[1]
+        R = sum(p.shape[0] for p in ps)
+        C = ps[0].shape[1]
+        dst = torch.empty((C, R) if transpose else (R, C), device=dev, dtype=_COMPUTE)
+        outs.append(dst)
+        ld = R if transpose else C
+        off = 0
+        for p in ps:
+            src = p.detach()
+            assert src.is_contiguous() and src.dtype == torch.float32 and src.shape[1] == C
+            segs.append((src.data_ptr(), dst.data_ptr(), p.shape[0], C, ld, 0 if transpose else off, off if transpose else 0,
+                         1 if transpose else 0))
+            shapes.append((p.shape[0], C))
+            off += p.shape[0]
+    sig = tuple(shapes)
+    tiles = _REFRESH_TILES.get((sig, dev))
+    if tiles is None:                                   # (segment, tile) per workgroup: depends on the shapes only
+        rows = []
+        for i, (r, c) in enumerate(shapes):
+            n = ((r + 31) // 32) * ((c + 31) // 32)
+            rows.append(np.stack([np.full(n, i, dtype=np.int32), np.arange(n, dtype=np.int32)], 1))
+        tiles = torch.from_numpy(np.concatenate(rows, 0)).to(dev)
+        _REFRESH_TILES[(sig, dev)] = tiles
+    tbl = torch.from_numpy(np.array(segs, dtype=hip.CAST_SEG_DTYPE).view(np.uint8).copy()).to(dev, non_blocking=True)
+    hip.cast_multi(tbl, tiles, tiles.shape[0], _COMPUTE)
+    for (key, ps), dst in zip(todo, outs):
+        ver = _ver(ps[0]) if len(key) == 3 else tuple(_ver(p) for p in ps)
+        _SHADOWS[key] = (ver, dst, tuple(weakref.ref(p) for p in ps))
 
 
 def _z(n, like):

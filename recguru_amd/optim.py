@@ -67,3 +67,4 @@ class Adam(object):
             hip.adam_multi(tdev, len(tbl), b1, b2, g["eps"])
             for p, _ in live:
                 ops.bump(p)
+            ops.refresh_shadows([p for p, _ in live])
