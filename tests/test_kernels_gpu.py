@@ -659,3 +659,82 @@ def test_gemm_tn_big_live_tile_list(N1, N2, gelu):
     Xn[dead_tile] = float("nan")                               # rows of fully padded 16-row tiles are really never read
     part2 = hip.gemm_tn(Y, Xn, None, None, live=live, **kw)
     assert torch.isfinite(part2).all()
+
+
+@pytest.mark.parametrize("N1,N2", [(512, 128), (128, 512), (384, 128), (128, 128)])
+def test_gemm_tn_partials_equal_atomics(N1, N2):
+    """Weight-gradient kernel: partial tiles through plain stores + the reduce launch (rg_gemm_tn_workspace) against
+    the float-atomic flush, accumulating into a non-zero dW, with and without a live-tile list; and against torch."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    B, L = 75, 120
+    T = B * L
+    mask = _pad_mask(B, L, N1)
+    live = hip.live_tiles(mask, T)
+    Y = rnd(T, N1, dt=dt, seed=3) * mask[:, None].to(dt)
+    X = rnd(T, N2, dt=dt, seed=4)
+    ref = Y.float().t() @ X.float()
+    for lv in (None, live):
+        base = rnd(N1, N2, dt=torch.float32, seed=5)
+        a, b = base.clone(), base.clone()
+        hip.gemm_tn(Y, X, a, None, live=lv, partials=True)
+        hip.gemm_tn(Y, X, b, None, live=lv, partials=False)
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-3)
+        torch.testing.assert_close(a - base, ref, rtol=2e-3, atol=0.5)
+
+
+def test_cast_multi_matches_cast():
+    """rg_cast_multi: plain, transposed and concatenated segments in one launch against per-tensor rg_cast."""
+    import numpy as np
+    from recguru_amd import hip
+    ws = [rnd(96, 128, dt=torch.float32, seed=1), rnd(33, 70, dt=torch.float32, seed=2), rnd(128, 128, dt=torch.float32, seed=3),
+          rnd(64, 128, dt=torch.float32, seed=4)]
+    for dt in (torch.bfloat16, torch.float32):
+        plain = torch.empty(96, 128, device="cuda", dtype=dt)
+        tr = torch.empty(70, 33, device="cuda", dtype=dt)
+        cat = torch.empty(192, 128, device="cuda", dtype=dt)          # [ws[2]; ws[3]]
+        cat_t = torch.empty(128, 192, device="cuda", dtype=dt)        # its transpose
+        segs = [(ws[0].data_ptr(), plain.data_ptr(), 96, 128, 128, 0, 0, 0),
+                (ws[1].data_ptr(), tr.data_ptr(), 33, 70, 33, 0, 0, 1),
+                (ws[2].data_ptr(), cat.data_ptr(), 128, 128, 128, 0, 0, 0),
+                (ws[3].data_ptr(), cat.data_ptr(), 64, 128, 128, 128, 0, 0),
+                (ws[2].data_ptr(), cat_t.data_ptr(), 128, 128, 192, 0, 0, 1),
+                (ws[3].data_ptr(), cat_t.data_ptr(), 64, 128, 192, 0, 128, 1)]
+        tiles = []
+        for i, sg in enumerate(segs):
+            n = ((sg[2] + 31) // 32) * ((sg[3] + 31) // 32)
+            tiles += [(i, t) for t in range(n)]
+        tiles = torch.tensor(tiles, dtype=torch.int32, device="cuda")
+        tbl = torch.from_numpy(np.array(segs, dtype=hip.CAST_SEG_DTYPE).view(np.uint8).copy()).cuda()
+        hip.cast_multi(tbl, tiles, tiles.shape[0], dt)
+        assert torch.equal(plain, ws[0].to(dt))
+        assert torch.equal(tr, ws[1].t().contiguous().to(dt))
+        assert torch.equal(cat, torch.cat([ws[2], ws[3]], 0).to(dt))
+        assert torch.equal(cat_t, torch.cat([ws[2], ws[3]], 0).t().contiguous().to(dt))
+        assert torch.equal(hip.cast(ws[1], dt, transpose=True), tr)
+
+
+def test_ln_bwd_two_stage_sums_and_dz_colsum():
+    """LayerNorm backward at a size where the column sums go through per-block partials + the reduce launch
+    (M >= 4096): dgamma / dbeta / the dz column sum against torch, accumulated into non-zero buffers, list-driven
+    and plain."""
+    from recguru_amd import hip
+    M, N = 75 * 120, 128
+    dt = torch.bfloat16
+    z = rnd(M, N, dt=torch.float32, seed=1).requires_grad_(True)
+    g = (1 + 0.1 * rnd(N, dt=torch.float32, seed=2)).requires_grad_(True)
+    b = (0.1 * rnd(N, dt=torch.float32, seed=3)).requires_grad_(True)
+    rm = _pad_mask(75, 120, 7)
+    y = torch.nn.functional.layer_norm(z, (N,), g, b, 1e-8) * rm[:, None]
+    dy = rnd(M, N, dt=dt, seed=4)
+    y.backward(dy.float())
+    rstd = 1 / torch.sqrt(z.detach().var(1, unbiased=False) + 1e-8)
+    live = hip.live_tiles(rm, M)
+    for lv in (None, live):
+        dg, db, dc = (torch.full((N,), 0.5, device="cuda") for _ in range(3))
+        dz = hip.ln_bwd(dy, y.detach().to(dt), rstd, g.detach(), b.detach(), rm, dg, db, live=lv, dz_colsum=dc)
+        keep = rm[:, None] != 0
+        torch.testing.assert_close(dz.float() * keep, z.grad * keep, rtol=3e-2, atol=3e-2)
+        torch.testing.assert_close(dg - 0.5, g.grad, rtol=3e-2, atol=0.5)
+        torch.testing.assert_close(db - 0.5, b.grad, rtol=3e-2, atol=0.5)
+        torch.testing.assert_close(dc - 0.5, (z.grad * keep).sum(0), rtol=3e-2, atol=0.5)
