@@ -434,9 +434,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < 4; ++rt) {
+          if constexpr (Precise<T>::value) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc[ct][rt][r] = gelu_t<Precise<T>::value>(acc[ct][rt][r]);
+            for (int r = 0; r < 4; ++r) acc[ct][rt][r] = gelu_t<true>(acc[ct][rt][r]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; r += 2) {
+              const f32x2 gg = gelu2_fast((f32x2){acc[ct][rt][r], acc[ct][rt][r + 1]});
+              acc[ct][rt][r] = gg.x;
+              acc[ct][rt][r + 1] = gg.y;
+            }
+          }
+        }
       regs_to_tile<T>(acc, Ag, n0, li, lg);
       STAMP(6);
       lds_barrier();
