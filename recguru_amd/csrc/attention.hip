@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
         load4f(kb, kbias + kt * 16 + 4 * lg);
         s[kt] = (f32x4){kb[0], kb[1], kb[2], kb[3]};     // the key bias rides in the accumulator: -2^100 + x == -2^100
         mma(kf, qf, s[kt]);
-        if (CAUSAL) {
+        if (CAUSAL && kt >= qt) {     // only the diagonal tile (and, for fully masked rows, the tiles above it) can hold a future key
 #pragma unroll
           for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + r > qrel) ? fminf(s[kt][r], MASK_BIG) : s[kt][r];     // keeps -inf beyond L
         }
@@ -272,24 +272,30 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     // with c2 are exact, so the argument is exactly 0 (uniform row, Q3) -- no cancellation residue.
     const float nmx = -mx * c2;
     float sum = 0.f;
+    f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
       if (kt < nkq) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[kt][r], c2, nmx));
-          s[kt][r] = p;
-          if constexpr (DM != 0) sum += p;      // DM == 0: the row sum comes out of the MFMA below
+        for (int r = 0; r < 4; r += 2) {        // pairs: the fma and the row-sum add as packed instructions
+          const f32x2 arg = (f32x2){s[kt][r], s[kt][r + 1]} * (f32x2){c2, c2} + (f32x2){nmx, nmx};
+          f32x2 p;
+          p.x = __builtin_amdgcn_exp2f(arg.x);
+          p.y = __builtin_amdgcn_exp2f(arg.y);
+          s[kt][r] = p.x;
+          s[kt][r + 1] = p.y;
+          if constexpr (DM != 0) sum2 += p;     // DM == 0: the row sum comes out of the MFMA below
         }
       }
     if constexpr (DM != 0) {
+      sum = sum2.x + sum2.y;
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
     }
     if constexpr (DM == 1) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
 #pragma unroll
       for (int kt = 0; kt < NKT; kt += 2)
-        if (kt < nkt) {
+        if (kt < nkq) {           // skipped (future) key tiles hold zeros already
           const unsigned int w = dmask[(kt >> 1) * LPK + q] >> (4 * lg);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lpad(L) + 4u * lg;
 #pragma unroll
       for (int kt = 0; kt < NKT; kt += 2)       // NKT is even; rows start on a hash-word boundary
-        if (kt < nkt) {
+        if (kt < nkq) {
           float k0[4], k1[4];
           rg_keep4_pair(drop, base + kt * 16, k0, k1);
 #pragma unroll
@@ -713,6 +719,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int q0 = qs * 32 + u * 16;
+        const bool diag = kt * 16 + 15 > q0;        // (uniform) this key tile reaches past the first query of the tile
         Frag<T> qf, gf;
         load_frag(qf, Qs + (q0 + li) * LDR + 8 * lg);
         load_frag(gf, Gs + (q0 + li) * LDR + 8 * lg);
@@ -733,10 +740,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 #pragma unroll
           for (int r = 0; r < 4; ++r) ks4[r] = rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * lp4 + key);
         }
+        if (CAUSAL && diag) {       // its own block AHEAD of the element loop (a uniform branch inside would split it)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) sv[r] = (key > q0 + 4 * lg + r) ? fminf(sv[r], MASK_BIG) : sv[r];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float sc = sv[r];                                             // -2^100 / -inf where replaced
-          if (CAUSAL) sc = (key > q0 + 4 * lg + r) ? fminf(sc, MASK_BIG) : sc;
+          const float sc = sv[r];                                       // -2^100 / -inf where replaced
           const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
           const float pu = pe + ((key < L) ? r4[r] : 0.f);              // uniform 1/L rows (Q3)
           if constexpr (DM == 1) {

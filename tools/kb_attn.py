@@ -1,0 +1,19 @@
+"""Attention forward / backward at the bench shape with the real pad mask, dropout 0 / 0.5 / 0.3, causal or not."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from recguru_amd import hip, synthetic
+from kbench import timeit
+B, L, H = 4096, 200, 4
+dom = synthetic.make_domain(B, 100000, L, 1, seed=1)
+ids = torch.as_tensor(dom["enc_in"]).cuda()
+mask = (ids != 0).float().reshape(-1).contiguous()
+dt = torch.bfloat16
+r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
+qkv = r(B, L, 3 * H * 32)
+dctx = r(B, L, H * 32) * mask.view(B, L, 1).to(dt)
+for causal in (False, True):
+    for p in (0.0, 0.5, 0.3):
+        us = timeit(lambda: hip.attn_fwd(qkv, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask))
+        ctx, lse = hip.attn_fwd(qkv, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask)
+        usb = timeit(lambda: hip.attn_bwd(qkv, dctx, ctx, lse, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask), n=10)
+        print("causal %d p=%.1f  fwd %7.1f us   bwd %7.1f us" % (causal, p, us, usb))
