@@ -734,7 +734,8 @@ def test_ln_bwd_two_stage_sums_and_dz_colsum():
         dg, db, dc = (torch.full((N,), 0.5, device="cuda") for _ in range(3))
         dz = hip.ln_bwd(dy, y.detach().to(dt), rstd, g.detach(), b.detach(), rm, dg, db, live=lv, dz_colsum=dc)
         keep = rm[:, None] != 0
-        torch.testing.assert_close(dz.float() * keep, z.grad * keep, rtol=3e-2, atol=3e-2)
+        rows = rm != 0                  # list mode leaves the rows of fully padded tiles unwritten: compare live rows only
+        torch.testing.assert_close(dz.float()[rows], z.grad[rows], rtol=3e-2, atol=3e-2)
         torch.testing.assert_close(dg - 0.5, g.grad, rtol=3e-2, atol=0.5)
         torch.testing.assert_close(db - 0.5, b.grad, rtol=3e-2, atol=0.5)
         torch.testing.assert_close(dc - 0.5, (z.grad * keep).sum(0), rtol=3e-2, atol=0.5)
