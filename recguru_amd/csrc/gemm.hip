@@ -377,27 +377,38 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(rg_gemm_tn_args a) {
   Frag<T> ones;
   frag_fill(ones, 1.f);
 
+  // Token chunks are software-pipelined one deep: the rows of chunk c+1 are in flight (raw 16/32-byte loads, clamped
+  // addresses, unconditional) while chunk c is in its MFMA phase; rows past the range become zeros at the LDS store,
+  // columns past N1 / N2 only feed accumulators that are never written back.
+  Frag<T> py[2], px[2];
+  auto load_rows = [&](int t0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+      const int t = min(t0 + r, a.T - 1);
+      load_frag(py[i], Y + (size_t)t * a.ldy + min(n1_0 + c8, a.N1 - 8));
+      load_frag(px[i], X + (size_t)t * a.ldx + min(n2_0 + c8, a.N2 - 8));
+    }
+  };
+  if (t_beg < t_end) load_rows(t_beg);
   for (int t0 = t_beg; t0 < t_end; t0 += TT) {
-    for (int c = tid; c < TT * 8; c += 256) {
-      const int r = c >> 3, c8 = (c & 7) * 8;
-      const int t = t0 + r;
-      float v[8], w[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { v[j] = 0.f; w[j] = 0.f; }
-      if (t < t_end) {
-        if (n1_0 + c8 < a.N1) load8(v, Y + (size_t)t * a.ldy + n1_0 + c8);
-        if (n2_0 + c8 < a.N2) {
-          load8(w, X + (size_t)t * a.ldx + n2_0 + c8);
-          if (a.prologue_x == RG_PRO_GELU) {
+    for (int i = 0; i < 2; ++i) {
+      const int c = tid + 256 * i, r = c >> 3, c8 = (c & 7) * 8;
+      Frag<T> yv = py[i], xv = px[i];
+      if (a.prologue_x == RG_PRO_GELU) {
+        float w[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) w[j] = gelu_t<Precise<T>::value>(w[j]);
-          }
-        }
+        for (int j = 0; j < 8; ++j) w[j] = gelu_t<Precise<T>::value>((float)px[i].v[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xv.v[j] = (T)w[j];
       }
-      store8(Ys + r * LD + c8, v);
-      store8(Xs + r * LD + c8, w);
+      if (t0 + r >= t_end) { frag_zero(yv); frag_zero(xv); }
+      *reinterpret_cast<Frag<T>*>(Ys + r * LD + c8) = yv;
+      *reinterpret_cast<Frag<T>*>(Xs + r * LD + c8) = xv;
     }
     __syncthreads();
+    load_rows(min(t0 + TT, a.T - 1));               // next chunk (past the end: a harmless re-read)
 #pragma unroll
     for (int ks = 0; ks < TT / 32; ++ks) {
       Frag<T> af;
