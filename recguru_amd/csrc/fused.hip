@@ -56,15 +56,21 @@ __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, i
 // acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
 template <typename T>
 __device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][4], const WSet<T>& w, const T* __restrict__ Act, int li, int lg) {
+  // the four token-tile fragments of k-step ks+1 are read while the MFMAs of k-step ks run (one LDS latency per GEMM
+  // step instead of four)
+  Frag<T> af[2][4];
+#pragma unroll
+  for (int rt = 0; rt < 4; ++rt) load_frag(af[0][rt], Act + Tile<T>::off(rt * 16 + li, 8 * lg));
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    Frag<T> af[4];                          // the k-step's four token-tile fragments in one LDS burst
+    if (ks < 3) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], Act + Tile<T>::off(rt * 16 + li, ks * 32 + 8 * lg));
+      for (int rt = 0; rt < 4; ++rt) load_frag(af[(ks + 1) & 1][rt], Act + Tile<T>::off(rt * 16 + li, (ks + 1) * 32 + 8 * lg));
+    }
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-      for (int ct = 0; ct < 2; ++ct) mma(w.f[ks][ct], af[rt], acc[ct][rt]);
+      for (int ct = 0; ct < 2; ++ct) mma(w.f[ks][ct], af[ks & 1][rt], acc[ct][rt]);
   }
 }
 
