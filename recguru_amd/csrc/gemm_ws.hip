@@ -123,15 +123,19 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b4[0], b4[1], b4[2], b4[3]};
           }
         }
+        Frag<T> af[2][4];                                 // k-step ks+1's fragments are read under the MFMAs of k-step ks
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) load_frag(af[0][rt], As + (rt * 16 + li) * WS_LD + 8 * lg);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-          Frag<T> af[4];
+          if (ks < 3) {
 #pragma unroll
-          for (int rt = 0; rt < 4; ++rt) load_frag(af[rt], As + (rt * 16 + li) * WS_LD + ks * 32 + 8 * lg);
+            for (int rt = 0; rt < 4; ++rt) load_frag(af[(ks + 1) & 1][rt], As + (rt * 16 + li) * WS_LD + (ks + 1) * 32 + 8 * lg);
+          }
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) mma(w[cb][kc][ks][ct], af[rt], acc[ct][rt]);
+            for (int ct = 0; ct < 2; ++ct) mma(w[cb][kc][ks][ct], af[ks & 1][rt], acc[ct][rt]);
         }
         if (kc == NKC - 1) {
           // ---- epilogue of this 128-feature block: packed tile -> coalesced 16-byte stores
