@@ -25,30 +25,44 @@ __device__ __forceinline__ void store_row32(T* p, const float* v) {
   for (int c = 0; c < 4; ++c) store8(p + 8 * c, v + 8 * c);
 }
 
-// scores of this lane's keys (raw dot * scale, replaced / -inf where masked), returns the row max
-template <typename T>
-__device__ __forceinline__ float lastq_scores(float (&s)[MAXKPL], const float* q, const T* __restrict__ kv, int ldkv, int koff,
+// a 32-element row as it sits in memory: loads of several rows are issued back to back and converted where used
+// (converting at the load made the compiler wait for every row before issuing the next)
+template <typename T> struct Row32 {
+  Frag<T> c[4];
+  __device__ __forceinline__ void load(const T* p) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) load_frag(c[k], p + 8 * k);
+  }
+  __device__ __forceinline__ float at(int j) const { return (float)c[j >> 3].v[j & 7]; }
+};
+
+// scores of this lane's keys (raw dot * scale, replaced / -inf where masked), returns the row max.  KPL = keys per
+// lane (64 KPL >= L): a template parameter, so that the loop is straight-line code with clamped, unconditional loads
+template <typename T, int KPL>
+__device__ __forceinline__ float lastq_scores(float (&s)[KPL], const float* q, const T* __restrict__ kv, int ldkv, int koff,
                                               const int64_t* __restrict__ ids, int64_t pad_value, int L, int lane, float scale) {
+  Row32<T> kr[KPL];
+  int64_t id[KPL];
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) {
+    const int kc = min(lane + 64 * i, L - 1);
+    kr[i].load(kv + (size_t)kc * ldkv + koff);
+    id[i] = ids[kc];
+  }
   float mx = -INFINITY;
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) {
-    const int key = lane + 64 * i;
-    float v = -INFINITY;
-    if (key < L) {
-      float k[32];
-      load_row32(k, kv + (size_t)key * ldkv + koff);
-      float d = 0.f;
+  for (int i = 0; i < KPL; ++i) {
+    float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) d += q[j] * k[j];
-      v = (ids[key] == pad_value) ? MASK_BIG : d * scale;
-    }
+    for (int j = 0; j < 32; ++j) d += q[j] * kr[i].at(j);
+    const float v = (lane + 64 * i < L) ? ((id[i] == pad_value) ? MASK_BIG : d * scale) : -INFINITY;
     s[i] = v;
     mx = fmaxf(mx, v);
   }
   return wave_max(mx);
 }
 
-template <typename T>
+template <typename T, int KPL>
 __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
                                                              const int64_t* __restrict__ key_ids, int64_t pad_value,
                                                              T* __restrict__ ctx, int B, int L, int H, float scale, DropCfg drop) {
@@ -59,38 +73,36 @@ __global__ __launch_bounds__(256) void attn_lastq_fwd_kernel(const T* __restrict
   float q[32];
   load_row32(q, qlast + (size_t)b * P + h * DK);
   const T* kvb = kv + (size_t)b * L * 2 * P;
-  float s[MAXKPL];
-  const float mx = lastq_scores<T>(s, q, kvb, 2 * P, h * DK, key_ids + (size_t)b * L, pad_value, L, lane, scale);
+  float s[KPL];
+  const float mx = lastq_scores<T, KPL>(s, q, kvb, 2 * P, h * DK, key_ids + (size_t)b * L, pad_value, L, lane, scale);
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+  for (int i = 0; i < KPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
   const unsigned int dbase = (((unsigned int)b * H + h) * L + (L - 1)) * rg_lpad(L);   // same index space as the full kernel
   if (drop.thresh) {
 #pragma unroll
-    for (int i = 0; i < MAXKPL; ++i) s[i] *= rg_keep(drop, dbase + lane + 64 * i);
+    for (int i = 0; i < KPL; ++i) s[i] *= rg_keep(drop, dbase + lane + 64 * i);
   }
   float o[32];
 #pragma unroll
   for (int j = 0; j < 32; ++j) o[j] = 0.f;
+  Row32<T> vr[KPL];
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) {
-    const int key = lane + 64 * i;
-    if (key < L) {
-      float v[32];
-      load_row32(v, kvb + (size_t)key * 2 * P + P + h * DK);
-      const float p = s[i] * inv;
+  for (int i = 0; i < KPL; ++i) vr[i].load(kvb + (size_t)min(lane + 64 * i, L - 1) * 2 * P + P + h * DK);
 #pragma unroll
-      for (int j = 0; j < 32; ++j) o[j] += p * v[j];
-    }
+  for (int i = 0; i < KPL; ++i) {
+    const float p = (lane + 64 * i < L) ? s[i] * inv : 0.f;       // keys past L: exp(-inf) = 0 already; the select guards NaN
+#pragma unroll
+    for (int j = 0; j < 32; ++j) o[j] += p * vr[i].at(j);
   }
 #pragma unroll
   for (int j = 0; j < 32; ++j) o[j] = wave_sum(o[j]);
   if (lane == 0) store_row32(ctx + (size_t)b * P + h * DK, o);
 }
 
-template <typename T>
+template <typename T, int KPL>
 __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict__ qlast, const T* __restrict__ kv,
                                                              const T* __restrict__ dctx, const int64_t* __restrict__ key_ids,
                                                              int64_t pad_value, T* __restrict__ dq, T* __restrict__ dkv,
@@ -106,28 +118,40 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict
   const T* kvb = kv + (size_t)b * L * 2 * P;
   T* dkvb = dkv + (size_t)b * L * 2 * P;
   const int64_t* ids = key_ids + (size_t)b * L;
-  float s[MAXKPL];
-  const float mx = lastq_scores<T>(s, q, kvb, 2 * P, h * DK, ids, pad_value, L, lane, scale);
+  float s[KPL];
+  const float mx = lastq_scores<T, KPL>(s, q, kvb, 2 * P, h * DK, ids, pad_value, L, lane, scale);
   const bool full = mx < 0.5f * MASK_BIG;          // every key replaced: uniform row, no gradient to q / k (Q3)
   float sum = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+  for (int i = 0; i < KPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
   sum = wave_sum(sum);
   const float inv = 1.f / sum;
-  float dp[MAXKPL];
+  float dp[KPL];
   float delta = 0.f;
+  Row32<T> vr[KPL], kr[KPL];
+  int64_t idk[KPL];
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) {
+  for (int i = 0; i < KPL; ++i) {               // all V rows, then all K rows and ids: one batch of loads in flight
+    const int kc = min(lane + 64 * i, L - 1);
+    vr[i].load(kvb + (size_t)kc * 2 * P + P + h * DK);
+  }
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) {
+    const int kc = min(lane + 64 * i, L - 1);
+    kr[i].load(kvb + (size_t)kc * 2 * P + h * DK);
+    idk[i] = ids[kc];
+  }
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) {
     const int key = lane + 64 * i;
     dp[i] = 0.f;
     s[i] *= inv;
     if (key < L) {
-      float v[32], dv[32];
-      load_row32(v, kvb + (size_t)key * 2 * P + P + h * DK);
+      float dv[32];
       const float ks = drop.thresh ? rg_keep(drop, dbase + key) : 1.f;
       float d = 0.f;
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { d += g[j] * v[j]; dv[j] = s[i] * ks * g[j]; }
+      for (int j = 0; j < 32; ++j) { d += g[j] * vr[i].at(j); dv[j] = s[i] * ks * g[j]; }
       dp[i] = d * ks;            // d(loss)/d(undropped probability)
       delta += s[i] * dp[i];
       store_row32(dkvb + (size_t)key * 2 * P + P + h * DK, dv);
@@ -138,15 +162,14 @@ __global__ __launch_bounds__(256) void attn_lastq_bwd_kernel(const T* __restrict
 #pragma unroll
   for (int j = 0; j < 32; ++j) dqa[j] = 0.f;
 #pragma unroll
-  for (int i = 0; i < MAXKPL; ++i) {
+  for (int i = 0; i < KPL; ++i) {
     const int key = lane + 64 * i;
     if (key < L) {
-      const bool masked = full || ids[key] == pad_value;
+      const bool masked = full || idk[i] == pad_value;
       const float ds = masked ? 0.f : s[i] * (dp[i] - delta) * scale;
-      float k[32], dk[32];
-      load_row32(k, kvb + (size_t)key * 2 * P + h * DK);
+      float dk[32];
 #pragma unroll
-      for (int j = 0; j < 32; ++j) { dqa[j] += ds * k[j]; dk[j] = ds * q[j]; }
+      for (int j = 0; j < 32; ++j) { dqa[j] += ds * kr[i].at(j); dk[j] = ds * q[j]; }
       store_row32(dkvb + (size_t)key * 2 * P + h * DK, dk);
     }
   }
@@ -162,11 +185,19 @@ extern "C" int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_
   if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((B * H + 3) / 4), block(256);
-  if (dtype == RG_BF16)
-    hipLaunchKernelGGL(attn_lastq_fwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, key_ids, pad_value, (__bf16*)ctx, B, L, H, scale, drop);
-  else if (dtype == RG_F32)
-    hipLaunchKernelGGL(attn_lastq_fwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, key_ids, pad_value, (float*)ctx, B, L, H, scale, drop);
+#define RG_LQF(T, K) hipLaunchKernelGGL((attn_lastq_fwd_kernel<T, K>), grid, block, 0, s, (const T*)qlast, (const T*)kv, key_ids, pad_value, (T*)ctx, B, L, H, scale, drop)
+#define RG_LQF_T(T)                 \
+  do {                              \
+    if (L <= 64) RG_LQF(T, 1);      \
+    else if (L <= 128) RG_LQF(T, 2);\
+    else if (L <= 256) RG_LQF(T, 4);\
+    else RG_LQF(T, 8);              \
+  } while (0)
+  if (dtype == RG_BF16) RG_LQF_T(__bf16);
+  else if (dtype == RG_F32) RG_LQF_T(float);
   else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_fwd: bad dtype");
+#undef RG_LQF_T
+#undef RG_LQF
   RG_CHECK_LAUNCH();
   return 0;
 }
@@ -179,11 +210,19 @@ extern "C" int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* 
   if (L > 64 * MAXKPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq: L > 512");
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((B * H + 3) / 4), block(256);
-  if (dtype == RG_BF16)
-    hipLaunchKernelGGL(attn_lastq_bwd_kernel<__bf16>, grid, block, 0, s, (const __bf16*)qlast, (const __bf16*)kv, (const __bf16*)dctx, key_ids, pad_value, (__bf16*)dq, (__bf16*)dkv, B, L, H, scale, drop);
-  else if (dtype == RG_F32)
-    hipLaunchKernelGGL(attn_lastq_bwd_kernel<float>, grid, block, 0, s, (const float*)qlast, (const float*)kv, (const float*)dctx, key_ids, pad_value, (float*)dq, (float*)dkv, B, L, H, scale, drop);
+#define RG_LQB(T, K) hipLaunchKernelGGL((attn_lastq_bwd_kernel<T, K>), grid, block, 0, s, (const T*)qlast, (const T*)kv, (const T*)dctx, key_ids, pad_value, (T*)dq, (T*)dkv, B, L, H, scale, drop)
+#define RG_LQB_T(T)                 \
+  do {                              \
+    if (L <= 64) RG_LQB(T, 1);      \
+    else if (L <= 128) RG_LQB(T, 2);\
+    else if (L <= 256) RG_LQB(T, 4);\
+    else RG_LQB(T, 8);              \
+  } while (0)
+  if (dtype == RG_BF16) RG_LQB_T(__bf16);
+  else if (dtype == RG_F32) RG_LQB_T(float);
   else return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_bwd: bad dtype");
+#undef RG_LQB_T
+#undef RG_LQB
   RG_CHECK_LAUNCH();
   return 0;
 }
