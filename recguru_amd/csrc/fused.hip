@@ -8,16 +8,19 @@
 // with every intermediate resident in LDS / registers: per token the kernel reads ctx and x
 // (2*d*sizeof(T) bytes) and writes out (d*sizeof(T)); the [tile, d_ff] activation never reaches HBM
 // unless the training path asks for it (h1_save) -- 2*(d*P + 2*d*d_ff) FLOP per token against
-// 3*d*sizeof(T) bytes = 341 FLOP/B at d=128, d_ff=512, bf16: MFMA-bound, unlike the four separate
-// GEMMs (43-102 FLOP/B each).
+// 3*d*sizeof(T) bytes = 341 FLOP/B at d=128, d_ff=512, bf16: far above the HBM ridge, unlike the four separate
+// GEMMs (43-102 FLOP/B each).  What bounds the kernel in practice is the VALU: 512 GELUs (two quarter-rate
+// transcendentals each), the dropout masks and two LayerNorms per token are ~2x the issue cycles of the token's
+// MFMAs (SQ counters: profiles/r01_final/sq_post_attn.txt).
 //
 // MFMA orientation: the WEIGHT fragment is the A operand (rows = output features) and the
 // activation fragment the B operand (columns = tokens), so an accumulator register holds 4
 // CONSECUTIVE FEATURES of one token: every LDS / global write of an intermediate is one packed
 // 8- or 16-byte vector, never a 2-byte scatter.  The four waves split the output features; each
 // weight element is fetched from L2 exactly once per tile, straight into its fragment.
-// LDS (bf16): ctx tile + g chunk + y tile = 3 x 17 KB; the f32 LayerNorm staging tile aliases the
-// first two (dead at those points) -> 52 KB per workgroup, 3 workgroups per CU.
+// LDS (bf16): ctx tile + g chunk + y tile (+ the h1 staging tile when saving) = 3-4 x 16 KB, XOR-swizzled rows,
+// + 8 KB of parameters and row statistics: 56-72 KB per workgroup, 2 workgroups per CU (256 VGPRs per wave allow
+// two waves per SIMD in any case).
 #include "rg_common.cuh"
 #include "../../include/recguru_hip.h"
 
