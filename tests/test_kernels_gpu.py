@@ -739,3 +739,28 @@ def test_ln_bwd_two_stage_sums_and_dz_colsum():
         torch.testing.assert_close(dg - 0.5, g.grad, rtol=3e-2, atol=0.5)
         torch.testing.assert_close(db - 0.5, b.grad, rtol=3e-2, atol=0.5)
         torch.testing.assert_close(dc - 0.5, (z.grad * keep).sum(0), rtol=3e-2, atol=0.5)
+
+
+@pytest.mark.parametrize("M", [16, 77, 4096 + 5, 16 * 9000])
+def test_live_tiles_list(M):
+    """rg_live_tiles: count, ascending ids of the 16-row tiles with a non-zero mask value, padded tile ids from the far
+    end backwards -- all-dead, all-live, ragged last tile, more tiles than one compaction pass (8192) holds."""
+    from recguru_amd import hip
+    g0 = torch.Generator().manual_seed(M)
+    nt = (M + 15) // 16
+    for kind in ("random", "dead", "live"):
+        if kind == "random":
+            tile_live = torch.rand(nt, generator=g0) < 0.6
+            m = (tile_live.repeat_interleave(16)[:M].float() * (torch.rand(M, generator=g0) < 0.7).float())
+            m[(torch.arange(nt)[tile_live] * 16).clamp(max=M - 1)] = 0.25       # every live tile keeps one non-zero row
+        else:
+            m = torch.zeros(M) if kind == "dead" else torch.ones(M)
+        m = m.cuda().contiguous()
+        lst = hip.live_tiles(m, M).cpu()
+        pad = torch.nn.functional.pad(m.cpu(), (0, nt * 16 - M)).view(nt, 16)
+        want = torch.nonzero(pad.abs().sum(1) != 0).flatten().to(torch.int32)
+        n = int(lst[0])
+        assert n == want.numel()
+        assert torch.equal(lst[1:1 + n], want)
+        dead = torch.nonzero(pad.abs().sum(1) == 0).flatten().to(torch.int32)
+        assert torch.equal(lst[1 + n:1 + nt].flip(0), dead)                     # dead ids, listed from the far end
