@@ -241,8 +241,11 @@ def critic_embed(netG, in_seq_a, in_seq_b, param, device):
 def critic_update(netD, ae, be, opt_d, device, dp):
     """W-loss, gradient penalty and Adam(D) of a critic update (gan_training.py:412-449)."""
     opt_d.zero_grad()
-    D_real = netD(ae)
-    D_fake = netD(be)
+    # D(real) and D(fake) as ONE pass over the stacked batch (the MLP is row-wise: same values row by row, half the
+    # launches of the forward and of the backward); gan_training.py:412-420 calls netD twice
+    nb = ae.shape[0]
+    D_both = netD(torch.cat([ae, be], 0))
+    D_real, D_fake = D_both[:nb], D_both[nb:]
     real_loss, fake_loss = mean(D_real), mean(D_fake)
     dis_loss = fake_loss - real_loss
     dp.scale_mean(dis_loss).backward()
