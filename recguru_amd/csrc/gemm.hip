@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   constexpr int A_BYTES = TM * LDA * (int)sizeof(T);
   constexpr int Z_LD = TN + 4;
   constexpr int Z_BYTES = TM * Z_LD * 4;
-  constexpr int SMEM = A_BYTES > Z_BYTES ? A_BYTES : Z_BYTES;   // A tile and the f32 epilogue tile alias
+  constexpr int A2 = sizeof(T) == 2 ? 2 * A_BYTES : A_BYTES;     // bf16: two A tiles (one barrier per chunk)
+  constexpr int SMEM = A2 > Z_BYTES ? A2 : Z_BYTES;             // A tiles and the f32 epilogue tile alias
   __shared__ __align__(16) unsigned char smem[SMEM];
   T* As = reinterpret_cast<T*>(smem);
 
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
       }
     }
   };
-  auto stage_chunk = [&](const Frag<T> (&pre)[4], int ci) {       // registers -> LDS, prologue applied on the way
+  auto stage_chunk = [&](const Frag<T> (&pre)[4], int ci, T* As) {       // registers -> LDS, prologue applied on the way
     const int klen = FULLK ? KC : min(KC, a.K - ci * KC), cpr = klen >> 3;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
       }
     }
   };
-  auto mma_chunk = [&](const Frag<T> (&w)[4][NTW], int ci) {
+  auto mma_chunk = [&](const Frag<T> (&w)[4][NTW], int ci, const T* As) {
     const int ksteps = FULLK ? 4 : min(KC, a.K - ci * KC) >> 5;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -103,27 +104,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
   if constexpr (sizeof(T) == 4) {     // f32 parity tier: fragments are twice as wide, one register set only
     for (int ci = 0; ci < nk; ++ci) {
       load_chunk(w0, p0, ci);
-      stage_chunk(p0, ci);
+      stage_chunk(p0, ci, As);
       __syncthreads();
-      mma_chunk(w0, ci);
+      mma_chunk(w0, ci, As);
       __syncthreads();
     }
   } else {
   Frag<T> w1[4][NTW], p1[4];
+  T* As1 = reinterpret_cast<T*>(smem + A_BYTES);
   load_chunk(w0, p0, 0);
   for (int ci = 0; ci < nk; ci += 2) {
     // the prefetch is UNCONDITIONAL (past the end it re-reads the last chunk): under a condition the compiler cannot
     // count the loads in flight at the join and waits for all of them before the MFMAs
-    stage_chunk(p0, ci);
-    __syncthreads();
+    // two A tiles in LDS: chunk c+1 is staged into the other tile while the MFMAs of chunk c are in flight, one
+    // barrier per chunk
+    if (ci == 0) {
+      stage_chunk(p0, 0, As);
+      __syncthreads();
+    }
     load_chunk(w1, p1, min(ci + 1, nk - 1));
-    mma_chunk(w0, ci);
+    mma_chunk(w0, ci, As);
+    stage_chunk(p1, min(ci + 1, nk - 1), As1);
     __syncthreads();
     if (ci + 1 >= nk) break;
-    stage_chunk(p1, ci + 1);
-    __syncthreads();
     load_chunk(w0, p0, min(ci + 2, nk - 1));
-    mma_chunk(w1, ci + 1);
+    mma_chunk(w1, ci + 1, As1);
+    stage_chunk(p0, min(ci + 2, nk - 1), As);
     __syncthreads();
   }
   }
