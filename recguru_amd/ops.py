@@ -77,6 +77,18 @@ def shadow_cat(ps, transpose=False):
     return ent[1]
 
 
+def bias_cat(ps):
+    """torch.cat of f32 bias vectors (the fused QKV bias), cached per parameter version: the critic phase runs every
+    layer ten times between two updates of the generator."""
+    key = (tuple(id(p) for p in ps), "bias_cat")
+    ver = tuple(_ver(p) for p in ps)
+    ent = _SHADOWS.get(key)
+    if ent is None or ent[0] != ver:
+        ent = (ver, torch.cat([p.detach() for p in ps]), tuple(weakref.ref(p) for p in ps))
+        _SHADOWS[key] = ent
+    return ent[1]
+
+
 _REFRESH_TILES = {}
 
 
@@ -92,6 +104,8 @@ def refresh_shadows(params):
         ps = tuple(r() for r in ent[2])
         if any(p is None for p in ps):
             dead.append(key)                            # its parameters are gone: drop the copy
+            continue
+        if key[-1] == "bias_cat":                       # f32 concatenations: rebuilt lazily (bias_cat)
             continue
         if key[2] != _COMPUTE or not any(id(p) in ids for p in ps) or ps[0].dim() != 2 or not ps[0].is_cuda:
             continue
@@ -334,7 +348,7 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     """rowmask [B*L]: the pad mask the layer output is multiplied by -- query tiles made of padded positions only are
     skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
-    bqkv = torch.cat([bq.detach(), bk.detach(), bv.detach()])
+    bqkv = bias_cat((bq, bk, bv))
     # every row is projected: a padded position is still a KEY unless its id equals pad_value (the reference masks
     # keys by pad_value and rows by id != 0 -- two different sets), so its K / V rows are real operands
     qkv = hip.gemm_nt(x2, wqkv, bqkv)
@@ -483,7 +497,7 @@ class EncoderLastLayerFn(_Fn):
         rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
         x_last = x[:, -1, :].contiguous()
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
-        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), torch.cat([bk.detach(), bv.detach()]))
+        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bias_cat((bk, bv)))
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
         c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0])
         if _fusable(x_last, Wo, W1):
