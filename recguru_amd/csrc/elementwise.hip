@@ -27,10 +27,11 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
     const long long tok = i / cpr;
     const int c8 = (int)(i - tok * cpr) * 8;
     const float m = mask[tok];
+    const int64_t id = ids[tok];          // with the mask, not behind it: mask -> id -> row was three dependent latencies
     float v[8];
     if (m != 0.f) {
       float p[8];
-      load8(v, table + (size_t)ids[tok] * d + c8);
+      load8(v, table + (size_t)id * d + c8);
       load8(p, pe + (size_t)(tok % L) * d + c8);
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
