@@ -750,20 +750,28 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
           for (int r = 0; r < 4; ++r) sv[r] = (key > q0 + 4 * lg + r) ? fminf(sv[r], MASK_BIG) : sv[r];
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sc = sv[r];                                       // -2^100 / -inf where replaced
-          const float pe = __builtin_amdgcn_exp2f(fmaf(sc, c2, -l4[r]));   // 0 where masked or row fully masked
-          const float pu = pe + ((key < L) ? r4[r] : 0.f);              // uniform 1/L rows (Q3)
+        for (int r = 0; r < 4; r += 2) {          // element pairs: the fma / add / sub / mul as packed v_pk_* instructions
+          const f32x2 arg = (f32x2){sv[r], sv[r + 1]} * (f32x2){c2, c2} - (f32x2){l4[r], l4[r + 1]};   // scores: -2^100 / -inf where replaced
+          f32x2 pe;                                                     // 0 where masked or row fully masked
+          pe.x = __builtin_amdgcn_exp2f(arg.x);
+          pe.y = __builtin_amdgcn_exp2f(arg.y);
+          // uniform 1/L rows (Q3); columns key >= L only reach dV rows that are never stored
+          const f32x2 pu = pe + (f32x2){r4[r], r4[r + 1]};
+          const f32x2 dl = (f32x2){d4[r], d4[r + 1]};
+          f32x2 dd, pp;
           if constexpr (DM == 1) {
-            ds[u][r] = pe * (rg_and(dp[r], km4[r]) - d4[r]);          // the 1/sqrt(d_k) is applied to dK / dQ on the way out
-            p[u][r] = rg_and(pu, km4[r]);                                // the dropped map feeds dV
+            dd = (f32x2){rg_and(dp[r], km4[r]), rg_and(dp[r + 1], km4[r + 1])};
+            pp = (f32x2){rg_and(pu.x, km4[r]), rg_and(pu.y, km4[r + 1])};      // the dropped map feeds dV
           } else if constexpr (DM == 2) {
-            ds[u][r] = pe * (dp[r] * ks4[r] - d4[r]);
-            p[u][r] = pu * ks4[r];
+            dd = (f32x2){dp[r], dp[r + 1]} * (f32x2){ks4[r], ks4[r + 1]};
+            pp = pu * (f32x2){ks4[r], ks4[r + 1]};
           } else {
-            ds[u][r] = pe * (dp[r] - d4[r]);
-            p[u][r] = pu;
+            dd = (f32x2){dp[r], dp[r + 1]};
+            pp = pu;
           }
+          const f32x2 dsv = pe * (dd - dl);       // the 1/sqrt(d_k) is applied to dK / dQ on the way out
+          ds[u][r] = dsv.x; ds[u][r + 1] = dsv.y;
+          p[u][r] = pp.x; p[u][r + 1] = pp.y;
         }
       }
       Frag<T> pf, dsf;

@@ -58,7 +58,9 @@ def shadow(p, transpose=False):
     key = (id(p), transpose, _COMPUTE)
     ent = _SHADOWS.get(key)
     ver = _ver(p)
-    if ent is None or ent[0] != ver:
+    # the entry must belong to THIS parameter object: id() and even the data pointer of a collected parameter are
+    # reused by later ones (a stale copy of another model's weight surfaced once in ~25 runs of the test suite)
+    if ent is None or ent[0] != ver or ent[2][0]() is not p:
         ent = (ver, hip.cast(p.detach(), _COMPUTE, transpose=transpose), (weakref.ref(p),))
         _SHADOWS[key] = ent
     return ent[1]
@@ -69,7 +71,7 @@ def shadow_cat(ps, transpose=False):
     key = (tuple(id(p) for p in ps), transpose, _COMPUTE, "cat")
     ver = tuple(_ver(p) for p in ps)
     ent = _SHADOWS.get(key)
-    if ent is None or ent[0] != ver:
+    if ent is None or ent[0] != ver or any(r() is not p for r, p in zip(ent[2], ps)):
         w = torch.cat([p.detach() for p in ps], 0).contiguous()
         ent = (ver, hip.cast(w, _COMPUTE, transpose=transpose) if (transpose or _COMPUTE != torch.float32) else w,
                tuple(weakref.ref(p) for p in ps))
@@ -83,7 +85,7 @@ def bias_cat(ps):
     key = (tuple(id(p) for p in ps), "bias_cat")
     ver = tuple(_ver(p) for p in ps)
     ent = _SHADOWS.get(key)
-    if ent is None or ent[0] != ver:
+    if ent is None or ent[0] != ver or any(r() is not p for r, p in zip(ent[2], ps)):
         ent = (ver, torch.cat([p.detach() for p in ps]), tuple(weakref.ref(p) for p in ps))
         _SHADOWS[key] = ent
     return ent[1]
