@@ -151,6 +151,18 @@ def refresh_shadows(params):
         _SHADOWS[key] = (ver, dst, tuple(weakref.ref(p) for p in ps))
 
 
+_EYES = {}
+
+
+def _head_eye(H, like):
+    """[1, H, H, 1] identity over heads in the dtype / device of `like` (cached)."""
+    key = (H, like.dtype, like.device)
+    e = _EYES.get(key)
+    if e is None:
+        e = _EYES[key] = torch.eye(H, device=like.device, dtype=like.dtype).view(1, H, H, 1)
+    return e
+
+
 def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
@@ -568,10 +580,10 @@ class DecoderLayerFn(_Fn):
         s_cross = None
         if drop_p > 0:
             s_cross = hip.cross_drop_scale(enc_ids.contiguous(), 0, H, drop_p, seeds[3])     # [B*L, H]
-            woS = shadow(cWo)
-            oh = torch.empty(B, H, d, device=x.device, dtype=torch.float32)
-            for hh in range(H):
-                hip.gemm_nt(c[:, hh * 32:(hh + 1) * 32], woS[:, hh * 32:(hh + 1) * 32], None, out=oh[:, hh, :])
+            # oh[b, h, :] = c[b, head-h block] @ Wo[:, head-h block]^T for every head in ONE GEMM: row (b, h) of the
+            # stacked operand is c[b] with the other heads' blocks zeroed
+            cm = (c.view(B, 1, H, 32) * _head_eye(H, c)).view(B * H, P)
+            oh = hip.gemm_nt(cm, shadow(cWo), None, out_f32=True).view(B, H, d)
             cross_kw = dict(cross=(None, cg.detach(), cbe.detach()), cross_drop=(s_cross, oh, cbo.detach(), H))
         else:
             o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)      # [B, d] f32
@@ -626,12 +638,14 @@ class DecoderLayerFn(_Fn):
             dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                            # [B, P]
         else:
             doh = hip.seq_wsum(dy1, s_cross, B, L, H)                                    # [B, H, d]
-            woT = shadow(cWo, transpose=True)                                            # [P, d]
-            dc = torch.empty(B, P, device=dev, dtype=c.dtype)
-            for hh in range(H):
-                blk = slice(hh * 32, (hh + 1) * 32)
-                hip.gemm_tn(doh[:, hh, :], c[:, blk], dcWo[:, blk])
-                hip.gemm_nt(doh[:, hh, :], woT[blk, :], out=dc[:, blk])
+            # all heads at once (see the forward): dWo[:, block h] += doh[:, h, :]^T c[:, block h] is one TN product
+            # against the head-masked stack of c; dc's block h is the diagonal block of doh[:, h, :] @ Wo
+            eye = _head_eye(H, c)
+            cm = (c.view(B, 1, H, 32) * eye).view(B * H, P)
+            doh2 = doh.reshape(B * H, d)
+            hip.gemm_tn(doh2, cm, dcWo)
+            full = hip.gemm_nt(doh2, shadow(cWo, transpose=True))                         # [B*H, P] = doh @ Wo
+            dc = (full.view(B, H, H, 32) * eye).sum(1).view(B, P)
         (dcWv, rcWv), (dcbv, rcbv) = _gt(cWv), _gt(cbv)
         hip.gemm_tn(dc, u, dcWv, dcbv)
         du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
