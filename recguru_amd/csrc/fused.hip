@@ -163,13 +163,15 @@ __device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restri
 // rows of a plain tile (mb[rt] = m0 + 16 rt), or the next 4 LIVE row tiles of the workgroup's range when padded row
 // tiles are compacted away.  Thread tid stages chunk i of the tile = row 16 i + (tid >> 4), columns 8 (tid & 15)..
 // cooperative, coalesced copy of a [64 x 128] LDS tile to its rows of a row-major HBM matrix
-template <typename T>
+template <typename T, bool NT = false>
 __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[4], int M, int tid) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
-    if (m < M)
-      *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
+    if (m < M) {
+      if constexpr (NT) frag_store_nt(dst + (size_t)m * ld + col0 + c8, *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8)));
+      else *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
+    }
   }
 }
 
@@ -340,7 +342,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     STAMP(2);
     if (a.o_bcast || a.cross_s) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
-      if (ysave) { lds_barrier(); tile_to_hbm<T>(Ay, ysave, FD, 0, mb, a.M, tid); }
+      if (ysave) { lds_barrier(); tile_to_hbm<T, true>(Ay, ysave, FD, 0, mb, a.M, tid); }
       // o rows: the (uniform) dropout / no-dropout switch sits outside the loops and the loads of a row tile are
       // issued together (inside the loops every (rt, ct, head) was a branch + load + wait: ~30 exposed L2 latencies
       // per tile, the decoder launches ran at half the rate of the encoder ones)
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
     {
       const bool cross = a.o_bcast || a.cross_s;
-      if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T>(Ay, cross ? y2save : ysave, FD, 0, mb, a.M, tid);
+      if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T, true>(Ay, cross ? y2save : ysave, FD, 0, mb, a.M, tid);
     }
     STAMP(3);
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
@@ -460,7 +462,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       STAMP(6);
       lds_barrier();
       STAMP(7);
-      if (h1save) tile_to_hbm<T>(Ah, h1save, a.dff, ch * FD, mb, a.M, tid);
+      if (h1save) tile_to_hbm<T, true>(Ah, h1save, a.dff, ch * FD, mb, a.M, tid);
       mma_wset<T>(acc2, wq, Ag, li, lg);                // out += g . W2[:, chunk]^T
       STAMP(8);
     }

@@ -114,6 +114,20 @@ __device__ __forceinline__ void store4(__bf16* p, const float* v) {
   *reinterpret_cast<bf16x4_t*>(p) = a;
 }
 
+// Nontemporal 16-byte store of a fragment: for activations SAVED for the backward pass (read tens of milliseconds
+// later) -- written with plain stores they evict the layer output the next kernel is about to read from the
+// Infinity Cache.
+typedef __attribute__((ext_vector_type(4))) float rg_f4;
+__device__ __forceinline__ void frag_store_nt(float* p, const Frag<float>& f) {
+  __builtin_nontemporal_store((rg_f4){f.v[0], f.v[1], f.v[2], f.v[3]}, reinterpret_cast<rg_f4*>(p));
+  __builtin_nontemporal_store((rg_f4){f.v[4], f.v[5], f.v[6], f.v[7]}, reinterpret_cast<rg_f4*>(p + 4));
+}
+__device__ __forceinline__ void frag_store_nt(__bf16* p, const Frag<__bf16>& f) {
+  union { bf16x8_t b; rg_f4 x; } u;
+  u.b = f.v;
+  __builtin_nontemporal_store(u.x, reinterpret_cast<rg_f4*>(p));
+}
+
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
