@@ -56,8 +56,8 @@ def parse():
                     help="loaders included: assemble every batch and draw fresh negatives on the GPU (recguru_amd.sampler) "
                          "instead of iterating pre-staged tensors")
     ap.add_argument("--no_overlap", action="store_true", help="critic encoder passes on the main stream (debug A/B)")
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4096, help="users per domain per GPU per draw")
     ap.add_argument("--seq_len", type=int, default=200)
     ap.add_argument("--d_model", type=int, default=128)
