@@ -199,6 +199,18 @@ typedef struct {
   float step_lr; float inv_bc2_sqrt;
 } rg_adam_seg;
 int rg_adam_multi(const rg_adam_seg* segs /* device */, int nsegs, float beta1, float beta2, float eps, void* stream);
+/* Same update with the per-parameter STEP COUNT kept in the device-resident table: block b reads segs[b].step (the
+ * number of updates this parameter has had), computes the bias corrections 1 - beta^(step+1) itself (in double, like
+ * torch.optim.Adam's Python arithmetic), updates its chunk and stores step + 1 back.  Nothing crosses PCIe per
+ * optimizer step -- a per-step table upload from pageable host memory blocks the host until the stream drains --
+ * and the learning rate (ScheduledOptim changes it every step, transformer.py:43-51) is a launch argument. */
+typedef struct {
+  float* p; const float* g; float* m; float* v;
+  long long n;
+  long long step;
+} rg_adam_seg_dev;
+int rg_adam_multi_dev(rg_adam_seg_dev* segs /* device, updated in place */, int nsegs, double lr, double beta1, double beta2,
+                      double eps, void* stream);
 int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
 /* Multi-tensor cast: ONE launch refreshes every operand-tier weight copy after an optimizer step (136 per-tensor casts
  * per training iteration otherwise).  Segment s: dst[(r + row_off) * ld + c + col_off] = src[r, c], or with transpose

@@ -468,6 +468,77 @@ def generator_step(pG, pD, cfg, batch_a, batch_b, opt_g, collapsed=False):
     return g_dis.detach(), la.detach(), lb.detach()
 
 
+def phase3_step(pG, cfg, rec_batch, recon_batch, opt, domain="a", fixed_enc=True, collapsed=False):
+    """Phase-3 body of train_gan_all, gan_training.py:529-567: reconstruction loss on the target domain's AE batch,
+    then the BPR loss of the recommender decoder on the rec batch (mask = dec_out != 0), one Adam step over G."""
+    opt.zero_grad()
+    l_rec = loss_ae_cross(pG, cfg, *recon_batch, domain=domain, collapsed=collapsed)
+    l_rec.backward()
+    enc_in, dec_in, dec_out, n_items = rec_batch
+    mask = nonpad(dec_out, cfg.pad_index).view(-1)
+    l_bpr = loss_bpr_cross(pG, cfg, enc_in, dec_in, dec_out, n_items, mask, domain, fixed_enc, collapsed)
+    l_bpr.backward()
+    opt.step()
+    return l_bpr.detach(), l_rec.detach()
+
+
+class _Loader(object):
+    """try: next(it) / except StopIteration: it = iter(loader) -- the reference's loader idiom
+    (gan_training.py:338-344, :391-398).  A batch is ((enc_in, dec_in, dec_out), n_items, val, test)."""
+
+    def __init__(self, loader):
+        self.loader, self.it = loader, iter(loader)
+
+    def next(self, restart=None):
+        try:
+            seqs, n_items, _, _ = next(self.it)
+        except StopIteration:
+            self.it = iter(restart if restart is not None else self.loader)
+            seqs, n_items, _, _ = next(self.it)
+        return seqs[0], seqs[1], seqs[2], n_items
+
+
+def train_recon_x(pG, cfg, steps, data, warmup, betas=(0.9, 0.98), eps=1e-9, collapsed=False):
+    """gan_training.py:818-892 with opt_type='schedule': one a-batch is consumed before the loop (:837), then `steps`
+    recon steps under the Noam learning rate.  Returns ([(loss_a, loss_b)], optimizer)."""
+    opt = Adam({k: v for k, v in pG.items() if v.requires_grad}, 1.0, betas, eps)
+    la, lb = _Loader(data[0]), _Loader(data[1])
+    next(la.it)
+    out = []
+    for i in range(steps):
+        ba, bb = la.next(), lb.next()
+        out.append(recon_step(pG, cfg, ba, bb, opt, lr=noam_lr(i + 1, cfg.d_model, warmup), collapsed=collapsed))
+    return out, opt
+
+
+def train_gan_all(pG, pD, cfg, gan_loader, rec_loaders, iterations, domain="a", collapsed=False):
+    """gan_training.py:353-587 with overlap=False and no evaluation point inside the run: phase 2 for
+    iteration < int(0.6 * iterations) (CRITIC_ITERS critic updates, alpha = torch.rand(B, 1) from the CPU default
+    generator as :39, then the generator update), phase 3 after that (opt_final_rec = Adam(1e-3, (0.9, 0.98)), :359;
+    the rec iterator restarts from rec_loaders[1] once iteration > int(0.8 * iterations), :531-537).
+    Returns (phase-2 rows [D_cost, Wasserstein_D, recon_a, recon_b, g_dis], phase-3 rows [loss_recommend, loss_recon])."""
+    gparams = {k: v for k, v in pG.items() if v.requires_grad}
+    opt_g = Adam(gparams, 1e-4, (0.5, 0.9))
+    opt_d = Adam(pD, 1e-4, (0.5, 0.9))
+    opt_final = Adam(gparams, 1e-3, (0.9, 0.98))
+    a_it, b_it = _Loader(gan_loader[0]), _Loader(gan_loader[1])
+    rec_task = _Loader(rec_loaders[0])
+    rec_it = _Loader(gan_loader[0] if domain == "a" else gan_loader[1])
+    p2, p3 = [], []
+    for iteration in range(int(iterations * 1.2)):
+        if iteration < int(iterations * 0.6):
+            for _ in range(CRITIC_ITERS):
+                sa, sb = a_it.next()[0], b_it.next()[0]
+                d_cost, w_d, _ = critic_step(pG, pD, cfg, sa, sb, opt_d, torch.rand(sa.shape[0], 1))
+            g_dis, la, lb = generator_step(pG, pD, cfg, a_it.next(), b_it.next(), opt_g, collapsed)
+            p2.append([float(d_cost), float(w_d), float(la), float(lb), float(g_dis)])
+        else:
+            rb = rec_task.next(restart=rec_loaders[1] if iteration > int(iterations * 0.8) else rec_loaders[0])
+            l_bpr, l_rec = phase3_step(pG, cfg, rb, rec_it.next(), opt_final, domain, True, collapsed)
+            p3.append([float(l_bpr), float(l_rec)])
+    return p2, p3
+
+
 # ----------------------------------------------------------------------------------------------
 # ranking evaluation  (SURVEY 8f row 2)
 # ----------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ def _stale(target, sources):
 
 def build(force=False, verbose=False, jobs=4):
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.cuh")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hip.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []

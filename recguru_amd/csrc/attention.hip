@@ -12,9 +12,9 @@
 // Layout: qkv is [B, L, 3P] row-major (P = H*32): Q | K | V column blocks, head h at h*32.
 // Whole key range of one head lives on chip (L <= 16*NKT): S^T = K.Q^T accumulators (key on the
 // register axis, query on the lane) are exponentiated in place and fed straight back as the B
-// operand of O^T = V^T.P^T (rg_common.cuh, stacked-accumulator mapping) -- P never touches LDS.
+// operand of O^T = V^T.P^T (rg_common.hip.h, stacked-accumulator mapping) -- P never touches LDS.
 #include <stdlib.h>
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define DK 32
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   int b, h;
-  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   int b, h;
-  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
@@ -599,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   int b, h;
-  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.cuh)
+  if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
   const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;

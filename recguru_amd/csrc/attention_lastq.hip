@@ -6,7 +6,7 @@
 // projection and the FFN are needed for ONE query per sequence.  Results are identical to row L-1 of
 // the full ScaledDotProductAttention (Transformer/transformer.py:119-129), incl. the -1e9 replace fill.
 // One wave per (sequence, head); lanes stride the keys; f32 math.
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define DK 32

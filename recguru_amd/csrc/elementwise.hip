@@ -1,7 +1,7 @@
 // HBM-bound kernels of the path: embedding gather / scatter, LayerNorm backward, the collapsed
 // cross-attention broadcast+LayerNorm, gradient-penalty helpers, Adam, casts and reductions.
 // All of them move 8-16 bytes per lane per access with lanes on consecutive addresses.
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define EW_BLOCK 256
@@ -441,6 +441,47 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_multi_kernel(const rg_adam_seg*
     v[i] = vi;
     p[i] = p[i] - sg.step_lr * (mi / (sqrtf(vi) * sg.inv_bc2_sqrt + eps));
   }
+}
+
+// The same with the step count living in the table (rg_adam_seg_dev): no per-step upload.  Every thread derives the two
+// bias corrections from the block's step count (two pow() in double per thread -- nothing against the chunk's traffic).
+__global__ __launch_bounds__(EW_BLOCK) void adam_multi_dev_kernel(rg_adam_seg_dev* __restrict__ segs, double lr, double b1d,
+                                                                  double b2d, float eps) {
+  const rg_adam_seg_dev sg = segs[blockIdx.x];
+  const double st = (double)(sg.step + 1);
+  const float step_lr = (float)(lr / (1.0 - pow(b1d, st)));
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(1.0 - pow(b2d, st)));
+  const float b1 = (float)b1d, b2 = (float)b2d;
+  float* __restrict__ p = sg.p;
+  const float* __restrict__ g = sg.g;
+  float* __restrict__ m = sg.m;
+  float* __restrict__ v = sg.v;
+  const long long n4 = (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) ? 0 : (sg.n >> 2);
+  for (long long i = threadIdx.x; i < n4; i += EW_BLOCK) {
+    const float4 g4 = reinterpret_cast<const float4*>(g)[i];
+    float4 m4 = reinterpret_cast<float4*>(m)[i], v4 = reinterpret_cast<float4*>(v)[i], p4 = reinterpret_cast<float4*>(p)[i];
+    const float gg[4] = {g4.x, g4.y, g4.z, g4.w};
+    float mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      mm[j] = b1 * mm[j] + (1.f - b1) * gg[j];
+      vv[j] = b2 * vv[j] + (1.f - b2) * gg[j] * gg[j];
+      pp[j] = pp[j] - step_lr * (mm[j] / (sqrtf(vv[j]) * inv_bc2_sqrt + eps));
+    }
+    reinterpret_cast<float4*>(m)[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    reinterpret_cast<float4*>(v)[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    reinterpret_cast<float4*>(p)[i] = make_float4(pp[0], pp[1], pp[2], pp[3]);
+  }
+  for (long long i = (n4 << 2) + threadIdx.x; i < sg.n; i += EW_BLOCK) {
+    const float gi = g[i];
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = p[i] - step_lr * (mi / (sqrtf(vi) * inv_bc2_sqrt + eps));
+  }
+  __syncthreads();                                               // every thread of the block has read its copy of sg
+  if (threadIdx.x == 0) segs[blockIdx.x].step = sg.step + 1;
 }
 
 // dst[c,r] (or dst[r,c]) = (T) src[r,c]
@@ -889,6 +930,16 @@ extern "C" int rg_adam_multi(const rg_adam_seg* segs_device, int nsegs, float be
   if (nsegs <= 0) return 0;
   if (!segs_device) return rg_set_error_msg(RG_ERR_INVALID, "adam_multi: null segment table");
   hipLaunchKernelGGL(adam_multi_kernel, dim3(nsegs), dim3(EW_BLOCK), 0, (hipStream_t)stream, segs_device, beta1, beta2, eps);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_adam_multi_dev(rg_adam_seg_dev* segs_device, int nsegs, double lr, double beta1, double beta2, double eps,
+                                 void* stream) {
+  if (nsegs <= 0) return 0;
+  if (!segs_device) return rg_set_error_msg(RG_ERR_INVALID, "adam_multi_dev: null segment table");
+  hipLaunchKernelGGL(adam_multi_dev_kernel, dim3(nsegs), dim3(EW_BLOCK), 0, (hipStream_t)stream, segs_device, lr, beta1, beta2,
+                     (float)eps);
   RG_CHECK_LAUNCH();
   return 0;
 }

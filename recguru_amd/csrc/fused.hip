@@ -21,7 +21,7 @@
 // LDS (bf16): ctx tile + g chunk + y tile (+ the h1 staging tile when saving) = 3-4 x 16 KB, XOR-swizzled rows,
 // + 8 KB of parameters and row statistics: 56-72 KB per workgroup, 2 workgroups per CU (256 VGPRs per wave allow
 // two waves per SIMD in any case).
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define FT_M 64      // tokens per tile

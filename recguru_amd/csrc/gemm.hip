@@ -9,7 +9,7 @@
 // B fragment (torch Linear weights are [out,in] = [N][K]: 8 consecutive k are 16 contiguous bytes).
 // The residual+LayerNorm epilogue needs whole rows and therefore a tile that spans N.
 #include <stdio.h>
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define TM 64
@@ -317,6 +317,11 @@ extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
     const int rc = rg_gemm_ws_try(a, dtype, s);
     if (rc <= 0) return rc;
   }
+  // the generic tile kernel reads EVERY row: a live-tile list means the padded tiles' rows of A / aux may never have
+  // been written by their producers (rg_ln_bwd, skip_dead_fill), so falling through silently would compute on garbage
+  if (a->live16)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: live16 given but the list-driven kernel does not take this "
+                            "problem (bf16, K and N multiples of 128 up to 512, M >= 4096 required)");
   if (dtype == RG_BF16) return launch_nt<__bf16>(*a, s);
   if (dtype == RG_F32) return launch_nt<float>(*a, s);
   return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: bad dtype");
@@ -473,6 +478,10 @@ extern "C" int rg_gemm_tn(const rg_gemm_tn_args* a, int dtype, void* stream) {
     const int rc = rg_gemm_tn_big_try(a, dtype, s);
     if (rc <= 0) return rc;
   }
+  // same contract as rg_gemm_nt: the generic kernel sums every row, so it must not be handed a list
+  if (a->live16)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn: live16 given but the list-driven kernel does not take this "
+                            "problem (bf16, T >= 8192, splits == 0, supported N1 x N2 required)");
   const int g1 = (a->N1 + 63) / 64, g2 = (a->N2 + 63) / 64;
   int splits = a->splits;
   if (splits <= 0) {

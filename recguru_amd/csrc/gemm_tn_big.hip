@@ -10,7 +10,7 @@
 // N1 / N2.  Partial results: with a.partials each workgroup stores its accumulators register-major (every store
 // instruction = 256 contiguous bytes) and tn_big_reduce_kernel sums the slices into dW; without it, f32 atomics
 // (a 16x16 accumulator register is 4 x 64-byte segments per instruction: 256 x |dW| of those cost more than the GEMM).
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define TB_T 64      // tokens per chunk: two MFMA k-steps per barrier pair and >= 80 KB of loads in flight per CU

@@ -11,7 +11,7 @@
 // barriers order LDS only (lds_barrier), and -- weight fragment as the A operand -- each
 // accumulator register holds 4 consecutive features of one token, so results leave through a
 // packed LDS tile and 16-byte coalesced stores (aux operands are read the same way).
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define WS_M 64

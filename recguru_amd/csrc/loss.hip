@@ -12,7 +12,7 @@
 // Backward recomputes the dots (rows come from L2 / Infinity Cache), forms
 // c_j = dl_t/dlogit_j * mask_t * gout / sum(mask), accumulates dh_t = sum_j c_j E[j] in registers and
 // scatters c_j * h_t into the dense f32 table gradient with full-row (256 B per instruction) atomics.
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define LW 4  // waves per block
@@ -680,14 +680,16 @@ __global__ __launch_bounds__(64 * LW) void rank_scores_kernel(rg_rank_args a) {
 extern "C" int rg_rank_scores(const rg_rank_args* a, int dtype, void* stream) {
   if (!a || a->B <= 0) return 0;
   if (a->C < 0 || a->C >= (1 << 24)) return rg_set_error_msg(RG_ERR_INVALID, "rank_scores: bad candidate count");
-  if (!(a->d == 64 || a->d == 128 || a->d == 256)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "rank_scores: d must be 64, 128 or 256");
+  if (!(a->d == 32 || a->d == 64 || a->d == 128 || a->d == 256))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "rank_scores: d must be 32, 64, 128 or 256");
   hipStream_t s = (hipStream_t)stream;
   int g = (a->B + LW - 1) / LW;
   if (g > 256 * 32) g = 256 * 32;
 #define RG_RK(T, LPR) hipLaunchKernelGGL((rank_scores_kernel<T, LPR>), dim3(g), dim3(64 * LW), 0, s, *a)
 #define RG_RK_T(T)                  \
   do {                              \
-    if (a->d == 64) RG_RK(T, 8);    \
+    if (a->d == 32) RG_RK(T, 4);    \
+    else if (a->d == 64) RG_RK(T, 8);    \
     else if (a->d == 128) RG_RK(T, 16); \
     else RG_RK(T, 32);              \
   } while (0)

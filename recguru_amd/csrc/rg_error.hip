@@ -1,5 +1,5 @@
 // Error plumbing shared by every launcher.
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 #include <stdio.h>
 #include <string.h>

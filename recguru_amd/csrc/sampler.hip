@@ -8,7 +8,7 @@
 // element does the padding arithmetic, one thread per draw maps a counter-based hash to the u-th ALLOWED item
 // (exact uniform over 1..V minus the exclusions, no rejection loop) or, for frequency^0.75 sampling, walks an
 // alias table and rejects excluded draws.
-#include "rg_common.cuh"
+#include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define SB 256

@@ -76,8 +76,32 @@ def device_loader_gen(files, param, num_n, domain="a", device="cuda", rank=0, wo
                         eos, n_neg, seed=seed, shuffle=True, rank=rank, world=world)
 
 
+def users_from_pickles(files):
+    seqs, val, test = [], [], []
+    for fn in files:
+        d = load_pickle(fn)
+        seqs.extend(d["seq"])
+        val.extend(d["val"])
+        test.extend(d["test"])
+    return seqs, val, test
+
+
+def eval_loader_gen(files, param, domain="a", device="cuda", rank=0, world=1, wf=None, seed=0):
+    """Dataloader.dataloader_gen(train=False, wf=item_freq) (data/data_loader.py:455-483 over pickle_loader_eval
+    :58-136): validation / test inputs with candidate_size frequency-weighted (n_items_f) and uniform (n_items_r)
+    candidates per user, assembled and sampled on the device."""
+    from .sampler import DeviceEvalLoader
+    eos = param.vocab_size_a if domain == "a" else param.vocab_size_b
+    seqs, val, test = users_from_pickles(files)
+    return DeviceEvalLoader(seqs, val, test, eos - 1, device, param.batch_size_val, param.enc_maxlen, param.rec_maxlen, eos,
+                            param.candidate_size, wf=wf, seed=seed, rank=rank, world=world)
+
+
 def dataloader_gen(files, param, num_n, domain="a", device=None, rank=0, world=1, seed=0, wf=None, batch_size=None):
-    """Counterpart of Dataloader.dataloader_gen(train=True) (data/data_loader.py:455-483)."""
+    """Pre-staged counterpart of Dataloader.dataloader_gen(train=True) (data/data_loader.py:455-483): ONE static draw
+    of negatives per user and a fixed order -- for benches and parity tests.  Training entry points use
+    device_loader_gen (shuffled, fresh negatives per batch, as the reference's DataLoader(shuffle=True) over
+    pickle_loader.__getitem__ gives)."""
     eos = param.vocab_size_a if domain == "a" else param.vocab_size_b
     dom = domain_from_pickles(files, param.enc_maxlen, eos, eos - 1, num_n, seed, wf)
     return TensorLoader(dom, batch_size or param.batch_size, device, rank, world)

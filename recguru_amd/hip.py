@@ -67,7 +67,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
-           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles"]
+           "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
+           "rg_adam_multi_dev"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -372,6 +373,17 @@ def adam_multi(seg_table_dev, nsegs, beta1, beta2, eps):
     _check(lib().rg_adam_multi(_vp(seg_table_dev), int(nsegs), c_f(beta1), c_f(beta2), c_f(eps), _stream()), "rg_adam_multi")
 
 
+# numpy mirror of rg_adam_seg_dev (48 bytes: 4 pointers, n, step)
+ADAM_SEG_DEV_DTYPE = [("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i8"), ("step", "<i8")]
+c_d = ctypes.c_double
+
+
+def adam_multi_dev(seg_table_dev, nsegs, lr, beta1, beta2, eps):
+    """seg_table_dev: uint8 CUDA tensor holding nsegs rg_adam_seg_dev records; their step counts advance on the device."""
+    _check(lib().rg_adam_multi_dev(_vp(seg_table_dev), int(nsegs), c_d(lr), c_d(beta1), c_d(beta2), c_d(eps), _stream()),
+           "rg_adam_multi_dev")
+
+
 CAST_SEG_DTYPE = [("src", "<u8"), ("dst", "<u8"), ("R", "<i4"), ("C", "<i4"), ("ld", "<i4"), ("row_off", "<i4"),
                   ("col_off", "<i4"), ("transpose", "<i4")]
 
@@ -662,7 +674,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["dropout_", "cross_rows", "adam_multi", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

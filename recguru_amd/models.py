@@ -33,6 +33,17 @@ class SampledLogits(object):
         """SampledCrossEntropyLoss with label 0 and masked mean (tools/lossfunctions.py:36-49)."""
         return ops.sampled_softmax_loss(self.h, self.table, self.pos, self.neg, mask, self.k, self.skip_row)
 
+    def dense(self):
+        """The [B, L, 1 + k] logits tensor the reference's forward returns (AutoEnc4Rec_cross.py:211-215: column 0 the
+        positive, then the k sampled negatives), f32, forward only (no autograd graph) -- for callers that inspect
+        logits; the training losses go through loss() / bpr(), which never materialise it."""
+        from . import hip
+        d = self.h.shape[-1]
+        h2 = self.h.detach().contiguous().view(-1, d)
+        scores, _ = hip.rank_scores(h2, ops.shadow(self.table), self.pos.contiguous().view(-1),
+                                    self.neg.contiguous().view(-1, self.k), want_rank=False)
+        return scores.view(tuple(self.h.shape[:-1]) + (self.k + 1,))
+
     def bpr(self, mask, sas=False):
         """BPRLoss (tools/lossfunctions.py:56-72); sas=True: BPRLoss_sas (:79-96), what train_auto.py uses (:26)."""
         return ops.bpr_loss(self.h, self.table, self.pos, self.neg, mask, self.k, self.skip_row, sas=sas)

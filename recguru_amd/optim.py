@@ -27,8 +27,10 @@ class Adam(object):
 
     @torch.no_grad()
     def step(self):
-        """One rg_adam_multi launch per parameter group: a device-resident segment table lists (chunks of) the
-        parameters that have a gradient; the pointer columns are rebuilt only when that set changes."""
+        """One rg_adam_multi_dev launch per parameter group over a DEVICE-RESIDENT segment table listing (chunks of) the
+        parameters that have a gradient.  The table -- pointers, chunk sizes and the per-parameter step counts, which the
+        kernel itself advances -- is uploaded (from pinned memory) only when that set of parameters or one of their
+        buffers changes; in steady state an optimizer step moves nothing across PCIe and never blocks the host."""
         import numpy as np
         for gi, g in enumerate(self.param_groups):
             b1, b2 = g["betas"]
@@ -40,31 +42,26 @@ class Adam(object):
                 if st is None:
                     st = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
                     self.state[p] = st
-                st["step"] += 1
                 if not p.grad.is_contiguous():
                     p.grad = p.grad.contiguous()
                 live.append((p, st))
             if not live:
                 continue
-            key = tuple((p.data_ptr(), p.grad.data_ptr()) for p, _ in live)
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr()) for p, st in live)
             cache = self._tables.get(gi)
             if cache is None or cache["key"] != key:
-                rows, owner = [], []
-                for i, (p, st) in enumerate(live):
+                rows = []
+                for p, st in live:                        # st["step"]: updates this parameter has had so far
                     n = p.numel()
                     for off in range(0, n, hip.ADAM_CHUNK):
                         rows.append((p.data_ptr() + 4 * off, p.grad.data_ptr() + 4 * off, st["exp_avg"].data_ptr() + 4 * off,
-                                     st["exp_avg_sq"].data_ptr() + 4 * off, min(hip.ADAM_CHUNK, n - off), 0.0, 0.0))
-                        owner.append(i)
-                cache = {"key": key, "tbl": np.array(rows, dtype=hip.ADAM_SEG_DTYPE), "owner": np.array(owner)}
+                                     st["exp_avg_sq"].data_ptr() + 4 * off, min(hip.ADAM_CHUNK, n - off), st["step"]))
+                tbl = np.array(rows, dtype=hip.ADAM_SEG_DEV_DTYPE)
+                host = torch.from_numpy(tbl.view(np.uint8).copy()).pin_memory()
+                cache = {"key": key, "n": len(tbl), "dev": host.to(live[0][0].device, non_blocking=True), "host": host}
                 self._tables[gi] = cache
-            steps = np.array([st["step"] for _, st in live], dtype=np.float64)
-            tbl = cache["tbl"]
-            tbl["step_lr"] = (g["lr"] / (1.0 - b1 ** steps))[cache["owner"]]
-            tbl["inv_bc2_sqrt"] = (1.0 / np.sqrt(1.0 - b2 ** steps))[cache["owner"]]
-            dev = live[0][0].device
-            tdev = torch.from_numpy(tbl.view(np.uint8).copy()).to(dev, non_blocking=True)
-            hip.adam_multi(tdev, len(tbl), b1, b2, g["eps"])
-            for p, _ in live:
+            hip.adam_multi_dev(cache["dev"], cache["n"], g["lr"], b1, b2, g["eps"])
+            for p, st in live:
+                st["step"] += 1                           # host mirror of the device counters (used when the table is rebuilt)
                 ops.bump(p)
             ops.refresh_shadows([p for p, _ in live])

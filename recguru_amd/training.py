@@ -26,17 +26,43 @@ date = "1209"       # gan_training.py:24 (series-name suffix)
 
 
 class ScalarLog(object):
-    """Device-side stand-in for tools/plot.py: keeps the series as device scalars and converts on
-    flush only (the reference forces 5 host syncs per iteration, gan_training.py:524-528)."""
+    """Device-side stand-in for tools/plot.py (:15-47): plot(name, value) files the value under the current tick,
+    tick() advances it, flush(result_path) writes `log.pkl` = {series name: {tick: value}} -- the reference's
+    _since_beginning layout -- and returns it.  Values stay device scalars until a flush converts them, ONE host sync per
+    flush instead of the reference's five per iteration (gan_training.py:524-528).  No PDFs are drawn."""
 
     def __init__(self):
-        self.series = {}
+        self.series = {}            # name -> {tick: value}
+        self._iter = 0
+
+    def tick(self):
+        self._iter += 1
 
     def plot(self, name, value):
-        self.series.setdefault(name, []).append(value.detach() if torch.is_tensor(value) else value)
+        self.series.setdefault(name, {})[self._iter] = value.detach() if torch.is_tensor(value) else value
 
-    def flush(self):
-        return {k: [float(v) for v in vs] for k, vs in self.series.items()}
+    def values(self, name):
+        """The series as a list of floats in tick order."""
+        d = self.series.get(name, {})
+        return [float(d[k]) for k in sorted(d)]
+
+    def flush(self, result_path=None):
+        import numpy as np
+        out = {}
+        for name, d in self.series.items():
+            keys = sorted(d)
+            dev = [d[k] for k in keys if torch.is_tensor(d[k])]
+            host = iter(torch.stack([v.reshape(()).float() for v in dev]).cpu().numpy()) if dev else iter(())
+            out[name] = {k: (np.asarray(next(host)) if torch.is_tensor(d[k]) else d[k]) for k in keys}
+            self.series[name] = dict(out[name])
+        if result_path is not None:
+            import pickle
+            with open(os.path.join(result_path, "log.pkl"), "wb") as f:
+                pickle.dump(out, f, -1)
+        return out
+
+    def reset(self):
+        self.series, self._iter = {}, 0
 
 
 plot = ScalarLog()
@@ -108,7 +134,10 @@ def mean(x):
 
 def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, device):
     """gan_training.py:38-55.  alpha ~ U[0,1) from the CPU default generator, as there (Q13)."""
-    alpha = torch.rand(BATCH_SIZE, 1).to(device)
+    alpha = torch.rand(BATCH_SIZE, 1)
+    if torch.device(device).type == "cuda":
+        # through pinned memory: a pageable host-to-device copy blocks the host until the stream has drained
+        alpha = alpha.pin_memory().to(device, non_blocking=True)
     D = _unwrap(netD)
     return ops.GradientPenaltyFn.run(real_data, fake_data, alpha, D.drop_p(), *D.params())
 
@@ -164,6 +193,9 @@ def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True,
             tag = "reconstruct_loss" if loss_type == "s_soft" else "bpr_loss"
             plot.plot(param.result_path + "/%s_a_%s" % (tag, param.date), la)
             plot.plot(param.result_path + "/%s_b_%s" % (tag, param.date), lb)
+            if dp.rank == 0 and os.path.isdir(param.result_path):
+                plot.flush(param.result_path)                           # gan_training.py:890-892
+            plot.tick()
     return losses
 
 
@@ -338,29 +370,62 @@ class _Cycler(object):
     def __init__(self, loader):
         self.loader, self.it = loader, iter(loader)
 
-    def next(self, device):
+    def next(self, device, restart=None):
         try:
             return get_next_batch(self.it, device)
         except StopIteration:
-            self.it = iter(self.loader)
+            self.it = iter(restart if restart is not None else self.loader)
             return get_next_batch(self.it, device)
+
+
+class History(list):
+    """Phase-2 rows (D_cost, Wasserstein_D, recon_a, recon_b, g_dis) of train_gan_all; .phase3 holds the phase-3
+    rows (loss_recommend, loss_recon_rec), .result the accumulated ranking metrics."""
+
+    def __init__(self):
+        super(History, self).__init__()
+        self.phase3 = []
+        self.result = None
+
+
+def _new_result(k_val):
+    names = ("ht_eval", "ndcg_eval", "mrr_eval", "ht_test", "ndcg_test", "mrr_test")
+    return [{str(k): {n: [] for n in names} for k in k_val} for _ in range(2)]     # [frequency-sampled, random]
+
+
+def _extend_result(result, result_tmp):
+    for key in result[0]:
+        for metric in result[0][key]:
+            result[0][key][metric].extend(result_tmp[0][key][metric])
+            result[1][key][metric].extend(result_tmp[1][key][metric])
+
+
+def _dump_result(result, path, dp):
+    if dp.rank == 0:
+        import pickle
+        with open(path, "wb") as f:
+            pickle.dump(result, f)
 
 
 def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iterations, train_overlap, rec_loaders,
                   test_loaders, domain="a", overlap=True, dp=None, evaluate=None):
     """Phases 2 and 3 (gan_training.py:353-587).  At the reference's evaluation points (:569-580) the ranking
-    evaluation (evaluation_2) runs over test_loaders and result_<domain>.pickle is rewritten; `evaluate(netG)`
-    (optional) replaces it."""
+    evaluation (evaluation_2, k = 5, 10, 20 as :361) runs over test_loaders and result_<domain>.pickle is rewritten;
+    `evaluate(netG)` (optional) replaces it.  Every 100 iterations the scalar log is flushed to
+    <result_path>/gan_loss/log.pkl (:583-586).  Under data parallelism every rank evaluates its own shard of the test
+    users and rank 0 writes the pickle."""
     if overlap:
         raise NotImplementedError("overlap=True (MSE on overlapped users) is off in main_2 (gan_training.py:1010)")
     dp = dp or _NoDP()
     g_params = list(netG.parameters())
-    opt_final_rec = Adam(g_params, lr=0.001, betas=(0.9, 0.98))
+    opt_final_rec = Adam(g_params, lr=0.001, betas=(0.9, 0.98))                  # :359
+    k_val = [5, 10, 20]                                                         # :361
+    result = _new_result(k_val)
     a_iter, b_iter = _Cycler(gan_loader[0]), _Cycler(gan_loader[1])
-    rec_task = _Cycler(rec_loaders[0]) if rec_loaders is not None else None
-    rec_iter = _Cycler(gan_loader[0] if domain == "a" else gan_loader[1])
-    history = []
-    result = [{}, {}]                                                           # [frequency-sampled, random] candidates
+    rec_task = _Cycler(rec_loaders[0]) if rec_loaders is not None else None     # :375
+    rec_iter = _Cycler(gan_loader[0] if domain == "a" else gan_loader[1])       # :377-380
+    history = History()
+    history.result = result
     for iteration in range(int(iterations * 1.2)):
         if iteration < int(iterations * 0.6):                                   # phase 2
             for p in netD.parameters():
@@ -377,9 +442,15 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
             plot.plot(param.result_path + "/join_recon_b%s" % date, lrb)
             plot.plot(param.result_path + "/gen cost_%s" % date, g_dis)
             history.append((D_cost, Wasserstein_D, lra, lrb, g_dis))
-        else:                                                                   # phase 3
+        else:                                                                   # phase 3 (:529-567)
+            if rec_task is None:
+                raise ValueError("train_gan_all: phase 3 needs rec_loaders = [random-negative loader, "
+                                 "frequency-negative loader] of the target domain")
             opt_final_rec.zero_grad()
-            enc_in, dec_in, dec_out, n_items, _, _, bs, sl = rec_task.next(device)
+            # on exhaustion the recommendation iterator restarts from the frequency-weighted loader once
+            # iteration > 0.8 * iterations, from the random one before that (:531-537)
+            restart = rec_loaders[1] if iteration > int(iterations * 0.8) else rec_loaders[0]
+            enc_in, dec_in, dec_out, n_items, _, _, bs, sl = rec_task.next(device, restart=restart)
             in_r, din_r, dout_r, n_r, _, _, bs, sl = rec_iter.next(device)
             mask_rec = get_pad_mask(dout_r, param.pad_index, device)
             loss_recon_rec = loss_ae(netG, in_r, din_r, dout_r, n_r, True, bs, sl, param, mask_rec, device, domain)
@@ -389,23 +460,65 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
             loss_recommend.backward()
             dp.sync_grads(g_params)
             opt_final_rec.step()
-            plot.plot(param.result_path + "/tuning_recommendation_loss", loss_recommend)
+            plot.plot(param.result_path + "/tuning_recommendation_loss", loss_recommend.detach())
+            history.phase3.append((loss_recommend.detach(), loss_recon_rec.detach()))
         if iteration > int(iterations * 0.8) and iteration % 30 == 29 and (evaluate is not None or test_loaders is not None):
             netG.eval()                          # gan_training.py:570-580
             if evaluate is not None:
                 evaluate(netG)
             else:
-                result_tmp = evaluation_2(netG, test_loaders, device, param, sas=False, domain=domain)
-                for key in ("1", "5", "10", "20", "30"):
-                    for metric in result_tmp[0][key]:
-                        result[0].setdefault(key, {}).setdefault(metric, []).extend(result_tmp[0][key][metric])
-                        result[1].setdefault(key, {}).setdefault(metric, []).extend(result_tmp[1][key][metric])
-                if dp.rank == 0:
-                    import pickle
-                    with open(os.path.join(param.result_path, "result_%s.pickle" % param.target_domain), "wb") as f:
-                        pickle.dump(result, f)
+                _extend_result(result, evaluation_2(netG, test_loaders, device, param, k_val=k_val, sas=False,
+                                                    domain=domain))
+                _dump_result(result, os.path.join(param.result_path, "result_%s.pickle" % param.target_domain), dp)
             netG.train()
+        if iteration % 100 == 99 and dp.rank == 0 and os.path.isdir(param.result_path):     # :583-586
+            os.makedirs(os.path.join(param.result_path, "gan_loss"), exist_ok=True)
+            plot.flush(os.path.join(param.result_path, "gan_loss"))
+        plot.tick()
     return history
+
+
+def recommendation_tune(model, rec_loader, test_loader, steps, param, device, domain, dp=None):
+    """gan_training.py:895-969: BPR fine-tuning of the recommender decoder of `domain` with Adam(lr=0.006,
+    betas=(0.9, 0.9)); mask = (dec_in != pad) (:934-936, where phase 3 of train_gan_all uses dec_out); the loader
+    restarts from rec_loader[1] (frequency-weighted negatives) only for domain "b" past half of the steps (:927-931);
+    every param.eval_step steps (the interval doubles after ten of them, :950-951) evaluation_2 runs with
+    k = 5, 10, 20, 30 and result_<domain>.pickle is rewritten.  Returns (losses, result)."""
+    dp = dp or _NoDP()
+    k_val = [5, 10, 20, 30]
+    model.train()
+    it = _Cycler(rec_loader[0])
+    result = _new_result(k_val)
+    params = list(model.parameters())
+    opt = Adam(params, lr=0.006, betas=(0.9, 0.9))                               # :920
+    losses = []
+    for i in range(steps):
+        restart = rec_loader[1] if (domain == "b" and i > int(steps / 2)) else rec_loader[0]
+        enc_in, dec_in, dec_out, n_items, _, _, bs, sl = it.next(device, restart=restart)
+        mask = get_pad_mask(dec_in, param.pad_index, device)
+        opt.zero_grad()
+        loss = loss_bpr_func(model, enc_in, dec_in, dec_out, n_items, mask, domain, param)
+        loss.backward()
+        dp.sync_grads(params)
+        opt.step()
+        losses.append(loss.detach())
+        if i % param.eval_step == (param.eval_step - 1):
+            if i > param.eval_step * 10:
+                param.eval_step *= 2
+            model.eval()
+            print("BPR loss after %d batch" % i, float(loss.detach()))
+            plot.plot(param.result_path + "/bpr_loss_%s" % domain, loss.detach())
+            if test_loader is not None:
+                result_tmp = evaluation_2(model, test_loader, device, param, k_val=k_val, sas=False, domain=domain)
+                print("eval HT@10 %f, test HT@10 %f" % (result_tmp[0]["10"]["ht_eval"][0], result_tmp[0]["10"]["ht_test"][0]))
+                print("eval HT@10 %f, test HT@10 %f" % (result_tmp[1]["10"]["ht_eval"][0], result_tmp[1]["10"]["ht_test"][0]))
+                _extend_result(result, result_tmp)
+                _dump_result(result, os.path.join(param.result_path, "result_%s.pickle" % domain), dp)
+            model.train()
+            if dp.rank == 0 and os.path.isdir(param.result_path):
+                plot.flush(param.result_path)
+            plot.tick()
+    return losses, result
 
 
 def main_2(auto_cross, opt_rec, netD, opt_gen, opt_dis, param, device_t, ae_loaders, rec_loaders, test_loaders,

@@ -52,3 +52,53 @@ def max_err(a, b):
     a = np.asarray(a, dtype=np.float64)
     b = np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max()), float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# ---- loss-curve fixture (oracle/gen_golden_curves.py) ------------------------------------------------------------
+def curve_meta(z):
+    names = ("B", "L", "d", "H", "N", "V_a", "V_b", "k", "nb", "phase1_steps", "iterations", "warmup", "alpha_seed")
+    return dict(zip(names, [int(x) for x in z["meta"]]))
+
+
+def curve_loaders(z, device=None):
+    """The four batch lists of the fixture in the reference's DataLoader layout:
+    ((enc_in, dec_in, dec_out), n_items, val, test) per batch."""
+    out = {}
+    for tag in ("ae_a", "ae_b", "rec0", "rec1"):
+        bl = []
+        for i in range(z[tag + ".enc_in"].shape[0]):
+            t = [torch.as_tensor(z["%s.%s" % (tag, nm)][i]) for nm in ("enc_in", "dec_in", "dec_out", "n_items")]
+            if device is not None:
+                t = [x.to(device) for x in t]
+            zero = torch.zeros(t[0].shape[0], dtype=torch.long, device=t[0].device)
+            bl.append(((t[0], t[1], t[2]), t[3], zero, zero))
+        out[tag] = bl
+    return out
+
+
+def curve_replay_oracle(z, dtype=torch.float32, collapsed=False):
+    """The fixture's 20 + 5 + 5 iterations through the oracle's restatement of the reference drivers.
+    Returns (phase1 [steps,2], phase2 [n,5] = D_cost, Wasserstein_D, recon_a, recon_b, g_dis, phase3 [n,2] =
+    loss_recommend, loss_recon_rec, last Noam lr)."""
+    from oracle import recguru_oracle as O
+    m = curve_meta(z)
+    cfg = O.Cfg(m["d"], m["H"], m["N"], m["L"], m["k"], m["V_a"] + 1, m["V_b"] + 1, n_bpr_neg=m["nb"])
+    st = {tag: state_of(z, tag) for tag in ("G", "D")}
+    for dom in "ab":
+        st["G"]["pos_emb_%s.pe" % dom] = O.positional_table(5000, m["d"]).unsqueeze(0)
+    pG, pD = O.leafify(st["G"], dtype), O.leafify(st["D"], dtype)
+    ld = curve_loaders(z)
+    p1, opt = O.train_recon_x(pG, cfg, m["phase1_steps"], [ld["ae_a"], ld["ae_b"]], m["warmup"], collapsed=collapsed)
+    torch.manual_seed(m["alpha_seed"])
+    p2, p3 = O.train_gan_all(pG, pD, cfg, [ld["ae_a"], ld["ae_b"]], [ld["rec0"], ld["rec1"]], m["iterations"], "a",
+                             collapsed=collapsed)
+    return np.array([[float(a), float(b)] for a, b in p1]), np.array(p2), np.array(p3), opt.lr
+
+
+def curve_bands(z):
+    """Per-series absolute tolerance for phases 2 / 3 of the curve fixture: 2 x the stored band + 2e-5.  The band
+    (oracle/gen_golden_curves.py add_bands) is the largest deviation from the reference's own float32 values among
+    replays of the same arithmetic under different rounding (float64; collapsed cross-attention).  From the second
+    phase-2 iteration on the trajectory is discontinuous in rounding noise -- ReLU masks inside the gradient penalty,
+    Adam's +-lr steps on rounding-level gradients -- so it is only defined up to that band."""
+    return {k[5:]: 2.0 * float(v) + 2e-5 for k, v in z.items() if k.startswith("band.")}

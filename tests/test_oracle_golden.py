@@ -233,3 +233,23 @@ def test_ranking_eval(name, collapsed):
         assert (ranks == ze["ranks.%s" % dom]).all()
         for i, k in enumerate((1, 5, 10, 20, 30)):
             np.testing.assert_allclose(O.metrics_at_k(ranks, k), ze["metrics.%s" % dom][i], rtol=1e-12, atol=0)
+
+
+def test_loss_curves_through_reference_drivers():
+    """20 phase-1 steps + 5 phase-2 + 5 phase-3 iterations of the reference's own train_recon_x / train_gan_all
+    (oracle/gen_golden_curves.py) replayed by the oracle's restatement of those drivers, point by point.
+
+    Tolerance: phase 1 rtol 1e-3.  From the second phase-2 iteration on the REFERENCE's trajectory is discontinuous
+    in rounding noise (ReLU masks inside the gradient penalty, Adam's +-lr steps on rounding-level gradients): the
+    fixture stores, per series, the band the same arithmetic spans under different rounding (gen_golden_curves.py
+    add_bands); parity_util.curve_bands turns it into the bound 2 x band + 2e-5 used here and by the GPU replay."""
+    from parity_util import curve_bands, curve_replay_oracle
+    z = load_case("curves1")
+    p1, p2, p3, lr_last = curve_replay_oracle(z, torch.float32)
+    np.testing.assert_allclose(p1, z["phase1.loss"], rtol=1e-3, atol=1e-5)
+    np.testing.assert_allclose(lr_last, float(z["phase1.lr_last"]), rtol=1e-12)
+    bands = curve_bands(z)
+    for i, nm in enumerate(("D_cost", "Wasserstein_D", "recon_a", "recon_b", "g_dis")):
+        np.testing.assert_allclose(p2[:, i], z["phase2." + nm], rtol=1e-3, atol=bands["phase2." + nm], err_msg=nm)
+    np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
+    np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-3, atol=bands["phase3.loss_recon_rec"])

@@ -303,7 +303,7 @@ def test_ranking_eval(name):
     ops.set_compute_dtype(torch.bfloat16)
 
 
-@pytest.mark.parametrize("d,C", [(64, 19), (128, 199), (256, 1000)])
+@pytest.mark.parametrize("d,C", [(32, 7), (64, 19), (128, 199), (256, 1000)])
 def test_rank_scores_kernel(d, C):
     from recguru_amd import hip
     B, V = 37, 500

@@ -1,0 +1,426 @@
+"""GPU parity of the SHIPPED step functions (training.critic_update / critic_phase / generator_iteration /
+train_recon_x / train_gan_all / recommendation_tune / main_2, the two entry scripts) -- not hand re-compositions of them:
+
+  * at the BENCH SHAPE (L=200, d=128, H=4, N=3, V=100 000, k=30; B=16 so that the CPU oracle finishes in seconds), both
+    tiers, against the oracle: user embeddings, loss_ae a/b, D_cost, Wasserstein_D, GP, parameters after the steps;
+  * the loss curves of the reference's own drivers (tests/golden/curves1.npz, oracle/gen_golden_curves.py);
+  * a checkpoint written by the reference (tests/golden/ref_pre_model.pt);
+  * the single-domain evaluation (tests/golden/eval_single_case*.npz, reference train_auto.py:164-253).
+
+Tolerances.  f32 tier: the north-star rtol=1e-3 / atol=1e-5 on forward outputs.  bf16 tier: operands carry 8
+significant bits; its bounds are set at <= 2x the drift this file prints (measured on an MI355X, see the constants).
+"""
+import os
+import pickle
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from golden_util import GOLDEN_DIR, load_case, make_state
+from parity_util import (batches, case_param, curve_bands, curve_loaders, curve_meta, make_args, max_err, state_of)
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEAD = ("dec_enc_attn.WQ", "dec_enc_attn.WK")
+NOISE = DEAD + ("WK.bias",)
+TIERS = {"f32": torch.float32, "bf16": torch.bfloat16}
+
+
+@pytest.fixture(autouse=True)
+def _restore_tier():
+    from recguru_amd import ops
+    yield
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def np_(t):
+    return t.detach().float().cpu().numpy()
+
+
+def seeded_state(module, seed):
+    manifest = [(k, tuple(v.shape)) for k, v in module.state_dict().items()]
+    return {k: torch.as_tensor(v) for k, v in make_state(manifest, seed).items()}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# bench shape, both tiers, through the shipped critic_update / generator_iteration
+# ----------------------------------------------------------------------------------------------------------------------
+BENCH = dict(B=16, L=200, d=128, H=4, N=3, V=100000, k=30)
+# bf16 bounds = 2x the drift printed by this test on an MI355X (round 2): see DESIGN.md section 2
+# measured: user_embed 0.0071 of max, loss_ae 2.1e-4, D_cost / W_D / g_dis 4.6e-4 abs, GP 5.7e-3, Adam-step mismatch 1.9 % (D)
+BF16_BOUNDS = {"ue_rel_to_max": 0.015, "loss_rel": 5e-4, "dcost_abs": 1e-3, "gp_rel": 0.012, "param_frac_bad": 0.04}
+
+
+def _bench_setup(device):
+    from recguru_amd import config, models, synthetic
+    c = BENCH
+    param = config.get_param(make_args(c["d"], c["H"], c["k"], c["L"], c["V"], c["V"], c["N"], c["B"]), make_dirs=False)
+    G = models.MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32)
+    D = models.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32)
+    sG, sD = seeded_state(G, 4101), seeded_state(D, 4102)
+    missing = G.load_state_dict(sG, strict=False)
+    assert all(k.endswith(".pe") for k in missing.missing_keys)
+    D.load_state_dict(sD)
+    D.eval()
+    doms = [synthetic.make_domain(c["B"], c["V"], c["L"], c["k"], seed=s) for s in (41, 42)]
+    bt = [tuple(torch.as_tensor(dm[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items")) for dm in doms]
+    return param, G.to(device), D.to(device), sG, sD, bt
+
+
+_ORACLE_BENCH = {}
+
+
+def _bench_oracle():
+    """One critic update + one generator update of the oracle at the bench shape (CPU, cached across the two tiers)."""
+    if _ORACLE_BENCH:
+        return _ORACLE_BENCH
+    from oracle import recguru_oracle as O
+    c = BENCH
+    param, G, D, sG, sD, bt = _bench_setup("cpu")
+    cfg = O.Cfg(c["d"], c["H"], c["N"], c["L"], c["k"], c["V"] + 1, c["V"] + 1)
+    for dom in "ab":
+        sG["pos_emb_%s.pe" % dom] = O.positional_table(5000, c["d"]).unsqueeze(0)
+    pG, pD = O.leafify(sG), O.leafify(sD)
+    out = {}
+    with torch.no_grad():
+        out["ue_a"] = O.get_user_embed(pG, cfg, bt[0][0], "a").numpy()
+        out["ue_b"] = O.get_user_embed(pG, cfg, bt[1][0], "b").numpy()
+    opt_d = O.Adam(pD, 1e-4, (0.5, 0.9))
+    torch.manual_seed(1234)
+    alpha = torch.rand(c["B"], 1)                             # what calc_gradient_penalty draws under the same seed
+    d_cost, w_d, gp = O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, alpha)
+    out.update(D_cost=float(d_cost), W_D=float(w_d), gp=float(gp))
+    out["D_after"] = {k: v.detach().numpy().copy() for k, v in pD.items()}
+    opt_g = O.Adam({k: v for k, v in pG.items() if v.requires_grad}, 1e-4, (0.5, 0.9))
+    g_dis, la, lb = O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g, collapsed=True)
+    out.update(g_dis=float(g_dis), la=float(la), lb=float(lb))
+    out["G_after"] = {k: v.detach().numpy().copy() for k, v in pG.items() if v.requires_grad}
+    out["G_before"] = {k: v.numpy().copy() for k, v in sG.items()}
+    _ORACLE_BENCH.update(out)
+    return _ORACLE_BENCH
+
+
+def _moved_frac_bad(new, ref, old, lr, tol):
+    """Fraction of elements whose Adam step differs from the reference step by more than tol * lr (first Adam step:
+    every element moves by about +-lr, so this compares step DIRECTIONS and sizes element by element)."""
+    return float((np.abs((new - old) - (ref - old)) > tol * lr).mean())
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16"])
+def test_bench_shape_steps_vs_oracle(tier, capsys):
+    from recguru_amd import ops, training as T
+    from recguru_amd.optim import Adam
+    ref = _bench_oracle()
+    ops.set_compute_dtype(TIERS[tier])
+    param, G, D, sG, sD, bt = _bench_setup("cuda")
+    c = BENCH
+    cb = [tuple(t.cuda() for t in b) for b in bt]
+    with torch.no_grad():
+        ue_a = np_(T.get_user_embed(G, cb[0][0], "a", param, "cuda", 0))
+        ue_b = np_(T.get_user_embed(G, cb[1][0], "b", param, "cuda", 0))
+    # ---- shipped critic update (stacked D pass, W-loss, GP with alpha from the CPU generator, Adam(D))
+    opt_d = Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    with torch.no_grad():
+        ae, be = T.critic_embed(G, cb[0][0], cb[1][0], param, "cuda")
+    torch.manual_seed(1234)
+    d_cost, w_d = T.critic_update(D, ae, be, opt_d, "cuda", T._NoDP())
+    gp = float(d_cost) + float(w_d)                           # D_cost = dis_loss + gp, Wasserstein_D = -dis_loss
+    # ---- shipped generator update
+    opt_g = Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.9))
+    g_dis, la, lb = T.generator_iteration(G, D, cb[0] + (c["B"], c["L"]), cb[1] + (c["B"], c["L"]), opt_g, param, "cuda",
+                                          T._NoDP())
+    torch.cuda.synchronize()
+    ue_err = max(max_err(ue_a, ref["ue_a"])[1], max_err(ue_b, ref["ue_b"])[1])
+    l_rel = max(abs(float(la) - ref["la"]) / ref["la"], abs(float(lb) - ref["lb"]) / ref["lb"])
+    dc_abs = max(abs(float(d_cost) - ref["D_cost"]), abs(float(w_d) - ref["W_D"]), abs(float(g_dis) - ref["g_dis"]))
+    gp_rel = abs(gp - ref["gp"]) / ref["gp"]
+    bad_d = max(_moved_frac_bad(np_(p), ref["D_after"][k], sD[k].numpy(), 1e-4, 0.5) for k, p in D.state_dict().items())
+    bad_g = 0.0
+    for k, p in G.named_parameters():
+        if any(s in k for s in NOISE) or k.startswith("recommend") or "src_emb" in k:
+            continue
+        bad_g = max(bad_g, _moved_frac_bad(np_(p), ref["G_after"][k], ref["G_before"][k].astype(np.float32), 1e-4, 0.5))
+    with capsys.disabled():
+        print("\n[bench shape, %s tier] user_embed err rel-to-max %.3g | loss_ae rel %.3g | D_cost/W_D/g_dis abs %.3g | "
+              "GP rel %.3g | Adam-step mismatch fraction D %.3g G %.3g" % (tier, ue_err, l_rel, dc_abs, gp_rel, bad_d, bad_g))
+    if tier == "f32":
+        np.testing.assert_allclose(ue_a, ref["ue_a"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(ue_b, ref["ue_b"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose([float(la), float(lb)], [ref["la"], ref["lb"]], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose([float(d_cost), float(w_d), float(g_dis)], [ref["D_cost"], ref["W_D"], ref["g_dis"]],
+                                   rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(gp, ref["gp"], rtol=1e-3, atol=1e-5)
+        assert bad_d <= 0.005 and bad_g <= 0.01
+    else:
+        b = BF16_BOUNDS
+        assert ue_err <= b["ue_rel_to_max"] and l_rel <= b["loss_rel"] and dc_abs <= b["dcost_abs"]
+        assert gp_rel <= b["gp_rel"]
+        assert bad_d <= b["param_frac_bad"]
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# critic_phase: encoder passes on the side stream == sequential
+# ----------------------------------------------------------------------------------------------------------------------
+def test_critic_phase_overlap_equals_sequential():
+    from parity_util import build_cross
+    from recguru_amd import ops, training as T
+    from recguru_amd.optim import Adam
+    ops.set_compute_dtype(torch.float32)
+    z = load_case("case2")
+    res = []
+    for overlap in (False, True):
+        param, G, D = build_cross(z)
+        bt = batches(z, "cuda")
+        seqs = [(bt["a"][0], bt["b"][0]), (bt["a"][0].flip(0), bt["b"][0]), (bt["a"][0], bt["b"][0].flip(0))]
+        opt_d = Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        torch.manual_seed(5)
+        d_cost, w_d = T.critic_phase(G, D, seqs, opt_d, param, "cuda", T._NoDP(), overlap=overlap)
+        torch.cuda.synchronize()
+        res.append((float(d_cost), float(w_d), {k: np_(p) for k, p in D.state_dict().items()}))
+    assert res[0][0] == res[1][0] and res[0][1] == res[1][1]
+    for k in res[0][2]:
+        np.testing.assert_array_equal(res[0][2][k], res[1][2][k], err_msg=k)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# loss curves of the reference's own drivers, replayed through train_recon_x / train_gan_all
+# ----------------------------------------------------------------------------------------------------------------------
+def _curve_models(z, device="cuda"):
+    from recguru_amd import config, models
+    m = curve_meta(z)
+    res = "/tmp/rg_curves_%d" % os.getpid()
+    os.makedirs(res, exist_ok=True)
+    param = config.get_param(make_args(m["d"], m["H"], m["k"], m["L"], m["V_a"], m["V_b"], m["N"], m["B"], result_path=res))
+    G = models.MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32)
+    G.load_state_dict(state_of(z, "G"), strict=False)
+    D = models.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32)
+    D.load_state_dict(state_of(z, "D"))
+    D.eval()
+    return m, param, G.to(device), D.to(device)
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16"])
+def test_loss_curves_replay(tier, capsys):
+    """20 train_recon_x steps + train_gan_all(iterations=9) = 5 phase-2 + 5 phase-3 iterations, as the reference's
+    drivers ran them (oracle/gen_golden_curves.py).  f32: rtol 1e-3 per point in phase 1; in phases 2 / 3 the
+    reference's own float32 trajectory is only defined up to its rounding sensitivity (parity_util.curve_bands: 3 x
+    |float64 replay - reference|), which is the bound used.  bf16: the same comparison with the stated wider band."""
+    from recguru_amd import blocks, ops, training as T
+    from recguru_amd.optim import Adam
+    ops.set_compute_dtype(TIERS[tier])
+    z = load_case("curves1")
+    m, param, G, D = _curve_models(z)
+    ld = curve_loaders(z)                        # CPU tensors: get_next_batch moves them, like the reference's loaders
+    T.plot.reset()
+    opt_rec = blocks.ScheduledOptim(Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-09), 1.0, m["d"], m["warmup"])
+    opt_gen = Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    opt_dis = Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    losses = T.train_recon_x(G, opt_rec, m["phase1_steps"], [ld["ae_a"], ld["ae_b"]], param, "cuda", neg_sample=True,
+                             loss_type="s_soft", opt_type="schedule", log_every=0)
+    p1 = np.array([[float(a), float(b)] for a, b in losses])
+    torch.manual_seed(m["alpha_seed"])
+    hist = T.train_gan_all(G, D, [ld["ae_a"], ld["ae_b"]], opt_dis, opt_gen, "cuda", param, m["iterations"], None,
+                           [ld["rec0"], ld["rec1"]], None, domain="a", overlap=False)
+    p2 = np.array([[float(x) for x in row] for row in hist])
+    p3 = np.array([[float(x) for x in row] for row in hist.phase3])
+    assert p2.shape == (5, 5) and p3.shape == (5, 2)
+    np.testing.assert_allclose(opt_rec.get_lr(), float(z["phase1.lr_last"]), rtol=1e-12)
+    bands = curve_bands(z)
+    names2 = ("D_cost", "Wasserstein_D", "recon_a", "recon_b", "g_dis")
+    worst1 = float(np.abs(p1 / z["phase1.loss"] - 1).max())
+    with capsys.disabled():
+        print("\n[curves, %s tier] phase-1 max rel err %.3g | phase-2 max abs err %s | phase-3 %s" % (
+            tier, worst1, {n: "%.2g (band %.2g)" % (np.abs(p2[:, i] - z["phase2." + n]).max(), bands["phase2." + n])
+                           for i, n in enumerate(names2)},
+            {n: "%.2g (band %.2g)" % (np.abs(p3[:, i] - z["phase3." + n]).max(), bands["phase3." + n])
+             for i, n in enumerate(("loss_recommend", "loss_recon_rec"))}))
+    if tier == "f32":
+        np.testing.assert_allclose(p1, z["phase1.loss"], rtol=1e-3, atol=1e-5)
+        for i, n in enumerate(names2):
+            np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=bands["phase2." + n], err_msg=n)
+        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
+        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-3, atol=bands["phase3.loss_recon_rec"])
+    else:
+        # bf16 operands (8 significant bits) over 30 optimizer steps, the first of them Noam steps at lr up to 0.06:
+        # bounds = 2x the drift measured on an MI355X (phase 1: 3.1 % of the loss at its worst point; phase 2: D_cost /
+        # W_D / g_dis 1.1e-3 abs, recon 0.012 abs; phase 3: loss_recommend 0.036 abs, loss_recon 0.015 abs)
+        np.testing.assert_allclose(p1, z["phase1.loss"], rtol=0.065, atol=1e-5)
+        for i, n in enumerate(names2):
+            np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=0, atol=0.025 if "recon" in n else 2.5e-3, err_msg=n)
+        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=0, atol=0.075)
+        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=0, atol=0.03)
+    # the scalar log carries the reference's series names (tools/plot.py layout)
+    assert len(T.plot.values(param.result_path + "/disc cost_%s" % T.date)) == 5
+    assert len(T.plot.values(param.result_path + "/tuning_recommendation_loss")) == 5
+
+
+def test_recommendation_tune_and_log_layout(tmp_path):
+    """recommendation_tune (gan_training.py:895-969) runs, evaluates at eval_step, and the log / result files have the
+    reference's layouts (tools/plot.py:19-47 log.pkl = {series: {tick: value}}; result = [freq, rand][k][metric])."""
+    from recguru_amd import ops, sampler, training as T
+    ops.set_compute_dtype(torch.float32)
+    z = load_case("curves1")
+    m, param, G, D = _curve_models(z)
+    param.result_path = str(tmp_path)
+    param.eval_step, param.eval_steps, param.candidate_size = 3, 1, 20
+    ld = curve_loaders(z)
+    rng = np.random.default_rng(0)
+    seqs = [rng.integers(1, m["V_a"] + 1, size=n).tolist() for n in rng.integers(3, 20, size=32)]
+    val, test = rng.integers(1, m["V_a"] + 1, size=32), rng.integers(1, m["V_a"] + 1, size=32)
+    ev = sampler.DeviceEvalLoader(seqs, val, test, m["V_a"], "cuda", 16, m["L"], m["L"], m["V_a"] + 1, 20)
+    T.plot.reset()
+    losses, result = T.recommendation_tune(G, [ld["rec0"], ld["rec1"]], ev, 7, param, "cuda", "a")
+    assert len(losses) == 7 and float(losses[-1]) < float(losses[0])
+    assert sorted(result[0]) == ["10", "20", "30", "5"] and len(result[0]["10"]["ht_eval"]) == 2
+    with open(os.path.join(str(tmp_path), "result_a.pickle"), "rb") as f:
+        assert pickle.load(f)[1]["10"]["ndcg_test"] == result[1]["10"]["ndcg_test"]
+    with open(os.path.join(str(tmp_path), "log.pkl"), "rb") as f:
+        log = pickle.load(f)
+    series = log[str(tmp_path) + "/bpr_loss_a"]
+    assert sorted(series) == [0, 1] and all(np.isfinite(float(v)) for v in series.values())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# checkpoints written by the reference; SampledLogits.dense
+# ----------------------------------------------------------------------------------------------------------------------
+def test_reference_written_checkpoint():
+    from recguru_amd import config, models, ops, training as T
+    ops.set_compute_dtype(torch.float32)
+    zi = load_case("ref_pre_model_io")
+    B, L, d, H, N, V_a, V_b, k, dff = [int(x) for x in zi["meta"]]
+    param = config.get_param(make_args(d, H, k, L, V_a, V_b, N, B, d_ff_model=dff), make_dirs=False)
+    G = models.MyAuto4Rec_c("cuda", param, wf=None, enc_share=True, dec_rec=False).to(torch.float32)
+    sd = torch.load(os.path.join(GOLDEN_DIR, "ref_pre_model.pt"), map_location="cpu", weights_only=True)
+    G.load_state_dict(sd, strict=True)                       # every key the reference wrote, nothing missing
+    G = G.cuda().eval()
+    for dom in "ab":
+        bt = tuple(torch.as_tensor(zi["%s.%s" % (nm, dom)]).cuda() for nm in ("enc_in", "dec_in", "dec_out", "n_items"))
+        with torch.no_grad():
+            ue = T.get_user_embed(G, bt[0], dom, param, "cuda", 0)
+            mask = T.get_pad_mask(bt[2], 0, "cuda")
+            la = T.loss_ae(G, *bt, True, B, L, param, mask, "cuda", domain=dom)
+            logits = G(*bt, dom, mask).dense()
+        np.testing.assert_allclose(np_(ue), zi["user_embed.%s" % dom], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(float(la), float(zi["loss_ae.%s" % dom]), rtol=1e-3, atol=1e-5)
+        # dense logits [B, L, k+1] reproduce the loss the fused kernel computed: masked CE with label 0
+        lg = logits.view(-1, k + 1).double()
+        ce = (torch.logsumexp(lg, 1) - lg[:, 0]) * mask.double()
+        np.testing.assert_allclose(float(ce.sum() / mask.sum()), float(zi["loss_ae.%s" % dom]), rtol=1e-3, atol=1e-5)
+        assert tuple(logits.shape) == (B, L, k + 1)
+    # and a checkpoint written by THIS build loads back bit-identically (torch.save(state_dict), gan_training.py:1003-1006)
+    path = "/tmp/rg_ckpt_%d.pt" % os.getpid()
+    torch.save(G.state_dict(), path)
+    back = torch.load(path, map_location="cpu", weights_only=True)
+    assert sorted(back) == sorted(sd)
+    for kk in sd:
+        np.testing.assert_array_equal(back[kk].numpy(), sd[kk].numpy(), err_msg=kk)
+    os.remove(path)
+
+
+@pytest.mark.parametrize("name", ["case1", "case2"])
+def test_single_domain_evaluation(name):
+    """auto_training.get_scores / evaluation against the reference's train_auto.get_scores / evaluation
+    (train_auto.py:164-253, oracle/gen_golden_eval.py run_single): scores within the f32 tolerance, metrics equal."""
+    from recguru_amd import auto_training as at, ops
+    from recguru_amd.models import MyRec
+    ops.set_compute_dtype(torch.float32)
+    z = load_case(name)
+    ze = load_case("eval_single_" + name)
+    param = case_param(z)
+    param.candidate_size = int(ze["candidate_size"])
+    R = MyRec("cuda", param, None, dec_rec=False, fix_enc=False, sas=False, pos_train=False).to(torch.float32)
+    R.load_state_dict(state_of(z, "R"), strict=False)
+    R = R.cuda().eval()
+    loader = []
+    for bi in range(2):
+        t = {nm: torch.as_tensor(ze["%s.%d" % (nm, bi)]).cuda() for nm in ("enc_in", "dec_in", "val", "test", "n_items_f",
+                                                                             "n_items_r")}
+        loader.append(((t["enc_in"], t["dec_in"], t["val"]), (t["enc_in"], t["dec_in"], t["test"]), t["n_items_f"],
+                       t["n_items_r"]))
+        sc = at.get_scores(R, t["enc_in"], t["dec_in"], t["val"], t["n_items_f"], param)
+        np.testing.assert_allclose(sc.cpu().numpy(), ze["scores_val_f.%d" % bi], rtol=1e-3, atol=2e-5)
+    res = at.evaluation(R, loader, "cuda", param)
+    names = ("ht_eval", "ndcg_eval", "mrr_eval", "ht_test", "ndcg_test", "mrr_test")
+    got_f = np.array([[res[0][kk][n][0] for n in names] for kk in ("5", "10", "20", "30")])
+    got_r = np.array([[res[1][kk][n][0] for n in names] for kk in ("5", "10", "20", "30")])
+    # an all-pad user (zero decoder state) ties every score at 0; the reference's unstable argsort ranks such a target
+    # arbitrarily.  Cases with such a user compare only the metrics of batches without one.
+    tie = any(np.all(ze["scores_val_f.%d" % bi] == ze["scores_val_f.%d" % bi][:, :1], axis=1).any() for bi in range(2))
+    if not tie:
+        np.testing.assert_allclose(got_f, ze["result_freq"], rtol=1e-12, atol=1e-15)
+        np.testing.assert_allclose(got_r, ze["result_rand"], rtol=1e-12, atol=1e-15)
+    else:
+        assert np.abs(got_f - ze["result_freq"]).max() <= 1.0 / sum(ze["val.%d" % bi].shape[0] for bi in range(2)) + 1e-12
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# entry scripts end to end (main_2: phase 1 + checkpoint + phases 2 / 3 + evaluation; train_auto: both stages + eval)
+# ----------------------------------------------------------------------------------------------------------------------
+def _run(cmd, timeout=900):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable] + cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                       timeout=timeout)
+    out = r.stdout.decode()
+    assert r.returncode == 0, out[-4000:]
+    return out
+
+
+def test_train_gan_entry_point(tmp_path):
+    res = str(tmp_path)
+    out = _run(["train_gan.py", "--cross", "True", "--synthetic", "256", "--seq_len", "32", "--d_model", "128", "--n_head", "4",
+                "--batch_size", "64", "--batch_size_val", "64", "--vocab_size_a", "500", "--vocab_size_b", "400",
+                "--n_negs", "5", "--phase1_steps", "3", "--steps_tune", "35", "--result_path", res])
+    assert "Reconstruction pre-training (Phase 1)" in out and "phase 2 and phase 3" in out
+    assert "final ranking evaluation" in out and "last phase-2 iteration" in out
+    sub = [d for d in os.listdir(res) if os.path.isdir(os.path.join(res, d))]
+    assert len(sub) == 1
+    rp = os.path.join(res, sub[0])
+    sd = torch.load(os.path.join(rp, "model", "pre_model"), map_location="cpu", weights_only=True)   # main_2's checkpoint
+    assert "encoder.layers.0.enc_self_attn.WQ.weight" in sd and "src_emb_b.weight" in sd
+    with open(os.path.join(rp, "log.pkl"), "rb") as f:
+        log = pickle.load(f)
+    # steps_tune=35: range(42) iterations, 21 of phase 2 and 21 of phase 3, evaluation at iteration 29 (> 28, % 30 == 29)
+    assert len(log[[k for k in log if "disc cost" in k][0]]) == 21
+    assert len(log[[k for k in log if "tuning_recommendation_loss" in k][0]]) == 21
+    with open(os.path.join(rp, "result_a.pickle"), "rb") as f:
+        result = pickle.load(f)
+    assert sorted(result[0]) == ["10", "20", "5"] and len(result[0]["10"]["ht_test"]) == 1
+    vals = [float(v) for v in log[[k for k in log if "join_recon_a" in k][0]].values()]
+    assert all(np.isfinite(vals))
+
+
+def test_train_auto_entry_point(tmp_path):
+    res = str(tmp_path)
+    out = _run(["train_auto.py", "--synthetic", "256", "--seq_len", "50", "--d_model", "64", "--n_head", "2", "--batch_size", "64",
+                "--batch_size_val", "64", "--vocab_size_a", "1000", "--n_negs", "5", "--steps", "6", "--tune_steps", "8",
+                "--epochs", "2", "--result_path", res])
+    assert "Reconstruction loss after" in out and "BPR loss after" in out and "Random eval HT@10" in out and "saved" in out
+    sub = [d for d in os.listdir(res) if os.path.isdir(os.path.join(res, d))]
+    rp = os.path.join(res, sub[0])
+    sd = torch.load(os.path.join(rp, "model", "model"), map_location="cpu", weights_only=True)
+    assert "AutoEnc.encoder.layers.0.enc_self_attn.WQ.weight" in sd and "recommend.layers.0.pos_ffn.l1.weight" in sd
+    with open(os.path.join(rp, "result_sas_org.pickle"), "rb") as f:
+        result = pickle.load(f)
+    assert sorted(result[1]) == ["10", "20", "30", "5"] and len(result[1]["10"]["ht_eval"]) >= 1
+
+
+def test_generic_gemm_refuses_a_live_tile_list():
+    """the generic GEMM kernels read every row, so a live-tile list they would ignore (producers leave the
+    padded tiles' rows unwritten) is an error, not a silent fall-through."""
+    from recguru_amd import hip
+    M = 32768
+    A = torch.randn(M, 128, device="cuda").bfloat16()
+    W = torch.randn(128, 128, device="cuda").bfloat16()
+    mask = (torch.rand(M, device="cuda") < 0.5).float()
+    live = hip.live_tiles(mask, M)
+    hip.gemm_nt(A, W, live=live)                                           # list-driven kernel: fine
+    with pytest.raises(RuntimeError, match="live16"):
+        hip.gemm_nt(A, W, live=live, debug_ablate=16)                      # forced generic kernel
+    with pytest.raises(RuntimeError, match="live16"):
+        hip.gemm_nt(A.float(), W.float(), live=live)                       # f32 tier has no list-driven kernel
+    hip.gemm_tn(A, A, live=live)
+    with pytest.raises(RuntimeError, match="live16"):
+        hip.gemm_tn(A, A, live=live, splits=4)

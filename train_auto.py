@@ -1,9 +1,10 @@
 #!/usr/bin/env python
 """Single-domain AutoRec training on MI355X -- the reference's train_auto.py flag surface
 (GURU/train_auto.py:373-432): reconstruction pre-training of MyRec/MyAuto4Rec with the Noam
-schedule, then BPR fine-tuning of the recommender decoder.  Ranking evaluation is a 'next' row.
+schedule, then BPR fine-tuning of the recommender decoder with the ranking evaluation (HR / NDCG / MRR over
+frequency-sampled and random candidates, train_auto.py:202-253) after every fine-tuning epoch.
 
-The reference loops 500 epochs over the loader (train_auto.py:101-106); --epochs / --steps bound it.
+The reference loops 500 epochs over the loader (train_auto.py:101-106); --epochs / --steps / --tune_steps bound it.
 """
 import argparse
 import os
@@ -42,6 +43,7 @@ def parse():
     p.add_argument("--data_path", type=str, default=None)
     p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
     p.add_argument("--synthetic", type=int, default=0)
+    p.add_argument("--epochs", type=int, default=500, help="epochs per stage (train_auto.py:101 hard-codes 500)")
     p.add_argument("--steps", type=int, default=200, help="pre-training steps")
     p.add_argument("--tune_steps", type=int, default=100, help="BPR fine-tuning steps")
     return p.parse_args()
@@ -56,8 +58,7 @@ def main():
         sys.exit("train_auto.py: the SASRec baseline (--sas True) is out of scope")
     if not torch.cuda.is_available():
         sys.exit("train_auto.py: no GPU visible -- the HIP path has no CPU fallback")
-    from recguru_amd import blocks, config, data, models, ops, synthetic
-    from recguru_amd.optim import Adam
+    from recguru_amd import auto_training as at, config, data, ops, sampler, synthetic
     if args.synthetic:
         args.vocab_size_a = args.vocab_size_a or 10000
         args.vocab_size_b = args.vocab_size_a
@@ -67,52 +68,30 @@ def main():
     device = "cuda:0"
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
     L, V = param.enc_maxlen, param.vocab_size - 1
+    item_fre = None
     if args.synthetic:
         ae = synthetic.TensorLoader(synthetic.make_domain(args.synthetic, V, L, param.n_negs, seed=1), param.batch_size, device)
         re = synthetic.TensorLoader(synthetic.make_domain(args.synthetic, V, L, param.num_train_neg, seed=2), param.batch_size, device)
+        re_f = re
+        seqs, val, test, _ = synthetic.make_users(args.synthetic, V, L, seed=1)
+        param.candidate_size = min(param.candidate_size, V - L - 3)
+        ev = sampler.DeviceEvalLoader(seqs, val, test, V, device, min(param.batch_size_val, args.synthetic), L, param.rec_maxlen,
+                                      V + 1, param.candidate_size)
     else:
-        files = data.discover(param.data_path, param.domain_name, "\0")["a"]
+        found = data.discover(param.data_path, param.domain_name, "\0")
+        files = found["a"]
+        if found["freq_a"]:
+            item_fre = data.load_pickle(found["freq_a"][0])                 # train_auto.py:411-414
         param.vocab_size_a = param.vocab_size
-        ae = data.dataloader_gen(files, param, param.n_negs, "a", device)
-        re = data.dataloader_gen(files, param, param.num_train_neg, "a", device, seed=1)
+        gen = lambda n, seed, **kw: data.device_loader_gen(files, param, n, "a", device, seed=seed, **kw)
+        ae = gen(param.n_negs, 1)                                           # train_auto.py:417-430
+        re = gen(param.n_bpr_neg, 2, rec=True)
+        re_f = gen(param.n_bpr_neg, 3, rec=True, wf=item_fre)
+        ev = data.eval_loader_gen(files, param, "a", device, wf=item_fre)
     torch.manual_seed(1)
-    model = models.MyRec(device, param, None, dec_rec=args.share_dec == "True", fix_enc=args.fix_enc,
-                         sas=False, pos_train=False).to(torch.float32).to(device)
-    opt = blocks.ScheduledOptim(Adam(model.parameters(), betas=(0.9, 0.99), eps=1e-09), 1.0, param.d_model,
-                                param.n_warmup_steps)                      # train_auto.py:354-356
-    step, done = 0, False
-    while not done:
-        for seqs, n_items, val, test in ae:
-            enc_in, dec_in, dec_out = seqs
-            opt.zero_grad()
-            mask = (dec_in != param.pad_index).view(-1).to(torch.float32)  # train_auto.py:109-110
-            loss = model(enc_in, dec_in, dec_out, n_items, recon=True).loss(mask)
-            loss.backward()
-            opt.step_and_update_lr()
-            step += 1
-            if step % 50 == 0:
-                print("reconstruction loss after %d batch" % step, float(loss.detach()))
-            if step >= args.steps:
-                done = True
-                break
-    opt2 = Adam(model.parameters(), lr=param.lr_rs)                        # train_auto.py:364
-    step, done = 0, args.tune_steps <= 0
-    while not done:
-        for seqs, n_items, val, test in re:
-            enc_in, dec_in, dec_out = seqs
-            opt2.zero_grad()
-            mask = (dec_in != param.pad_index).view(-1).to(torch.float32)
-            loss = model(enc_in, dec_in, dec_out, n_items, recon=False).bpr(mask, sas=True)   # lf.BPRLoss_sas, train_auto.py:26
-            loss.backward()
-            opt2.step()
-            step += 1
-            if step % 50 == 0:
-                print("BPR loss after %d batch" % step, float(loss.detach()))
-            if step >= args.tune_steps:
-                done = True
-                break
-    torch.save(model.state_dict(), os.path.join(param.model_path, "model"))  # train_auto.py:367-370
-    print("saved", os.path.join(param.model_path, "model"))
+    at.main(param, device, ae, re, ev, re_f, item_freq=item_fre, sas_=args.sas, shared=args.share_dec, fix_enc=args.fix_enc,
+            epochs=args.epochs, max_steps=args.steps, tune_max_steps=args.tune_steps)
+    print("saved", os.path.join(param.result_path, "model/model"))
 
 
 if __name__ == "__main__":

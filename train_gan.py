@@ -97,16 +97,21 @@ def main():
         test_loaders = sampler.DeviceEvalLoader(seqs, val, test, Vt, device, param.batch_size_val, L, param.rec_maxlen, Vt + 1,
                                                 param.candidate_size, rank=rank, world=world)
     else:
-        test_loaders = None
         files = Dataloader.discover(param.data_path, param.domain_name_a, param.domain_name_b)
         print("=================\n", files, "\n*****************")
-        ae_loaders = [Dataloader.dataloader_gen(files["a"], param, k, "a", device, rank, world),
-                      Dataloader.dataloader_gen(files["b"], param, k, "b", device, rank, world)]
         t = args.target_domain
+        for need in ("a", "b", "freq_" + t):
+            if not files[need]:
+                sys.exit("train_gan.py: no '%s' pickle under %s (train_gan.py:65-79 naming)" % (need, param.data_path))
+        # shuffled loaders with FRESH negatives per batch (data_loader.py:276-316,455-483), on the device
+        gen = lambda f, n, dom, seed, **kw: Dataloader.device_loader_gen(f, param, n, dom, device, rank, world, seed=seed, **kw)
+        ae_loaders = [gen(files["a"], k, "a", 11), gen(files["b"], k, "b", 12)]
         freq = Dataloader.load_pickle(files["freq_" + t][0])
-        rec_loaders = [Dataloader.dataloader_gen(files[t], param, param.n_bpr_neg, t, device, rank, world, seed=1),
-                       Dataloader.dataloader_gen(files[t], param, param.n_bpr_neg, t, device, rank, world, seed=2, wf=freq)]
-    torch.manual_seed(1)                                           # gan_training.py:20
+        rec_loaders = [gen(files[t], param.n_bpr_neg, t, 13, rec=True),
+                       gen(files[t], param.n_bpr_neg, t, 14, rec=True, wf=freq)]
+        # train_loader_re_test_{a,b} (train_gan.py:91-92,100-101): evaluated every 30 iterations past 0.8 * iterations
+        test_loaders = Dataloader.eval_loader_gen(files[t], param, t, device, rank, world, wf=freq)
+    torch.manual_seed(1)                                           # gan_training.py:20 (same initial weights on every rank)
     enc_model = Model.MyAuto4Rec_c(device, param, wf=None, enc_share=args.enc_share != "False",
                                    dec_rec=False).to(torch.float32).to(device)
     opt_rec = all_module.ScheduledOptim(Adam(enc_model.parameters(), betas=(0.9, 0.98), eps=1e-09),
@@ -114,6 +119,10 @@ def main():
     opt_gen = Adam(enc_model.parameters(), lr=0.0001, betas=(0.5, 0.9))
     netD = Model.Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
     opt_dis = Adam(netD.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    # per-rank random streams AFTER the (identical) initialisation: dropout masks and the gradient-penalty alpha of a
+    # shard must be independent of the other shards', as the elements of one big batch are
+    ops.manual_seed(1, rank)
+    torch.manual_seed(1 + rank)
     hist = gt.main_2(enc_model, opt_rec, netD, opt_gen, opt_dis, param, device, ae_loaders, rec_loaders, test_loaders, None,
                      dp=dp, phase1_steps=args.phase1_steps)
     if rank == 0 and test_loaders is not None:
@@ -122,10 +131,7 @@ def main():
             "HR@%s %.4f NDCG@%s %.4f" % (kk, res[1][kk]["ht_test"][0], kk, res[1][kk]["ndcg_test"][0]) for kk in ("5", "10", "20")))
         enc_model.train()
     if rank == 0:
-        log = gt.plot.flush()
-        import pickle
-        with open(os.path.join(param.result_path, "log.pkl"), "wb") as f:
-            pickle.dump(log, f)
+        gt.plot.flush(param.result_path)                          # log.pkl in tools/plot.py's layout
         if hist:
             print("last phase-2 iteration: D_cost %.4f  W_D %.4f  recon_a %.4f  recon_b %.4f  g_dis %.4f"
                   % tuple(float(x) for x in hist[-1]))
