@@ -87,6 +87,8 @@ typedef struct {
                                  sums them into dW (256 x |dW| of 64-byte-segment float atomics ran at a fraction of the
                                  memory-side atomic rate and cost more than the GEMM itself).  NULL: atomics.  Must not be
                                  shared by calls that may run concurrently on different streams. */
+  int colsum_T;               /* > 0: colsum sums rows t < colsum_T only (the fused discriminator stacks rows whose bias
+                                 gradient is zero by construction behind the ones that have one); 0: all T rows */
 } rg_gemm_tn_args;
 int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
 /* bytes of `partials` scratch rg_gemm_tn can use for these arguments (0: the kernel it would run has no use for it) */
@@ -179,6 +181,45 @@ int rg_colsum(const void* x, const void* aux /* or NULL */, const float* coef /*
 int rg_outer_posmask(const float* coef /* [M] or NULL */, const float* w /* [N] */, const void* aux, void* out,
                      long long M, int N, float scale, int dtype,
                      void* stream);                             /* out = scale*coef[m]*w[n]*[aux>0]     */
+/* Fused discriminator + gradient penalty (csrc/disc.hip): ONE row-parallel launch walks, per tile of rows and with the
+ * activations in LDS, the forward MLP (tools/utils.py:41-57), the backward chain of the W-loss rows (stacked
+ * [real; fake], d loss / d D(x_r) = coef_real | coef_fake) and, when alpha != NULL, the whole gradient-penalty branch of
+ * calc_gradient_penalty (gan_training.py:38-55) in closed form (interpolation, forward, dD/dxhat, penalty, second-order
+ * chain).  It leaves the row-stacked operand pairs of the weight gradients in HBM -- rows [0, 2B) from the W rows,
+ * rows [2B, 3B) from the GP rows:
+ *     dW1 += Y1^T X1 ([3B,n1] x [3B,d]),  dW2 += Y2^T X2 ([3B,n2] x [3B,n1]),  dW3 += Y3^T X3 ([3B,n3] x [3B,n2])
+ * (three rg_gemm_tn calls by the caller, with colsum = db_i and colsum_T = 2B: only the W rows have a bias gradient;
+ * T = 2B rows when alpha == NULL) -- and accumulates itself (f32 atomics) dw4, db4 and scalars[0] += mean(D(real)),
+ * scalars[1] += mean(D(fake)), scalars[2] += gp_coef * mean((|g|-1)^2).
+ * Weights in operand dtype, FRAGMENT-PACKED (rg_cast with RG_CAST_PACK): W_i = pack(W_i [out,in]) and W_it =
+ * pack(W_i^T [in,out]); biases, w4 f32.  drop_p: Dropout(0.2) of
+ * the discriminator in train mode (stateless hash of seed_* and the element index); 0 = eval.
+ * rg_disc_supported: widths multiples of 32, n2 the widest, tile fits the 160 KB LDS (d_model 32..128 on both tiers,
+ * 256 on none: callers fall back to rg_gemm_nt chains). */
+typedef struct {
+  const void* real; const void* fake;          /* [B,d] dtype */
+  const float* alpha;                          /* [B] or NULL (no gradient-penalty rows) */
+  const void *W1, *W2, *W3, *W1t, *W2t, *W3t;
+  const float *b1, *b2, *b3, *w4, *b4;
+  int B, d, n1, n2, n3;
+  float drop_p;
+  unsigned long long seed_w[3];                /* dropout seeds of the W rows, one per hidden layer */
+  unsigned long long seed_g[3];                /* ... of the GP rows */
+  float coef_real, coef_fake;                  /* d loss / d D(x_r) for r < B, r >= B */
+  float gp_coef;                               /* lambda (x data-parallel scale): penalty = gp_coef * mean((|g|-1)^2) */
+  float* out;                                  /* [2B] f32 D(x) or NULL */
+  float* scalars;                              /* [3] f32, accumulated */
+  void *Y1, *X1, *Y2, *X2, *Y3, *X3;           /* stacked operands, dtype; any may be NULL when no weight gradient is wanted */
+  float *db1, *db2, *db3, *dw4, *db4;          /* dw4, db4: accumulated when need_wgrad; db1..db3 unused (rg_gemm_tn colsum) */
+  void* dx;                                    /* [2B,d] dtype or NULL: d loss / d x of the W rows */
+  void* hscratch;                              /* unused (the masks live in LDS as bit masks) */
+  int need_wgrad;
+  int debug_ablate;                            /* profiling only (tools/kb_disc.py): 1 no column-sum atomics, 2 weight loads
+                                                  of one k-step only, 4 no MFMAs, 8 no flushes to HBM; 0 in production */
+  long long* stamps;                           /* profiling only: [grid][16] s_memtime stamps at the stage boundaries, or NULL */
+} rg_disc_args;
+int rg_disc_supported(int d, int n1, int n2, int n3, int dtype);
+int rg_disc_rows(const rg_disc_args* args /* host */, int dtype, void* stream);
 int rg_interpolate(const float* alpha, const void* real, const void* fake, void* out, long long B, int d,
                    int dtype, void* stream);                   /* gan_training.py:39-43               */
 int rg_gp_penalty(const float* g, void* dg, float* gp, long long B, int d, float lambda, int dtype,
@@ -211,6 +252,13 @@ typedef struct {
 } rg_adam_seg_dev;
 int rg_adam_multi_dev(rg_adam_seg_dev* segs /* device, updated in place */, int nsegs, double lr, double beta1, double beta2,
                       double eps, void* stream);
+/* transpose: bit 0 = dst is the transpose of src; bit 1 (RG_CAST_PACK) = dst holds the logical operand M (= src or src^T)
+ * [N][K] as consecutive MFMA fragments: block (n / 16, k / 32) = 64 lanes x 8 elements, lane 16 g + i = M[16 nb + i]
+ * [32 kb + 8 g .. + 8], blocks ordered nb-major -- a wave's operand fragment is then one contiguous 1 KB (bf16) read.
+ * Needs R, C multiples of 32.  In rg_cast_seg the same bits apply; ld = logical K of the (possibly concatenated) dst,
+ * row_off / col_off = n / k offsets (multiples of 16 / 32). */
+#define RG_CAST_TRANSPOSE 1
+#define RG_CAST_PACK 2
 int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
 /* Multi-tensor cast: ONE launch refreshes every operand-tier weight copy after an optimizer step (136 per-tensor casts
  * per training iteration otherwise).  Segment s: dst[(r + row_off) * ld + c + col_off] = src[r, c], or with transpose

@@ -424,7 +424,13 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(rg_gemm_tn_args a) {
     for (int ks = 0; ks < TT / 32; ++ks) {
       Frag<T> af;
       load_frag_tr(af, Ys, LD, ks * 32, wave * 16, li, lg, a.use_tr);
-      if (do_colsum) mma(af, ones, csum);
+      if (do_colsum) {
+        if (a.colsum_T > 0) {              // slot (g, j) of the ones fragment is row t0 + ks * 32 + 8 g + j
+#pragma unroll
+          for (int j = 0; j < 8; ++j) ones.v[j] = (T)((t0 + ks * 32 + 8 * lg + j < a.colsum_T) ? 1.f : 0.f);
+        }
+        mma(af, ones, csum);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         Frag<T> bf;

@@ -235,7 +235,7 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
 
 // 1 if an instantiation takes this problem
 int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
-  if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7)) return 0;
+  if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7) || a->colsum_T > 0) return 0;
   return (a->N2 == 128 && (a->N1 == 512 || a->N1 == 384 || a->N1 == 256 || a->N1 == 128)) || (a->N1 == 128 && a->N2 == 512);
 }
 

@@ -33,7 +33,7 @@ class GemmNtArgs(ctypes.Structure):
 class GemmTnArgs(ctypes.Structure):
     _fields_ = [("Y", c_p), ("ldy", c_i), ("X", c_p), ("ldx", c_i), ("dW", c_p), ("lddw", c_i), ("colsum", c_p),
                 ("T", c_i), ("N1", c_i), ("N2", c_i), ("prologue_x", c_i), ("scale", c_f), ("splits", c_i),
-                ("use_tr", c_i), ("live16", c_p), ("partials", c_p)]
+                ("use_tr", c_i), ("live16", c_p), ("partials", c_p), ("colsum_T", c_i)]
 
 
 class AttnArgs(ctypes.Structure):
@@ -68,7 +68,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
-           "rg_adam_multi_dev"]
+           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -173,7 +173,8 @@ def _tn_workspace(dev, nbytes, kind="tn"):
     return ws
 
 
-def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None, partials=True):
+def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None, partials=True,
+            colsum_rows=0):
     """dW[N1,N2] += Y[T,N1].T @ pro(X[T,N2]) (f32, accumulated); colsum[N1] += Y.sum(0)."""
     T, N1 = Y.shape
     N2 = X.shape[1]
@@ -183,7 +184,7 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     if T == 0:
         return dW
     a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
-                   prologue_x, scale, splits, use_tr, _p(live), None)
+                   prologue_x, scale, splits, use_tr, _p(live), None, int(colsum_rows))
     if partials:
         fn = lib().rg_gemm_tn_workspace
         fn.restype = ctypes.c_size_t
@@ -394,14 +395,19 @@ def cast_multi(seg_table_dev, tiles_dev, ntiles, dtype):
     _check(lib().rg_cast_multi(_vp(seg_table_dev), _vp(tiles_dev), int(ntiles), code, _stream()), "rg_cast_multi")
 
 
+CAST_TRANSPOSE, CAST_PACK = 1, 2
+
+
 def cast(src, dtype, transpose=False):
-    """f32 [R,C] -> dtype [R,C] or [C,R]."""
+    """f32 [R,C] -> dtype [R,C] or [C,R].  transpose may also be a mode: bit 0 transpose, bit 1 (CAST_PACK) the
+    MFMA-fragment-packed layout of the (transposed) matrix (include/recguru_hip.h, rg_cast)."""
     assert src.dtype == torch.float32 and src.is_contiguous()
     src2 = src.reshape(src.shape[0], -1) if src.dim() > 1 else src.reshape(1, -1)
     R, C = src2.shape
-    dst = torch.empty((C, R) if transpose else (R, C), device=src.device, dtype=dtype)
-    _check(lib().rg_cast(_vp(src2), _vp(dst), R, C, int(transpose), dt_of(dst), _stream()), "rg_cast")
-    return dst if (transpose or src.dim() > 1) else dst.reshape(src.shape)
+    mode = int(transpose)
+    dst = torch.empty((C, R) if (mode & 1) else (R, C), device=src.device, dtype=dtype)
+    _check(lib().rg_cast(_vp(src2), _vp(dst), R, C, mode, dt_of(dst), _stream()), "rg_cast")
+    return dst if (mode or src.dim() > 1) else dst.reshape(src.shape)
 
 
 def item_loss_fwd(h, table, pos, neg, mask, k, mode):
@@ -503,6 +509,42 @@ def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_r
                      d, k, mode, skip_row)
     _check(lib().rg_item_loss_bwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_bwd")
     return dh
+
+
+class DiscArgs(ctypes.Structure):
+    _fields_ = [("real", c_p), ("fake", c_p), ("alpha", c_p),
+                ("W1", c_p), ("W2", c_p), ("W3", c_p), ("W1t", c_p), ("W2t", c_p), ("W3t", c_p),
+                ("b1", c_p), ("b2", c_p), ("b3", c_p), ("w4", c_p), ("b4", c_p),
+                ("B", c_i), ("d", c_i), ("n1", c_i), ("n2", c_i), ("n3", c_i), ("drop_p", c_f),
+                ("seed_w", c_u64 * 3), ("seed_g", c_u64 * 3), ("coef_real", c_f), ("coef_fake", c_f), ("gp_coef", c_f),
+                ("out", c_p), ("scalars", c_p), ("Y1", c_p), ("X1", c_p), ("Y2", c_p), ("X2", c_p), ("Y3", c_p), ("X3", c_p),
+                ("db1", c_p), ("db2", c_p), ("db3", c_p), ("dw4", c_p), ("db4", c_p), ("dx", c_p), ("hscratch", c_p),
+                ("need_wgrad", c_i), ("debug_ablate", c_i), ("stamps", c_p)]
+
+
+def disc_supported(d, n1, n2, n3, dtype):
+    return bool(lib().rg_disc_supported(int(d), int(n1), int(n2), int(n3), BF16 if dtype == torch.bfloat16 else F32))
+
+
+def disc_rows(real, fake, alpha, W, Wt, biases, w4, b4, drop_p, seeds_w, seeds_g, coef_real, coef_fake, gp_coef, scalars,
+              ops_xy, bias_grads=None, out=None, dx=None, hscratch=None, debug_ablate=0, stamps=None):
+    """The fused discriminator row kernel (csrc/disc.hip).  W = (W1, W2, W3) operand-tier [out,in], Wt the transposed
+    copies, both fragment-packed (CAST_PACK); biases = (b1, b2, b3) f32, w4 [n3] f32, b4 [1] f32.  ops_xy = (Y1, X1, Y2,
+    X2, Y3, X3), entries may be None when no weight gradient is wanted.  bias_grads = (None, None, None, dw4, db4) f32
+    accumulators (db1..db3 come out of gemm_tn's colsum) or None."""
+    B, d = real.shape
+    n1, n2, n3 = W[0].shape[0], W[1].shape[0], W[2].shape[0]
+    assert real.is_contiguous() and fake.is_contiguous() and fake.shape == real.shape and real.dtype == W[0].dtype
+    assert all(w.is_contiguous() for w in W) and all(w.is_contiguous() for w in Wt)
+    Y1, X1, Y2, X2, Y3, X3 = ops_xy
+    bg = bias_grads if bias_grads is not None else (None,) * 5
+    a = DiscArgs(_p(real), _p(fake), _p(alpha), _p(W[0]), _p(W[1]), _p(W[2]), _p(Wt[0]), _p(Wt[1]), _p(Wt[2]),
+                 _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(w4), _p(b4), B, d, n1, n2, n3, drop_p,
+                 (c_u64 * 3)(*seeds_w), (c_u64 * 3)(*seeds_g), coef_real, coef_fake, gp_coef,
+                 _p(out), _p(scalars), _p(Y1), _p(X1), _p(Y2), _p(X2), _p(Y3), _p(X3),
+                 _p(bg[0]), _p(bg[1]), _p(bg[2]), _p(bg[3]), _p(bg[4]), _p(dx), _p(hscratch),
+                 1 if bias_grads is not None else 0, debug_ablate, _p(stamps))
+    _check(lib().rg_disc_rows(ctypes.byref(a), dt_of(real), _stream()), "rg_disc_rows")
 
 
 def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H, drop_p=0.0, seed=0):
@@ -674,7 +716,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
 
 _WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

@@ -52,8 +52,10 @@ def _ver(p):
     return (p.data_ptr(), p._version, getattr(p, "_rg_gen", 0))
 
 
-def shadow(p, transpose=False):
-    """Operand-tier copy of a 2-D f32 parameter: [out,in] or, transposed, [in,out]."""
+def shadow(p, transpose=False, pack=False):
+    """Operand-tier copy of a 2-D f32 parameter: [out,in] or, transposed, [in,out]; pack=True: in the MFMA-fragment-packed
+    layout (hip.CAST_PACK) the fused discriminator kernel reads."""
+    transpose = int(bool(transpose)) | (hip.CAST_PACK if pack else 0)       # cast mode; rides in the key's transpose slot
     if _COMPUTE == torch.float32 and not transpose:
         return p.detach()
     key = (id(p), transpose, _COMPUTE)
@@ -132,7 +134,8 @@ def refresh_shadows(params):
         for _ in range(2):
             segs, outs = [], []
             for key, ps in todo:
-                transpose = key[1]
+                mode = int(key[1])                              # bit 0 transpose, bit 1 fragment-packed (hip.CAST_PACK)
+                transpose = mode & 1
                 R = sum(p.shape[0] for p in ps)
                 C = ps[0].shape[1]
                 dst = torch.empty((C, R) if transpose else (R, C), device=dev, dtype=_COMPUTE)
@@ -143,7 +146,7 @@ def refresh_shadows(params):
                     src = p.detach()
                     assert src.is_contiguous() and src.dtype == torch.float32 and src.shape[1] == C
                     segs.append((src.data_ptr(), dst.data_ptr(), p.shape[0], C, ld, 0 if transpose else off,
-                                 off if transpose else 0, 1 if transpose else 0))
+                                 off if transpose else 0, mode))
                     if not gens:
                         shapes.append((p.shape[0], C))
                     off += p.shape[0]
@@ -804,3 +807,102 @@ class GradientPenaltyFn(_Fn):
     def backward(ctx, gout):
         dW1, dW2, dW3, dW4 = ctx.saved_tensors
         return (None, None, None, None, dW1 * gout, None, dW2 * gout, None, dW3 * gout, None, dW4 * gout, None)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused discriminator + gradient penalty (csrc/disc.hip): the critic update and the generator's W-loss without autograd
+# between the discriminator's layers
+# ------------------------------------------------------------------------------------------------
+_DISC_WS = {}
+
+
+def disc_fusable(D):
+    """The fused row kernel takes this discriminator in the current tier (widths, LDS budget)."""
+    W1, _, W2, _, W3, _, W4, _ = D.params()
+    return (W4.shape[0] == 1 and W1.is_cuda and
+            hip.disc_supported(W1.shape[1], W1.shape[0], W2.shape[0], W3.shape[0], _COMPUTE))
+
+
+def _disc_ws(dev, B, d, n1, n2, n3, rows):
+    """Row-stacked operand buffers of the weight-gradient products, cached per shape and stream."""
+    key = (dev.index, torch.cuda.current_stream(dev).cuda_stream, B, d, n1, n2, n3, rows, _COMPUTE)
+    ws = _DISC_WS.get(key)
+    if ws is None:
+        if len(_DISC_WS) >= 8:
+            _DISC_WS.pop(next(iter(_DISC_WS)))
+        e = lambda n: torch.empty(rows * B, n, device=dev, dtype=_COMPUTE)
+        ws = _DISC_WS[key] = {"Y1": e(n1), "X1": e(d), "Y2": e(n2), "X2": e(n1), "Y3": e(n3), "X3": e(n2)}
+    return ws
+
+
+def _disc_operands(D):
+    W1, b1, W2, b2, W3, b3, W4, b4 = D.params()
+    W = (shadow(W1, pack=True), shadow(W2, pack=True), shadow(W3, pack=True))
+    Wt = (shadow(W1, True, pack=True), shadow(W2, True, pack=True), shadow(W3, True, pack=True))
+    return W, Wt, (b1.detach(), b2.detach(), b3.detach()), W4.detach().view(-1), b4.detach()
+
+
+def critic_fused(D, real, fake, alpha, scale=1.0):
+    """W-loss + gradient penalty of one critic update and their gradients with respect to every discriminator
+    parameter (gan_training.py:430-448), accumulated into p.grad: one row kernel + three weight-gradient GEMMs.
+    dis_loss = mean(D(fake)) - mean(D(real)); GP = lambda mean((|dD/dxhat| - 1)^2) at xhat = alpha real + (1 - alpha) fake;
+    `scale` multiplies both losses' gradients (1 / world under data parallelism).
+    Returns a [3] f32 device tensor: mean(D(real)), mean(D(fake)), GP (unscaled)."""
+    W1, b1, W2, b2, W3, b3, W4, b4 = D.params()
+    B, d = real.shape
+    dev = real.device
+    drop_p = D.drop_p()
+    W, Wt, biases, w4, b4v = _disc_operands(D)
+    real = real.detach().to(_COMPUTE).contiguous()
+    fake = fake.detach().to(_COMPUTE).contiguous()
+    ws = _disc_ws(dev, B, d, W1.shape[0], W2.shape[0], W3.shape[0], 3)
+    seeds_w = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
+    seeds_g = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
+    sc = torch.zeros(3, device=dev, dtype=torch.float32)
+    (dW1, _), (db1, _), (dW2, _), (db2, _) = _gt(W1), _gt(b1), _gt(W2), _gt(b2)
+    (dW3, _), (db3, _), (dW4, _), (db4, _) = _gt(W3), _gt(b3), _gt(W4), _gt(b4)
+    hip.disc_rows(real, fake, alpha.reshape(-1).to(torch.float32).contiguous(), W, Wt, biases, w4, b4v, drop_p, seeds_w,
+                  seeds_g, -scale / B, scale / B, GP_LAMBDA * scale, sc,
+                  (ws["Y1"], ws["X1"], ws["Y2"], ws["X2"], ws["Y3"], ws["X3"]),
+                  bias_grads=(None, None, None, dW4.view(-1), db4))
+    # rows [0, 2B) of Y_i are e_i of the W rows: their column sums are the bias gradients (the GP has none)
+    hip.gemm_tn(ws["Y1"], ws["X1"], dW1, db1, colsum_rows=2 * B)
+    hip.gemm_tn(ws["Y2"], ws["X2"], dW2, db2, colsum_rows=2 * B)
+    hip.gemm_tn(ws["Y3"], ws["X3"], dW3, db3, colsum_rows=2 * B)
+    if scale != 1.0:
+        sc[2:3] /= scale
+    return sc
+
+
+class DiscMeansFn(_Fn):
+    """(mean(D(a)), mean(D(b))) with the gradient with respect to a and b only (the generator update runs with the
+    discriminator frozen, gan_training.py:455-456,482-491): one launch of the fused row kernel."""
+
+    @staticmethod
+    def forward(ctx, a, b, D):
+        B, d = a.shape
+        dev = a.device
+        drop_p = D.drop_p()
+        W, Wt, biases, w4, b4v = _disc_operands(D)
+        W1, _, W2, _, W3, _, _, _ = D.params()
+        a_ = a.detach().to(_COMPUTE).contiguous()
+        b_ = b.detach().to(_COMPUTE).contiguous()
+        seeds_w = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
+        sc = torch.zeros(3, device=dev, dtype=torch.float32)
+        need = _needs_grad(ctx)
+        dx = torch.empty(2 * B, d, device=dev, dtype=_COMPUTE) if need else None
+        hip.disc_rows(a_, b_, None, W, Wt, biases, w4, b4v, drop_p, seeds_w, (0, 0, 0), 1.0 / B, 1.0 / B, 0.0, sc,
+                      (None,) * 6, bias_grads=None, dx=dx)
+        ctx.dx, ctx.B, ctx.dtypes = dx, B, (a.dtype, b.dtype)
+        return sc[0], sc[1]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        dx, B = ctx.dx, ctx.B
+        da = (dx[:B] * ga).to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        db = (dx[B:] * gb).to(ctx.dtypes[1]) if ctx.needs_input_grad[1] else None
+        return da, db, None
+
+
+def disc_means(D, a, b):
+    return DiscMeansFn.run(a, b, D)

@@ -134,10 +134,7 @@ def mean(x):
 
 def calc_gradient_penalty(netD, real_data, fake_data, BATCH_SIZE, device):
     """gan_training.py:38-55.  alpha ~ U[0,1) from the CPU default generator, as there (Q13)."""
-    alpha = torch.rand(BATCH_SIZE, 1)
-    if torch.device(device).type == "cuda":
-        # through pinned memory: a pageable host-to-device copy blocks the host until the stream has drained
-        alpha = alpha.pin_memory().to(device, non_blocking=True)
+    alpha = _gp_alpha(BATCH_SIZE, device)
     D = _unwrap(netD)
     return ops.GradientPenaltyFn.run(real_data, fake_data, alpha, D.drop_p(), *D.params())
 
@@ -270,30 +267,54 @@ def critic_embed(netG, in_seq_a, in_seq_b, param, device):
     return ae, be
 
 
-def critic_update(netD, ae, be, opt_d, device, dp):
-    """W-loss, gradient penalty and Adam(D) of a critic update (gan_training.py:412-449)."""
+FUSED_DISC = True       # one row kernel + three weight-gradient GEMMs per critic update (csrc/disc.hip) where supported
+
+
+def _gp_alpha(batch_size, device):
+    """alpha of calc_gradient_penalty: torch.rand(B, 1) on the CPU default generator (gan_training.py:39, Q13)."""
+    alpha = torch.rand(batch_size, 1)
+    if torch.device(device).type == "cuda":
+        # through pinned memory: a pageable host-to-device copy blocks the host until the stream has drained
+        return alpha.pin_memory().to(device, non_blocking=True)
+    return alpha.to(device)
+
+
+def critic_update(netD, ae, be, opt_d, device, dp, want_scalars=True):
+    """W-loss, gradient penalty and Adam(D) of a critic update (gan_training.py:412-449).  Returns (D_cost,
+    Wasserstein_D) as device scalars; want_scalars=False (fused path only) skips the three tiny launches that form them --
+    the reference keeps only the LAST critic update's values of an iteration (:446-447, plotted at :524-525)."""
     opt_d.zero_grad()
-    # D(real) and D(fake) as ONE pass over the stacked batch (the MLP is row-wise: same values row by row, half the
-    # launches of the forward and of the backward); gan_training.py:412-420 calls netD twice
-    nb = ae.shape[0]
-    D_both = netD(torch.cat([ae, be], 0))
-    D_real, D_fake = D_both[:nb], D_both[nb:]
-    real_loss, fake_loss = mean(D_real), mean(D_fake)
-    dis_loss = fake_loss - real_loss
-    dp.scale_mean(dis_loss).backward()
-    gradient_penalty = calc_gradient_penalty(netD, ae, be, ae.shape[0], device)
-    dp.scale_mean(gradient_penalty).backward()
-    D_cost = dis_loss.detach() + gradient_penalty.detach()
-    Wasserstein_D = -dis_loss.detach()
+    D = _unwrap(netD)
+    if FUSED_DISC and ops.disc_fusable(D) and all(p.requires_grad for p in D.parameters()):
+        # D(real), D(fake), dis_loss.backward(), calc_gradient_penalty(...).backward() as ONE row-parallel launch over
+        # the stacked rows [real; fake; xhat] + three weight-gradient GEMMs; the gradients land in p.grad
+        sc = ops.critic_fused(D, ae, be, _gp_alpha(ae.shape[0], device), scale=1.0 / dp.world)
+        D_cost = Wasserstein_D = None
+        if want_scalars:
+            dis_loss = sc[1] - sc[0]
+            D_cost, Wasserstein_D = dis_loss + sc[2], -dis_loss
+    else:
+        # D(real) and D(fake) as ONE pass over the stacked batch (the MLP is row-wise: same values row by row, half the
+        # launches of the forward and of the backward); gan_training.py:412-420 calls netD twice
+        nb = ae.shape[0]
+        D_both = netD(torch.cat([ae, be], 0))
+        D_real, D_fake = D_both[:nb], D_both[nb:]
+        real_loss, fake_loss = mean(D_real), mean(D_fake)
+        dis_loss = fake_loss - real_loss
+        dp.scale_mean(dis_loss).backward()
+        gradient_penalty = calc_gradient_penalty(netD, ae, be, ae.shape[0], device)
+        dp.scale_mean(gradient_penalty).backward()
+        D_cost = dis_loss.detach() + gradient_penalty.detach()
+        Wasserstein_D = -dis_loss.detach()
     dp.sync_grads(list(netD.parameters()))
     opt_d.step()
     return D_cost, Wasserstein_D
 
 
-def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp):
+def critic_iteration(netG, netD, in_seq_a, in_seq_b, opt_d, param, device, dp, want_scalars=True):
     """One critic update (gan_training.py:399-449): two no-grad encoder passes, W-loss, GP, Adam(D)."""
     ae, be = critic_embed(netG, in_seq_a, in_seq_b, param, device)
-    return critic_update(netD, ae, be, opt_d, device, dp)
+    return critic_update(netD, ae, be, opt_d, device, dp, want_scalars)
 
 
 _SIDE = {}
@@ -308,8 +329,8 @@ def critic_phase(netG, netD, batches, opt_d, param, device, dp, overlap=True):
     dropout seeds are drawn in a different (still deterministic) order."""
     if not (overlap and torch.cuda.is_available() and len(batches) > 1):
         out = None
-        for in_a, in_b in batches:
-            out = critic_iteration(netG, netD, in_a, in_b, opt_d, param, device, dp)
+        for i, (in_a, in_b) in enumerate(batches):
+            out = critic_iteration(netG, netD, in_a, in_b, opt_d, param, device, dp, want_scalars=i == len(batches) - 1)
         return out
     main = torch.cuda.current_stream()
     side = _SIDE.get(main.device)
@@ -333,7 +354,7 @@ def critic_phase(netG, netD, batches, opt_d, param, device, dp, overlap=True):
         main.wait_event(ev)
         ae.record_stream(main)
         be.record_stream(main)
-        out = critic_update(netD, ae, be, opt_d, device, dp)
+        out = critic_update(netD, ae, be, opt_d, device, dp, want_scalars=i == len(batches) - 1)
     side.wait_stream(main)                       # nothing of this phase outlives it on the side stream
     main.wait_stream(side)
     return out
@@ -349,7 +370,12 @@ def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, 
     in_b, din_b, dout_b, n_b, bs, sl = batch_b
     ae = get_user_embed(netG, in_a, "a", param, device, 0)
     be = get_user_embed(netG, in_b, "b", param, device, 0)
-    g_dis_loss = mean(netD(ae)) - mean(netD(be))
+    D = _unwrap(netD)
+    if FUSED_DISC and ops.disc_fusable(D):
+        m_real, m_fake = ops.disc_means(D, ae, be)         # both passes and their input gradients in one launch
+        g_dis_loss = m_real - m_fake
+    else:
+        g_dis_loss = mean(netD(ae)) - mean(netD(be))
     dp.scale_mean(g_dis_loss).backward()
     mask_a = get_pad_mask(dout_a, param.pad_index, device)
     loss_recon_a = loss_ae(netG, in_a, din_a, dout_a, n_a, True, bs, sl, param, mask_a, device, domain="a")
