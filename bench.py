@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
 MFMA_KERNELS = ("gemm", "attn", "post_attn")           # kernels priced against the MFMA peak; the rest against HBM
-PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+PMC_FILES = [os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")]
 
 
 def pmc_traffic(kernel):
@@ -40,13 +40,16 @@ def pmc_traffic(kernel):
     by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the gfx950
     correction of MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests as 64 B, so read bytes = 2 x FETCH_SIZE).
     None when no counter profile of this kernel has been committed."""
-    try:
-        with open(PMC_FILE) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
-        return None
-    e = t.get("kernels", {}).get(kernel)
-    return None if e is None else e.get("hbm_bytes_per_launch")
+    for fn in PMC_FILES:                    # the current round's counter passes first
+        try:
+            with open(fn) as f:
+                t = json.load(f)
+        except (OSError, ValueError):
+            continue
+        e = t.get("kernels", {}).get(kernel)
+        if e is not None:
+            return e.get("hbm_bytes_per_launch")
+    return None
 
 
 def parse():
@@ -70,7 +73,9 @@ def parse():
                     help="transformer dropout (reference config_auto4rec.py:225: 0.5); the discriminator's 0.2 is active too")
     ap.add_argument("--batches_per_domain", type=int, default=2, help="distinct synthetic batches cycled")
     ap.add_argument("--no_cpu_baseline", action="store_true")
-    ap.add_argument("--cpu_batch", type=int, default=8)
+    ap.add_argument("--cpu_batch", type=int, default=64, help="users per domain per draw of the CPU-oracle sample (SURVEY 8d: 64..128)")
+    ap.add_argument("--min_len", type=int, default=5,
+                    help="synthetic user lengths are U{min_len..L+20}; 5 (default) pads 44 %% of the positions, >= L-1 none")
     ap.add_argument("--no_roofline", action="store_true")
     return ap.parse_args()
 
@@ -102,12 +107,12 @@ def build(args, device, rank, world):
         if args.device_sampler:
             # loaders INCLUDED in the step: batches assembled and fresh negatives drawn on the GPU for every draw
             from recguru_amd import sampler
-            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed)
+            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed, min_len=args.min_len)
             dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
             loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
                                                 args.seq_len * args.n_negs, seed=seed, shuffle=False))
         else:
-            dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed)
+            dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed, min_len=args.min_len)
             loaders.append(synthetic.TensorLoader(dom, args.batch, device))
     return param, G, D, opt_g, opt_d, loaders
 
@@ -130,13 +135,10 @@ def make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args):
 
 
 def cpu_baseline(args):
-    """The CPU oracle on the same workload shape with a small batch (memory: SURVEY.md 6)."""
-    import numpy as np
+    """The CPU oracle on the same workload shape with a bounded batch (memory: SURVEY.md 6; 8d asks for B in {64, 128}
+    and both dropout settings): one AE+GAN iteration with the reference's dropout (the `value`) and one with dropout 0."""
     from oracle import recguru_oracle as O
     from recguru_amd import synthetic
-    torch.manual_seed(0)
-    O.DROPOUT = args.dropout
-    O.DROPOUT_D = 0.2 if args.dropout > 0 else 0.0
     B, L, d, H, N, V, k = args.cpu_batch, args.seq_len, args.d_model, args.n_head, args.n_blocks, args.items, args.n_negs
     cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
     P = H * 32
@@ -144,44 +146,59 @@ def cpu_baseline(args):
     def lin(o, i):
         return torch.randn(o, i) / i ** 0.5
 
-    pG = {}
-    for dom in "ab":
-        pG["src_emb_%s.weight" % dom] = torch.randn(V + 2, d)
-        pG["pos_emb_%s.pe" % dom] = O.positional_table(5000, d).unsqueeze(0)
+    def build():
+        torch.manual_seed(0)
+        pG = {}
+        for dom in "ab":
+            pG["src_emb_%s.weight" % dom] = torch.randn(V + 2, d)
+            pG["pos_emb_%s.pe" % dom] = O.positional_table(5000, d).unsqueeze(0)
 
-    def mha(pre):
-        for nm, (o, i) in (("WQ", (P, d)), ("WK", (P, d)), ("WV", (P, d)), ("linear", (d, P))):
-            pG[pre + nm + ".weight"], pG[pre + nm + ".bias"] = lin(o, i), torch.zeros(o)
-        pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+        def mha(pre):
+            for nm, (o, i) in (("WQ", (P, d)), ("WK", (P, d)), ("WV", (P, d)), ("linear", (d, P))):
+                pG[pre + nm + ".weight"], pG[pre + nm + ".bias"] = lin(o, i), torch.zeros(o)
+            pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
 
-    def ffn(pre):
-        pG[pre + "l1.weight"], pG[pre + "l1.bias"] = lin(512, d), torch.zeros(512)
-        pG[pre + "l2.weight"], pG[pre + "l2.bias"] = lin(d, 512), torch.zeros(d)
-        pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
-    for i in range(N):
-        mha("encoder.layers.%d.enc_self_attn." % i)
-        ffn("encoder.layers.%d.pos_ffn." % i)
-        for dec in ("decoder_a.", "decoder_b."):
-            mha("%slayers.%d.dec_self_attn." % (dec, i))
-            mha("%slayers.%d.dec_enc_attn." % (dec, i))
-            ffn("%slayers.%d.pos_ffn." % (dec, i))
-    pD = {}
-    for idx, (o, i) in zip((0, 3, 6, 9), ((5 * d, d), (10 * d, 5 * d), (5 * d, 10 * d), (1, 5 * d))):
-        pD["main.%d.weight" % idx], pD["main.%d.bias" % idx] = lin(o, i), torch.zeros(o)
-    pG, pD = O.leafify(pG), O.leafify(pD)
-    opt_g = O.Adam({k_: v for k_, v in pG.items() if v.requires_grad}, 1e-4, (0.5, 0.9))
-    opt_d = O.Adam(pD, 1e-4, (0.5, 0.9))
-    doms = [synthetic.make_domain(B, V, L, k, seed=s) for s in (1, 2)]
+        def ffn(pre):
+            pG[pre + "l1.weight"], pG[pre + "l1.bias"] = lin(512, d), torch.zeros(512)
+            pG[pre + "l2.weight"], pG[pre + "l2.bias"] = lin(d, 512), torch.zeros(d)
+            pG[pre + "layer_norm.weight"], pG[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+        for i in range(N):
+            mha("encoder.layers.%d.enc_self_attn." % i)
+            ffn("encoder.layers.%d.pos_ffn." % i)
+            for dec in ("decoder_a.", "decoder_b."):
+                mha("%slayers.%d.dec_self_attn." % (dec, i))
+                mha("%slayers.%d.dec_enc_attn." % (dec, i))
+                ffn("%slayers.%d.pos_ffn." % (dec, i))
+        pD = {}
+        for idx, (o, i) in zip((0, 3, 6, 9), ((5 * d, d), (10 * d, 5 * d), (5 * d, 10 * d), (1, 5 * d))):
+            pD["main.%d.weight" % idx], pD["main.%d.bias" % idx] = lin(o, i), torch.zeros(o)
+        return O.leafify(pG), O.leafify(pD)
+
+    doms = [synthetic.make_domain(B, V, L, k, seed=s, min_len=args.min_len) for s in (1, 2)]
     bt = [tuple(torch.as_tensor(dm[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items")) for dm in doms]
-    t0 = time.perf_counter()
-    for _ in range(O.CRITIC_ITERS):
-        O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
-    O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
-    dt = time.perf_counter() - t0
+
+    def iteration(drop, drop_d):
+        O.DROPOUT, O.DROPOUT_D = drop, drop_d
+        pG, pD = build()
+        opt_g = O.Adam({k_: v for k_, v in pG.items() if v.requires_grad}, 1e-4, (0.5, 0.9))
+        opt_d = O.Adam(pD, 1e-4, (0.5, 0.9))
+        t0 = time.perf_counter()
+        for _ in range(O.CRITIC_ITERS):
+            O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
+        O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
+        return time.perf_counter() - t0
+    try:
+        dt = iteration(args.dropout, 0.2 if args.dropout > 0 else 0.0)
+        # bounded: the second (dropout-free) iteration is skipped when the first already took more than a minute
+        dt0 = dt if args.dropout == 0 else (iteration(0.0, 0.0) if dt < 60.0 else None)
+    finally:
+        O.DROPOUT, O.DROPOUT_D = 0.0, 0.0
     return {"value": 12 * B / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "1 AE+GAN iteration (5 critic + 1 generator), B=%d users/domain/draw, L=%d d=%d H=%d N=%d "
-                      "V=%d k=%d, fp32, dropout %g (D: %g), torch %s CPU kernels, %.1f s"
-                      % (B, L, d, H, N, V, k, O.DROPOUT, O.DROPOUT_D, torch.__version__, dt)}
+            "value_dropout0": (12 * B / dt0) if dt0 else None,
+            "sample": "1 AE+GAN iteration (5 critic + 1 generator), B=%d users/domain/draw, L=%d d=%d H=%d N=%d V=%d k=%d, fp32, "
+                      "torch %s CPU kernels: dropout %g (D: %g) %.1f s = `value`; dropout 0 %s s = `value_dropout0`"
+                      % (B, L, d, H, N, V, k, torch.__version__, args.dropout, 0.2 if args.dropout > 0 else 0.0, dt,
+                         ("%.1f" % dt0) if dt0 else "skipped")}
 
 
 def main():
@@ -243,6 +260,7 @@ def main():
             against the ridge point peak_flops / peak_bandwidth); both achieved rates are reported."""
             sec = a["ms"] * 1e-3
             tf, gbs = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
+            tf_x, gbs_x = a["flops_exec"] / sec / 1e12, a["bytes_exec"] / sec / 1e9
             mfma = name.startswith(MFMA_KERNELS) and a["flops"] / (peak_tf * 1e12) >= a["bytes"] / (HBM_PEAK_GBS * 1e9)
             if mfma:
                 r = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
@@ -250,6 +268,12 @@ def main():
             else:
                 r = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(gbs / HBM_PEAK_GBS, 4)}
+            # `achieved` / `frac` price the NOMINAL work of a launch (every row, as the reference computes it); the
+            # *_executed fields price only the 16-row tiles the kernel really processed (padded tiles are skipped)
+            r.update({"frac_executed": round((tf_x / peak_tf) if mfma else (gbs_x / HBM_PEAK_GBS), 4),
+                      "tflops_executed": round(tf_x, 2), "hbm_gbs_executed": round(gbs_x, 1),
+                      "executed_share_of_nominal_work": round(a["flops_exec"] / a["flops"], 3) if a["flops"] else
+                      (round(a["bytes_exec"] / a["bytes"], 3) if a["bytes"] else 1.0)})
             r.update({"tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "launches_per_step": a["launches"],
                       "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
                       "share_of_kernel_time": round(a["ms"] / total_ms, 3)})
@@ -281,6 +305,7 @@ def main():
                                    "two %d-item domains" % args.items,
                        "per_gpu_batch": B, "seq_len": args.seq_len, "d_model": args.d_model, "n_head": args.n_head,
                        "n_blocks": args.n_blocks, "d_ff": 512, "n_negs": args.n_negs, "dropout": args.dropout,
+                       "user_lengths": "U{%d..%d}" % (min(args.min_len, args.seq_len + 20), args.seq_len + 20),
                        "discriminator_dropout": 0.2 if args.dropout > 0 else 0.0,
                        "sequences_per_step": 12 * B * world, "generator_step_sequences_per_sec":
                            round(2 * B * world * args.steps / dt, 1),

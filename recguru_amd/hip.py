@@ -637,17 +637,38 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
 # ------------------------------------------------------------------------------------------------
 class Profiler(object):
     def __init__(self):
-        self.records = []      # (kernel name, flops, bytes, start event, end event)
+        self.records = []      # (kernel name, flops, bytes, start event, end event, row mask / live list or None)
+
+    @staticmethod
+    def _live_frac(ref, cache):
+        """Fraction of 16-row tiles a list-driven / mask-driven launch actually processed (1.0 without a mask)."""
+        if ref is None:
+            return 1.0
+        key = (ref.data_ptr(), ref.numel(), ref.dtype)
+        if key not in cache:
+            if ref.dtype == torch.int32:                       # live-tile list: [count, ids..., flags...]
+                nt = (ref.numel() - 1) // 2
+                cache[key] = float(ref[0]) / max(nt, 1)
+            else:                                              # f32 row mask
+                m = ref.reshape(-1)
+                pad = (-m.numel()) % 16
+                if pad:
+                    m = torch.cat([m, m.new_zeros(pad)])
+                cache[key] = float((m.view(-1, 16).abs().amax(1) > 0).float().mean())
+        return cache[key]
 
     def summary(self):
         torch.cuda.synchronize()
-        agg = {}
-        for name, fl, by, e0, e1 in self.records:
-            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        agg, cache = {}, {}
+        for name, fl, by, e0, e1, ref in self.records:
+            a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "flops_exec": 0.0, "bytes_exec": 0.0})
+            lf = self._live_frac(ref, cache)
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
             a["flops"] += fl
             a["bytes"] += by
+            a["flops_exec"] += fl * lf
+            a["bytes_exec"] += by * lf
         return agg
 
 
@@ -744,7 +765,17 @@ def start_profile():
             e1.record()
             if _PLAN_NAME is not None:      # GEMMs: the kernel the library actually picked
                 kname = _PLAN_NAME
-            _PROF.records.append((kname, fl, by, e0, e1))
+            # the row mask / live-tile list that lets this launch skip padded 16-row tiles (executed-work accounting)
+            ref = k.get("live")
+            if ref is None:
+                ref = k.get("rowmask")
+            if ref is None and name == "post_attn_fwd" and len(a) > 12:
+                ref = a[12]
+                if ref is not None and (a[0].shape[0] < COMPACT_MIN_ROWS or not k.get("compact", True)):
+                    ref = None
+            if ref is None and name == "ln_bwd" and len(a) > 5 and k.get("live") is None:
+                ref = None                  # without a list ln_bwd walks every row
+            _PROF.records.append((kname, fl, by, e0, e1, ref))
             return out
         return timed
     for name in list(_WORK) + _PLAIN:

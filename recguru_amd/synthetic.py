@@ -28,12 +28,13 @@ def pad_sequences(seqs, L, eos):
     return enc, dec_in, dec_out
 
 
-def make_users(n_users, V, L, seed, zipf_s=1.0):
-    """Raw users: (seqs [list of int64 arrays], val [n], test [n]) -- Zipf popularity, lengths U{5..L+20}."""
+def make_users(n_users, V, L, seed, zipf_s=1.0, min_len=5):
+    """Raw users: (seqs [list of int64 arrays], val [n], test [n]) -- Zipf popularity, lengths U{min_len..L+20}
+    (min_len = 5: 44 % of the L positions are padding; min_len >= L - 1: full-length users, no padding at all)."""
     rng = np.random.default_rng(seed)
     pop = 1.0 / np.arange(1, V + 1, dtype=np.float64) ** zipf_s
     cdf = np.cumsum(pop / pop.sum())
-    lens = rng.integers(5, L + 21, size=n_users)
+    lens = rng.integers(min(min_len, L + 20), L + 21, size=n_users)
     seqs, val, test = [], np.zeros(n_users, np.int64), np.zeros(n_users, np.int64)
     for i in range(n_users):
         items = np.searchsorted(cdf, rng.random(lens[i] + 2)) + 1
@@ -45,9 +46,9 @@ def make_users(n_users, V, L, seed, zipf_s=1.0):
     return seqs, val, test, rng
 
 
-def make_domain(n_users, V, L, k, seed, zipf_s=1.0):
+def make_domain(n_users, V, L, k, seed, zipf_s=1.0, min_len=5):
     """Returns dict of int64 arrays: enc_in/dec_in/dec_out [n,L], n_items [n,L*k], val/test [n]."""
-    seqs, val, test, rng = make_users(n_users, V, L, seed, zipf_s)
+    seqs, val, test, rng = make_users(n_users, V, L, seed, zipf_s, min_len)
     enc, dec_in, dec_out = pad_sequences(seqs, L, V + 1)
     neg = rng.integers(1, V + 1, size=(n_users, L * k))
     for i in range(n_users):                                # rejection against the user's own items

@@ -1,0 +1,124 @@
+"""BASELINE.json configs[4] ("large-catalog stress": 2M items per domain, seq_len=400, hidden=256, k=1024) on the GPU.
+
+Parity tier: L = 400 is beyond the exact-f32 attention backward (L <= 256) and the f32 forward's LDS budget, so this
+configuration has NO f32 parity tier; what is checked is
+  * the bf16 tier against the CPU oracle (float32) at the full width / length / catalogue / negative count with a batch the
+    oracle finishes in seconds: user embeddings and reconstruction loss, within the bf16 bounds measured on an MI355X;
+  * size-independent properties at a larger batch: finite loss and gradients, exact zeros on padded rows, user-permutation
+    equivariance of the embeddings, gradients only on the table rows that were touched;
+  * the gather-dot-loss kernels at k = 1024 against plain torch f32.
+"""
+import numpy as np
+import pytest
+import torch
+
+from parity_util import make_args, max_err
+
+pytestmark = pytest.mark.gpu
+C5 = dict(d=256, H=8, L=400, N=3, V=2_000_000, k=1024)
+
+
+@pytest.fixture(autouse=True)
+def _restore_tier():
+    from recguru_amd import ops
+    yield
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+def _setup(B, device, seed=7):
+    from recguru_amd import config, models, synthetic
+    c = C5
+    param = config.get_param(make_args(c["d"], c["H"], c["k"], c["L"], c["V"], c["V"], c["N"], B), make_dirs=False)
+    torch.manual_seed(seed)
+    G = models.MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32)
+    with torch.no_grad():                                   # N(0, 1) tables make |logit| ~ 16: scale them like a trained model's
+        G.src_emb_a.weight.mul_(0.25)
+        G.src_emb_b.weight.mul_(0.25)
+    dom = synthetic.make_domain(B, c["V"], c["L"], c["k"], seed=seed)
+    bt = tuple(torch.as_tensor(dom[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+    return param, G, bt
+
+
+def test_config5_bf16_vs_oracle(capsys):
+    from oracle import recguru_oracle as O
+    from recguru_amd import ops, training as T
+    c = C5
+    B = 4
+    param, G, bt = _setup(B, "cpu")
+    sd = {k: v.detach().clone() for k, v in G.state_dict().items()}
+    cfg = O.Cfg(c["d"], c["H"], c["N"], c["L"], c["k"], c["V"] + 1, c["V"] + 1)
+    with torch.no_grad():
+        ue_ref = O.get_user_embed(sd, cfg, bt[0], "a").numpy()
+        la_ref = float(O.loss_ae_cross(sd, cfg, *bt, domain="a", collapsed=True))
+    ops.set_compute_dtype(torch.bfloat16)
+    G = G.cuda()
+    cb = tuple(t.cuda() for t in bt)
+    with torch.no_grad():
+        ue = T.get_user_embed(G, cb[0], "a", param, "cuda", 0).float().cpu().numpy()
+    mask = T.get_pad_mask(cb[2], 0, "cuda")
+    la = T.loss_ae(G, *cb, True, B, c["L"], param, mask, "cuda", domain="a")
+    la.backward()
+    ue_err, l_rel = max_err(ue, ue_ref)[1], abs(float(la) - la_ref) / la_ref
+    with capsys.disabled():
+        print("\n[config-5 shape, bf16 tier] user_embed err rel-to-max %.3g | loss_ae %.5f vs %.5f (rel %.3g)"
+              % (ue_err, float(la), la_ref, l_rel))
+    assert ue_err <= 0.03 and l_rel <= 2e-3            # measured 0.0096 / 3.6e-4 (<= 2x ... see DESIGN.md section 2)
+    g = G.src_emb_a.weight.grad
+    assert g is not None and torch.isfinite(g).all()
+    touched = torch.zeros(c["V"] + 2, dtype=torch.bool, device="cuda")
+    for t in (cb[0], cb[1], cb[2], cb[3]):
+        touched[t.reshape(-1)] = True
+    assert float(g[~touched].abs().max()) == 0.0        # dense gradient, but only gathered rows are non-zero
+
+
+def test_config5_properties():
+    from recguru_amd import ops, training as T
+    c = C5
+    B = 64
+    ops.set_compute_dtype(torch.bfloat16)
+    param, G, bt = _setup(B, "cuda", seed=9)
+    G = G.cuda()
+    cb = tuple(t.cuda() for t in bt)
+    with torch.no_grad():
+        full = G.get_seq_embed(cb[0], "a", (cb[0] != 0).float())
+        ue = T.get_user_embed(G, cb[0], "a", param, "cuda", 0)
+        perm = torch.randperm(B, device="cuda")
+        ue_p = T.get_user_embed(G, cb[0][perm], "a", param, "cuda", 0)
+    # the last-position-only path == row L-1 of the full encoder (different kernels: bf16 rounding apart)
+    s_ = float(full[:, -1, :].float().abs().max())
+    assert float((ue.float() - full[:, -1, :].float()).abs().max()) <= 0.03 * s_
+    pad = (cb[0] == 0)
+    assert float(full[pad].abs().max()) == 0.0                                   # `* pad_mask` after every layer
+    torch.testing.assert_close(ue_p.float(), ue[perm].float(), rtol=0, atol=0)   # users are independent: exact
+    mask = T.get_pad_mask(cb[2], 0, "cuda")
+    la = T.loss_ae(G, *cb, True, B, c["L"], param, mask, "cuda", domain="a")
+    la.backward()
+    assert np.isfinite(float(la)) and 0.5 * np.log(c["k"] + 1) < float(la) < 3 * np.log(c["k"] + 1)
+    for k_, p in G.named_parameters():
+        if p.grad is not None:
+            assert torch.isfinite(p.grad).all(), k_
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("d", [128, 256])
+def test_item_loss_k1024(dt, d):
+    """Sampled-softmax kernels at config-5's negative count (k = 1024): forward, dh and the table gradient vs torch f32."""
+    from recguru_amd import hip
+    ntok, V, k = 96, 5000, 1024
+    g0 = torch.Generator().manual_seed(d)
+    h = (torch.randn(ntok, d, generator=g0) * 0.3).to(dt).cuda()
+    table = (torch.randn(V + 2, d, generator=g0) * 0.5).to(dt).cuda()
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.3).float().cuda()
+    hf, tf = h.float().requires_grad_(True), table.float().requires_grad_(True)
+    lg = torch.cat([(hf * tf[pos]).sum(1, keepdim=True), torch.einsum("td,tkd->tk", hf, tf[neg])], 1)
+    ref = ((torch.logsumexp(lg, 1) - lg[:, 0]) * mask).sum() / mask.sum()
+    ref.backward()
+    sums, aux = hip.item_loss_fwd(h, table, pos, neg.view(-1), mask, k, hip.LOSS_SAMPLED_CE)
+    torch.testing.assert_close(sums[0] / sums[1], ref.detach(), rtol=1e-5 if dt == torch.float32 else 2e-2, atol=1e-5)
+    dE = torch.zeros(V + 2, d, device="cuda")
+    dh = hip.item_loss_bwd(h, table, pos, neg.view(-1), mask, k, hip.LOSS_SAMPLED_CE, aux, sums, torch.ones(1, device="cuda"), dE)
+    t = dict(rtol=1e-4, atol=1e-6) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-3)
+    torch.testing.assert_close(dh.float(), hf.grad, **t)
+    torch.testing.assert_close(dE, tf.grad, **t)
