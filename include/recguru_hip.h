@@ -62,11 +62,14 @@ typedef struct {
                                  dropout that precedes GELU (transformer.py:182-184), aux = dropped h1 */
   float drop_p; unsigned long long drop_seed;   /* RELU: C = dropout(relu(.)), tools/utils.py:43-44 */
   const int* live16;          /* optional list of live 16-row tiles (rg_live_tiles): rows of the other tiles are not read and
-                                 their rows of C are written as zeros; honoured by the weight-stationary kernel, ignored
-                                 (every row computed) by the generic one */
-  int skip_dead_fill;         /* with live16: leave the rows of C of the padded tiles UNWRITTEN -- for outputs whose every
-                                 consumer is list- or rowmask-driven (the list-driven GEMMs never read them; rg_attn_bwd takes
-                                 dctx rows with rowmask == 0 as zero) */
+                                 their rows of C are written as zeros; honoured by the weight-stationary kernel, an error
+                                 (RG_ERR_UNSUPPORTED) where only the generic one takes the problem */
+  int skip_dead_fill;         /* with live16: 0 = rows of C of the padded tiles are written as zeros; 1 = left UNWRITTEN -- for
+                                 outputs whose every consumer is list- or rowmask-driven (the list-driven GEMMs never read
+                                 them; rg_attn_bwd takes dctx rows with rowmask == 0 as zero); 2 = written as the BIAS row
+                                 (epilogue NONE) -- exact when the caller guarantees that those rows of A are all zero: the
+                                 padded positions of a layer input (transformer.py:594 / :539 multiply every layer output by
+                                 the pad mask, and the embedding by it, :105), whose Q / K / V rows are the biases */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 

@@ -158,10 +158,13 @@ class EncoderM(nn.Module):
         """last_only=True returns enc_outputs[:, -1, :] ([B, d]) without computing the other rows of
         the last layer (identical values and gradients)."""
         n = len(self.layers)
-        for i, layer in enumerate(self.layers):
-            if last_only and i == n - 1:
-                return layer.forward_last(x, key_ids, pad_value, pad_mask)
-            x = layer(x, key_ids, pad_value, pad_mask)
+        # x comes from the embedding stage `(E[ids] + pe) * pad_mask` (transformer.py:105) and every layer output is
+        # multiplied by the same pad_mask (:594): rows at padded positions are exactly zero (ops.masked_input)
+        with ops.masked_input():
+            for i, layer in enumerate(self.layers):
+                if last_only and i == n - 1:
+                    return layer.forward_last(x, key_ids, pad_value, pad_mask)
+                x = layer(x, key_ids, pad_value, pad_mask)
         return x[:, -1, :] if last_only else x
 
 
@@ -180,6 +183,7 @@ class DecoderM(nn.Module):
     def forward(self, x, u, dec_ids, enc_ids, pad_m):
         """enc_ids: the encoder input ids; their (== 0) positions are the masked keys of the
         decoder-encoder attention (AutoEnc4Rec_cross.py:134) -- only needed when dropout is active."""
-        for layer in self.layers:
-            x = layer(x, u, dec_ids, enc_ids, pad_m)
+        with ops.masked_input():            # same contract as EncoderM: x rows are zero wherever pad_m is (transformer.py:539)
+            for layer in self.layers:
+                x = layer(x, u, dec_ids, enc_ids, pad_m)
         return x

@@ -198,18 +198,29 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
   }
-  if (a.live16 && !a.skip_dead_fill) {                    // rows of the padded tiles: C = 0
-    const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
-    Frag<T> z;
-    frag_zero(z);
+  if (a.live16 && a.skip_dead_fill != 1) {                // rows of the padded tiles: C = 0, or C = bias (skip_dead_fill == 2:
+    const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];     // the caller guarantees that those rows of A are zero)
+    Frag<T> z[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      if (a.skip_dead_fill == 2 && a.epilogue == RG_EPI_NONE) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = bs[cb * 128 + (tid & 15) * 8 + j];
+        store8(reinterpret_cast<T*>(&z[cb]), v);
+      } else {
+        frag_zero(z[cb]);
+      }
+    }
     for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (j + i < ndead) {
           const int m = a.live16[nrt - (j + i)] * 16 + (tid >> 4);
           if (m < a.M) {
+#pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              *reinterpret_cast<Frag<T>*>(C + (size_t)m * a.ldc + cb * 128 + (tid & 15) * 8) = z;
+              *reinterpret_cast<Frag<T>*>(C + (size_t)m * a.ldc + cb * 128 + (tid & 15) * 8) = z[cb];
           }
         }
       }

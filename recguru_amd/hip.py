@@ -137,14 +137,15 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
             gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
             epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N].  live: list of live 16-row tiles
-    (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill
-    (only for outputs whose consumers are all list- or rowmask-driven)."""
+    (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill=True
+    (only for outputs whose consumers are all list- or rowmask-driven), or come out as the bias row with
+    skip_dead_fill=2 (exact when those rows of A are zero)."""
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.dtype == A.dtype
     if out is None:
         out = torch.empty(M, N, device=A.device, dtype=torch.float32 if out_f32 else A.dtype)
-        if POISON_UNWRITTEN and live is not None and skip_dead_fill:
+        if POISON_UNWRITTEN and live is not None and skip_dead_fill == 1:
             out.fill_(float("nan"))
     if M == 0:
         return out
@@ -152,7 +153,7 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed, _p(live), 1 if (live is not None and skip_dead_fill) else 0)
+                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0)
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")

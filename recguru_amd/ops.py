@@ -318,6 +318,21 @@ def _inv_keep(p):
 # K1: embedding + positional encoding + mask (+ dropout)
 # ------------------------------------------------------------------------------------------------
 _GRAD_MODE = True
+_X_MASKED = False      # set by masked_input(): the layer functions' input rows are zero wherever their row mask is
+
+
+class masked_input(object):
+    """Context of the model stacks (blocks.EncoderM / DecoderM): inside it every layer input x satisfies
+    x[row] == 0 wherever rowmask[row] == 0 (the embedding and each layer output were multiplied by that mask), which
+    lets the Q / K / V projections fill padded tiles with the bias row instead of computing them."""
+
+    def __enter__(self):
+        global _X_MASKED
+        self.prev, _X_MASKED = _X_MASKED, True
+
+    def __exit__(self, *a):
+        global _X_MASKED
+        _X_MASKED = self.prev
 
 
 class _Fn(torch.autograd.Function):
@@ -375,25 +390,39 @@ def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
 
 
+def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
+    """Live-tile list for a projection whose input rows are ZERO wherever rowmask is (x_masked: the caller guarantees it
+    -- the model stacks do: the embedding and every layer output are multiplied by this very mask, transformer.py:105,
+    :594, :539): those rows of the output are the bias, no read, no MFMA (rg_gemm_nt skip_dead_fill = 2)."""
+    if not x_masked or rowmask is None or _COMPUTE != torch.bfloat16 or M < max(hip.COMPACT_MIN_ROWS, 4096):
+        return None
+    if K != 128 or N not in (128, 256, 384, 512):          # the shapes the list-driven (weight-stationary) GEMM takes
+        return None
+    return hip.live_tiles(rowmask, M)
+
+
 def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0,
-                  rowmask=None):
+                  rowmask=None, x_masked=False):
     """rowmask [B*L]: the pad mask the layer output is multiplied by -- query tiles made of padded positions only are
     skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = bias_cat((bq, bk, bv))
-    # every row is projected: a padded position is still a KEY unless its id equals pad_value (the reference masks
-    # keys by pad_value and rows by id != 0 -- two different sets), so its K / V rows are real operands
-    qkv = hip.gemm_nt(x2, wqkv, bqkv)
+    # every row gets its Q / K / V: a padded position is still a KEY unless its id equals pad_value (the reference masks
+    # keys by pad_value and rows by id != 0 -- two different sets), so its K / V rows are real operands.  Inside the
+    # model stacks such a position's input row is exactly zero, so its projection IS the bias row: 16-row tiles made of
+    # padded positions only are filled with it instead of being read and multiplied (44 % of the tiles at the bench shape)
+    live = _zero_rows_live(rowmask, x2.shape[0], x_masked, x2.shape[1], wqkv.shape[0])
+    qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=2)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
                              rowmask=rowmask)
     return qkv, ctx_, lse
 
 
 def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be, need_grad,
-                    drop_p=0.0, seed=0, rowmask=None):
+                    drop_p=0.0, seed=0, rowmask=None, x_masked=False):
     """MultiHeadAttention.forward (transformer.py:151-161), unfused (any width): returns y and what backward needs."""
     qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p, seed,
-                                   rowmask)
+                                   rowmask, x_masked)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
     y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
                     gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
@@ -480,9 +509,10 @@ class EncoderLayerFn(_Fn):
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
+        xm = _X_MASKED
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
-                                           drop_p, seeds[0], rowmask)
+                                           drop_p, seeds[0], rowmask, xm)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
@@ -491,7 +521,7 @@ class EncoderLayerFn(_Fn):
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
             y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
-                                    drop_p, seeds[0], rowmask)
+                                    drop_p, seeds[0], rowmask, xm)
             out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
@@ -529,7 +559,9 @@ class EncoderLastLayerFn(_Fn):
         rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
         x_last = x[:, -1, :].contiguous()
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
-        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bias_cat((bk, bv)))
+        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bias_cat((bk, bv)),
+                         live=_zero_rows_live(rowmask.reshape(-1).contiguous(), B * L, _X_MASKED, d, 2 * Wk.shape[0]),
+                         skip_dead_fill=2)
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
         c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0])
         if _fusable(x_last, Wo, W1):
@@ -608,7 +640,7 @@ class DecoderLayerFn(_Fn):
             cross_kw = dict(cross=(o, cg.detach(), cbe.detach()))
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
-                                           rowmask)
+                                           rowmask, _X_MASKED)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
                                         rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
@@ -618,7 +650,7 @@ class DecoderLayerFn(_Fn):
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
             y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
-                                     drop_p, seeds[0], rowmask)
+                                     drop_p, seeds[0], rowmask, _X_MASKED)
             if drop_p > 0:          # per-row cross-attention output under attention-map dropout
                 o_rows = hip.cross_rows(s_cross, oh, cbo.detach(), L)
                 y2, rstd_c = hip.bcast_add_ln(y1, o_rows, cg.detach(), cbe.detach(), 1, LN_EPS)

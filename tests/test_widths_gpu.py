@@ -87,3 +87,39 @@ def test_live_tile_lists_end_to_end(dropout):
     for kk, g in res["plain"][1].items():
         scale = float(g.abs().max())
         torch.testing.assert_close(res["lists"][1][kk], g, rtol=1e-3, atol=1e-6 + 1e-4 * scale, msg=kk)
+
+
+def test_qkv_bias_fill_for_padded_tiles_is_exact():
+    """Inside the model stacks a padded position's layer input is exactly zero, so its Q / K / V rows are the bias rows:
+    the projection with the live-tile list (padded tiles filled with the bias, not read, not multiplied) must equal the
+    projection of every row BIT FOR BIT -- user embeddings, reconstruction loss and gradients included."""
+    import numpy as np
+    from recguru_amd import config, hip, models, ops, synthetic, training as T
+    from parity_util import make_args
+    ops.set_compute_dtype(torch.bfloat16)
+    B, L, d, H, N, V, k = 96, 200, 128, 4, 3, 5000, 6
+    param = config.get_param(make_args(d, H, k, L, V, V, N, B), make_dirs=False)
+    torch.manual_seed(3)
+    G = models.MyAuto4Rec_c("cuda", param, wf=None, enc_share=True, dec_rec=False).to(torch.float32).cuda()
+    dom = synthetic.make_domain(B, V, L, k, seed=5)
+    bt = tuple(torch.as_tensor(dom[n]).cuda() for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+    res = []
+    for fill in (True, False):
+        real = ops._zero_rows_live
+        if not fill:
+            ops._zero_rows_live = lambda *a, **kw: None
+        try:
+            G.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                ue = T.get_user_embed(G, bt[0], "a", param, "cuda", 0).float()
+            mask = T.get_pad_mask(bt[2], 0, "cuda")
+            la = T.loss_ae(G, *bt, True, B, L, param, mask, "cuda", domain="a")
+            la.backward()
+            res.append((ue, float(la), {k_: p.grad.clone() for k_, p in G.named_parameters() if p.grad is not None}))
+        finally:
+            ops._zero_rows_live = real
+    assert B * L >= hip.COMPACT_MIN_ROWS                    # the list is really in use in the first pass
+    assert torch.equal(res[0][0], res[1][0])
+    np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5)         # the loss sums are f32 atomics
+    for k_, g in res[1][2].items():
+        torch.testing.assert_close(res[0][2][k_], g, rtol=1e-5, atol=1e-7, msg=k_)     # f32 atomics arrive in any order
