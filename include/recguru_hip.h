@@ -119,8 +119,15 @@ typedef struct {
   /* optional [B*L] f32: rows with rowmask == 0 are the padded positions whose layer output the caller multiplies by
    * the pad mask (transformer.py:594 / :539) -- a 16-query tile made only of such rows is skipped (ctx rows = 0). */
   const float* rowmask;
+  /* x-input form (inference only, lse == NULL): x != NULL replaces qkv by the LAYER INPUT x [B,L,d] and the kernel
+   * projects its head's Q, K, V itself with wqkv [3P,d] (rows Q | K | V, torch Linear layout, dtype) and bqkv [3P] f32 --
+   * MultiHeadAttention.forward's WQ / WK / WV (transformer.py:151-156) fused into the attention core.  x_masked: the
+   * caller guarantees that the rows of x at positions with rowmask == 0 are all zero (their K / V are then the bias rows,
+   * not computed).  rg_attn_fwd_x_supported(d, dtype, drop_p): bf16, d = 128, dropout off or 0.5. */
+  const void* x; const void* wqkv; const float* bqkv; int d; int x_masked;
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
+int rg_attn_fwd_x_supported(int d, int dtype, float drop_p);
 
 typedef struct {
   const void* qkv; const void* dctx; const void* ctx; const float* lse;
@@ -376,6 +383,7 @@ typedef struct {
   const int* live16;
   int skip_dead_saves;   /* with live16: 1 = leave the padded tiles' rows of the *_save / rstd* buffers untouched (every
                             consumer is list-driven as well), 0 = write zeros / finite placeholders there */
+  int w_packed;          /* 1: Wo, W1, W2 are fragment-packed copies (rg_cast RG_CAST_PACK: contiguous 1 KB operand fragments) */
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 /* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their

@@ -110,7 +110,12 @@ __device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, con
 // DM: dropout mode -- 0 none, 1 p == 0.5 (bit table in LDS, AND masks), 2 generic p (16-bit hash fields)
 // (256, 2): a register budget of 256 makes hipcc select the VGPR form of the MFMAs; with the default budget
 // of 512 it parks every score accumulator in AGPRs and copies it out and back (~6 v_accvgpr moves per score).
-template <typename T, int NKT, bool CAUSAL, int DM>
+// XIN: the kernel gets the layer INPUT x [B, L, d] and the fused projection weight [3P, d] + bias instead of qkv and
+// projects its head's K, V (into the LDS tiles) and Q itself -- inference passes only (nothing is saved for a backward):
+// the separate Q/K/V GEMM, its [M, 3P] write and this kernel's read of it disappear (the matrix pipe is idle > 90 % of
+// this kernel's time, so the 24 extra MFMAs per 16-key tile are free).  A Q tile goes to the wave's own rows of the ctx
+// output (which it overwrites with the context later) and comes back through the same prefetch that read qkv.
+template <typename T, int NKT, bool CAUSAL, int DM, bool XIN = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   int b, h;
   if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
-  const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  const T* __restrict__ qkv = XIN ? nullptr : reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
   const int nqt = (L + 15) / 16;
   DropCfg drop = make_drop(a.drop_p, a.seed);
@@ -158,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const int t = wave + 4 * (lg + 4 * rd), row = t * 16 + li;
     // unconditional load from a clamped address (a load under a condition makes hipcc wait for it at the join,
     // i.e. BEFORE the staging loads below are issued); without a rowmask any readable float stands in
-    const float* __restrict__ rmp = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(a.qkv);
+    const float* __restrict__ rmp = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(XIN ? a.x : a.qkv);
     const float v = rmp[a.rowmask ? (size_t)b * L + min(row, L - 1) : 0];
     rmw[rd] = (t < nqt && row < L) ? (a.rowmask ? v : 1.f) : 0.f;
   }
@@ -170,6 +175,106 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const int64_t kid = a.key_ids[(size_t)b * L + min(key, L - 1)];
     padk_r[i] = key < L && kid == a.pad_value;
   }
+  unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
+#pragma unroll
+  for (int rd = 0; rd < NRD; ++rd) {
+    const unsigned long long m = __ballot(rmw[rd] != 0.f);
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      if ((m >> (16 * g)) & 0xFFFFull) wl |= 1u << (g + 4 * rd);
+  }
+  if constexpr (XIN) {
+    // ---- project this head's K, V and Q from x: wave w owns the 16-row tiles w, w + 4, ...
+    //   D[n][row] = sum_c W[n][c] x[row][c]  (weight fragment = A operand, x fragment = B operand), so that a lane holds 4
+    //   consecutive head features of one row: 8-byte stores into the K / V tiles and into the Q rows.
+    constexpr int XD = 128, XKS = XD / 32;             // d_model of this instantiation
+    const T* __restrict__ xb = reinterpret_cast<const T*>(a.x) + (size_t)b * L * XD;
+    const T* __restrict__ Wp = reinterpret_cast<const T*>(a.wqkv);
+    T* __restrict__ qrows = reinterpret_cast<T*>(a.ctx) + (size_t)b * L * P + h * DK;
+    constexpr int NOWN = (NKT + 3) / 4;
+    // K pass, then V pass (one weight slice in registers at a time: with both, the projection phase -- not the score
+    // loop -- set the kernel's register count, 130 > 128, and a workgroup per CU was lost)
+#pragma unroll
+    for (int pv = 0; pv < 2; ++pv) {
+      Frag<T> wf[2][XKS];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks)
+          load_frag(wf[nb][ks], Wp + (size_t)((1 + pv) * P + h * DK + nb * 16 + li) * XD + ks * 32 + 8 * lg);
+      float br[2][4];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) load4f(br[nb], a.bqkv + (1 + pv) * P + h * DK + nb * 16 + 4 * lg);
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i) {
+        const int t = wave + 4 * i;
+        if (t >= NKT) break;
+        const int key = t * 16 + li;
+        f32x4 ac[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        // a tile of padded positions only has all-zero x rows when the caller says so (x_masked): K = bk, V = bv
+        const bool proj = t < nqt && (!a.x_masked || ((wl >> i) & 1u));
+        if (proj) {
+          Frag<T> xf[XKS];
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks) load_frag(xf[ks], xb + (size_t)min(key, L - 1) * XD + ks * 32 + 8 * lg);
+#pragma unroll
+          for (int ks = 0; ks < XKS; ++ks)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) mma(wf[nb][ks], xf[ks], ac[nb]);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+          float o4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = key < L ? ac[nb][r] + br[nb][r] : 0.f;
+          if (pv == 0) {
+            store4(Ks + kofs(key, 2 * nb + (lg >> 1)) + 4 * (lg & 1), o4);
+          } else if (VT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Vs[(nb * 16 + 4 * lg + r) * LDV + key] = (T)o4[r];
+          } else {
+            store4(Vs + key * LDV + nb * 16 + 4 * lg, o4);
+          }
+        }
+      }
+    }
+    {
+      Frag<T> wq[2][XKS];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks)
+          load_frag(wq[nb][ks], Wp + (size_t)(h * DK + nb * 16 + li) * XD + ks * 32 + 8 * lg);
+      float bqr[2][4];
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) load4f(bqr[nb], a.bqkv + h * DK + nb * 16 + 4 * lg);
+#pragma unroll
+      for (int i = 0; i < NOWN; ++i) {
+        const int t = wave + 4 * i;
+        if (t >= nqt || !((wl >> i) & 1u)) continue;           // Q only for the query tiles that will be processed
+        const int q = t * 16 + li;
+        f32x4 aq[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        Frag<T> xf[XKS];
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks) load_frag(xf[ks], xb + (size_t)min(q, L - 1) * XD + ks * 32 + 8 * lg);
+#pragma unroll
+        for (int ks = 0; ks < XKS; ++ks)
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) mma(wq[nb][ks], xf[ks], aq[nb]);
+        if (q < L) {
+#pragma unroll
+          for (int nb = 0; nb < 2; ++nb) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = aq[nb][r] + bqr[nb][r];
+            store4(qrows + (size_t)q * P + nb * 16 + 4 * lg, v);
+          }
+        }
+      }
+      // the Q rows are read back by this same wave (global memory, its own rows of ctx): stores complete first
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  } else {
   // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
   // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
   // per thread, not one per chunk (the rolled copy loop spent as long staging as computing)
@@ -205,6 +310,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
     }
   }
+  }
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
     const int key = i * 256 + tid;
@@ -213,20 +319,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     kbias[key] = key >= L ? -INFINITY : (pad ? MASK_BIG : 0.f);
     if (CAUSAL && key < L && !pad) atomicMin(&klo_s, key);
   }
-  unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
-#pragma unroll
-  for (int rd = 0; rd < NRD; ++rd) {
-    const unsigned long long m = __ballot(rmw[rd] != 0.f);
-#pragma unroll
-    for (int g = 0; g < 4; ++g)
-      if ((m >> (16 * g)) & 0xFFFFull) wl |= 1u << (g + 4 * rd);
-  }
-  // first live tile's Q fragment: in flight across the barrier
+  // first live tile's Q fragment: in flight across the barrier.  Q rows: columns h*32.. of qkv, or (XIN) this wave's
+  // own rows of ctx
+  const T* __restrict__ qsrc = XIN ? reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK : qkv + h * DK;
+  const int qld = XIN ? P : ld;
   Frag<T> qnext;
   frag_zero(qnext);
   if (wl) {
     const int q = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
-    if (q < L) load_frag(qnext, qkv + (size_t)q * ld + h * DK + 8 * lg);
+    if (q < L) load_frag(qnext, qsrc + (size_t)q * qld + 8 * lg);
   }
   const unsigned int wl0 = wl;
   lds_barrier();
@@ -243,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const Frag<T> qf = qnext;
     if (wl) {
       const int q2 = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
-      if (q2 < L) load_frag(qnext, qkv + (size_t)q2 * ld + h * DK + 8 * lg);
+      if (q2 < L) load_frag(qnext, qsrc + (size_t)q2 * qld + 8 * lg);
       else frag_zero(qnext);
     }
     // causal: a key tile that lies entirely in the future of every row of this query tile contributes exact zeros --
@@ -919,6 +1020,37 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   }
 }
 
+// the x-input (fused projection) form: bf16, d_model 128, dropout off or 0.5
+static int launch_fwd_x(const rg_attn_args& a, hipStream_t s) {
+  const int nkt = (a.L + 31) / 32 * 2;
+  dim3 grid(rg_head_grid(a.B, a.H)), block(256);
+  const int dm = a.drop_p <= 0.f ? 0 : 1;
+#define RG_FWDX2(N, C)                                                                                       \
+  do {                                                                                                       \
+    if (dm == 0) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, N, C, 0, true>), grid, block, 0, s, a);         \
+    else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, N, C, 1, true>), grid, block, 0, s, a);                 \
+  } while (0)
+#define RG_FWDX(N)                       \
+  do {                                   \
+    if (a.causal) RG_FWDX2(N, true);     \
+    else RG_FWDX2(N, false);             \
+  } while (0)
+  if (nkt <= 4) RG_FWDX(4);
+  else if (nkt <= 8) RG_FWDX(8);
+  else if (nkt <= 14) RG_FWDX(14);
+  else if (nkt <= 16) RG_FWDX(16);
+  else if (nkt <= 26) RG_FWDX(26);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: L > 416 not supported yet");
+#undef RG_FWDX
+#undef RG_FWDX2
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_attn_fwd_x_supported(int d, int dtype, float drop_p) {
+  return dtype == RG_BF16 && d == 128 && (drop_p <= 0.f || drop_p == 0.5f);
+}
+
 template <typename T>
 static int launch_fwd(const rg_attn_args& a, hipStream_t s) {
   const int nkt = (a.L + 31) / 32 * 2;
@@ -997,6 +1129,12 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
 extern "C" int rg_attn_fwd(const rg_attn_args* a, int dtype, void* stream) {
   if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: empty problem");
   if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: d_k must be 32");
+  if (a->x) {
+    if (!rg_attn_fwd_x_supported(a->d, dtype, a->drop_p) || !a->wqkv || !a->bqkv)
+      return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: the x-input form needs bf16, d_model 128, dropout 0 or 0.5, wqkv and bqkv");
+    if (a->lse) return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: the x-input form is inference only (lse must be NULL)");
+    return launch_fwd_x(*a, (hipStream_t)stream);
+  }
   if (dtype == RG_BF16) return launch_fwd<__bf16>(*a, (hipStream_t)stream);
   if (dtype == RG_F32) return launch_fwd<float>(*a, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: bad dtype");

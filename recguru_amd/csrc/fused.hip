@@ -48,8 +48,22 @@ template <typename T> struct Tile {
 // before the MFMAs of set s), against a [64 x 128] activation tile in LDS.
 template <typename T> struct WSet { Frag<T> f[4][2]; };
 
+// packed: W is the fragment-packed copy (rg_cast RG_CAST_PACK; ldw = its logical K): the 8 fragments of a step are 8
+// contiguous 1 KB reads.  From the row-major [out][in] layout a wave's fragment load touches 16 rows x 64 B, and the
+// vector L1 spends a tag lookup per row and 16-lane pass: with 288 such loads per 64-token tile and two workgroups per CU
+// the load pipe, not the VALU, was what the waves waited on.
 template <typename T>
-__device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, int ldw, int row0, int k0, int li, int lg) {
+__device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, int ldw, int row0, int k0, int li, int lg,
+                                          int packed = 0) {
+  if (packed) {
+    const int nks = ldw >> 5;
+    const T* base = W + (((size_t)(row0 >> 4) * nks + (k0 >> 5)) * 64 + (lg * 16 + li)) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) load_frag(w.f[ks][ct], base + ((size_t)ct * nks + ks) * 512);
+    return;
+  }
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -274,7 +288,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   int mb[4], mbn[4];
   bool have = next_group(mb);
   if (have) {
-    load_wset(wp, Wo, FD, n0, 0, li, lg);
+    load_wset(wp, Wo, FD, n0, 0, li, lg, a.w_packed);
     prefetch_rows(mb);
   }
   for (; have;) {
@@ -319,7 +333,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     f32x4 acc[2][4];
     init_acc(acc, p_bo, n0, lg);
     mma_wset<T>(acc, wp, Actx, li, lg);
-    load_wset(wp, W1, FD, n0, 0, li, lg);               // prefetch FFN chunk 0 (hidden behind LN1)
+    load_wset(wp, W1, FD, n0, 0, li, lg, a.w_packed);   // prefetch FFN chunk 0 (hidden behind LN1)
     // + residual x (from LDS), LayerNorm 1 on the registers
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -412,13 +426,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     init_acc(acc2, p_b2, n0, lg);
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
-      load_wset(wq, W2, a.dff, n0, ch * FD, li, lg);    // needed after the GELU below
+      load_wset(wq, W2, a.dff, n0, ch * FD, li, lg, a.w_packed);    // needed after the GELU below
       init_acc(acc, p_b1 + ch * FD, n0, lg);
       mma_wset<T>(acc, wp, Ay, li, lg);                 // h1 chunk = y . W1[chunk]^T + b1
       // next weight set: W1 chunk ch+1, or Wo for the next tile -- ONE unconditional load sequence from a selected
       // pointer (loads under a branch made hipcc drain vmcnt(0) at the join: the W2 fragments just issued above, i.e.
       // one exposed L2 latency per chunk; Wo is fetched needlessly after a workgroup's last tile, 32 KB once)
-      load_wset(wp, (ch + 1 < nchunk) ? W1 + (size_t)(ch + 1) * FD * FD : Wo, FD, n0, 0, li, lg);
+      load_wset(wp, (ch + 1 < nchunk) ? W1 + (size_t)(ch + 1) * FD * FD : Wo, FD, n0, 0, li, lg, a.w_packed);
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);

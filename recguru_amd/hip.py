@@ -38,7 +38,8 @@ class GemmTnArgs(ctypes.Structure):
 
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
-                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p)]
+                ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p),
+                ("x", c_p), ("wqkv", c_p), ("bqkv", c_p), ("d", c_i), ("x_masked", c_i)]
 
 
 class AttnBwdArgs(ctypes.Structure):
@@ -56,7 +57,7 @@ class PostAttnArgs(ctypes.Structure):
                 ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f),
                 ("drop_p", c_f), ("seed_h1", c_u64), ("seed_out", c_u64),
                 ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i), ("live16", c_p),
-                ("skip_dead_saves", c_i)]
+                ("skip_dead_saves", c_i), ("w_packed", c_i)]
 
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
@@ -68,7 +69,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
-           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported"]
+           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -205,9 +206,26 @@ def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask))
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, None, 0, 0)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
+
+
+def attn_fwd_x_supported(d, dtype, drop_p):
+    return bool(lib().rg_attn_fwd_x_supported(int(d), BF16 if dtype == torch.bfloat16 else F32, c_f(drop_p)))
+
+
+def attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None, x_masked=False):
+    """Inference form of the attention core with the Q / K / V projections fused in: x [B,L,d] (the layer input), wqkv
+    [3*H*32, d], bqkv [3*H*32] f32 -> ctx [B,L,H*32].  Nothing is kept for a backward."""
+    B, L, d = x.shape
+    assert x.is_contiguous() and wqkv.is_contiguous() and wqkv.shape == (3 * H * 32, d) and wqkv.dtype == x.dtype
+    assert bqkv.dtype == torch.float32 and bqkv.numel() == 3 * H * 32 and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
+    ctx = torch.empty(B, L, H * 32, device=x.device, dtype=x.dtype)
+    a = AttnArgs(None, _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), None, B, L, H, 32,
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)))
+    _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(x), _stream()), "rg_attn_fwd")
+    return ctx
 
 
 def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None):
@@ -595,7 +613,7 @@ def live_tiles(rowmask, M):
 
 
 def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,
-                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True, skip_dead_saves=False):
+                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True, skip_dead_saves=False, w_packed=False):
     """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta);
     under dropout cross = (None, gamma, beta) and cross_drop = (s [M,H], oh [B,H,d] f32, bo [d], H).
     Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
@@ -627,7 +645,7 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
                      _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
                      _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
                      _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH,
-                     _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0)
+                     _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0, 1 if w_packed else 0)
     _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 
@@ -736,7 +754,14 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
             2.0 * M * (d * P + 2 * d * dff), by)
 
 
-_WORK = {"post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
+def _work_attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, *a, **k):
+    B, L, d = x.shape
+    P3 = wqkv.shape[0]
+    return ("attn_fwd_kernel<bf16,x-input>", 4.0 * B * H * L * L * 32 + 2.0 * B * L * d * P3,
+            B * L * (d + P3 // 3) * _esize(x) + P3 * d * _esize(x))
+
+
+_WORK = {"attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]

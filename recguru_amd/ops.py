@@ -318,6 +318,10 @@ def _inv_keep(p):
 # K1: embedding + positional encoding + mask (+ dropout)
 # ------------------------------------------------------------------------------------------------
 _GRAD_MODE = True
+FUSE_QKV_INFERENCE = False  # True: no-grad layer passes project Q / K / V inside the attention kernel (rg_attn_fwd x-input
+                            # form).  Correct (tests) but SLOWER at the bench shape: 467 us against 254 + 122 us -- the per-head
+                            # projection needs 252 row-strided fragment loads per workgroup and the vector L1 / TA becomes the
+                            # bound at four workgroups per CU
 _X_MASKED = False      # set by masked_input(): the layer functions' input rows are zero wherever their row mask is
 
 
@@ -407,6 +411,12 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
     bqkv = bias_cat((bq, bk, bv))
+    if not need_grad and FUSE_QKV_INFERENCE and hip.attn_fwd_x_supported(x2.shape[1], _COMPUTE, drop_p):
+        # inference pass (the critic's encoder passes, evaluation): nothing is saved, so the projection is done INSIDE the
+        # attention kernel, head by head -- no Q/K/V GEMM launch, no [M, 3P] round trip through HBM
+        ctx_ = hip.attn_fwd_x(x2.view(B, L, -1), wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=drop_p, seed=seed,
+                              rowmask=rowmask, x_masked=x_masked and rowmask is not None)
+        return None, ctx_, None
     # every row gets its Q / K / V: a padded position is still a KEY unless its id equals pad_value (the reference masks
     # keys by pad_value and rows by id != 0 -- two different sets), so its K / V rows are real operands.  Inside the
     # model stacks such a position's input row is exactly zero, so its projection IS the bias row: 16-row tiles made of
@@ -513,9 +523,10 @@ class EncoderLayerFn(_Fn):
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
                                            drop_p, seeds[0], rowmask, xm)
-            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rowmask, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+                                        be2.detach(),
+                                        rowmask, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
                                         skip_dead_saves=_lists_everywhere(W1, B * L))
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
@@ -565,9 +576,10 @@ class EncoderLastLayerFn(_Fn):
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
         c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0])
         if _fusable(x_last, Wo, W1):
-            out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rm_last, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
+            out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+                                        be2.detach(),
+                                        rm_last, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
             if need:
                 y, rstd1, sf = sv["y"], sv["rstd1"], (sv["h1"], sv["rstd2"])
         else:
@@ -641,9 +653,10 @@ class DecoderLayerFn(_Fn):
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
                                            rowmask, _X_MASKED)
-            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1), b1.detach(), shadow(W2), b2.detach(), g2.detach(), be2.detach(),
-                                        rowmask, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+                                        be2.detach(),
+                                        rowmask, w_packed=True, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
                                         seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1, B * L), **cross_kw)
             if need:
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]

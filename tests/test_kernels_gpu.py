@@ -764,3 +764,37 @@ def test_live_tiles_list(M):
         assert torch.equal(lst[1:1 + n], want)
         dead = torch.nonzero(pad.abs().sum(1) == 0).flatten().to(torch.int32)
         assert torch.equal(lst[1 + n:1 + nt].flip(0), dead)                     # dead ids, listed from the far end
+
+
+@pytest.mark.parametrize("B,L,H,causal,drop_p", [(3, 200, 4, False, 0.0), (5, 200, 4, False, 0.5), (2, 77, 4, True, 0.0),
+                                                  (4, 400, 4, False, 0.5), (6, 50, 4, True, 0.5), (2, 16, 4, False, 0.0)])
+@pytest.mark.parametrize("x_masked", [False, True])
+def test_attn_fwd_x_equals_projection_plus_attention(B, L, H, causal, drop_p, x_masked):
+    """The x-input attention forward (Q / K / V projected inside the kernel, transformer.py:151-156 fused into :119-129)
+    against the two-kernel path it replaces on inference passes: rg_gemm_nt (projection) + rg_attn_fwd, same dropout seed."""
+    from recguru_amd import hip
+    d, P = 128, H * 32
+    g0 = torch.Generator().manual_seed(L + B)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0] = L
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0                      # left padding
+    ids[:, -1] = 51                                         # EOS = the key-pad value of the cross model (quirk Q2)
+    ids = ids.cuda()
+    rowmask = (ids != 0).float().view(-1)
+    x = (torch.randn(B, L, d, generator=g0) * 0.8).cuda()
+    if x_masked:
+        x = x * rowmask.view(B, L, 1)
+    x = x.bfloat16().contiguous()
+    w = (torch.randn(3 * P, d, generator=g0) / d ** 0.5).bfloat16().cuda()
+    bias = (torch.randn(3 * P, generator=g0) * 0.2).cuda()
+    pad_value = 0 if causal else 51
+    qkv = hip.gemm_nt(x.view(B * L, d), w, bias)
+    ref, _ = hip.attn_fwd(qkv.view(B, L, 3 * P), ids, pad_value, causal, H, need_lse=False, drop_p=drop_p, seed=77, rowmask=rowmask)
+    got = hip.attn_fwd_x(x, w, bias, ids, pad_value, causal, H, drop_p=drop_p, seed=77, rowmask=rowmask, x_masked=x_masked)
+    live = rowmask.view(B, L) != 0
+    # rows of padded-only 16-query tiles are zeros in both; Q / K / V may differ by one bf16 rounding of the accumulator
+    torch.testing.assert_close(got.float()[live], ref.float()[live], rtol=2e-2, atol=2e-2)
+    assert float((got.float() - ref.float()).abs().mean()) < 2e-3
+    assert torch.isfinite(got.float()).all()
