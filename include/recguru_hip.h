@@ -182,6 +182,11 @@ size_t rg_ln_bwd_workspace(long long M, int N);
 int rg_bcast_add_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
                     long long M, int L, int N, float eps, int dtype, void* stream);
 int rg_seq_sum(const void* x, void* out /* [B,N] dtype */, int B, int L, int N, int dtype, void* stream);
+/* out[i] = (ids[i] != pad) as f32: get_pad_mask (gan_training.py:347-350) and its inline copies (:399-401, tools/utils.py:76) */
+int rg_pad_mask(const int64_t* ids, int64_t pad, float* out, long long n, void* stream);
+/* x_last[b,:] = x[b,L-1,:] ([B,d] dtype), m_last[b] = rowmask[b*L + L-1] (may be NULL): the rows the last encoder layer
+ * evaluates (every hot-path caller reads enc_outputs[:, -1, :], AutoEnc4Rec_cross.py:122,154) */
+int rg_last_rows(const void* x, const float* rowmask, void* x_last, float* m_last, int B, int L, int d, int dtype, void* stream);
 
 /* ---- discriminator / W-GAN gradient-penalty helpers ----------------------------------------------
  * tools/utils.py:41-57 and gan_training.py:38-55 (closed-form double backward). */

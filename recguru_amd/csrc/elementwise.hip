@@ -785,6 +785,44 @@ extern "C" int rg_live_tiles(const float* rowmask, long long M, int* list, void*
   return 0;
 }
 
+// mask[i] = (ids[i] != pad) as f32: get_pad_mask (gan_training.py:347-350) and the inline copies -- one launch instead of
+// a compare and a cast
+__global__ __launch_bounds__(EW_BLOCK) void pad_mask_kernel(const int64_t* __restrict__ ids, int64_t pad, float* __restrict__ out, long long n) {
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * EW_BLOCK)
+    out[i] = ids[i] != pad ? 1.f : 0.f;
+}
+
+// x_last[b, :] = x[b, L-1, :], m_last[b] = rowmask[b * L + L - 1]: the one row per sequence the last encoder layer
+// evaluates (EncoderLastLayerFn) -- one launch instead of two strided copies
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void last_rows_kernel(const T* __restrict__ x, const float* __restrict__ rowmask, T* __restrict__ x_last,
+                                                            float* __restrict__ m_last, int B, int L, int d) {
+  const long long total = (long long)B * d;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const int b = (int)(i / d), c = (int)(i - (long long)b * d);
+    x_last[i] = x[((size_t)b * L + L - 1) * d + c];
+    if (c == 0 && m_last) m_last[b] = rowmask[(size_t)b * L + L - 1];
+  }
+}
+
+extern "C" int rg_pad_mask(const int64_t* ids, int64_t pad, float* out, long long n, void* stream) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_mask_kernel, dim3(ew_grid(n, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, ids, pad, out, n);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+extern "C" int rg_last_rows(const void* x, const float* rowmask, void* x_last, float* m_last, int B, int L, int d, int dtype,
+                            void* stream) {
+  if (B <= 0 || L <= 0 || d <= 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid((long long)B * d, EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(last_rows_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)x, rowmask, (__bf16*)x_last, m_last, B, L, d),
+             hipLaunchKernelGGL(last_rows_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)x, rowmask, (float*)x_last, m_last, B, L, d),
+             "last_rows")
+}
+
 extern "C" int rg_dropout(void* x, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream) {
   if (M <= 0 || N <= 0 || drop_p <= 0.f) return 0;
   const DropCfg drop = make_drop(drop_p, seed);

@@ -69,7 +69,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
-           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported"]
+           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -309,6 +309,24 @@ def cross_rows(s, oh, bo, L):
     out = torch.empty(M, N, device=s.device, dtype=torch.float32)
     _check(lib().rg_cross_rows(_vp(s), _vp(oh), _vp(bo), _vp(out), c_ll(M), L, H, N, _stream()), "rg_cross_rows")
     return out
+
+
+def pad_mask(ids, pad):
+    """(ids != pad).float(), same shape -- one launch."""
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    out = torch.empty(ids.shape, device=ids.device, dtype=torch.float32)
+    _check(lib().rg_pad_mask(_vp(ids), c_l(int(pad)), _vp(out), c_ll(ids.numel()), _stream()), "rg_pad_mask")
+    return out
+
+
+def last_rows(x, rowmask):
+    """x [B,L,d] contiguous, rowmask [B*L] f32 -> (x[:, -1, :] contiguous, rowmask[b*L + L-1]) in one launch."""
+    B, L, d = x.shape
+    assert x.is_contiguous() and rowmask.dtype == torch.float32 and rowmask.numel() == B * L and rowmask.is_contiguous()
+    xl = torch.empty(B, d, device=x.device, dtype=x.dtype)
+    ml = torch.empty(B, device=x.device, dtype=torch.float32)
+    _check(lib().rg_last_rows(_vp(x), _vp(rowmask), _vp(xl), _vp(ml), B, L, d, dt_of(x), _stream()), "rg_last_rows")
+    return xl, ml
 
 
 def seq_sum(x, B, L):

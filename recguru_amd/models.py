@@ -19,6 +19,9 @@ from . import blocks, ops
 
 def _f32_mask(ids, pad):
     """(1 - (ids == pad)).float() -- gan_training.py:347-350 and the inline copies."""
+    if ids.is_cuda and ids.dtype == torch.int64:
+        from . import hip
+        return hip.pad_mask(ids.contiguous(), pad)
     return (ids != pad).to(torch.float32)
 
 

@@ -565,10 +565,10 @@ class EncoderLastLayerFn(_Fn):
                 Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2):
         B, L, d = x.shape
         need = _needs_grad(ctx)
-        x2 = x.contiguous().view(B * L, d)
+        x = x.contiguous()
+        x2 = x.view(B * L, d)
         key_ids = key_ids.contiguous()
-        rm_last = rowmask.reshape(B, L)[:, -1].contiguous()
-        x_last = x[:, -1, :].contiguous()
+        x_last, rm_last = hip.last_rows(x, rowmask.reshape(-1).to(torch.float32).contiguous())
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bias_cat((bk, bv)),
                          live=_zero_rows_live(rowmask.reshape(-1).contiguous(), B * L, _X_MASKED, d, 2 * Wk.shape[0]),

@@ -86,7 +86,12 @@ def load_batch_data(data_iterator, data, device):
 
 
 def get_pad_mask(seq, pad_index, device):
-    return (seq != pad_index).reshape(-1).to(torch.float32).to(device)
+    """gan_training.py:347-350: (1 - (seq == pad)) as a flat f32 mask."""
+    seq = seq.to(device)
+    if seq.is_cuda and seq.dtype == torch.int64:
+        from . import hip
+        return hip.pad_mask(seq.contiguous(), pad_index).reshape(-1)
+    return (seq != pad_index).reshape(-1).to(torch.float32)
 
 
 def _unwrap(model):

@@ -28,7 +28,16 @@ def run_steps(z, rank, world, dp, device="cuda"):
     sh = {dom: tuple(t[rank::world].contiguous() for t in bt[dom]) for dom in "ab"}
     alpha = torch.as_tensor(z["alpha"])[rank::world].contiguous()
     # the alpha draw of calc_gradient_penalty (torch.rand on the CPU generator) is replaced by the shard of the golden one
+    real_alpha = T._gp_alpha
     T._gp_alpha = lambda bs, dev: alpha.to(dev)
+    try:
+        return _steps(T, ops, Adam, param, G, D, sh, dp, device)
+    finally:
+        T._gp_alpha = real_alpha
+
+
+def _steps(T, ops, Adam, param, G, D, sh, dp, device):
+    import numpy as np
     ndp = dp or T._NoDP()
     opt_d = Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.9))
     opt_g = Adam(G.parameters(), lr=1e-4, betas=(0.5, 0.9))

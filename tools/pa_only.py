@@ -11,7 +11,9 @@ mask = (ids != 0).float().reshape(-1).contiguous()
 dt = torch.bfloat16
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
 x, ctx = r(M, d), r(M, d)
-wo, w1, w2 = r(d, d), r(512, d), r(d, 512)
+# fragment-packed operand copies, as ops.shadow(..., pack=True) hands them to the kernel in production
+pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK)
+wo, w1, w2 = pk(r(d, d)), pk(r(512, d)), pk(r(d, 512))
 z = lambda n: torch.zeros(n, device="cuda")
 g = torch.ones(d, device="cuda")
 mode = sys.argv[1] if len(sys.argv) > 1 else "train"
@@ -19,7 +21,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 for _ in range(n):
     if mode == "train":
         hip.post_attn_fwd(ctx, x, wo, z(d), g, z(d), w1, z(512), w2, z(d), g, z(d), mask, save=True, drop_p=0.5, seed_h1=3,
-                          seed_out=4, skip_dead_saves=True)
+                          seed_out=4, skip_dead_saves=True, w_packed=True)
     else:
-        hip.post_attn_fwd(ctx, x, wo, z(d), g, z(d), w1, z(512), w2, z(d), g, z(d), mask)
+        hip.post_attn_fwd(ctx, x, wo, z(d), g, z(d), w1, z(512), w2, z(d), g, z(d), mask, w_packed=True)
 torch.cuda.synchronize()

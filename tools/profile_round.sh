@@ -1,20 +1,28 @@
 #!/bin/bash
-# Everything profiles/<round>/ holds, in one GPU-box call:  bash tools/profile_round.sh
-# (kernel trace + stats of the bench command, the two --pmc traffic passes, the plain bench lines, SQ counter passes on the
-# dominant kernels).  Counter passes never share a run with a trace domain.
+# Everything profiles/<round>/ holds, in one GPU-box call:  bash tools/profile_round.sh [round-dir-name]
+# (kernel trace + stats of the bench command, the two --pmc traffic passes, the plain bench lines incl. full-length users,
+# host-side profile, micro-benchmarks, SQ counter passes on the dominant kernels).  Counter passes never share a run with a
+# trace domain.
+RD=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/prof
+O=$R/gpurun_out/prof_$RD
 rm -rf $O && mkdir -p $O
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 4 --warmup 1 --no_cpu_baseline > $O/bench_under_rocprof.json 2> $O/kt.err
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > /dev/null 2> $O/pmcF.err
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > /dev/null 2> $O/pmcW.err
 cd $R
 python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1
-cp $O/pmc_traffic.json profiles/pmc_traffic.json      # bench.py reads roofline.traffic from here
-timeout 400 python3 bench.py 2> $O/bench.err | tail -1 > $O/bench.json
+mkdir -p profiles/$RD && cp $O/pmc_traffic.json profiles/$RD/pmc_traffic.json      # bench.py reads roofline.traffic from here
+timeout 600 python3 bench.py 2> $O/bench.err | tail -1 > $O/bench.json
 timeout 300 python3 bench.py --dropout 0 --no_cpu_baseline 2>> $O/bench.err | tail -1 > $O/bench_dropout0.json
 timeout 300 python3 bench.py --device_sampler --no_cpu_baseline 2>> $O/bench.err | tail -1 > $O/bench_device_sampler.json
+timeout 300 python3 bench.py --min_len 199 --no_cpu_baseline 2>> $O/bench.err | tail -1 > $O/bench_full_length_users.json
+timeout 300 python3 bench.py --batch 32 --steps 20 --no_cpu_baseline --no_roofline 2>> $O/bench.err | tail -1 > $O/bench_tiny_batch_host_only.json
+timeout 300 python3 tools/hostprof.py > $O/hostprof.txt 2>&1
+timeout 300 python3 tools/hostprof2.py > $O/hostprof_torch_kernels.txt 2>&1
+timeout 300 python3 tools/kb_disc.py > $O/kb_disc.txt 2>&1
+timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table.txt 2>&1
 bash tools/pmc_pa.sh train > $O/sq_post_attn.txt 2>&1
 bash tools/pmc_attn.sh 0.5 > $O/sq_attention.txt 2>&1
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
