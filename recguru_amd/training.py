@@ -443,8 +443,8 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
     """Phases 2 and 3 (gan_training.py:353-587).  At the reference's evaluation points (:569-580) the ranking
     evaluation (evaluation_2, k = 5, 10, 20 as :361) runs over test_loaders and result_<domain>.pickle is rewritten;
     `evaluate(netG)` (optional) replaces it.  Every 100 iterations the scalar log is flushed to
-    <result_path>/gan_loss/log.pkl (:583-586).  Under data parallelism every rank evaluates its own shard of the test
-    users and rank 0 writes the pickle."""
+    <result_path>/gan_loss/log.pkl (:583-586).  Under data parallelism the entry points hand every rank the SAME
+    (unsharded) evaluation loader, so every rank computes the full metrics and rank 0 writes the pickle."""
     if overlap:
         raise NotImplementedError("overlap=True (MSE on overlapped users) is off in main_2 (gan_training.py:1010)")
     dp = dp or _NoDP()

@@ -94,8 +94,11 @@ def main():
         seqs, val, test, _ = synthetic.make_users(args.synthetic, Vt, L, seed=1 if args.target_domain == "a" else 2)
         param.candidate_size = min(param.candidate_size, Vt - L - 3)
         param.eval_steps = max(1, min(param.eval_steps, args.synthetic // param.batch_size_val))
+        # the evaluation set is NOT sharded: every rank ranks the same users with the same candidates (identical
+        # metrics on every rank; rank 0 writes result_<domain>.pickle) -- a rank-0 dump of a rank::world shard would
+        # report a different user population than the reference's single-process evaluation
         test_loaders = sampler.DeviceEvalLoader(seqs, val, test, Vt, device, param.batch_size_val, L, param.rec_maxlen, Vt + 1,
-                                                param.candidate_size, rank=rank, world=world)
+                                                param.candidate_size, rank=0, world=1)
     else:
         files = Dataloader.discover(param.data_path, param.domain_name_a, param.domain_name_b)
         print("=================\n", files, "\n*****************")
@@ -110,7 +113,7 @@ def main():
         rec_loaders = [gen(files[t], param.n_bpr_neg, t, 13, rec=True),
                        gen(files[t], param.n_bpr_neg, t, 14, rec=True, wf=freq)]
         # train_loader_re_test_{a,b} (train_gan.py:91-92,100-101): evaluated every 30 iterations past 0.8 * iterations
-        test_loaders = Dataloader.eval_loader_gen(files[t], param, t, device, rank, world, wf=freq)
+        test_loaders = Dataloader.eval_loader_gen(files[t], param, t, device, 0, 1, wf=freq)        # unsharded, see above
     torch.manual_seed(1)                                           # gan_training.py:20 (same initial weights on every rank)
     enc_model = Model.MyAuto4Rec_c(device, param, wf=None, enc_share=args.enc_share != "False",
                                    dec_rec=False).to(torch.float32).to(device)
