@@ -124,7 +124,11 @@ typedef struct {
    * MultiHeadAttention.forward's WQ / WK / WV (transformer.py:151-156) fused into the attention core.  x_masked: the
    * caller guarantees that the rows of x at positions with rowmask == 0 are all zero (their K / V are then the bias rows,
    * not computed).  rg_attn_fwd_x_supported(d, dtype, drop_p): bf16, d = 128, dropout off or 0.5. */
-  const void* x; const void* wqkv; const float* bqkv; int d; int x_masked;
+  const void* x; const void* wqkv; const float* bqkv; int d;
+  /* x_masked, qkv form: the caller guarantees that the K and V rows at positions with rowmask == 0 are all IDENTICAL (the
+   * projection of an all-zero layer-input row is the bias row).  A non-causal head then evaluates a leading run of such
+   * keys (left padding) once: same max, (count of kept copies) more terms in the row sum and the context. */
+  int x_masked;
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
 int rg_attn_fwd_x_supported(int d, int dtype, float drop_p);

@@ -149,8 +149,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   DropCfg drop = make_drop(a.drop_p, a.seed);
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
-  if (tid == 0) klo_s = L;
+  if (tid == 0) { klo_s = L; zpre_s = L; }
   __syncthreads();                    // klo_s initialised (nothing in flight yet: a cheap barrier)
+  // Zero-input keys (x_masked: the caller guarantees that the layer input rows at positions with rowmask == 0 are all
+  // zero, so their K rows all equal bk and their V rows bv).  A non-causal head whose FIRST nz >= 2 key tiles consist of
+  // such keys only (left padding) computes the scores of tile 0 and treats tiles 1 .. nz-1 as (nz-1)*16 more copies of
+  // key 0: same max, (nz-1)*16 (kept: popcount of the dropout bits) more terms exp(s_0 - m) in the row sum, that
+  // many times bv in the context -- no MFMA, no exp, no dropout work for 40 % of the key tiles at the bench's lengths.
+  constexpr bool ZKEYS = !CAUSAL && !XIN && DM != 2;
+  const bool zkeys = ZKEYS && a.x_masked && a.rowmask != nullptr;
 
   // This wave's query tiles are wave, wave+4, ...; a tile made of padded positions only is skipped (the layer
   // multiplies those rows by the pad mask, nothing downstream reads their context).  The wave finds its live tiles
@@ -169,11 +176,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   }
   constexpr int NKR = (LPK + 255) / 256;
   bool padk_r[NKR];                                // key ids: loaded ahead of the staging loads as well
+  float rmk_r[NKR];                                // the row mask at this thread's keys (zero-input keys)
 #pragma unroll
   for (int i = 0; i < NKR; ++i) {
     const int key = i * 256 + tid;
     const int64_t kid = a.key_ids[(size_t)b * L + min(key, L - 1)];
     padk_r[i] = key < L && kid == a.pad_value;
+    rmk_r[i] = 1.f;
+    if constexpr (ZKEYS) {
+      const float* __restrict__ rmp2 = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(a.qkv);
+      rmk_r[i] = rmp2[a.rowmask ? (size_t)b * L + min(key, L - 1) : 0];
+    }
   }
   unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
 #pragma unroll
@@ -318,6 +331,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const bool pad = padk_r[i];
     kbias[key] = key >= L ? -INFINITY : (pad ? MASK_BIG : 0.f);
     if (CAUSAL && key < L && !pad) atomicMin(&klo_s, key);
+    if (ZKEYS && key < L && (pad || rmk_r[i] != 0.f)) atomicMin(&zpre_s, key);      // the prefix ends at the first other key
   }
   // first live tile's Q fragment: in flight across the barrier.  Q rows: columns h*32.. of qkv, or (XIN) this wave's
   // own rows of ctx
@@ -332,6 +346,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   const unsigned int wl0 = wl;
   lds_barrier();
   const int klo = klo_s;
+  const int nz = zkeys ? (zpre_s >> 4) : 0;        // leading key tiles made of zero-input keys only
+  const int nskip = nz >= 2 ? (nz - 1) * 16 : 0;   // keys of tiles 1 .. nz-1, folded into key 0
   ASTAMP(0);
 
   // scores stay RAW dot products; the reference's 1/sqrt(d_k) and log2(e) are folded into the exp2 argument
@@ -355,8 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      if (kt >= nkq) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (kt < nkq) {
+      const bool kskip = ZKEYS && kt >= 1 && kt < nz;      // a copy of tile 0 (zero-input keys): folded in below
+      if (kt >= nkq || kskip) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (kt < nkq && !kskip) {
         Frag<T> kf;
         load_frag(kf, Ks + kofs(kt * 16 + li, lg));
         float kb[4];
@@ -381,7 +398,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
-      if (kt < nkq) {
+      if (kt < nkq && !(ZKEYS && kt >= 1 && kt < nz)) {
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {        // pairs: the fma and the row-sum add as packed instructions
           const f32x2 arg = (f32x2){s[kt][r], s[kt][r + 1]} * (f32x2){c2, c2} + (f32x2){nmx, nmx};
@@ -393,10 +410,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
           if constexpr (DM != 0) sum2 += p;     // DM == 0: the row sum comes out of the MFMA below
         }
       }
+    // zero-input keys: p of key 0 (every key of tile 0 has it) stands for each of the nskip folded keys
+    const float pz = (ZKEYS && nskip) ? s[0][0] : 0.f;
     if constexpr (DM != 0) {
       sum = sum2.x + sum2.y;
+      if (ZKEYS && nskip) sum += (float)(nskip >> 2) * pz;        // a quarter in each of the row's four lanes
       sum += __shfl_xor(sum, 16);
       sum += __shfl_xor(sum, 32);
+    }
+    float zcnt = (float)nskip;                    // folded keys that survive the attention-map dropout
+    if constexpr (DM == 1 && ZKEYS) {
+      if (nskip) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          const int lo = max(16, 32 * w), hi = min(16 * nz, 32 * w + 32);      // folded keys covered by hash word w
+          if (lo < hi) {
+            const unsigned int m = (hi - 32 * w == 32 ? 0xFFFFFFFFu : ((1u << (hi - 32 * w)) - 1u)) & ~((1u << (lo - 32 * w)) - 1u);
+            c += __popc(dmask[w * LPK + min(q, L - 1)] & m);
+          }
+        }
+        zcnt = (float)c;
+      }
     }
     if constexpr (DM == 1) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
 #pragma unroll
@@ -429,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
 #pragma unroll
     for (int ks = 0; ks < NKT / 2; ++ks)
-      if (2 * ks < nkq) {
+      if (2 * ks < nkq && !(ZKEYS && 2 * ks >= 1 && 2 * ks + 1 < nz)) {     // a pair of folded tiles holds zeros only
         Frag<T> pf;
         acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
 #pragma unroll
@@ -443,7 +478,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
         // exactly the (rounded) P that multiplies V
         if constexpr (DM == 0) mma(ones, pf, osum);
       }
-    if constexpr (DM == 0) sum = osum[0];
+    if constexpr (DM == 0) sum = osum[0] + (float)nskip * pz;
+    if (ZKEYS && nskip) {                         // + (kept folded keys) x p_0 x bv: V row of key 0
+      const float wz = pz * zcnt;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int dv = dt * 16 + 4 * lg + r;
+          o[dt][r] += wz * (float)(VT ? Vs[dv * LDV] : Vs[dv]);
+        }
+    }
     float inv = __builtin_amdgcn_rcpf(sum);
     if constexpr (DM == 1) inv *= drop.inv_keep;       // dropped entries were ANDed to zero, the 1/(1-p) rides on the normaliser
     ASTAMP(3);

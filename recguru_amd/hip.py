@@ -199,14 +199,15 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     return dW
 
 
-def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None):
-    """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32)."""
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False):
+    """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32).  x_masked: the K / V rows at positions with rowmask == 0
+    are all identical (the projection of an all-zero input row = the bias): a leading run of such keys is folded into one."""
     B, L, P3 = qkv.shape
     assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, None, 0, 0)
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, None, 0, 1 if (x_masked and rowmask is not None) else 0)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 

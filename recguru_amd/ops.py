@@ -424,7 +424,7 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     live = _zero_rows_live(rowmask, x2.shape[0], x_masked, x2.shape[1], wqkv.shape[0])
     qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=2)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
-                             rowmask=rowmask)
+                             rowmask=rowmask, x_masked=x_masked)
     return qkv, ctx_, lse
 
 

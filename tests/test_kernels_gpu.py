@@ -798,3 +798,39 @@ def test_attn_fwd_x_equals_projection_plus_attention(B, L, H, causal, drop_p, x_
     torch.testing.assert_close(got.float()[live], ref.float()[live], rtol=2e-2, atol=2e-2)
     assert float((got.float() - ref.float()).abs().mean()) < 2e-3
     assert torch.isfinite(got.float()).all()
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("B,L,H,drop_p", [(6, 200, 4, 0.0), (6, 200, 4, 0.5), (3, 77, 2, 0.5), (4, 40, 4, 0.0), (3, 200, 4, 0.3)])
+def test_attn_fwd_zero_input_keys_folded(dt, B, L, H, drop_p):
+    """x_masked: keys whose layer input is zero all have K = bk, V = bv; a leading run of them is folded into key 0
+    (counts instead of MFMA / exp work).  Same context and lse as evaluating every key, forward of backward included."""
+    from recguru_amd import hip
+    if dt == torch.float32 and L > 128:
+        pytest.skip("f32 tier: LDS")
+    d, P = 128, H * 32
+    g0 = torch.Generator().manual_seed(L * 7 + B)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 3
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids[:, -1] = 51
+    ids = ids.cuda()
+    rowmask = (ids != 0).float().view(-1)
+    x = ((torch.randn(B, L, d, generator=g0) * 0.8).cuda() * rowmask.view(B, L, 1)).to(dt).contiguous()
+    w = (torch.randn(3 * P, d, generator=g0) / d ** 0.5).to(dt).cuda()
+    bias = (torch.randn(3 * P, generator=g0) * 0.3).cuda()
+    qkv = hip.gemm_nt(x.view(B * L, d), w, bias).view(B, L, 3 * P)
+    ref, lse_ref = hip.attn_fwd(qkv, ids, 51, False, H, need_lse=True, drop_p=drop_p, seed=99, rowmask=rowmask, x_masked=False)
+    got, lse = hip.attn_fwd(qkv, ids, 51, False, H, need_lse=True, drop_p=drop_p, seed=99, rowmask=rowmask, x_masked=True)
+    live = rowmask.view(B, L) != 0
+    tol = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=1e-2)
+    torch.testing.assert_close(got.float()[live], ref.float()[live], **tol)
+    lm = live.unsqueeze(1).expand(B, H, L)
+    torch.testing.assert_close(lse[lm], lse_ref[lm], rtol=1e-5, atol=1e-5)
+    # the backward (which evaluates every key) agrees with the folded forward's lse / ctx
+    dctx = (torch.randn(B, L, P, generator=g0).cuda() * rowmask.view(B, L, 1)).to(dt)
+    d1 = hip.attn_bwd(qkv, dctx, got, lse, ids, 51, False, H, drop_p=drop_p, seed=99, rowmask=rowmask)
+    d0 = hip.attn_bwd(qkv, dctx, ref, lse_ref, ids, 51, False, H, drop_p=drop_p, seed=99, rowmask=rowmask)
+    torch.testing.assert_close(d1.float(), d0.float(), rtol=tol["rtol"] * 2, atol=tol["atol"] * 2)

@@ -16,4 +16,5 @@ for causal in (False, True):
         us = timeit(lambda: hip.attn_fwd(qkv, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask))
         ctx, lse = hip.attn_fwd(qkv, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask)
         usb = timeit(lambda: hip.attn_bwd(qkv, dctx, ctx, lse, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask), n=10)
-        print("causal %d p=%.1f  fwd %7.1f us   bwd %7.1f us" % (causal, p, us, usb))
+        usz = timeit(lambda: hip.attn_fwd(qkv, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask, x_masked=True))
+        print("causal %d p=%.1f  fwd %7.1f us (zero-input keys folded: %7.1f us)   bwd %7.1f us" % (causal, p, us, usz, usb))

@@ -8,7 +8,8 @@ dt = torch.bfloat16
 M, d, P, dff = 4096 * 200, 128, 128, 512
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
 ctx, x = r(M, P), r(M, d)
-wo, w1, w2 = r(d, P), r(dff, d), r(d, dff)
+pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK)      # fragment-packed, as in production
+wo, w1, w2 = pk(r(d, P)), pk(r(dff, d)), pk(r(d, dff))
 z = lambda n: torch.zeros(n, device="cuda")
 g, be = torch.ones(d, device="cuda"), z(d)
 rm = torch.ones(M, device="cuda")
@@ -16,7 +17,8 @@ out = torch.empty(M, d, device="cuda", dtype=dt)
 dbg = torch.zeros(4096 * 12, device="cuda", dtype=torch.int64)
 a = hip.PostAttnArgs(ctx.data_ptr(), x.data_ptr(), wo.data_ptr(), z(d).data_ptr(), g.data_ptr(), be.data_ptr(), None, None, None, 0,
                      w1.data_ptr(), z(dff).data_ptr(), w2.data_ptr(), z(d).data_ptr(), g.data_ptr(), be.data_ptr(), rm.data_ptr(),
-                     out.data_ptr(), None, None, dbg.data_ptr(), None, None, None, M, d, P, dff, 1e-8)
+                     out.data_ptr(), None, None, dbg.data_ptr(), None, None, None, M, d, P, dff, 1e-8,
+                     float(sys.argv[1]) if len(sys.argv) > 1 else 0.0, 3, 4, None, None, None, 0, None, 0, 1)   # drop_p, seeds, ..., w_packed
 for _ in range(3):
     hip._check(hip.lib().rg_post_attn_fwd(ctypes.byref(a), 1, hip._stream()), "x")
 torch.cuda.synchronize()
