@@ -37,6 +37,7 @@ class DataParallel(object):
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.bucket_elems = bucket_bytes // 4
+        self.big_elems = 1 << 20                    # gradients of >= 4 MB are all-reduced in place, on their own
 
     def scale_mean(self, loss):
         return loss / self.world
@@ -52,11 +53,28 @@ class DataParallel(object):
         return y[0] / self.world
 
     def sync_grads(self, params):
-        """SUM all-reduce of every present gradient, in flat buckets (few large collectives:
-        xGMI links are point-to-point, so per-collective latency matters more than on a switch)."""
-        grads = [p.grad for p in params if p.grad is not None]
+        """SUM all-reduce of every present gradient.  Large contiguous gradients (the embedding tables: 51 MB each at the
+        bench catalogue) are reduced IN PLACE, one collective each -- no staging copy; the many small ones travel in flat
+        buckets (few large collectives: xGMI links are point-to-point, so per-collective latency matters more than on a
+        switch) and come back with one multi-tensor copy.  Gradients that are row slices of one shared buffer (the fused
+        Q/K/V gradient base of ops._gt_cat) are reduced once, as that buffer."""
+        seen, big, small = set(), [], []
+        for p in params:
+            g = p.grad
+            if g is None:
+                continue
+            base = getattr(p, "_rg_gbase", None)
+            if base is not None and getattr(p, "_rg_gbuf", None) is not None and g.data_ptr() == p._rg_gbuf.data_ptr():
+                g = base                                    # the whole shared buffer, once
+            key = (g.data_ptr(), g.numel())
+            if key in seen:
+                continue
+            seen.add(key)
+            (big if (g.numel() >= self.big_elems and g.is_contiguous()) else small).append(g)
+        for g in big:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
         bucket, size = [], 0
-        for g in grads:
+        for g in small:
             if bucket and size + g.numel() > self.bucket_elems:
                 self._reduce(bucket)
                 bucket, size = [], 0
@@ -71,11 +89,12 @@ class DataParallel(object):
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
+        outs, off = [], 0
         for g in bucket:
             n = g.numel()
-            g.copy_(flat[off:off + n].view_as(g))
+            outs.append(flat[off:off + n].view_as(g))
             off += n
+        torch._foreach_copy_(bucket, outs)
 
     def barrier(self):
         dist.barrier(group=self.group)
