@@ -425,3 +425,84 @@ def test_generic_gemm_refuses_a_live_tile_list():
     hip.gemm_tn(A, A, live=live)
     with pytest.raises(RuntimeError, match="live16"):
         hip.gemm_tn(A, A, live=live, splits=4)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the kernels that only LARGE batches select (weight-stationary GEMM M >= 4096, gemm_tn_big T >= 8192, live-tile lists
+# >= 16384 rows, binned item-loss backward >= 65536 positions) in the END-TO-END bf16 composition, against the oracle
+# ----------------------------------------------------------------------------------------------------------------------
+def test_large_batch_bf16_composition_vs_oracle(capsys):
+    from oracle import recguru_oracle as O
+    from recguru_amd import config, hip, models, ops, synthetic, training as T
+    B, L, d, H, N, V, k = 336, 200, 128, 4, 3, 100000, 30
+    assert B * L >= 65536 and B * L >= hip.COMPACT_MIN_ROWS
+    param = config.get_param(make_args(d, H, k, L, V, V, N, B), make_dirs=False)
+    G = models.MyAuto4Rec_c("cuda", param, wf=None, enc_share=True, dec_rec=False).to(torch.float32)
+    sG = seeded_state(G, 5101)
+    G.load_state_dict(sG, strict=False)
+    G = G.cuda()
+    dom = synthetic.make_domain(B, V, L, k, seed=51)
+    bt = tuple(torch.as_tensor(dom[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+    cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
+    sG["pos_emb_a.pe"] = O.positional_table(5000, d).unsqueeze(0)
+    pG = O.leafify(sG)
+    la_ref = O.loss_ae_cross(pG, cfg, *bt, domain="a", collapsed=True)
+    la_ref.backward()
+    ops.set_compute_dtype(torch.bfloat16)
+    cb = tuple(t.cuda() for t in bt)
+    mask = T.get_pad_mask(cb[2], 0, "cuda")
+    seen = []
+    real_binned = hip.item_loss_bwd_binned
+    hip.item_loss_bwd_binned = lambda *a, **kw: (seen.append("binned"), real_binned(*a, **kw))[1]
+    try:
+        la = T.loss_ae(G, *cb, True, B, L, param, mask, "cuda", domain="a")
+        la.backward()
+    finally:
+        hip.item_loss_bwd_binned = real_binned
+    torch.cuda.synchronize()
+    assert seen == ["binned"]                                   # the counting-sort table gradient was the one that ran
+    l_rel = abs(float(la) - float(la_ref)) / float(la_ref)
+    worst = {}
+    for name in ("encoder.layers.0.pos_ffn.l1.weight", "encoder.layers.2.enc_self_attn.WV.weight",
+                 "decoder_a.layers.1.pos_ffn.l2.weight", "decoder_a.layers.2.dec_self_attn.linear.weight",
+                 "decoder_a.layers.0.dec_enc_attn.WV.weight", "src_emb_a.weight"):
+        g = dict(G.named_parameters())[name].grad.float().cpu().numpy()
+        r = pG[name].grad.numpy()
+        worst[name] = max_err(g, r)[1]
+    with capsys.disabled():
+        print("\n[B=336 x L=200, bf16 tier vs oracle] loss_ae rel %.3g | grad max-err / max-value: %s"
+              % (l_rel, {".".join(n.split(".")[-3:-1]): "%.3g" % v for n, v in worst.items()}))
+    assert l_rel <= 6e-4                                        # measured 2.7e-4
+    assert all(v <= 0.015 for v in worst.values()), worst       # measured <= 0.0073 of each gradient's largest element
+
+
+def test_single_domain_bench_shape_vs_oracle(capsys):
+    """BASELINE configs[1] (single-domain AutoRec, 100k items, L=200, d=128) at a batch the oracle finishes in seconds:
+    MyRec reconstruction loss (train_auto.py:29-54, mask = dec_in != 0) and the recommender's BPR-sas loss, both tiers."""
+    from oracle import recguru_oracle as O
+    from recguru_amd import auto_training as at, config, models, ops, synthetic
+    B, L, d, H, N, V, k = 16, 200, 128, 4, 3, 100000, 30
+    param = config.get_param(make_args(d, H, k, L, V, V, N, B, cross="False"), make_dirs=False)
+    R = models.MyRec("cuda", param, None, dec_rec=False, fix_enc=False, sas=False, pos_train=False).to(torch.float32)
+    sR = seeded_state(R, 6101)
+    R.load_state_dict(sR, strict=False)
+    R = R.cuda().eval()
+    dom = synthetic.make_domain(B, V, L, k, seed=61)
+    bt = tuple(torch.as_tensor(dom[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+    nb = torch.as_tensor(synthetic.make_domain(B, V, L, param.num_train_neg, seed=62)["n_items"])
+    cfg = O.Cfg(d, H, N, L, k, V + 1, n_bpr_neg=param.num_train_neg)
+    sR["AutoEnc.pos_emb.pe"] = O.positional_table(5000, d).unsqueeze(0)
+    with torch.no_grad():
+        la_ref = float(O.loss_ae_single(sR, cfg, *bt, collapsed=True))
+        pl, nl = O.myrec_bpr_logits(sR, cfg, bt[0], bt[1], bt[2], nb, collapsed=True)
+        lb_ref = float(O.bpr_loss_sas(pl, nl, O.nonpad(bt[1]).view(-1)))
+    cb = tuple(t.cuda() for t in bt)
+    m_in = (cb[1] != 0).view(-1).float()
+    for tier, tol in (("f32", 1e-3), ("bf16", 7e-4)):           # measured: f32 5e-7, bf16 3e-4
+        ops.set_compute_dtype(TIERS[tier])
+        with torch.no_grad():
+            la = float(at.loss_ae(R, *cb, True, B, L, param, m_in))
+            lb = float(at.loss_bpr_func(R, cb[0], cb[1], cb[2], nb.cuda(), m_in))
+        with capsys.disabled():
+            print("\n[single-domain, bench shape, %s] loss_ae %.6f vs %.6f | bpr_sas %.6f vs %.6f" % (tier, la, la_ref, lb, lb_ref))
+        np.testing.assert_allclose([la, lb], [la_ref, lb_ref], rtol=tol, atol=1e-5)
