@@ -395,6 +395,32 @@ typedef struct {
   int w_packed;          /* 1: Wo, W1, W2 are fragment-packed copies (rg_cast RG_CAST_PACK: contiguous 1 KB operand fragments) */
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
+
+/* ---- FFN block, backward data path in one launch ---------------------------------------------------
+ * Backward of  out = l2(gelu(dropout(l1(y))))  (PositionWiseFeedForwardNet, Transformer/transformer.py:181-188) with
+ * respect to its input, after the LayerNorm backward has produced dl2 (gradient at the l2 output, output-dropout mask
+ * applied) and dz (gradient through the residual):
+ *     dh1 = (dl2 . W2) * gelu'(h1) [* (h1 != 0 ? nz_scale : 0)]        [M, dff]   written for the dW1 product
+ *     dy  = dh1 . W1 + dz                                                [M, 128]
+ * 64-token tiles, d_ff streamed in 128-wide chunks: dh1 is written once and never read back (the two separate
+ * products read 3.75 KB and this kernel 2.75 KB per token at d_ff = 512, bf16).  W2t = W2^T [dff,128] and
+ * W1t = W1^T [128,dff] as the [out][in] operands of the two products, row-major or fragment-packed (w_packed).
+ * Needs d == 128, dff % 128 == 0.  live16 (rg_live_tiles): only live 16-row tiles are computed, the padded tiles'
+ * rows of dy are written as zeros and those of dh1 left untouched. */
+typedef struct {
+  const void* dl2;
+  const void* dz;      /* may alias dl2 (no dropout) */
+  const void* h1;      /* [M,dff] saved pre-activation (zeros where dropped) */
+  const void* W2t;
+  const void* W1t;
+  void* dh1;
+  void* dy;
+  int M, d, dff, w_packed;
+  float nz_scale;      /* > 0: dropout on h1 was active, 1/(1-p) */
+  const int* live16;
+} rg_ffn_bwd_args;
+int rg_ffn_bwd_data(const rg_ffn_bwd_args* args /* host */, int dtype, void* stream);
+int rg_ffn_bwd_data_supported(int d, int dff);
 /* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their
  * indices ascending; the remaining (padded) tiles are listed from the far end backwards (list[nt], list[nt-1], ..);
  * list[1+nt ..] is scratch (the per-tile flags). */

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
   __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
+  __shared__ int zpre_s;              // ZKEYS: length of the leading run of zero-input keys (L if all of them are)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -412,6 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
     // zero-input keys: p of key 0 (every key of tile 0 has it) stands for each of the nskip folded keys
     const float pz = (ZKEYS && nskip) ? s[0][0] : 0.f;
+    const float pzr = (float)(T)pz;               // as the P operand of the MFMAs sees it (bf16 tier: rounded)
     if constexpr (DM != 0) {
       sum = sum2.x + sum2.y;
       if (ZKEYS && nskip) sum += (float)(nskip >> 2) * pz;        // a quarter in each of the row's four lanes
@@ -478,9 +480,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
         // exactly the (rounded) P that multiplies V
         if constexpr (DM == 0) mma(ones, pf, osum);
       }
-    if constexpr (DM == 0) sum = osum[0] + (float)nskip * pz;
+    if constexpr (DM == 0) sum = osum[0] + (float)nskip * pzr;   // the MFMA row sum adds the ROUNDED P
     if (ZKEYS && nskip) {                         // + (kept folded keys) x p_0 x bv: V row of key 0
-      const float wz = pz * zcnt;
+      const float wz = pzr * zcnt;
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt)
 #pragma unroll

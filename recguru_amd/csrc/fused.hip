@@ -600,3 +600,192 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   RG_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// FFN block, backward data path (rg_ffn_bwd_data): same tiling, weight streaming and LDS tiles as the forward kernel
+// above.  Per 64-token tile: dl2 / dz rows and the h1 chunks arrive through coalesced 16-byte loads issued one stage
+// ahead (registers -> LDS), the chunk's dg = dl2 . W2t[chunk]^T sits in the accumulators, is multiplied by gelu'(h1)
+// (and the dropout mask read back from h1 != 0), goes to LDS as the B operand of the second product and to HBM as dh1
+// for the weight-gradient kernel; dy accumulates across chunks and leaves with the residual gradient added.
+// LDS: 4 tiles (dl2 -> dy staging | dz | dh1 chunk | h1 chunk) = 64 KB (bf16): two workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_kernel(rg_ffn_bwd_args a) {
+  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Adl = reinterpret_cast<T*>(smem);
+  T* Adz = reinterpret_cast<T*>(smem + ACT_BYTES);
+  T* Adh = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
+  T* Ah = reinterpret_cast<T*>(smem + 3 * ACT_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const T* __restrict__ dl2 = reinterpret_cast<const T*>(a.dl2);
+  const T* __restrict__ dz = reinterpret_cast<const T*>(a.dz);
+  const T* __restrict__ h1 = reinterpret_cast<const T*>(a.h1);
+  const T* __restrict__ W2t = reinterpret_cast<const T*>(a.W2t);
+  const T* __restrict__ W1t = reinterpret_cast<const T*>(a.W1t);
+  T* __restrict__ dh1 = reinterpret_cast<T*>(a.dh1);
+  T* __restrict__ dy = reinterpret_cast<T*>(a.dy);
+  const int n0 = wave * 32;
+  const int ntiles = (a.M + FT_M - 1) / FT_M;
+  const int nchunk = a.dff / FD;
+  const float nz = a.nz_scale;
+
+  WSet<T> wp, wq;                           // wp: W2t chunks (first product), wq: W1t chunks (second product)
+  Frag<T> cpre[4], xpre[4], hpre[4];        // dl2 / dz rows of the next tile, h1 rows of the next chunk
+
+  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
+  int cur = (int)blockIdx.x;
+  auto next_group = [&](int (&g)[4]) -> bool {
+    if (cur >= nwork) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = a.M;
+      return false;
+    }
+    if (!a.live16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
+    } else {
+      const int nlive = a.live16[0];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = 4 * cur + rt < nlive ? a.live16[1 + 4 * cur + rt] * 16 : a.M;
+    }
+    cur += gridDim.x;
+    return true;
+  };
+  auto prefetch_h = [&](const int (&g)[4], int ch) {    // rows >= M: clamped address, never stored
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(hpre[i], h1 + (size_t)m * a.dff + ch * FD + c8);
+    }
+  };
+  auto prefetch_rows = [&](const int (&g)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(cpre[i], dl2 + (size_t)m * FD + c8);
+      load_frag(xpre[i], dz + (size_t)m * FD + c8);
+    }
+  };
+  auto h_to_lds = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+      *reinterpret_cast<Frag<T>*>(Ah + Tile<T>::off(r, c8)) = hpre[i];
+    }
+  };
+  int mb[4], mbn[4];
+  bool have = next_group(mb);
+  if (have) {
+    load_wset(wp, W2t, FD, n0, 0, li, lg, a.w_packed);
+    prefetch_rows(mb);
+    prefetch_h(mb, 0);
+  }
+  for (; have;) {
+    const bool have_next = next_group(mbn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+      *reinterpret_cast<Frag<T>*>(Adl + Tile<T>::off(r, c8)) = cpre[i];
+      *reinterpret_cast<Frag<T>*>(Adz + Tile<T>::off(r, c8)) = xpre[i];
+    }
+    h_to_lds();
+    lds_barrier();
+    f32x4 acc[2][4], acc2[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc2[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ch = 0; ch < nchunk; ++ch) {
+      load_wset(wq, W1t, a.dff, n0, ch * FD, li, lg, a.w_packed);
+      {   // h1 rows of the next chunk, or chunk 0 of the next tile: one unconditional load sequence from selected rows
+          // (a branch around loads drains vmcnt at the join)
+        const bool last = ch + 1 == nchunk;
+        int gs[4];
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) gs[rt] = last ? mbn[rt] : mb[rt];
+        prefetch_h(gs, last ? 0 : ch + 1);
+      }
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      mma_wset<T>(acc, wp, Adl, li, lg);                 // dg chunk = dl2 . W2t[chunk]^T
+      load_wset(wp, W2t + (size_t)((ch + 1 < nchunk) ? ch + 1 : 0) * FD * FD, FD, n0, 0, li, lg, a.w_packed);
+      if (ch > 0) lds_barrier();                         // readers of the previous dh1 chunk are done, h1 chunk visible
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < 4; ++rt) {
+          float x4[4];
+          load4t(x4, Ah + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float v = acc[ct][rt][r] * gelu_grad_t<Precise<T>::value>(x4[r]);
+            if (nz > 0.f) v = x4[r] != 0.f ? v * nz : 0.f;
+            acc[ct][rt][r] = v;
+          }
+        }
+      regs_to_tile<T>(acc, Adh, n0, li, lg);
+      lds_barrier();                                     // dh1 chunk complete, h1 chunk no longer read
+      if (ch + 1 < nchunk) h_to_lds();
+      tile_to_hbm<T>(Adh, dh1, a.dff, ch * FD, mb, a.M, tid);
+      mma_wset<T>(acc2, wq, Adh, li, lg);                // dy += dh1 chunk . W1t[:, chunk]^T
+    }
+    prefetch_rows(mbn);
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) {
+        float r4[4];
+        load4t(r4, Adz + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
+      }
+    regs_to_tile<T>(acc2, Adl, n0, li, lg);              // every wave is past its last read of the dl2 tile
+    lds_barrier();
+    tile_to_hbm<T>(Adl, dy, FD, 0, mb, a.M, tid);
+    lds_barrier();
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+    have = have_next;
+  }
+  if (a.live16) {                                        // padded row tiles: dy rows = 0
+    const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
+    for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
+      int md[4];
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
+      zero_to_hbm<T>(dy, FD, 0, md, a.M, tid);
+    }
+  }
+}
+
+extern "C" int rg_ffn_bwd_data_supported(int d, int dff) { return d == FD && dff > 0 && (dff % FD) == 0; }
+
+extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream) {
+  if (!a || a->M <= 0) return 0;
+  if (!rg_ffn_bwd_data_supported(a->d, a->dff))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ffn_bwd_data: needs d_model == 128 and d_ff % 128 == 0");
+  if (!a->dl2 || !a->dz || !a->h1 || !a->W2t || !a->W1t || !a->dh1 || !a->dy)
+    return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: NULL operand");
+  hipStream_t s = (hipStream_t)stream;
+  const int ntiles = (a->M + FT_M - 1) / FT_M;
+  const int esz = dtype == RG_BF16 ? 2 : 4;
+  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz;
+  const int per_cu = (160 * 1024) / smem;
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  if (grid > ntiles) grid = ntiles;
+#define RG_FB(T)                                                                                                          \
+  do {                                                                                                                    \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_data_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((ffn_bwd_data_kernel<T>), dim3(grid), dim3(256), smem, s, *a);                                     \
+  } while (0)
+  if (dtype == RG_BF16) RG_FB(__bf16);
+  else if (dtype == RG_F32) RG_FB(float);
+  else return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: bad dtype");
+#undef RG_FB
+  RG_CHECK_LAUNCH();
+  return 0;
+}

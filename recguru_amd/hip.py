@@ -60,6 +60,11 @@ class PostAttnArgs(ctypes.Structure):
                 ("skip_dead_saves", c_i), ("w_packed", c_i)]
 
 
+class FfnBwdArgs(ctypes.Structure):
+    _fields_ = [("dl2", c_p), ("dz", c_p), ("h1", c_p), ("W2t", c_p), ("W1t", c_p), ("dh1", c_p), ("dy", c_p),
+                ("M", c_i), ("d", c_i), ("dff", c_i), ("w_packed", c_i), ("nz_scale", c_f), ("live16", c_p)]
+
+
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
            "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
@@ -69,7 +74,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
-           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows"]
+           "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
+           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -669,6 +675,27 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     return out, sv
 
 
+def ffn_bwd_data_supported(d, dff):
+    return bool(lib().rg_ffn_bwd_data_supported(int(d), int(dff)))
+
+
+def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False):
+    """Data path of the FFN block's backward in one launch (rg_ffn_bwd_data): returns (dh1 [M,dff], dy [M,d]) with
+    dh1 = (dl2 W2) * gelu'(h1) [* dropout mask read back from h1 != 0], dy = dh1 W1 + dz.  W2t / W1t are the transposed
+    operand copies ([dff,d] / [d,dff]), fragment-packed when w_packed.  With a live-tile list the padded tiles' rows of
+    dh1 stay unwritten and those of dy are zeros."""
+    M, d = dl2.shape
+    dff = h1.shape[1]
+    dh1 = torch.empty(M, dff, device=dl2.device, dtype=dl2.dtype)
+    if POISON_UNWRITTEN and live is not None:
+        dh1.fill_(float("nan"))
+    dy = torch.empty(M, d, device=dl2.device, dtype=dl2.dtype)
+    a = FfnBwdArgs(_p(dl2), _p(dz), _p(h1), _p(W2t), _p(W1t), _p(dh1), _p(dy), M, d, dff, 1 if w_packed else 0,
+                   float(nz_scale), _p(live))
+    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), dt_of(dl2), _stream()), "rg_ffn_bwd_data")
+    return dh1, dy
+
+
 # ------------------------------------------------------------------------------------------------
 # live per-kernel timing (bench.py roofline): HIP events recorded on the launch stream around each
 # launch, with the ALGORITHMIC work of that launch computed from its shapes.
@@ -780,7 +807,14 @@ def _work_attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, *a, **k):
             B * L * (d + P3 // 3) * _esize(x) + P3 * d * _esize(x))
 
 
-_WORK = {"attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
+def _work_ffn_bwd(dl2, dz, h1, *a, **k):
+    M, d = dl2.shape
+    dff = h1.shape[1]
+    return ("ffn_bwd_data_kernel<%s>" % ("bf16" if dl2.dtype == torch.bfloat16 else "f32"), 4.0 * M * d * dff,
+            M * (3 * d + 2 * dff) * _esize(dl2))
+
+
+_WORK = {"ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]

@@ -484,6 +484,9 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
     return out, (h1, rstd)
 
 
+FUSE_FFN_BWD = True      # rg_ffn_bwd_data for d_model == 128, d_ff % 128 == 0 (False: the two separate products)
+
+
 def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, seed_out=0):
     """Backward of the FFN block; prm = (W1, b1, W2, b2, g, be).  Under dropout h1 holds the DROPPED
     pre-activation (zeros where dropped), the l2-output mask is regenerated from seed_out and the h1 mask is read
@@ -499,9 +502,15 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
         dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
+    (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
+    if FUSE_FFN_BWD and hip.ffn_bwd_data_supported(d, dff):
+        # one launch for both data-path products: dh1 is written once (for dW1) and never read back
+        dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),
+                                   nz_scale=_inv_keep(drop_p), live=live, w_packed=True)
+        hip.gemm_tn(dh1, y, dW1, db1, live=live)
+        return dy, (rW1, rb1, rW2, rb2, rg, rbe)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
                       epi_nonzero_scale=_inv_keep(drop_p), live=live, skip_dead_fill=True)   # both consumers list-driven
-    (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
     hip.gemm_tn(dh1, y, dW1, db1, live=live)
     dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dy, (rW1, rb1, rW2, rb2, rg, rbe)

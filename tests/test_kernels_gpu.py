@@ -834,3 +834,60 @@ def test_attn_fwd_zero_input_keys_folded(dt, B, L, H, drop_p):
     d1 = hip.attn_bwd(qkv, dctx, got, lse, ids, 51, False, H, drop_p=drop_p, seed=99, rowmask=rowmask)
     d0 = hip.attn_bwd(qkv, dctx, ref, lse_ref, ids, 51, False, H, drop_p=drop_p, seed=99, rowmask=rowmask)
     torch.testing.assert_close(d1.float(), d0.float(), rtol=tol["rtol"] * 2, atol=tol["atol"] * 2)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,dff,drop_p,listed", [(64, 128, 0.0, False), (203, 512, 0.0, False), (131, 512, 0.5, False),
+                                                 (9000, 512, 0.3, True), (9000, 256, 0.0, True)])
+def test_ffn_bwd_data_vs_two_products_and_torch(dt, M, dff, drop_p, listed):
+    """rg_ffn_bwd_data (dh1 and dy of the FFN block's backward in one launch) against torch on the same operands and
+    against the two separate products it replaces; with a live-tile list: live rows identical to the unlisted launch,
+    padded rows of dy zero, padded rows of dh1 untouched."""
+    from recguru_amd import hip
+    d = 128
+    dl2, dz = rnd(M, d, dt=dt, seed=1), rnd(M, d, dt=dt, seed=2)
+    h1 = rnd(M, dff, dt=dt, seed=3)
+    nz = 0.0
+    if drop_p > 0:
+        keep = (torch.rand(M, dff, generator=torch.Generator().manual_seed(4)) >= drop_p).cuda()
+        h1 = h1 * keep.to(dt)
+        nz = 1.0 / (1.0 - drop_p)
+    W1, W2 = rnd(dff, d, dt=torch.float32, scale=d ** -0.5, seed=5), rnd(d, dff, dt=torch.float32, scale=dff ** -0.5, seed=6)
+    W2t, W1t = W2.t().contiguous().to(dt), W1.t().contiguous().to(dt)            # [dff,d], [d,dff]: the [out][in] operands
+    W2tp, W1tp = hip.cast(W2, dt, transpose=hip.CAST_TRANSPOSE | hip.CAST_PACK), hip.cast(W1, dt, transpose=hip.CAST_TRANSPOSE | hip.CAST_PACK)
+    mask = live = None
+    if listed:
+        mask = _pad_mask(M // 120, 120, M + dff)
+        live = hip.live_tiles(mask, M)
+        dl2, dz, h1 = (t * mask[:, None].to(dt) for t in (dl2, dz, h1))
+    dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, W2tp, W1tp, nz_scale=nz, w_packed=True)
+    dh1u, dyu = hip.ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=nz, w_packed=False)
+    assert torch.equal(dh1, dh1u) and torch.equal(dy, dyu)                       # packed == row-major operand copies
+    # torch, f32 arithmetic on the operand values the kernel saw
+    x = h1.float().requires_grad_(True)
+    gg, = torch.autograd.grad(gelu_tanh(x).sum(), x)
+    x = x.detach()
+    ref_dh = (dl2.float() @ W2t.float().T) * gg
+    if drop_p > 0:
+        ref_dh = torch.where(x != 0, ref_dh * nz, torch.zeros_like(ref_dh))
+    ref_dy = ref_dh.to(dt).float() @ W1t.float().T + dz.float()
+    t = dict(rtol=2e-4, atol=2e-4) if dt == torch.float32 else dict(rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(dh1.float(), ref_dh, **t)
+    torch.testing.assert_close(dy.float(), ref_dy, **t)
+    # the two separate launches of the unfused path
+    dh1_b = hip.gemm_nt(dl2, W2t, epilogue=hip.EPI_GELU_GRAD, aux=h1, epi_nonzero_scale=nz)
+    dy_b = hip.gemm_nt(dh1_b, W1t, epilogue=hip.EPI_ADD, aux=dz)
+    torch.testing.assert_close(dh1.float(), dh1_b.float(), **t)
+    torch.testing.assert_close(dy.float(), dy_b.float(), **t)
+    if listed:
+        hip.POISON_UNWRITTEN = True
+        try:
+            dh1_l, dy_l = hip.ffn_bwd_data(dl2, dz, h1, W2tp, W1tp, nz_scale=nz, live=live, w_packed=True)
+        finally:
+            hip.POISON_UNWRITTEN = False
+        rows16 = torch.zeros((M + 15) // 16 * 16, device="cuda")
+        rows16[:M] = mask
+        live_rows = rows16.view(-1, 16).amax(1).repeat_interleave(16)[:M] != 0    # rows of tiles that hold a live row
+        assert torch.equal(dh1_l[live_rows], dh1[live_rows]) and torch.equal(dy_l[live_rows], dy[live_rows])
+        assert float(dy_l[~live_rows].abs().max()) == 0.0
+        assert bool(torch.isnan(dh1_l[~live_rows].float()).all())                 # untouched (poisoned by the binding)
