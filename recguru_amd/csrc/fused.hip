@@ -48,6 +48,18 @@ template <typename T> struct Tile {
 // before the MFMAs of set s), against a [64 x 128] activation tile in LDS.
 template <typename T> struct WSet { Frag<T> f[4][2]; };
 
+// Global addresses are formed as (uniform base pointer) + (32-bit element offset): hipcc then keeps the base in scalar
+// registers and one 32-bit offset per lane (the saddr form of global_load / global_store) instead of a 64-bit pointer
+// per lane and access -- those pointer pairs were what spilled (27 VGPRs, each reload followed by a vmcnt(0) that also
+// waited for the previous STORE to be acknowledged), and their 64-bit adds were a tenth of the FFN loop's VALU work.
+// The launchers refuse shapes whose offsets do not fit 32 bits.
+template <typename T> __device__ __forceinline__ T* gofs(T* base, unsigned int elem) {
+  return reinterpret_cast<T*>(reinterpret_cast<char*>(base) + (size_t)(elem * (unsigned int)sizeof(T)));
+}
+template <typename T> __device__ __forceinline__ const T* gofs(const T* base, unsigned int elem) {
+  return reinterpret_cast<const T*>(reinterpret_cast<const char*>(base) + (size_t)(elem * (unsigned int)sizeof(T)));
+}
+
 // packed: W is the fragment-packed copy (rg_cast RG_CAST_PACK; ldw = its logical K): the 8 fragments of a step are 8
 // contiguous 1 KB reads.  From the row-major [out][in] layout a wave's fragment load touches 16 rows x 64 B, and the
 // vector L1 spends a tag lookup per row and 16-lane pass: with 288 such loads per 64-token tile and two workgroups per CU
@@ -55,19 +67,16 @@ template <typename T> struct WSet { Frag<T> f[4][2]; };
 template <typename T>
 __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, int ldw, int row0, int k0, int li, int lg,
                                           int packed = 0) {
-  if (packed) {
-    const int nks = ldw >> 5;
-    const T* base = W + (((size_t)(row0 >> 4) * nks + (k0 >> 5)) * 64 + (lg * 16 + li)) * 8;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-      for (int ct = 0; ct < 2; ++ct) load_frag(w.f[ks][ct], base + ((size_t)ct * nks + ks) * 512);
-    return;
-  }
+  // one code path for both layouts: fragment (ks, ct) sits at (uniform base) + (uniform step) + (lane offset)
+  const unsigned int nks = (unsigned int)ldw >> 5;
+  const T* base = W + (packed ? ((unsigned int)(row0 >> 4) * nks + (unsigned int)(k0 >> 5)) * 512u
+                              : (unsigned int)row0 * (unsigned int)ldw + (unsigned int)k0);
+  const unsigned int lofs = packed ? (unsigned int)(lg * 16 + li) * 8u : (unsigned int)li * (unsigned int)ldw + 8u * lg;
+  const unsigned int sct = packed ? nks * 512u : 16u * (unsigned int)ldw, sks = packed ? 512u : 32u;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-    for (int ct = 0; ct < 2; ++ct) load_frag(w.f[ks][ct], W + (size_t)(row0 + ct * 16 + li) * ldw + k0 + ks * 32 + 8 * lg);
+    for (int ct = 0; ct < 2; ++ct) load_frag(w.f[ks][ct], gofs(base + (ct * sct + ks * sks), lofs));
 }
 
 // acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
@@ -183,8 +192,9 @@ __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __res
   for (int i = 0; i < 4; ++i) {
     const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
     if (m < M) {
-      if constexpr (NT) frag_store_nt(dst + (size_t)m * ld + col0 + c8, *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8)));
-      else *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
+      T* g = gofs(dst, (unsigned int)m * (unsigned int)ld + (unsigned int)(col0 + c8));
+      if constexpr (NT) frag_store_nt(g, *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8)));
+      else *reinterpret_cast<Frag<T>*>(g) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
     }
   }
 }
@@ -197,7 +207,7 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
-    if (m < M) *reinterpret_cast<Frag<T>*>(dst + (size_t)m * ld + col0 + c8) = z;
+    if (m < M) *reinterpret_cast<Frag<T>*>(gofs(dst, (unsigned int)m * (unsigned int)ld + (unsigned int)(col0 + c8))) = z;
   }
 }
 
@@ -228,7 +238,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   float *p_bo = prm, *p_g1 = prm + FD, *p_be1 = prm + 2 * FD, *p_b2 = prm + 3 * FD, *p_g2 = prm + 4 * FD,
         *p_be2 = prm + 5 * FD, *p_gc = prm + 6 * FD, *p_bec = prm + 7 * FD, *p_b1 = prm + 8 * FD;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar address math
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ ctx = reinterpret_cast<const T*>(a.ctx);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
@@ -281,8 +291,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
-      load_frag(cpre[i], ctx + (size_t)m * FD + c8);
-      load_frag(xpre[i], x + (size_t)m * FD + c8);
+      load_frag(cpre[i], gofs(ctx, (unsigned int)(m * FD + c8)));
+      load_frag(xpre[i], gofs(x, (unsigned int)(m * FD + c8)));
     }
   };
   int mb[4], mbn[4];
@@ -432,7 +442,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       // next weight set: W1 chunk ch+1, or Wo for the next tile -- ONE unconditional load sequence from a selected
       // pointer (loads under a branch made hipcc drain vmcnt(0) at the join: the W2 fragments just issued above, i.e.
       // one exposed L2 latency per chunk; Wo is fetched needlessly after a workgroup's last tile, 32 KB once)
-      load_wset(wp, (ch + 1 < nchunk) ? W1 + (size_t)(ch + 1) * FD * FD : Wo, FD, n0, 0, li, lg, a.w_packed);
+      load_wset(wp, (ch + 1 < nchunk) ? W1 + (unsigned int)(ch + 1) * (FD * FD) : Wo, FD, n0, 0, li, lg, a.w_packed);
       STAMP(4);
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
@@ -570,6 +580,8 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   if (!a || a->M <= 0) return 0;
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
+  if ((long long)a->M * a->dff * (dtype == RG_BF16 ? 2 : 4) >= (1ll << 32))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: M * d_ff * element size must be below 4 GiB (32-bit offsets)");
   if ((a->o_bcast || a->cross_s) && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross stage needs L");
   if (a->cross_s && (!a->cross_oh || !a->cross_bo || a->H != 4)) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross_s needs cross_oh, cross_bo, H == P / 32 == 4");
   hipStream_t s = (hipStream_t)stream;
@@ -616,7 +628,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
   T* Adz = reinterpret_cast<T*>(smem + ACT_BYTES);
   T* Adh = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
   T* Ah = reinterpret_cast<T*>(smem + 3 * ACT_BYTES);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar address math
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ dl2 = reinterpret_cast<const T*>(a.dl2);
   const T* __restrict__ dz = reinterpret_cast<const T*>(a.dz);
@@ -656,15 +668,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
-      load_frag(hpre[i], h1 + (size_t)m * a.dff + ch * FD + c8);
+      load_frag(hpre[i], gofs(h1, (unsigned int)m * (unsigned int)a.dff + (unsigned int)(ch * FD + c8)));
     }
   };
   auto prefetch_rows = [&](const int (&g)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
-      load_frag(cpre[i], dl2 + (size_t)m * FD + c8);
-      load_frag(xpre[i], dz + (size_t)m * FD + c8);
+      load_frag(cpre[i], gofs(dl2, (unsigned int)(m * FD + c8)));
+      load_frag(xpre[i], gofs(dz, (unsigned int)(m * FD + c8)));
     }
   };
   auto h_to_lds = [&]() {
@@ -712,7 +724,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
       mma_wset<T>(acc, wp, Adl, li, lg);                 // dg chunk = dl2 . W2t[chunk]^T
-      load_wset(wp, W2t + (size_t)((ch + 1 < nchunk) ? ch + 1 : 0) * FD * FD, FD, n0, 0, li, lg, a.w_packed);
+      load_wset(wp, W2t + (unsigned int)((ch + 1 < nchunk) ? ch + 1 : 0) * (FD * FD), FD, n0, 0, li, lg, a.w_packed);
       if (ch > 0) lds_barrier();                         // readers of the previous dh1 chunk are done, h1 chunk visible
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
@@ -768,6 +780,8 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
   if (!a || a->M <= 0) return 0;
   if (!rg_ffn_bwd_data_supported(a->d, a->dff))
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ffn_bwd_data: needs d_model == 128 and d_ff % 128 == 0");
+  if ((long long)a->M * a->dff * (dtype == RG_BF16 ? 2 : 4) >= (1ll << 32))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ffn_bwd_data: M * d_ff * element size must be below 4 GiB (32-bit offsets)");
   if (!a->dl2 || !a->dz || !a->h1 || !a->W2t || !a->W1t || !a->dh1 || !a->dy)
     return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: NULL operand");
   hipStream_t s = (hipStream_t)stream;
