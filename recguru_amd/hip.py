@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librecguru_hip.so")
+LIB_PATH = os.environ.get("RG_HIP_LIB") or os.path.join(_HERE, "librecguru_hip.so")   # RG_HIP_LIB: another build of the SAME library (A/B kernel experiments, tools/ab_variants.sh)
 _lib = None
 
 F32, BF16 = 0, 1
