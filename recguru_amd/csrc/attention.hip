@@ -1027,7 +1027,11 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     if (CAUSAL && r < L && !padk) atomicMin(&klo_s, r);
   }
   lds_barrier();
-  const int klo = klo_s;
+  const int klo = __builtin_amdgcn_readfirstlane(klo_s);
+  // bit t: query tile t is live -- as a SCALAR (read from LDS per step, the skip test was a full LDS round trip and a
+  // vector compare in front of every step's first MFMA)
+  const unsigned int qmask = (unsigned int)__builtin_amdgcn_readfirstlane(
+      (int)(unsigned int)__ballot(lane < NKT && qlive[min(lane, NKT - 1)] != 0));
 
   typedef __attribute__((ext_vector_type(4))) short s16x4;
   typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -1052,7 +1056,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         ktf16[dt] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(Ks + (kt * 16 + 4 * lg + (li >> 2)) * LDR + dt * 16 + 4 * (li & 3)));
     }
     auto qstep = [&](const int qs) {
-      if (!(qlive[2 * qs] | qlive[2 * qs + 1])) return;     // padded query rows only: dO = 0 there, nothing to add to dK / dV
+      if (!((qmask >> (2 * qs)) & 3u)) return;             // padded query rows only: dO = 0 there, nothing to add to dK / dV
       if (CAUSAL && 2 * qs + 1 < kt && qs * 32 >= klo) return;     // keys entirely in the future of both query tiles: P = dS = 0
       f32x4 p[2], ds[2];
 #pragma unroll
@@ -1073,8 +1077,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         unsigned int km4[4] = {~0u, ~0u, ~0u, ~0u};
         if constexpr (DM == 1) {        // dO is pre-scaled by 1/(1-p): a dropped entry is an AND with 0
           const uint4 w4 = *reinterpret_cast<const uint4*>(dmask + (key >> 5) * LPK + q0 + 4 * lg);
-          km4[0] = rg_bitmask(w4.x >> (key & 31), 0); km4[1] = rg_bitmask(w4.y >> (key & 31), 0);
-          km4[2] = rg_bitmask(w4.z >> (key & 31), 0); km4[3] = rg_bitmask(w4.w >> (key & 31), 0);
+          km4[0] = rg_bitmask(w4.x, key & 31); km4[1] = rg_bitmask(w4.y, key & 31);     // one v_bfe_i32 each
+          km4[2] = rg_bitmask(w4.z, key & 31); km4[3] = rg_bitmask(w4.w, key & 31);
         } else if constexpr (DM == 2) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) ks4[r] = rg_keep(drop, (dbase + min(q0 + 4 * lg + r, L - 1)) * lp4 + key);
@@ -1172,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     const float lse_q = lse2_s[q], dl_q = dl_s[q];
     const int qrel = q - 4 * lg;
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    const int nks = !qlive[qt] ? 0 : ((CAUSAL && qt * 16 >= klo) ? min(nt / 2, qt / 2 + 1) : nt / 2);
+    const int nks = !((qmask >> qt) & 1u) ? 0 : ((CAUSAL && qt * 16 >= klo) ? min(nt / 2, qt / 2 + 1) : nt / 2);
     for (int ks = 0; ks < nks; ++ks) {      // padded query tile: dQ rows stay 0; causal: future key pairs contribute 0
       f32x4 ds[2];
       float kd[2][4] = {{1.f, 1.f, 1.f, 1.f}, {1.f, 1.f, 1.f, 1.f}};
