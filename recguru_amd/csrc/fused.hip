@@ -234,7 +234,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   float* prm = reinterpret_cast<float*>(smem + 3 * ACT_BYTES);           // 8*128 + dff floats
   float* redA = prm + 8 * FD + a.dff;                                     // [64][4]
   float* redB = redA + FT_M * 4;
-  T* Ah = reinterpret_cast<T*>(redB + FT_M * 4);                          // only when h1_save != NULL
+  // p == 0.5 dropout: nibble of hash bits -> 4 multipliers (0 or 1/(1-p)) from a 16-entry table: 2 address ops, one
+  // ds_read_b128 and 4 multiplies per 4 elements instead of a bit extract, an AND and a multiply per element
+  float* klut = redB + FT_M * 4;                                          // [16][4]
+  T* Ah = reinterpret_cast<T*>(klut + 64);                                // only when h1_save != NULL
   float *p_bo = prm, *p_g1 = prm + FD, *p_be1 = prm + 2 * FD, *p_b2 = prm + 3 * FD, *p_g2 = prm + 4 * FD,
         *p_be2 = prm + 5 * FD, *p_gc = prm + 6 * FD, *p_bec = prm + 7 * FD, *p_b1 = prm + 8 * FD;
 
@@ -261,6 +264,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     p_gc[i] = a.gc ? a.gc[i] : 1.f; p_bec[i] = a.bec ? a.bec[i] : 0.f;
   }
   for (int i = tid; i < a.dff; i += 256) p_b1[i] = a.b1[i];
+  if (tid < 64) klut[tid] = (((tid >> 2) >> (tid & 3)) & 1) ? drop1.inv_keep : 0.f;
+  const unsigned int rot0 = (4u * lg + 28u) & 31u, rot1 = (4u * lg + 12u) & 31u;   // hash bit 4 lg + j (16 + 4 lg + j) -> bit 4 + j
 
   WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
   Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
@@ -451,12 +456,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
         for (int rt = 0; rt < 4; ++rt) {
           const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
           if constexpr (DM == 1) {       // rb & 31 == 4*lg: both feature tiles of this lane sit in one hash word
-            const unsigned int w = rg_hash(drop1.seed, rb >> 5) >> (4 * lg);
+            const unsigned int w = rg_hash(drop1.seed, rb >> 5);
+            float k0[4], k1[4];
+            load4f(k0, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
+            load4f(k1, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              acc[0][rt][r] = rg_and(acc[0][rt][r], rg_bitmask(w, r)) * drop1.inv_keep;
-              acc[1][rt][r] = rg_and(acc[1][rt][r], rg_bitmask(w, 16 + r)) * drop1.inv_keep;
-            }
+            for (int r = 0; r < 4; ++r) { acc[0][rt][r] *= k0[r]; acc[1][rt][r] *= k1[r]; }
           } else {
             float k0[4], k1[4];
             rg_keep4_pair(drop1, rb, k0, k1);
@@ -497,12 +502,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       for (int rt = 0; rt < 4; ++rt) {
         const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
         if constexpr (DM == 1) {
-          const unsigned int w = rg_hash(drop2.seed, rb >> 5) >> (4 * lg);
+          const unsigned int w = rg_hash(drop2.seed, rb >> 5);
+          float k0[4], k1[4];
+          load4f(k0, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
+          load4f(k1, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            acc2[0][rt][r] = rg_and(acc2[0][rt][r], rg_bitmask(w, r)) * drop2.inv_keep;
-            acc2[1][rt][r] = rg_and(acc2[1][rt][r], rg_bitmask(w, 16 + r)) * drop2.inv_keep;
-          }
+          for (int r = 0; r < 4; ++r) { acc2[0][rt][r] *= k0[r]; acc2[1][rt][r] *= k1[r]; }
         } else {
           float k0[4], k1[4];
           rg_keep4_pair(drop2, rb, k0, k1);
@@ -588,7 +593,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   const int ntiles = (a->M + FT_M - 1) / FT_M;
   const int esz = dtype == RG_BF16 ? 2 : 4;
   const int act = FT_M * (dtype == RG_BF16 ? FD : FLD) * esz;
-  const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * FT_M * 4 * 4 + (a->h1_save ? act : 0);
+  const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * FT_M * 4 * 4 + 64 * 4 + (a->h1_save ? act : 0);
   const int per_cu = (160 * 1024) / smem;
   int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
   if (grid > ntiles) grid = ntiles;
