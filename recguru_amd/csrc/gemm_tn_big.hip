@@ -10,6 +10,7 @@
 // N1 / N2.  Partial results: with a.partials each workgroup stores its accumulators register-major (every store
 // instruction = 256 contiguous bytes) and tn_big_reduce_kernel sums the slices into dW; without it, f32 atomics
 // (a 16x16 accumulator register is 4 x 64-byte segments per instruction: 256 x |dW| of those cost more than the GEMM).
+#include <cstdlib>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -183,13 +184,228 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product with the token chunks brought in by LDS-DMA (global_load_lds_dwordx4): no staging registers, so a
+// ring of NST 32-token stages fits beside the 128 accumulator registers and NST - 1 chunks (80 KB and more per CU) are in
+// flight at ALL times -- the register-staged kernel above has one 64-token chunk in flight, and only between its LDS
+// store and the next iteration's wait: its chunk time was the HBM latency, 40-46 % of the HBM rate on executed rows.
+//   * a stage is the row-major image [32][N1] | [32][N2] with NO padding (a wave's DMA instruction writes 1 KB
+//     contiguously: wave-uniform base + lane x 16 B); bank conflicts of the transposing fragment reads are avoided by an XOR
+//     swizzle of the 16-byte chunks of a row by 2 (row & 3), applied to the SOURCE address of the DMA and to the reads;
+//   * one raw barrier per chunk: wait (counted vmcnt) for this wave's DMAs of chunk i -> barrier (every wave's have landed,
+//     and everyone is done reading the stage of chunk i - 1) -> issue the DMAs of chunk i + NST - 1 into that stage ->
+//     fragments + MFMAs of chunk i;
+//   * rows past T / absent list entries are DMA'd from clamped (valid, finite) rows so that every chunk is exactly NPER
+//     instructions per wave, and their Y rows are zeroed in LDS behind one extra barrier (last chunk of the kernel only);
+//   * the GELU of the l2 weight gradient (dW2 += dl2^T gelu(h1)) is applied to the X fragments after the read.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int NPER, int K> __device__ __forceinline__ void wait_chunks(int k) {      // at most k chunks stay in flight
+  if constexpr (K == 0) wait_vmcnt<0>();
+  else { if (k >= K) wait_vmcnt<NPER * K>(); else wait_chunks<NPER, K - 1>(k); }
+}
+
+template <int N1, int N2> struct TnDma {
+  static constexpr int CT = 32;
+  static constexpr int YB = CT * N1 * 2, XB = CT * N2 * 2, STG = YB + XB;
+  static constexpr int KY = YB / 8192, KX = XB / 8192, NPER = KY + KX;
+  static constexpr int NSTF = (159 * 1024) / STG;
+  static constexpr int NST = NSTF > 8 ? 8 : NSTF;
+};
+
+template <int N1, int N2, bool GELU_X>
+__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
+  typedef __bf16 T;
+  typedef TnDma<N1, N2> C;
+  constexpr bool SPLIT1 = N1 >= N2;
+  constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;      // n1 tiles per wave
+  constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;      // n2 tiles per wave
+  constexpr int CT = C::CT, KY = C::KY, NPER = C::NPER, NST = C::NST, STG = C::STG;
+  static_assert(NST >= 3 && (NST - 1) * NPER < 64, "ring depth / vmcnt range");
+  extern __shared__ __align__(16) unsigned char smem_td[];                       // the ONLY LDS object (hipcc waits vmcnt(0) before reads otherwise)
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const char* __restrict__ Y = reinterpret_cast<const char*>(a.Y);
+  const char* __restrict__ X = reinterpret_cast<const char*>(a.X);
+  const int m1 = SPLIT1 ? wave * MT * 16 : 0;
+  const int m2 = SPLIT1 ? 0 : wave * NT * 16;
+  const int nlive = a.live16 ? a.live16[0] : 0;
+  const int nchunks = a.live16 ? (nlive + 1) >> 1 : (a.T + CT - 1) / CT;
+  const int per = (nchunks + gridDim.x - 1) / gridDim.x;
+  const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
+  if (c_beg >= c_end) return;
+  const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
+
+  // per-lane source of DMA instruction k: row r of the chunk (r >> 4: which of its two 16-row tiles), swizzled 16-byte chunk
+  int srow[NPER];                   // row inside the chunk (0 .. 31)
+  unsigned int scb[NPER];           // byte offset of the (swizzled) 16-byte chunk inside the row
+#pragma unroll
+  for (int k = 0; k < NPER; ++k) {
+    const bool isy = k < KY;
+    const int n = isy ? N1 : N2;
+    const int o = (wave + 8 * (isy ? k : k - KY)) * 1024 + lane * 16;      // byte offset inside the Y (X) image
+    const int r = o / (2 * n), c = (o % (2 * n)) >> 4;
+    srow[k] = r;
+    scb[k] = (unsigned int)((c ^ ((r & 3) << 1)) * 16);
+  }
+  // This workgroup's slice of the live-tile list goes to LDS once, BEFORE the first DMA: beside LDS-DMAs in flight hipcc
+  // waits vmcnt(0) for any ordinary (register-destination) global load, i.e. a list read per chunk drained the ring
+  int* lst = reinterpret_cast<int*>(smem_td + NST * STG);           // [2 * (c_end - c_beg)] first rows (>= T: absent)
+  if (a.live16) {
+    for (int i = tid; i < 2 * (c_end - c_beg); i += 512) {
+      const int e = 2 * c_beg + i;
+      lst[i] = e < nlive ? a.live16[1 + min(e, nlive - 1)] * 16 : a.T;
+    }
+    __syncthreads();
+  }
+  // LDS reads inside the chunk loop are inline asm: for an LDS read it can see, hipcc waits until EVERY LDS-DMA issued
+  // before it has completed (it cannot tell the stages of the ring apart) -- vmcnt(0) in front of each chunk's fragments.
+  // Ordering is by hand instead: counted vmcnt + barrier before a stage is read (above), lgkmcnt(0) before use.
+  auto bases = [&](int chunk, int& b0, int& b1) {        // first rows of the chunk's two 16-row tiles (>= T: absent)
+    if (a.live16) {
+      long long v;
+      const unsigned int ad = (unsigned int)(size_t)(lst + 2 * (chunk - c_beg));
+      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad) : "memory");
+      b0 = (int)(v & 0xFFFFFFFFll);
+      b1 = (int)(v >> 32);
+    } else {
+      b0 = chunk * CT;
+      b1 = chunk * CT + 16;
+    }
+  };
+  auto issue = [&](int chunk) {
+    int b0, b1;
+    bases(chunk, b0, b1);
+    unsigned char* stage = smem_td + (chunk % NST) * STG;
+#pragma unroll
+    for (int k = 0; k < NPER; ++k) {
+      const bool isy = k < KY;
+      const unsigned int ld2 = (unsigned int)(isy ? a.ldy : a.ldx) * 2u;
+      // rows past the end: clamped to the last row (finite data; their Y rows are zeroed before use)
+      const int row = min((srow[k] >= 16 ? b1 : b0) + (srow[k] & 15), a.T - 1);
+      const char* src = (isy ? Y : X) + (size_t)(unsigned int)row * ld2 + scb[k];
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(stage + (isy ? 0 : C::YB) + (wave + 8 * (isy ? k : k - KY)) * 1024),
+                                       16, 0, 0);
+    }
+  };
+
+  f32x4 acc[MT][NT];
+  f32x4 cs[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    cs[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  Frag<T> ones;
+  frag_fill(ones, 1.f);
+  // fragment (token-major, see frag_tr16) of the 16 columns of column tile ti from the swizzled row-major image [32][n]:
+  // rows 8 lg + q (+ 4), 16-byte chunk (2 ti + (pp >> 1)) ^ (q << 1) = 2 (ti ^ q) + (pp >> 1), 8-byte half pp & 1
+  const int q = li >> 2, pp = li & 3;
+  const unsigned int smem0 = (unsigned int)(size_t)smem_td;
+  const unsigned int ly0 = (unsigned int)((8 * lg + q) * (2 * N1) + ((pp >> 1) << 4) + (pp & 1) * 8);
+  const unsigned int lx0 = (unsigned int)((8 * lg + q) * (2 * N2) + ((pp >> 1) << 4) + (pp & 1) * 8) + (unsigned int)C::YB;
+  typedef long long i64;
+  auto rd_y = [&](i64& lo, i64& hi, unsigned int stage_ofs, int ti) {
+    const unsigned int ad = smem0 + stage_ofs + ly0 + (((unsigned int)ti ^ (unsigned int)q) << 5);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(ad), "n"(8 * N1) : "memory");
+  };
+  auto rd_x = [&](i64& lo, i64& hi, unsigned int stage_ofs, int ti) {
+    const unsigned int ad = smem0 + stage_ofs + lx0 + (((unsigned int)ti ^ (unsigned int)q) << 5);
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %2 offset:%3" : "=&v"(lo), "=&v"(hi) : "v"(ad), "n"(8 * N2) : "memory");
+  };
+  auto to_frag = [&](Frag<T>& f, i64 lo, i64 hi, bool gelu) {
+    union { i64 l; bf16x4_t b; } u0, u1;
+    u0.l = lo; u1.l = hi;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      f.v[j] = gelu ? (T)gelu_t<false>((float)u0.b[j]) : u0.b[j];
+      f.v[4 + j] = gelu ? (T)gelu_t<false>((float)u1.b[j]) : u1.b[j];
+    }
+  };
+
+  // prologue: NST - 1 chunks in flight
+#pragma unroll 1
+  for (int c = c_beg; c < c_end && c < c_beg + NST - 1; ++c) issue(c);
+#pragma unroll 1
+  for (int chunk = c_beg; chunk < c_end; ++chunk) {
+    wait_chunks<NPER, NST - 2>(min(NST - 2, c_end - 1 - chunk));      // this wave's DMAs of `chunk` have landed
+    lds_barrier();                                                      // ... and everyone else's; stage of chunk - 1 is free
+    if (chunk + NST - 1 < c_end) issue(chunk + NST - 1);
+    unsigned char* stage = smem_td + (chunk % NST) * STG;
+    if (chunk == nchunks - 1) {                       // only the kernel's last chunk can hold rows that do not exist
+      int b0, b1;
+      bases(chunk, b0, b1);
+      b0 = __builtin_amdgcn_readfirstlane(b0);
+      b1 = __builtin_amdgcn_readfirstlane(b1);
+      if (b0 + 16 > a.T || b1 + 16 > a.T) {           // zero their Y rows
+        for (int i = tid; i < CT * N1 / 8; i += 512) {
+          const int r = i / (N1 / 8);
+          const int row = (r < 16 ? b0 : b1) + (r & 15);
+          if (row >= a.T) *reinterpret_cast<uint4*>(stage + i * 16) = make_uint4(0u, 0u, 0u, 0u);
+        }
+        lds_barrier();
+      }
+    }
+    const unsigned int sofs = (unsigned int)((chunk % NST) * STG);
+    i64 ya[MT][2], xb[NT][2];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rd_y(ya[i][0], ya[i][1], sofs, (m1 >> 4) + i);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) rd_x(xb[j][0], xb[j][1], sofs, (m2 >> 4) + j);
+    // every read has landed before any fragment is used (the registers pass through the wait: no MFMA moves above it)
+    if constexpr (MT + NT == 12) {
+      asm volatile("s_waitcnt lgkmcnt(0)"
+                   : "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(ya[1][0]), "+v"(ya[1][1]), "+v"(ya[2][0]), "+v"(ya[2][1]),
+                     "+v"(ya[3][0]), "+v"(ya[3][1]), "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]),
+                     "+v"(xb[2][0]), "+v"(xb[2][1]), "+v"(xb[3][0]), "+v"(xb[3][1]),
+                     "+v"((MT > NT ? ya : xb)[4][0]), "+v"((MT > NT ? ya : xb)[4][1]), "+v"((MT > NT ? ya : xb)[5][0]),
+                     "+v"((MT > NT ? ya : xb)[5][1]), "+v"((MT > NT ? ya : xb)[6][0]), "+v"((MT > NT ? ya : xb)[6][1]),
+                     "+v"((MT > NT ? ya : xb)[7][0]), "+v"((MT > NT ? ya : xb)[7][1]));
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[i][0]), "+v"(ya[i][1]));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
+    }
+    Frag<T> af[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      to_frag(af[i], ya[i][0], ya[i][1], false);
+      if (do_cs) mma(af[i], ones, cs[i]);
+    }
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      Frag<T> bf;
+      to_frag(bf, xb[j][0], xb[j][1], GELU_X);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+    }
+  }
+  float* __restrict__ part = a.partials ? a.partials + (size_t)blockIdx.x * (N1 * N2) + tid : nullptr;
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (part) part[((i * NT + j) * 4 + r) * 512] = acc[i][j][r];     // element e = slot * 512 + tid of this workgroup's slice
+        else atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
+      }
+    if (do_cs && li == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
+    }
+  }
+}
+
 // dW += scale * sum over the active workgroups' slices.  Thread = one element e of the register-major slice layout
 // (coalesced across threads for every slice); blockIdx.y splits the slices so that small dW still fill the chip.
 template <int N1, int N2>
-__global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, int grid1) {
+__global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, int grid1, int ct) {     // ct: tokens per chunk of the first launch
   constexpr bool SPLIT1 = N1 >= N2;
   constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;
-  const int nchunks = a.live16 ? (a.live16[0] + 3) >> 2 : (a.T + TB_T - 1) / TB_T;
+  const int nchunks = a.live16 ? (a.live16[0] + ct / 16 - 1) / (ct / 16) : (a.T + ct - 1) / ct;
   if (nchunks <= 0) return;
   const int per = (nchunks + grid1 - 1) / grid1;
   const int nact = (nchunks + per - 1) / per;          // workgroups of the first launch that had a token range
@@ -212,22 +428,38 @@ __global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, i
   atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, ((s0 + s1) + (s2 + s3)) * a.scale);
 }
 
+static int tn_use_dma() {            // RG_TN_REGSTAGE=1: the register-staged kernel (kept for A/B timing, tools/kb_tn.py)
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("RG_TN_REGSTAGE"); v = (e && e[0] == '1') ? 0 : 1; }
+  return v;
+}
+
 template <int N1, int N2>
 static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
-  const int nchunks = (a.T + TB_T - 1) / TB_T;
+  // the DMA kernel keeps its slice of the live-tile list in LDS behind the ring: T up to ~4 M rows (64 K chunks per workgroup)
+  const bool dma = tn_use_dma() != 0 && (long long)TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + ((a.T + 31) / 32 / 256 + 2) * 8 <= 160 * 1024;
+  const int ct = dma ? TnDma<N1, N2>::CT : TB_T;
+  const int nchunks = (a.T + ct - 1) / ct;
   int grid = nchunks < 256 ? nchunks : 256;
-  const int smem = TB_T * (N1 + 8 + N2 + 8) * 2;
+  const int per = (nchunks + grid - 1) / grid;
+  const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + 2 * per * 4 : TB_T * (N1 + 8 + N2 + 8) * 2;
+#define RG_TNB(KERN)                                                                                                     \
+  do {                                                                                                                    \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, smem);           \
+    hipLaunchKernelGGL((KERN), dim3(grid), dim3(512), smem, s, a);                                                        \
+  } while (0)
   if (a.prologue_x == RG_PRO_GELU) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<N1, N2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, true>), dim3(grid), dim3(512), smem, s, a);
+    if (dma) RG_TNB((gemm_tn_dma_kernel<N1, N2, true>));
+    else RG_TNB((gemm_tn_big_kernel<N1, N2, true>));
   } else {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_big_kernel<N1, N2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    hipLaunchKernelGGL((gemm_tn_big_kernel<N1, N2, false>), dim3(grid), dim3(512), smem, s, a);
+    if (dma) RG_TNB((gemm_tn_dma_kernel<N1, N2, false>));
+    else RG_TNB((gemm_tn_big_kernel<N1, N2, false>));
   }
+#undef RG_TNB
   if (a.partials) {
     const int gx = N1 * N2 / 256;
     const int gy = gx >= 256 ? 4 : (gx >= 128 ? 8 : 16);
-    hipLaunchKernelGGL((tn_big_reduce_kernel<N1, N2>), dim3(gx, gy), dim3(256), 0, s, a, grid);
+    hipLaunchKernelGGL((tn_big_reduce_kernel<N1, N2>), dim3(gx, gy), dim3(256), 0, s, a, grid, ct);
   }
   RG_CHECK_LAUNCH();
   return 0;

@@ -17,7 +17,7 @@ for n1, n2 in ((512, 128), (128, 512), (384, 128), (128, 128)):
     Y, X = r(M, n1) * mk, r(M, n2)
     dW = torch.zeros(n1, n2, device="cuda"); cs = torch.zeros(n1, device="cuda")
     for nm, lv, pt in (("full", None, True), ("live", live, True), ("live/atomics", live, False)):
-        us = timeit(lambda: hip.gemm_tn(Y, X, dW=dW, colsum=cs, live=lv, partials=pt))
+        us = min(timeit(lambda: hip.gemm_tn(Y, X, dW=dW, colsum=cs, live=lv, partials=pt), n=10, warm=2) for _ in range(5))
         by = M * (n1 + n2) * 2 * (1.0 if lv is None else float(mask.view(-1, 16).amax(1).mean()))
         print("tn_big %3dx%3d %-12s %7.1f us  %6.0f GB/s actual" % (n1, n2, nm, us, by / us / 1e3))
 if len(sys.argv) > 1:
