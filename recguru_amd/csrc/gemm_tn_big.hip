@@ -348,34 +348,30 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
       }
     }
     const unsigned int sofs = (unsigned int)((chunk % NST) * STG);
+    // Y fragments and the first X fragment up front; X fragment j + 1 is read while the MFMAs of fragment j run.  LDS reads
+    // return in order: with the two reads of fragment j + 1 outstanding, lgkmcnt(2) says everything before them has landed.
+    // The registers pass through the wait statements, so no MFMA moves above the wait that covers its operands.
     i64 ya[MT][2], xb[NT][2];
 #pragma unroll
     for (int i = 0; i < MT; ++i) rd_y(ya[i][0], ya[i][1], sofs, (m1 >> 4) + i);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) rd_x(xb[j][0], xb[j][1], sofs, (m2 >> 4) + j);
-    // every read has landed before any fragment is used (the registers pass through the wait: no MFMA moves above it)
-    if constexpr (MT + NT == 12) {
-      asm volatile("s_waitcnt lgkmcnt(0)"
-                   : "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(ya[1][0]), "+v"(ya[1][1]), "+v"(ya[2][0]), "+v"(ya[2][1]),
-                     "+v"(ya[3][0]), "+v"(ya[3][1]), "+v"(xb[0][0]), "+v"(xb[0][1]), "+v"(xb[1][0]), "+v"(xb[1][1]),
-                     "+v"(xb[2][0]), "+v"(xb[2][1]), "+v"(xb[3][0]), "+v"(xb[3][1]),
-                     "+v"((MT > NT ? ya : xb)[4][0]), "+v"((MT > NT ? ya : xb)[4][1]), "+v"((MT > NT ? ya : xb)[5][0]),
-                     "+v"((MT > NT ? ya : xb)[5][1]), "+v"((MT > NT ? ya : xb)[6][0]), "+v"((MT > NT ? ya : xb)[6][1]),
-                     "+v"((MT > NT ? ya : xb)[7][0]), "+v"((MT > NT ? ya : xb)[7][1]));
-    } else {
-#pragma unroll
-      for (int i = 0; i < MT; ++i) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(ya[i][0]), "+v"(ya[i][1]));
-#pragma unroll
-      for (int j = 0; j < NT; ++j) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
-    }
+    rd_x(xb[0][0], xb[0][1], sofs, m2 >> 4);
     Frag<T> af[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      to_frag(af[i], ya[i][0], ya[i][1], false);
-      if (do_cs) mma(af[i], ones, cs[i]);
-    }
-#pragma unroll
     for (int j = 0; j < NT; ++j) {
+      if (j + 1 < NT) {
+        rd_x(xb[j + 1][0], xb[j + 1][1], sofs, (m2 >> 4) + j + 1);
+        asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
+      } else {
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
+      }
+      if (j == 0) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          asm volatile("" : "+v"(ya[i][0]), "+v"(ya[i][1]));          // (landed with x_0: read before it)
+          to_frag(af[i], ya[i][0], ya[i][1], false);
+          if (do_cs) mma(af[i], ones, cs[i]);
+        }
+      }
       Frag<T> bf;
       to_frag(bf, xb[j][0], xb[j][1], GELU_X);
 #pragma unroll
