@@ -418,7 +418,18 @@ typedef struct {
   int M, d, dff, w_packed;
   float nz_scale;      /* > 0: dropout on h1 was active, 1/(1-p) */
   const int* live16;
+  /* Optional: the LayerNorm backward in front (rg_ln_bwd: nn.LayerNorm of transformer.py:188 from its saved OUTPUT, the
+   * `* pad_mask` of :594 / :539 and the output dropout of :186-187) computed inside the kernel from the rows it stages
+   * anyway.  ln_dout != NULL: dl2 / dz above are ignored as inputs; dz stays on chip, dl2 (= dz, or dz * dropmask /
+   * (1 - p)) is WRITTEN to dl2_out [M,128] for the l2 weight-gradient product, dgamma / dbeta are accumulated (through
+   * ln_partials, >= rg_ffn_bwd_ln_workspace() bytes, then a reduce launch).  Rows of padded tiles (live16) of dl2_out are
+   * left untouched.  Saves the dz / dl2 round trip through HBM: 3.75 KB -> 3 KB per token for the pair of launches. */
+  const void* ln_dout; const void* ln_out; const float* ln_rstd; const float* ln_gamma; const float* ln_beta;
+  const float* ln_rowmask;     /* optional [M] */
+  void* dl2_out; float* ln_dgamma; float* ln_dbeta; float* ln_partials;
+  float ln_drop_p; unsigned long long ln_drop_seed;
 } rg_ffn_bwd_args;
+size_t rg_ffn_bwd_ln_workspace(int M);
 int rg_ffn_bwd_data(const rg_ffn_bwd_args* args /* host */, int dtype, void* stream);
 int rg_ffn_bwd_data_supported(int d, int dff);
 /* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their

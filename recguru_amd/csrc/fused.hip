@@ -625,7 +625,9 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 // (and the dropout mask read back from h1 != 0), goes to LDS as the B operand of the second product and to HBM as dh1
 // for the weight-gradient kernel; dy accumulates across chunks and leaves with the residual gradient added.
 // LDS: 4 tiles (dl2 -> dy staging | dz | dh1 chunk | h1 chunk) = 64 KB (bf16): two workgroups per CU.
-template <typename T>
+// LNF: the LayerNorm backward (+ row mask + output dropout) in front of the block is computed here, on the rows as they
+// arrive -- the staging layout (16 lanes x 8 features per row) is rg_ln_bwd's; dz never leaves the chip.
+template <typename T, bool LNF>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_kernel(rg_ffn_bwd_args a) {
   constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
@@ -635,8 +637,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
   T* Ah = reinterpret_cast<T*>(smem + 3 * ACT_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar address math
   const int li = lane & 15, lg = lane >> 4;
-  const T* __restrict__ dl2 = reinterpret_cast<const T*>(a.dl2);
-  const T* __restrict__ dz = reinterpret_cast<const T*>(a.dz);
+  const T* __restrict__ dl2 = reinterpret_cast<const T*>(LNF ? a.ln_dout : a.dl2);      // LNF: dout and the saved LN output
+  const T* __restrict__ dz = reinterpret_cast<const T*>(LNF ? a.ln_out : a.dz);
+  T* __restrict__ dl2o = reinterpret_cast<T*>(a.dl2_out);
   const T* __restrict__ h1 = reinterpret_cast<const T*>(a.h1);
   const T* __restrict__ W2t = reinterpret_cast<const T*>(a.W2t);
   const T* __restrict__ W1t = reinterpret_cast<const T*>(a.W1t);
@@ -649,6 +652,15 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 
   WSet<T> wp, wq;                           // wp: W2t chunks (first product), wq: W1t chunks (second product)
   Frag<T> cpre[4], xpre[4], hpre[4];        // dl2 / dz rows of the next tile, h1 rows of the next chunk
+  float rs_pre[4], rm_pre[4];               // LNF: rstd and row mask of this thread's 4 rows of the next tile
+  float dg[8], db[8];                       // LNF: this thread's column sums (features 8 (tid & 15) ..)
+  const DropCfg ldrop = make_drop(a.ln_drop_p, a.ln_drop_seed);
+  float* lnp = reinterpret_cast<float*>(smem + 4 * ACT_BYTES);      // LNF: gamma | beta | 1 / gamma
+  if constexpr (LNF) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+    for (int i = tid; i < FD; i += 256) { lnp[i] = a.ln_gamma[i]; lnp[FD + i] = a.ln_beta[i]; lnp[2 * FD + i] = 1.f / a.ln_gamma[i]; }
+  }
 
   const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
   int cur = (int)blockIdx.x;
@@ -682,6 +694,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
       load_frag(cpre[i], gofs(dl2, (unsigned int)(m * FD + c8)));
       load_frag(xpre[i], gofs(dz, (unsigned int)(m * FD + c8)));
+      if constexpr (LNF) {
+        // unconditional loads (a load under a condition is waited for at the join, i.e. with everything issued before it)
+        const float* __restrict__ rmp = a.ln_rowmask ? a.ln_rowmask : a.ln_rstd;
+        const float rv = rmp[m];
+        rs_pre[i] = a.ln_rstd[m];
+        rm_pre[i] = a.ln_rowmask ? rv : 1.f;
+      }
     }
   };
   auto h_to_lds = [&]() {
@@ -700,11 +719,61 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
   }
   for (; have;) {
     const bool have_next = next_group(mbn);
+    if constexpr (LNF) {
+      // LayerNorm backward of this thread's 4 row pieces (rg_ln_bwd's arithmetic, statistic by statistic):
+      //   g = dy * rowmask * gamma ; dz = rstd * (g - mean(g) - xhat * mean(g * xhat)), xhat = (y / rowmask - beta) / gamma
+      const int c8 = (tid & 15) * 8;
+      float gam[8], bet[8], igam[8];
+      load8(gam, lnp + c8);
+      load8(bet, lnp + FD + c8);
+      load8(igam, lnp + 2 * FD + c8);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      *reinterpret_cast<Frag<T>*>(Adl + Tile<T>::off(r, c8)) = cpre[i];
-      *reinterpret_cast<Frag<T>*>(Adz + Tile<T>::off(r, c8)) = xpre[i];
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * i + (tid >> 4), m = mb[i] + (tid >> 4);
+        const bool live = m < a.M;
+        const float rm = live ? rm_pre[i] : 0.f;
+        float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+        if (rm != 0.f) {
+          const float irm = 1.f / rm;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = (float)cpre[i].v[j] * rm;
+            xh[j] = ((float)xpre[i].v[j] * irm - bet[j]) * igam[j];
+            g[j] = d * gam[j];
+            dg[j] += d * xh[j];
+            db[j] += d;
+            s1 += g[j];
+            s2 += g[j] * xh[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { g[j] = 0.f; xh[j] = 0.f; }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float rstd = rm != 0.f ? rs_pre[i] : 0.f;
+        s1 *= 1.f / FD;
+        s2 *= 1.f / FD;
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
+        store8(Adz + Tile<T>::off(r, c8), o8);
+        if (ldrop.thresh != 0u || ldrop.onebit) {
+          float k8[8];
+          rg_keep8(ldrop, (unsigned int)m * (unsigned int)FD + (unsigned int)c8, k8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o8[j] *= k8[j];
+        }
+        store8(Adl + Tile<T>::off(r, c8), o8);
+        if (live) store8(gofs(dl2o, (unsigned int)(m * FD + c8)), o8);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
+        *reinterpret_cast<Frag<T>*>(Adl + Tile<T>::off(r, c8)) = cpre[i];
+        *reinterpret_cast<Frag<T>*>(Adz + Tile<T>::off(r, c8)) = xpre[i];
+      }
     }
     h_to_lds();
     lds_barrier();
@@ -777,9 +846,50 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
       zero_to_hbm<T>(dy, FD, 0, md, a.M, tid);
     }
   }
+  if constexpr (LNF) {
+    // dgamma / dbeta: lanes with the same feature octet -> waves -> this workgroup's slice of the partials
+#pragma unroll
+    for (int o = 16; o < 64; o <<= 1)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { dg[j] += __shfl_xor(dg[j], o); db[j] += __shfl_xor(db[j], o); }
+    float* red = reinterpret_cast<float*>(smem);          // [2][4][128] over the (dead) first tile
+    __syncthreads();
+    if (lane < 16) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { red[(0 * 4 + wave) * FD + lane * 8 + j] = dg[j]; red[(1 * 4 + wave) * FD + lane * 8 + j] = db[j]; }
+    }
+    __syncthreads();
+    const int w = tid >> 7, n = tid & 127;                // 256 threads = 2 x 128
+    a.ln_partials[((size_t)blockIdx.x * 2 + w) * FD + n] = (red[(w * 4 + 0) * FD + n] + red[(w * 4 + 1) * FD + n]) + (red[(w * 4 + 2) * FD + n] + red[(w * 4 + 3) * FD + n]);
+  }
+}
+
+// dgamma / dbeta += column sums of the workgroups' partials [nblocks][2][128]
+__global__ __launch_bounds__(256) void ffn_bwd_ln_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                                                float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = threadIdx.x;                              // 0 .. 255: [2][128]
+  float* dst = c < FD ? dgamma : dbeta;
+  if (!dst) return;
+  float s0 = 0.f, s1 = 0.f;
+  int b = blockIdx.x;
+  for (; b + (int)gridDim.x < nblocks; b += 2 * gridDim.x) {
+    s0 += partials[(size_t)b * 2 * FD + c];
+    s1 += partials[(size_t)(b + gridDim.x) * 2 * FD + c];
+  }
+  if (b < nblocks) s0 += partials[(size_t)b * 2 * FD + c];
+  atomicAdd(dst + (c & (FD - 1)), s0 + s1);
 }
 
 extern "C" int rg_ffn_bwd_data_supported(int d, int dff) { return d == FD && dff > 0 && (dff % FD) == 0; }
+
+static int ffn_bwd_grid(int M, int dtype) {               // persistent workgroups: two per CU (bf16), one (f32)
+  const int ntiles = (M + FT_M - 1) / FT_M;
+  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * (dtype == RG_BF16 ? 2 : 4);
+  const int per_cu = (160 * 1024) / smem;
+  const int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
+  return grid > ntiles ? ntiles : grid;
+}
+extern "C" size_t rg_ffn_bwd_ln_workspace(int M) { return (size_t)(M <= 0 ? 0 : 512) * 2 * FD * sizeof(float); }
 
 extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;
@@ -787,24 +897,27 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ffn_bwd_data: needs d_model == 128 and d_ff % 128 == 0");
   if ((long long)a->M * a->dff * (dtype == RG_BF16 ? 2 : 4) >= (1ll << 32))
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "ffn_bwd_data: M * d_ff * element size must be below 4 GiB (32-bit offsets)");
-  if (!a->dl2 || !a->dz || !a->h1 || !a->W2t || !a->W1t || !a->dh1 || !a->dy)
+  const bool lnf = a->ln_dout != nullptr;
+  if ((!lnf && (!a->dl2 || !a->dz)) || !a->h1 || !a->W2t || !a->W1t || !a->dh1 || !a->dy)
     return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: NULL operand");
+  if (lnf && (!a->ln_out || !a->ln_rstd || !a->ln_gamma || !a->ln_beta || !a->dl2_out || !a->ln_partials))
+    return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: the fused LayerNorm backward needs ln_out, ln_rstd, ln_gamma, ln_beta, dl2_out, ln_partials");
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (a->M + FT_M - 1) / FT_M;
   const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz;
-  const int per_cu = (160 * 1024) / smem;
-  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
-  if (grid > ntiles) grid = ntiles;
-#define RG_FB(T)                                                                                                          \
+  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz + (lnf ? 3 * FD * 4 : 0);
+  const int grid = ffn_bwd_grid(a->M, dtype);
+#define RG_FB(T, L)                                                                                                       \
   do {                                                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_data_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-    hipLaunchKernelGGL((ffn_bwd_data_kernel<T>), dim3(grid), dim3(256), smem, s, *a);                                     \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_bwd_data_kernel<T, L>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((ffn_bwd_data_kernel<T, L>), dim3(grid), dim3(256), smem, s, *a);                                  \
   } while (0)
-  if (dtype == RG_BF16) RG_FB(__bf16);
-  else if (dtype == RG_F32) RG_FB(float);
+  if (dtype == RG_BF16) { if (lnf) RG_FB(__bf16, true); else RG_FB(__bf16, false); }
+  else if (dtype == RG_F32) { if (lnf) RG_FB(float, true); else RG_FB(float, false); }
   else return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: bad dtype");
 #undef RG_FB
+  if (lnf && (a->ln_dgamma || a->ln_dbeta))
+    hipLaunchKernelGGL(ffn_bwd_ln_reduce_kernel, dim3(grid < 32 ? grid : 32), dim3(256), 0, s, a->ln_partials, grid, a->ln_dgamma, a->ln_dbeta);
   RG_CHECK_LAUNCH();
   return 0;
 }

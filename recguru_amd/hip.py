@@ -62,7 +62,10 @@ class PostAttnArgs(ctypes.Structure):
 
 class FfnBwdArgs(ctypes.Structure):
     _fields_ = [("dl2", c_p), ("dz", c_p), ("h1", c_p), ("W2t", c_p), ("W1t", c_p), ("dh1", c_p), ("dy", c_p),
-                ("M", c_i), ("d", c_i), ("dff", c_i), ("w_packed", c_i), ("nz_scale", c_f), ("live16", c_p)]
+                ("M", c_i), ("d", c_i), ("dff", c_i), ("w_packed", c_i), ("nz_scale", c_f), ("live16", c_p),
+                ("ln_dout", c_p), ("ln_out", c_p), ("ln_rstd", c_p), ("ln_gamma", c_p), ("ln_beta", c_p), ("ln_rowmask", c_p),
+                ("dl2_out", c_p), ("ln_dgamma", c_p), ("ln_dbeta", c_p), ("ln_partials", c_p),
+                ("ln_drop_p", c_f), ("ln_drop_seed", c_u64)]
 
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
@@ -75,7 +78,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
-           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported"]
+           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -679,21 +682,38 @@ def ffn_bwd_data_supported(d, dff):
     return bool(lib().rg_ffn_bwd_data_supported(int(d), int(dff)))
 
 
-def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False):
+def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False, ln=None):
     """Data path of the FFN block's backward in one launch (rg_ffn_bwd_data): returns (dh1 [M,dff], dy [M,d]) with
     dh1 = (dl2 W2) * gelu'(h1) [* dropout mask read back from h1 != 0], dy = dh1 W1 + dz.  W2t / W1t are the transposed
     operand copies ([dff,d] / [d,dff]), fragment-packed when w_packed.  With a live-tile list the padded tiles' rows of
-    dh1 stay unwritten and those of dy are zeros."""
-    M, d = dl2.shape
+    dh1 stay unwritten and those of dy are zeros.
+    ln = (dout, out, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p, drop_seed): the LayerNorm backward in front
+    (ln_bwd's arguments) runs inside the kernel; dl2 / dz are not inputs then (pass None) and the call returns
+    (dh1, dy, dl2) with dl2 the gradient at the l2 output (for the weight-gradient product)."""
+    src = ln[0] if ln is not None else dl2
+    M, d = src.shape
     dff = h1.shape[1]
-    dh1 = torch.empty(M, dff, device=dl2.device, dtype=dl2.dtype)
+    dh1 = torch.empty(M, dff, device=src.device, dtype=src.dtype)
     if POISON_UNWRITTEN and live is not None:
         dh1.fill_(float("nan"))
-    dy = torch.empty(M, d, device=dl2.device, dtype=dl2.dtype)
+    dy = torch.empty(M, d, device=src.device, dtype=src.dtype)
     a = FfnBwdArgs(_p(dl2), _p(dz), _p(h1), _p(W2t), _p(W1t), _p(dh1), _p(dy), M, d, dff, 1 if w_packed else 0,
                    float(nz_scale), _p(live))
-    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), dt_of(dl2), _stream()), "rg_ffn_bwd_data")
-    return dh1, dy
+    dl2o = None
+    if ln is not None:
+        dout, out, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p, drop_seed = ln
+        assert dout.is_contiguous() and out.is_contiguous() and dout.dtype == out.dtype
+        dl2o = torch.empty(M, d, device=src.device, dtype=src.dtype)
+        if POISON_UNWRITTEN and live is not None:
+            dl2o.fill_(float("nan"))
+        fn = lib().rg_ffn_bwd_ln_workspace
+        fn.restype = ctypes.c_size_t
+        ws = _tn_workspace(src.device, int(fn(M)), "ffn_ln")
+        a.ln_dout, a.ln_out, a.ln_rstd, a.ln_gamma, a.ln_beta, a.ln_rowmask = _p(dout), _p(out), _p(rstd), _p(gamma), _p(beta), _p(rowmask)
+        a.dl2_out, a.ln_dgamma, a.ln_dbeta, a.ln_partials = _p(dl2o), _p(dgamma), _p(dbeta), _p(ws)
+        a.ln_drop_p, a.ln_drop_seed = float(drop_p), int(drop_seed)
+    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), dt_of(src), _stream()), "rg_ffn_bwd_data")
+    return (dh1, dy, dl2o) if ln is not None else (dh1, dy)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -808,10 +828,11 @@ def _work_attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, *a, **k):
 
 
 def _work_ffn_bwd(dl2, dz, h1, *a, **k):
-    M, d = dl2.shape
+    src = k["ln"][0] if k.get("ln") is not None else dl2
+    M, d = src.shape
     dff = h1.shape[1]
-    return ("ffn_bwd_data_kernel<%s>" % ("bf16" if dl2.dtype == torch.bfloat16 else "f32"), 4.0 * M * d * dff,
-            M * (3 * d + 2 * dff) * _esize(dl2))
+    return ("ffn_bwd_data_kernel<%s>" % ("bf16" if src.dtype == torch.bfloat16 else "f32"), 4.0 * M * d * dff,
+            M * ((4 if k.get("ln") is not None else 3) * d + 2 * dff) * _esize(src))
 
 
 _WORK = {"ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,

@@ -485,6 +485,7 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
 
 
 FUSE_FFN_BWD = True      # rg_ffn_bwd_data for d_model == 128, d_ff % 128 == 0 (False: the two separate products)
+FUSE_FFN_BWD_LN = True   # ... with the LayerNorm backward in front computed inside it (False: a separate rg_ln_bwd launch)
 
 
 def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, seed_out=0):
@@ -496,13 +497,21 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     d, dff = W2.shape
     live = _live(rowmask, dout.shape[0], d == 128 and dff == 512)   # padded 16-row tiles: zero upstream gradient, skipped
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
+    (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
+    (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
+    if FUSE_FFN_BWD and FUSE_FFN_BWD_LN and hip.ffn_bwd_data_supported(d, dff):
+        # LayerNorm backward + both data-path products in ONE launch: dz never reaches HBM, dl2 is written once
+        dh1, dy, dl2 = hip.ffn_bwd_data(None, None, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),
+                                        nz_scale=_inv_keep(drop_p), live=live, w_packed=True,
+                                        ln=(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out))
+        hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
+        hip.gemm_tn(dh1, y, dW1, db1, live=live)
+        return dy, (rW1, rb1, rW2, rb2, rg, rbe)
     if drop_p > 0:
         dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out, live=live)
     else:
         dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
-    (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
-    (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
     if FUSE_FFN_BWD and hip.ffn_bwd_data_supported(d, dff):
         # one launch for both data-path products: dh1 is written once (for dW1) and never read back
         dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),

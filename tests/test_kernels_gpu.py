@@ -891,3 +891,54 @@ def test_ffn_bwd_data_vs_two_products_and_torch(dt, M, dff, drop_p, listed):
         assert torch.equal(dh1_l[live_rows], dh1[live_rows]) and torch.equal(dy_l[live_rows], dy[live_rows])
         assert float(dy_l[~live_rows].abs().max()) == 0.0
         assert bool(torch.isnan(dh1_l[~live_rows].float()).all())                 # untouched (poisoned by the binding)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,dff,drop_p,listed", [(203, 512, 0.0, False), (131, 256, 0.5, False), (9000, 512, 0.5, True),
+                                                 (9000, 512, 0.3, True), (9000, 128, 0.0, True)])
+def test_ffn_bwd_data_with_layernorm_backward_inside(dt, M, dff, drop_p, listed):
+    """rg_ffn_bwd_data with the LayerNorm backward in front computed in-kernel == rg_ln_bwd followed by the plain form:
+    dl2 (the gradient at the l2 output, dropout mask applied), dh1, dy and the accumulated dgamma / dbeta."""
+    from recguru_amd import hip
+    d = 128
+    f32 = torch.float32
+    g, be = 1 + 0.1 * rnd(d, dt=f32, seed=1), 0.1 * rnd(d, dt=f32, seed=2)
+    mask = _pad_mask(M // 120, 120, M) if listed else (torch.arange(M) % 7 != 3).float().cuda()
+    live = hip.live_tiles(mask, M) if listed else None
+    z = rnd(M, d, dt=f32, seed=3)
+    rstd = 1 / torch.sqrt(z.var(1, unbiased=False) + 1e-8)
+    out = (torch.nn.functional.layer_norm(z, (d,), g, be, 1e-8) * mask[:, None]).to(dt)
+    dout = rnd(M, d, dt=dt, seed=4)
+    h1 = rnd(M, dff, dt=dt, seed=5)
+    nz = 0.0
+    if drop_p > 0:
+        h1 = h1 * (torch.rand(M, dff, generator=torch.Generator().manual_seed(6)) >= drop_p).cuda().to(dt)
+        nz = 1.0 / (1.0 - drop_p)
+    W1, W2 = rnd(dff, d, dt=f32, scale=d ** -0.5, seed=7), rnd(d, dff, dt=f32, scale=dff ** -0.5, seed=8)
+    W2tp, W1tp = hip.cast(W2, dt, transpose=hip.CAST_TRANSPOSE | hip.CAST_PACK), hip.cast(W1, dt, transpose=hip.CAST_TRANSPOSE | hip.CAST_PACK)
+    # reference: the two launches
+    dg0, db0 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    if drop_p > 0:
+        dz, dl2 = hip.ln_bwd(dout, out, rstd, g, be, mask, dg0, db0, drop_p, 77, live=live)
+    else:
+        dz = dl2 = hip.ln_bwd(dout, out, rstd, g, be, mask, dg0, db0, live=live)
+    dh1_0, dy_0 = hip.ffn_bwd_data(dl2, dz, h1, W2tp, W1tp, nz_scale=nz, live=live, w_packed=True)
+    # one launch
+    dg1, db1 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dh1_1, dy_1, dl2_1 = hip.ffn_bwd_data(None, None, h1, W2tp, W1tp, nz_scale=nz, live=live, w_packed=True,
+                                          ln=(dout, out, rstd, g, be, mask, dg1, db1, drop_p, 77))
+    rows = torch.ones(M, dtype=torch.bool, device="cuda")
+    if listed:
+        r16 = torch.zeros((M + 15) // 16 * 16, device="cuda")
+        r16[:M] = mask
+        rows = r16.view(-1, 16).amax(1).repeat_interleave(16)[:M] != 0
+    assert torch.equal(dl2_1[rows], dl2[rows])                   # same arithmetic, statistic by statistic
+    assert torch.equal(dh1_1[rows], dh1_0[rows]) and torch.equal(dy_1[rows], dy_0[rows])
+    if listed:
+        assert float(dy_1[~rows].abs().max()) == 0.0
+    torch.testing.assert_close(dg1, dg0, rtol=2e-4, atol=2e-4 * float(dg0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=2e-4, atol=2e-4 * float(db0.abs().max()))
+    # accumulation into existing gradients
+    hip.ffn_bwd_data(None, None, h1, W2tp, W1tp, nz_scale=nz, live=live, w_packed=True,
+                     ln=(dout, out, rstd, g, be, mask, dg1, db1, drop_p, 77))
+    torch.testing.assert_close(dg1, 2 * dg0, rtol=2e-4, atol=4e-4 * float(dg0.abs().max()))
