@@ -98,7 +98,8 @@ int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
 size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* args /* host */, int dtype);
 /* Plan queries (no launch): the name of the kernel rg_gemm_nt / rg_gemm_tn would run for these arguments --
  * "gemm_ws_kernel<K/128,N/128>" (persistent weight-stationary), "gemm_nt_kernel<dtype,NTW>" (generic tiles),
- * "gemm_tn_big_kernel<N1,N2>" or "gemm_tn_kernel<dtype>" -- written NUL-terminated into name[cap].  Used by the
+ * "gemm_tn_dma_kernel<N1,N2>" / "gemm_tn_big_kernel<N1,N2>" (big shapes: LDS-DMA ring / register-staged) or
+ * "gemm_tn_kernel<dtype>" -- written NUL-terminated into name[cap].  Used by the
  * host-side profiler so that per-kernel times match rocprofv3's kernel names. */
 int rg_gemm_nt_plan(const rg_gemm_nt_args* args /* host */, int dtype, char* name, int cap);
 int rg_gemm_tn_plan(const rg_gemm_tn_args* args /* host */, int dtype, char* name, int cap);
@@ -432,9 +433,9 @@ typedef struct {
 size_t rg_ffn_bwd_ln_workspace(int M);
 int rg_ffn_bwd_data(const rg_ffn_bwd_args* args /* host */, int dtype, void* stream);
 int rg_ffn_bwd_data_supported(int d, int dff);
-/* list [1 + 2*nt], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their
+/* list [1 + 2*nt + 4], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their
  * indices ascending; the remaining (padded) tiles are listed from the far end backwards (list[nt], list[nt-1], ..);
- * list[1+nt ..] is scratch (the per-tile flags). */
+ * list[1+nt ..] is scratch (64-tile bit masks). */
 int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream);
 
 /* ---- single-query attention for the last encoder layer --------------------------------------------

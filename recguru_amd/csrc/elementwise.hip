@@ -643,43 +643,44 @@ __global__ __launch_bounds__(EW_BLOCK) void seq_wsum_kernel(const T* __restrict_
   }
 }
 
-// Live-tile list in two launches.  (1) flags, fully parallel: flag[t] = any(rowmask[16t..16t+15] != 0).  (2) one
-// workgroup compacts: list[0] = number of live tiles, list[1 + i] = index of the i-th live one (ascending), and the dead
-// ones from the far end backwards (list[nt - j] = j-th dead tile).  The flags live in list[1 + nt ..] (scratch).
-__global__ __launch_bounds__(EW_BLOCK) void live_flags_kernel(const float* __restrict__ rowmask, long long M, int* __restrict__ flags) {
-  const long long nt = (M + 15) >> 4;
-  for (long long t = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; t < nt; t += (long long)gridDim.x * EW_BLOCK) {
+// Live-tile list in two launches.  (1) fully parallel: one 64-bit mask per 64 tiles, bit = any(rowmask[16t..16t+15] != 0).
+// (2) one workgroup: masks -> LDS (one coalesced load per thread), scan of their popcounts, then the waves write
+// list[0] = number of live tiles, list[1 + i] = index of the i-th live one (ascending) and the dead ones from the far end
+// backwards (list[nt - j] = j-th dead tile) with coalesced stores -- no global load inside a loop (the first version read the
+// per-tile flags twice in 50-iteration loops per wave: 39 us for 51 200 tiles, 16 times per training step).
+// The masks live in list[1 + nt ..] (scratch, 8-byte aligned part of it).
+__global__ __launch_bounds__(EW_BLOCK) void live_flags_kernel(const float* __restrict__ rowmask, long long M, unsigned long long* __restrict__ masks) {
+  const long long nt = (M + 15) >> 4, ntp = (nt + 63) & ~63ll;
+  for (long long t = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; t < ntp; t += (long long)gridDim.x * EW_BLOCK) {
     int live = 0;
-    if (16 * t + 16 <= M && (reinterpret_cast<uintptr_t>(rowmask) & 15) == 0) {
+    if (t < nt) {
+      if (16 * t + 16 <= M && (reinterpret_cast<uintptr_t>(rowmask) & 15) == 0) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 v = reinterpret_cast<const float4*>(rowmask + 16 * t)[j];
-        live |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        for (int j = 0; j < 4; ++j) {
+          const float4 v = reinterpret_cast<const float4*>(rowmask + 16 * t)[j];
+          live |= (v.x != 0.f) | (v.y != 0.f) | (v.z != 0.f) | (v.w != 0.f);
+        }
+      } else {
+        for (long long r = 16 * t; r < min(16 * t + 16, M); ++r) live |= rowmask[r] != 0.f;
       }
-    } else {
-      for (long long r = 16 * t; r < min(16 * t + 16, M); ++r) live |= rowmask[r] != 0.f;
     }
-    flags[t] = live;
+    const unsigned long long m = __ballot(live != 0);          // t of lane 0 is a multiple of 64
+    if ((threadIdx.x & 63) == 0) masks[t >> 6] = m;
   }
 }
 
 #define LIVE_MAXW 8192     // 64-tile words the single compaction workgroup can scan: M <= 8.4 M rows
-__global__ __launch_bounds__(1024) void live_compact_kernel(long long nt, int* __restrict__ list) {
-  __shared__ int woff[LIVE_MAXW];                       // live tiles per 64-tile word, then their exclusive prefix
-  __shared__ int part[1024];
-  const int* __restrict__ flags = list + 1 + nt;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(1024) void live_compact_kernel(long long nt, int* __restrict__ list, const unsigned long long* __restrict__ masks) {
+  extern __shared__ __align__(8) unsigned char live_smem[];
   const int nwords = (int)((nt + 63) >> 6);
-  for (int w = wave; w < nwords; w += 16) {              // coalesced: one wave, one 64-tile word
-    const long long t = 64ll * w + lane;
-    const unsigned long long m = __ballot(t < nt && flags[t] != 0);
-    if (lane == 0) woff[w] = __popcll(m);
-  }
-  __syncthreads();
+  unsigned long long* wm = reinterpret_cast<unsigned long long*>(live_smem);            // [nwords] masks
+  int* woff = reinterpret_cast<int*>(live_smem + (size_t)nwords * 8);                   // [nwords] exclusive prefix of the popcounts
+  __shared__ int part[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nwords + 1023) / 1024;
   const int w0 = min(tid * per, nwords), w1 = min(w0 + per, nwords);
   int cnt = 0;
-  for (int w = w0; w < w1; ++w) cnt += woff[w];
+  for (int w = w0; w < w1; ++w) { const unsigned long long m = masks[w]; wm[w] = m; cnt += __popcll(m); }
   part[tid] = cnt;
   __syncthreads();
   for (int o = 1; o < 1024; o <<= 1) {                  // Hillis-Steele inclusive scan of the per-thread sums
@@ -689,14 +690,14 @@ __global__ __launch_bounds__(1024) void live_compact_kernel(long long nt, int* _
     __syncthreads();
   }
   int run = part[tid] - cnt;
-  for (int w = w0; w < w1; ++w) { const int c = woff[w]; woff[w] = run; run += c; }
+  for (int w = w0; w < w1; ++w) { woff[w] = run; run += __popcll(wm[w]); }
   if (tid == 1023) list[0] = part[1023];
   __syncthreads();
   for (int w = wave; w < nwords; w += 16) {
     const long long t = 64ll * w + lane;
+    const unsigned long long m = wm[w];
     const bool in = t < nt;
-    const bool live = in && flags[t] != 0;
-    const unsigned long long m = __ballot(live);
+    const bool live = (m >> lane) & 1ull;
     const int rank = __popcll(m & ((1ull << lane) - 1ull));             // live tiles of this word before this lane
     if (live) list[1 + woff[w] + rank] = (int)t;
     else if (in) list[nt - ((64ll * w - woff[w]) + (lane - rank))] = (int)t;   // j-th dead tile goes to list[nt - j]
@@ -778,9 +779,14 @@ extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int 
 extern "C" int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream) {
   if (M <= 0) return 0;
   const long long nt = (M + 15) >> 4;
-  if (((nt + 63) >> 6) > LIVE_MAXW) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "live_tiles: more than 8.4 M rows");
-  hipLaunchKernelGGL(live_flags_kernel, dim3(ew_grid(nt, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rowmask, M, list + 1 + nt);
-  hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, nt, list);
+  const int nwords = (int)((nt + 63) >> 6);
+  if (nwords > LIVE_MAXW) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "live_tiles: more than 8.4 M rows");
+  // masks: the scratch part of the list (nt + 4 ints), from its first 8-byte aligned int on
+  unsigned long long* masks = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(list + 1 + nt) + 7) & ~(uintptr_t)7);
+  hipLaunchKernelGGL(live_flags_kernel, dim3(ew_grid(nt, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rowmask, M, masks);
+  const int smem = nwords * 12;
+  hipFuncSetAttribute(reinterpret_cast<const void*>(live_compact_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipLaunchKernelGGL(live_compact_kernel, dim3(1), dim3(1024), smem, (hipStream_t)stream, nt, list, masks);
   RG_CHECK_LAUNCH();
   return 0;
 }

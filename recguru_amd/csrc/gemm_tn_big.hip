@@ -467,6 +467,12 @@ int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
   return (a->N2 == 128 && (a->N1 == 512 || a->N1 == 384 || a->N1 == 256 || a->N1 == 128)) || (a->N1 == 128 && a->N2 == 512);
 }
 
+// kernel family that runs the big shapes (profiler names: rg_gemm_tn_plan)
+const char* rg_gemm_tn_big_name(const rg_gemm_tn_args* a) {
+  const bool fits = (long long)3 * 40 * 1024 + ((a->T + 31) / 32 / 256 + 2) * 8 <= 160 * 1024;
+  return tn_use_dma() && fits ? "gemm_tn_dma_kernel" : "gemm_tn_big_kernel";
+}
+
 // bytes of partial-sum scratch the big kernel can use for this problem (0 if it does not take it)
 size_t rg_gemm_tn_big_workspace(const rg_gemm_tn_args* a, int dtype) {
   if (!rg_gemm_tn_big_select(a, dtype)) return 0;

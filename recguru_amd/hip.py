@@ -632,7 +632,7 @@ def live_tiles(rowmask, M):
     hit = _LIVE.get(key)
     if hit is not None:
         return hit[1]
-    flags = torch.empty(1 + 2 * ((M + 15) // 16), device=rowmask.device, dtype=torch.int32)
+    flags = torch.empty(1 + 2 * ((M + 15) // 16) + 4, device=rowmask.device, dtype=torch.int32)
     _check(lib().rg_live_tiles(_vp(rowmask), c_ll(M), _vp(flags), _stream()), "rg_live_tiles")
     if len(_LIVE) >= 32:
         _LIVE.pop(next(iter(_LIVE)))          # oldest entry out
@@ -732,7 +732,7 @@ class Profiler(object):
         key = (ref.data_ptr(), ref.numel(), ref.dtype)
         if key not in cache:
             if ref.dtype == torch.int32:                       # live-tile list: [count, ids..., flags...]
-                nt = (ref.numel() - 1) // 2
+                nt = (ref.numel() - 5) // 2
                 cache[key] = float(ref[0]) / max(nt, 1)
             else:                                              # f32 row mask
                 m = ref.reshape(-1)

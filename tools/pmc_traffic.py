@@ -55,7 +55,7 @@ def short(name):
         return "attn_bwd_kernel<bf16>"
     if base == "attn_bwd_kernel":
         return "attn_bwd_kernel<f32>"
-    if base in ("gemm_nt_kernel", "gemm_ws_kernel", "gemm_tn_big_kernel"):
+    if base in ("gemm_nt_kernel", "gemm_ws_kernel", "gemm_tn_big_kernel", "gemm_tn_dma_kernel"):
         return "%s<%s,%s>" % (base, parts[0], parts[1])
     return base
 
