@@ -128,8 +128,17 @@ typedef struct {
   const void* x; const void* wqkv; const float* bqkv; int d;
   /* x_masked, qkv form: the caller guarantees that the K and V rows at positions with rowmask == 0 are all IDENTICAL (the
    * projection of an all-zero layer-input row is the bias row).  A non-causal head then evaluates a leading run of such
-   * keys (left padding) once: same max, (count of kept copies) more terms in the row sum and the context. */
+   * keys (left padding) once: same max, (count of kept copies) more terms in the row sum and the context.
+   * x_masked == 2: additionally the rows of qkv in 16-row tiles (of the flattened [B*L] rows) made of such positions
+   * only may be UNWRITTEN (rg_gemm_nt skip_dead_fill = 1 on the projection): the kernel substitutes the bias rows bqkv
+   * [3*H*32] f32 for every position with rowmask == 0 instead of reading -- the projection then neither computes nor
+   * writes the padded tiles (a third of its traffic at the bench shape). */
   int x_masked;
+  /* optional [B] (rg_first_live): index of the first position of each sequence with rowmask != 0 (L if none).  With
+   * x_masked == 2 the rows before it are not even addressed (their loads are pointed at that first live row, whose lines
+   * are hot, and the data replaced by the bias rows) -- unwritten rows are cold lines, reading them cost more than the
+   * projection saved by not writing them. */
+  const int* first_live;
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
 int rg_attn_fwd_x_supported(int d, int dtype, float drop_p);
@@ -142,6 +151,10 @@ typedef struct {
   float scale;
   float drop_p; unsigned long long seed;   /* must equal the forward's */
   const float* rowmask;       /* optional, as in the forward: dctx of those rows is zero, their tiles are skipped */
+  /* x_masked == 2 (as in rg_attn_args): the Q / K / V rows at positions with rowmask == 0 are NOT read -- the bias rows
+   * bqkv [3*H*32] f32 (Q | K | V) stand in, bit for bit what the projection of an all-zero input row gives */
+  const float* bqkv; int x_masked;
+  const int* first_live;      /* optional [B], as in rg_attn_args */
 } rg_attn_bwd_args;
 int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream);
 
@@ -437,6 +450,8 @@ int rg_ffn_bwd_data_supported(int d, int dff);
  * indices ascending; the remaining (padded) tiles are listed from the far end backwards (list[nt], list[nt-1], ..);
  * list[1+nt ..] is scratch (64-tile bit masks). */
 int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream);
+/* first[b] = smallest l with rowmask[b*L + l] != 0, L if the sequence has none (left padding: the padded prefix) */
+int rg_first_live(const float* rowmask, int B, int L, int* first, void* stream);
 
 /* ---- single-query attention for the last encoder layer --------------------------------------------
  * Only enc_outputs[:, -1, :] is consumed on the hot path (AutoEnc4Rec_cross.py:122,154;

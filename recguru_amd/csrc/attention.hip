@@ -318,22 +318,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
   // per thread, not one per chunk (the rolled copy loop spent as long staging as computing)
   constexpr int NCH = (LPK * 4 + 255) / 256;
+  // x_masked == 2: rows at positions with rowmask == 0 may be unwritten -- the bias rows stand in (this thread always
+  // stages chunk tid & 3 of a row: its 8 K-bias and 8 V-bias values are converted once)
+  const bool sub = a.x_masked == 2 && a.rowmask != nullptr && a.bqkv != nullptr;
+  // rows before the sequence's first live position are bias rows for sure: their loads are pointed at that first live row
+  // (hot lines) instead of at unwritten, cold ones
+  const int first = (sub && a.first_live) ? min(a.first_live[b], L - 1) : 0;
+  Frag<T> kbf, vbf;
+  frag_zero(kbf);
+  frag_zero(vbf);
+  if (sub) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      kbf.v[j] = (T)a.bqkv[P + h * DK + (tid & 3) * 8 + j];
+      vbf.v[j] = (T)a.bqkv[2 * P + h * DK + (tid & 3) * 8 + j];
+    }
+  }
 #pragma unroll
   for (int i0 = 0; i0 < NCH; i0 += 4) {
     Frag<T> kr[4], vr[4];
+    float rms[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * (i0 + i), key = c >> 2, c8 = (c & 3) * 8;
-      const int kc = min(key, L - 1);                 // clamped address, zeroed below: no branch between the loads
+      const int kc = max(min(key, L - 1), first);     // clamped address, zeroed / replaced below: no branch between the loads
+      rms[i] = 1.f;
       if (i0 + i < NCH) {
         load_frag(kr[i], qkv + (size_t)kc * ld + P + h * DK + c8);
         load_frag(vr[i], qkv + (size_t)kc * ld + 2 * P + h * DK + c8);
+        const float* __restrict__ rmp3 = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(a.qkv);
+        rms[i] = rmp3[a.rowmask ? (size_t)b * L + kc : 0];       // unconditional (see above)
       }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int key = (tid + 256 * (i0 + i)) >> 2;
       if (i0 + i >= NCH || key >= L) { frag_zero(kr[i]); frag_zero(vr[i]); }
+      else if (sub && (rms[i] == 0.f || key < first)) { kr[i] = kbf; vr[i] = vbf; }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -964,6 +985,20 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 
   // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
   constexpr int NCH = (LPK * 4 + 255) / 256;
+  const bool sub = a.x_masked == 2 && a.rowmask != nullptr && a.bqkv != nullptr;
+  const int first = (sub && a.first_live) ? min(a.first_live[b], L - 1) : 0;      // see the forward
+  Frag<T> qbf, kbf, vbf;              // bias rows of this head, this thread's chunk (tid & 3)
+  frag_zero(qbf);
+  frag_zero(kbf);
+  frag_zero(vbf);
+  if (sub) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      qbf.v[j] = (T)a.bqkv[h * DK + (tid & 3) * 8 + j];
+      kbf.v[j] = (T)a.bqkv[P + h * DK + (tid & 3) * 8 + j];
+      vbf.v[j] = (T)a.bqkv[2 * P + h * DK + (tid & 3) * 8 + j];
+    }
+  }
 #pragma unroll
   for (int i0 = 0; i0 < NCH; i0 += 4) {
     Frag<T> qr[4], kr[4], vr[4], gr[4], orow[4];
@@ -971,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
-      const int rc = min(row, L - 1);                 // clamped address, zeroed below: no branch between the loads
+      const int rc = max(min(row, L - 1), first);     // clamped address, zeroed / replaced below: no branch between the loads
       rmr[i] = 1.f;
       if (i0 + i < NCH) {
         load_frag(qr[i], qkv + (size_t)rc * ld + h * DK + c8);
@@ -990,7 +1025,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     for (int i = 0; i < 4; ++i) {
       const int row = (tid + 256 * (i0 + i)) >> 2;
       if (i0 + i >= NCH || row >= L) { frag_zero(qr[i]); frag_zero(kr[i]); frag_zero(vr[i]); frag_zero(gr[i]); frag_zero(orow[i]); }
-      else if (rmr[i] == 0.f) frag_zero(gr[i]);
+      else if (rmr[i] == 0.f || row < first) {
+        frag_zero(gr[i]);
+        // x_masked == 2: the qkv rows of such positions may be unwritten -- bias rows; ctx rows of padded query tiles are
+        // placeholders either way and only meet dO = 0
+        if (sub) { qr[i] = qbf; kr[i] = kbf; vr[i] = vbf; frag_zero(orow[i]); }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1020,8 +1060,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     if (r >= LPK) break;
     const float lse = lse_r[i];
     const bool full = lse < -5e8f;                  // -1e9 + log L rounds to -1e9: row was uniform 1/L (Q3)
-    lse2_s[r] = (r < L && !full) ? lse * 1.4426950408889634f : INFINITY;     // exp2(x - inf) = 0
-    rowp_s[r] = (r < L && full) ? 1.f / (float)L : 0.f;
+    // a query row with rowmask == 0 has dO = 0 by contract: its P and dS only ever meet zeros.  Making its P exactly 0
+    // changes nothing -- and keeps NaNs out when its lse / ctx / Q were never written (rows of padded tiles under
+    // x_masked == 2: the forward skips or mis-feeds them, nothing list-driven reads them)
+    const bool deadq = ql.has_mask && ql.v[i] == 0.f;
+    lse2_s[r] = (r < L && !full && !deadq) ? lse * 1.4426950408889634f : INFINITY;     // exp2(x - inf) = 0
+    rowp_s[r] = (r < L && full && !deadq) ? 1.f / (float)L : 0.f;
     const bool padk = padk_r[i];
     kbias[r] = r >= L ? -INFINITY : (padk ? MASK_BIG : 0.f);
     if (CAUSAL && r < L && !padk) atomicMin(&klo_s, r);
@@ -1380,6 +1424,8 @@ extern "C" int rg_attn_bwd(const rg_attn_bwd_args* a, int dtype, void* stream) {
   if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: empty problem");
   if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: d_k must be 32");
   if (dtype == RG_BF16) return launch_bwd<__bf16>(*a, (hipStream_t)stream);
+  if (dtype == RG_F32 && a->x_masked == 2)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: bias-row substitution (x_masked == 2) is a bf16-tier form");
   if (dtype == RG_F32) return launch_bwd<float>(*a, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: bad dtype");
 }

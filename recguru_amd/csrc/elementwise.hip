@@ -776,6 +776,26 @@ extern "C" int rg_seq_wsum(const void* x, const float* s, void* out, int B, int 
   else return rg_set_error_msg(RG_ERR_INVALID, name ": bad dtype");                       \
   RG_CHECK_LAUNCH(); return 0;
 
+// first[b] = index of the first position of sequence b with rowmask != 0 (L if none): one wave per sequence
+__global__ __launch_bounds__(EW_BLOCK) void first_live_kernel(const float* __restrict__ rowmask, int B, int L, int* __restrict__ first) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int b = blockIdx.x * (EW_BLOCK / 64) + wave; b < B; b += gridDim.x * (EW_BLOCK / 64)) {
+    int f = L;
+    for (int l0 = 0; l0 < L && f == L; l0 += 64) {
+      const int l = l0 + lane;
+      const unsigned long long m = __ballot(l < L && rowmask[(size_t)b * L + l] != 0.f);
+      if (m) f = l0 + __builtin_ctzll(m);
+    }
+    if (lane == 0) first[b] = f;
+  }
+}
+extern "C" int rg_first_live(const float* rowmask, int B, int L, int* first, void* stream) {
+  if (B <= 0 || L <= 0) return 0;
+  hipLaunchKernelGGL(first_live_kernel, dim3(ew_grid((long long)B * 64, EW_BLOCK)), dim3(EW_BLOCK), 0, (hipStream_t)stream, rowmask, B, L, first);
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int rg_live_tiles(const float* rowmask, long long M, int* list, void* stream) {
   if (M <= 0) return 0;
   const long long nt = (M + 15) >> 4;

@@ -39,13 +39,13 @@ class GemmTnArgs(ctypes.Structure):
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
                 ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p),
-                ("x", c_p), ("wqkv", c_p), ("bqkv", c_p), ("d", c_i), ("x_masked", c_i)]
+                ("x", c_p), ("wqkv", c_p), ("bqkv", c_p), ("d", c_i), ("x_masked", c_i), ("first_live", c_p)]
 
 
 class AttnBwdArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("dctx", c_p), ("ctx", c_p), ("lse", c_p), ("key_ids", c_p), ("pad_value", c_l),
                 ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f),
-                ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p)]
+                ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p), ("bqkv", c_p), ("x_masked", c_i), ("first_live", c_p)]
 
 
 class PostAttnArgs(ctypes.Structure):
@@ -78,7 +78,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
-           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace"]
+           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -208,15 +208,18 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     return dW
 
 
-def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False):
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False, bqkv=None):
     """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32).  x_masked: the K / V rows at positions with rowmask == 0
-    are all identical (the projection of an all-zero input row = the bias): a leading run of such keys is folded into one."""
+    are all identical (the projection of an all-zero input row = the bias): a leading run of such keys is folded into one.
+    bqkv (with x_masked): those rows of qkv may be UNWRITTEN -- the kernel substitutes the bias rows [3*H*32] f32."""
     B, L, P3 = qkv.shape
     assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, None, 0, 1 if (x_masked and rowmask is not None) else 0)
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, _p(bqkv) if x_masked else None, 0,
+                 (2 if bqkv is not None else 1) if (x_masked and rowmask is not None) else 0,
+                 _p(first_live(rowmask, B, L)) if (x_masked and rowmask is not None and bqkv is not None) else None)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 
@@ -233,17 +236,20 @@ def attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=0.0, seed=0,
     assert bqkv.dtype == torch.float32 and bqkv.numel() == 3 * H * 32 and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=x.device, dtype=x.dtype)
     a = AttnArgs(None, _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), None, B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)))
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)), None)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(x), _stream()), "rg_attn_fwd")
     return ctx
 
 
-def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None):
+def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None, bqkv=None):
+    """bqkv: the forward ran with unwritten qkv rows at the positions with rowmask == 0 (attn_fwd's bqkv): same here."""
     B, L, _ = qkv.shape
     assert dctx.is_contiguous() and ctx.is_contiguous() and qkv.is_contiguous()
     dqkv = torch.empty_like(qkv)
+    sub = bqkv is not None and rowmask is not None
     a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
-                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask))
+                    _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(bqkv) if sub else None, 2 if sub else 0,
+                    _p(first_live(rowmask, B, L)) if sub else None)
     _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
     return dqkv
 
@@ -638,6 +644,23 @@ def live_tiles(rowmask, M):
         _LIVE.pop(next(iter(_LIVE)))          # oldest entry out
     _LIVE[key] = (rowmask, flags)
     return flags
+
+
+_FIRST = {}
+
+
+def first_live(rowmask, B, L):
+    """int32 [B]: index of the first position of each sequence with rowmask != 0 (L if none); cached like live_tiles."""
+    key = (rowmask.data_ptr(), rowmask._version, B, L)
+    hit = _FIRST.get(key)
+    if hit is not None:
+        return hit[1]
+    out = torch.empty(B, device=rowmask.device, dtype=torch.int32)
+    _check(lib().rg_first_live(_vp(rowmask), B, L, _vp(out), _stream()), "rg_first_live")
+    if len(_FIRST) >= 32:
+        _FIRST.pop(next(iter(_FIRST)))
+    _FIRST[key] = (rowmask, out)
+    return out
 
 
 def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,

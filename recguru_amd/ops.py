@@ -394,6 +394,9 @@ def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
 
 
+QKV_BIAS_ROWS_IN_ATTENTION = True
+
+
 def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
     """Live-tile list for a projection whose input rows are ZERO wherever rowmask is (x_masked: the caller guarantees it
     -- the model stacks do: the embedding and every layer output are multiplied by this very mask, transformer.py:105,
@@ -406,7 +409,7 @@ def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
 
 
 def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p=0.0, seed=0,
-                  rowmask=None, x_masked=False):
+                  rowmask=None, x_masked=False, allow_unwritten=False):
     """rowmask [B*L]: the pad mask the layer output is multiplied by -- query tiles made of padded positions only are
     skipped by the attention kernels (nothing downstream reads those rows)."""
     wqkv = shadow_cat((Wq, Wk, Wv))
@@ -422,9 +425,14 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     # model stacks such a position's input row is exactly zero, so its projection IS the bias row: 16-row tiles made of
     # padded positions only are filled with it instead of being read and multiplied (44 % of the tiles at the bench shape)
     live = _zero_rows_live(rowmask, x2.shape[0], x_masked, x2.shape[1], wqkv.shape[0])
-    qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=2)
+    # ... and with a list in use they are not even written: both attention kernels substitute the bias rows for the
+    # positions with rowmask == 0 while staging (QKV_BIAS_ROWS_IN_ATTENTION; False: the projection writes them)
+    # (allow_unwritten: the caller's consumer of ctx is list-driven too -- the fused block; the rows of ctx in padded
+    # tiles are then placeholders computed from unwritten Q rows)
+    sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten
+    qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
-                             rowmask=rowmask, x_masked=x_masked)
+                             rowmask=rowmask, x_masked=x_masked, bqkv=bqkv if sub else None)
     return qkv, ctx_, lse
 
 
@@ -439,7 +447,8 @@ def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv,
     return y, (qkv, ctx_, lse, rstd)
 
 
-def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, drop_p=0.0, seed=0, rowmask=None):
+def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, drop_p=0.0, seed=0, rowmask=None,
+                    x_masked=False):
     """Backward of the attention block; prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be).  Returns dx and, in that
     order, what autograd gets for each parameter (None where the gradient went straight into p.grad)."""
     Wq, bq, Wk, bk, Wv, bv, Wo, bo, g, be = prm
@@ -454,8 +463,11 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
     dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
+    # the forward's decision (same inputs; x_masked == 2: it was the fused block's forward): were the padded tiles' rows of
+    # qkv left unwritten?
+    sub = QKV_BIAS_ROWS_IN_ATTENTION and x_masked == 2 and _zero_rows_live(rowmask, x2.shape[0], True, d, 3 * P) is not None
     dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
-                        drop_p=drop_p, seed=seed, rowmask=rowmask)
+                        drop_p=drop_p, seed=seed, rowmask=rowmask, bqkv=bias_cat((bq, bk, bv)) if sub else None)
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)                 # every row: a padded position that is a live key has dK, dV != 0
@@ -540,7 +552,8 @@ class EncoderLayerFn(_Fn):
         xm = _X_MASKED
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
-                                           drop_p, seeds[0], rowmask, xm)
+                                           drop_p, seeds[0], rowmask, xm, allow_unwritten=True)
+            xm = 2 if xm else 0
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
                                         be2.detach(),
@@ -555,18 +568,18 @@ class EncoderLayerFn(_Fn):
         if need:
             ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
-            ctx.meta = (B, L, pad_value, causal, H, drop_p, seeds)
+            ctx.meta = (B, L, pad_value, causal, H, drop_p, seeds, xm)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
         x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2 = ctx.saved_tensors
-        B, L, pad_value, causal, H, drop_p, seeds = ctx.meta
+        B, L, pad_value, causal, H, drop_p, seeds, xm = ctx.meta
         d = x2.shape[1]
         dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, ctx.prm[10:],
                                 drop_p, seeds[1], seeds[2])
         dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
-                                 ctx.prm[:10], drop_p, seeds[0], rowmask)
+                                 ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
         return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
@@ -670,7 +683,8 @@ class DecoderLayerFn(_Fn):
             cross_kw = dict(cross=(o, cg.detach(), cbe.detach()))
         if _fusable(x2, Wo, W1):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
-                                           rowmask, _X_MASKED)
+                                           rowmask, _X_MASKED, allow_unwritten=True)
+            xm_d = 2 if _X_MASKED else 0
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
                                         be2.detach(),
@@ -680,6 +694,7 @@ class DecoderLayerFn(_Fn):
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
+            xm_d = 1 if _X_MASKED else 0
             y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
                                      drop_p, seeds[0], rowmask, _X_MASKED)
             if drop_p > 0:          # per-row cross-attention output under attention-map dropout
@@ -692,12 +707,12 @@ class DecoderLayerFn(_Fn):
             extra = (s_cross,) if s_cross is not None else ()
             ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf, *extra)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, cWv, cbv, cWo, cbo, cg, cbe, W1, b1, W2, b2, g2, be2)
-            ctx.meta = (B, L, H, drop_p, seeds)
+            ctx.meta = (B, L, H, drop_p, seeds, xm_d)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
-        B, L, H, drop_p, seeds = ctx.meta
+        B, L, H, drop_p, seeds, xm = ctx.meta
         sav = ctx.saved_tensors
         x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2 = sav[:15]
         s_cross = sav[15] if len(sav) > 15 else None
@@ -731,7 +746,7 @@ class DecoderLayerFn(_Fn):
         hip.gemm_tn(dc, u, dcWv, dcbv)
         du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
         dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
-                                 ctx.prm[:10], drop_p, seeds[0], rowmask)
+                                 ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
         return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
 
 

@@ -942,3 +942,45 @@ def test_ffn_bwd_data_with_layernorm_backward_inside(dt, M, dff, drop_p, listed)
     hip.ffn_bwd_data(None, None, h1, W2tp, W1tp, nz_scale=nz, live=live, w_packed=True,
                      ln=(dout, out, rstd, g, be, mask, dg1, db1, drop_p, 77))
     torch.testing.assert_close(dg1, 2 * dg0, rtol=2e-4, atol=4e-4 * float(dg0.abs().max()))
+
+
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_attention_substitutes_bias_rows_for_unwritten_qkv(causal, drop_p):
+    """x_masked == 2: the qkv rows of 16-row tiles made of positions with rowmask == 0 only may be unwritten (NaN here) --
+    forward and backward substitute the bias rows and give, bit for bit, what they give when the projection wrote them."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    B, L, H, d = 5, 200, 4, 128
+    P = H * 32
+    g0 = torch.Generator().manual_seed(17)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 3
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids = ids.cuda()
+    pad_value = 0 if causal else 51
+    rowmask = (ids != 0).float().view(-1)
+    x = ((torch.randn(B, L, d, generator=g0) * 0.8).cuda() * rowmask.view(B, L, 1)).to(dt).contiguous()
+    w = (torch.randn(3 * P, d, generator=g0) / d ** 0.5).to(dt).cuda()
+    bias = (torch.randn(3 * P, generator=g0) * 0.3).cuda()
+    qkv = hip.gemm_nt(x.view(B * L, d), w, bias).view(B, L, 3 * P)
+    holes = qkv.clone()
+    r16 = torch.zeros((B * L + 15) // 16 * 16, device="cuda")
+    r16[:B * L] = rowmask
+    dead16 = (r16.view(-1, 16).amax(1) == 0).repeat_interleave(16)[:B * L]      # rows of 16-row tiles without a live row:
+    holes.view(B * L, 3 * P)[dead16] = float("nan")                               # what skip_dead_fill = 1 leaves unwritten
+    assert int(dead16.sum()) > 300
+    kw = dict(drop_p=drop_p, seed=5, rowmask=rowmask)
+    ref, lse_ref = hip.attn_fwd(qkv, ids, pad_value, causal, H, need_lse=True, x_masked=True, **kw)
+    got, lse = hip.attn_fwd(holes, ids, pad_value, causal, H, need_lse=True, x_masked=True, bqkv=bias, **kw)
+    live = rowmask.view(B, L) != 0
+    assert torch.equal(got[live], ref[live])
+    assert torch.isfinite(got.float().view(B * L, P)[~dead16]).all()       # what the (list-driven) consumers read
+    lm = live.unsqueeze(1).expand(B, H, L)
+    assert torch.equal(lse[lm], lse_ref[lm])
+    dctx = (torch.randn(B, L, P, generator=g0).cuda() * rowmask.view(B, L, 1)).to(dt)
+    d0 = hip.attn_bwd(qkv, dctx, ref, lse_ref, ids, pad_value, causal, H, **kw)
+    d1 = hip.attn_bwd(holes, dctx, got, lse, ids, pad_value, causal, H, bqkv=bias, **kw)
+    assert torch.equal(d1, d0)
