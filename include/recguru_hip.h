@@ -459,10 +459,14 @@ int rg_first_live(const float* rowmask, int B, int L, int* first, void* stream);
  * with the key-pad replace-fill.  qlast [B,H*32], kv [B,L,2*H*32] (K | V), ctx / dq [B,H*32],
  * dkv [B,L,2*H*32] fully overwritten. */
 int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids, int64_t pad_value, void* ctx,
-                      int B, int L, int H, float scale, float drop_p, unsigned long long seed, int dtype, void* stream);
+                      int B, int L, int H, float scale, float drop_p, unsigned long long seed, int dtype, void* stream,
+                      const float* bkv, const int* first_live);
 int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
                       void* dq, void* dkv, int B, int L, int H, float scale, float drop_p, unsigned long long seed,
-                      int dtype, void* stream);
+                      int dtype, void* stream, const float* bkv, const int* first_live);
+/* bkv [2*H*32] f32 (K | V bias) + first_live [B] (rg_first_live), both optional (NULL): the caller guarantees that the
+ * K / V rows before a sequence's first live position are the bias rows (x_masked contract of rg_attn_args): the kernels
+ * then do not fetch them (one score, one probability mass for the whole padded prefix). */
 
 /* ---- decoder cross-attention under dropout ---------------------------------------------------------
  * s[b*L+q, h] = (1/n_b) * sum_{keys j live} keep(seed, ((b*H+h)*L+q)*L+j)   (keep = 0 or 1/(1-p)),

@@ -600,23 +600,32 @@ def disc_rows(real, fake, alpha, W, Wt, biases, w4, b4, drop_p, seeds_w, seeds_g
     _check(lib().rg_disc_rows(ctypes.byref(a), dt_of(real), _stream()), "rg_disc_rows")
 
 
-def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H, drop_p=0.0, seed=0):
-    """q_last [B,P], kv [B,L,2P] (K|V) -> ctx_last [B,P]: row L-1 of the attention."""
+def _lastq_fold(rowmask, bkv, B, L):
+    if rowmask is None or bkv is None:
+        return _vp(None), _vp(None)
+    return _vp(bkv), _vp(first_live(rowmask, B, L))
+
+
+def attn_lastq_fwd(q_last, kv, key_ids, pad_value, H, drop_p=0.0, seed=0, rowmask=None, bkv=None):
+    """q_last [B,P], kv [B,L,2P] (K|V) -> ctx_last [B,P]: row L-1 of the attention.  rowmask [B*L] + bkv ([2P] f32 bias):
+    the K / V rows of each sequence's padded prefix are the bias rows (x_masked contract) -- they are not fetched."""
     B, L, P2 = kv.shape
     assert P2 == 2 * H * 32 and kv.is_contiguous() and q_last.is_contiguous() and key_ids.is_contiguous()
     ctx = torch.empty_like(q_last)
     _check(lib().rg_attn_lastq_fwd(_vp(q_last), _vp(kv), _vp(key_ids), c_l(int(pad_value)), _vp(ctx), B, L, H,
-                                   c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream()), "rg_attn_lastq_fwd")
+                                   c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream(),
+                                   *_lastq_fold(rowmask, bkv, B, L)), "rg_attn_lastq_fwd")
     return ctx
 
 
-def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H, drop_p=0.0, seed=0):
+def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H, drop_p=0.0, seed=0, rowmask=None, bkv=None):
     B, L, P2 = kv.shape
     assert dctx.is_contiguous()
     dq = torch.empty_like(q_last)
     dkv = torch.empty_like(kv)
     _check(lib().rg_attn_lastq_bwd(_vp(q_last), _vp(kv), _vp(dctx), _vp(key_ids), c_l(int(pad_value)), _vp(dq), _vp(dkv),
-                                   B, L, H, c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream()),
+                                   B, L, H, c_f(32 ** -0.5), c_f(drop_p), c_u64(seed), dt_of(kv), _stream(),
+                                   *_lastq_fold(rowmask, bkv, B, L)),
            "rg_attn_lastq_bwd")
     return dq, dkv
 

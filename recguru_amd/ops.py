@@ -395,6 +395,7 @@ def _fusable(x2, Wo, W1):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
+LASTQ_FOLD_PREFIX = True
 
 
 def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
@@ -599,13 +600,18 @@ class EncoderLastLayerFn(_Fn):
         x = x.contiguous()
         x2 = x.view(B * L, d)
         key_ids = key_ids.contiguous()
-        x_last, rm_last = hip.last_rows(x, rowmask.reshape(-1).to(torch.float32).contiguous())
+        rmf = rowmask.reshape(-1).to(torch.float32).contiguous()
+        x_last, rm_last = hip.last_rows(x, rmf)
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
-        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bias_cat((bk, bv)),
-                         live=_zero_rows_live(rowmask.reshape(-1).contiguous(), B * L, _X_MASKED, d, 2 * Wk.shape[0]),
-                         skip_dead_fill=2)
+        bkv = bias_cat((bk, bv))
+        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bkv,
+                         live=_zero_rows_live(rmf, B * L, _X_MASKED, d, 2 * Wk.shape[0]), skip_dead_fill=2)
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
-        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0])
+        # inside the model stacks (x_masked) the K / V rows of a sequence's padded prefix are the bias rows: the
+        # single-query kernels then score and weigh the whole prefix once instead of fetching it
+        fold = bool(_X_MASKED) and LASTQ_FOLD_PREFIX
+        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0],
+                                    rowmask=rmf if fold else None, bkv=bkv if fold else None)
         if _fusable(x_last, Wo, W1):
             out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
@@ -619,16 +625,16 @@ class EncoderLastLayerFn(_Fn):
                             gamma=g1.detach(), beta=be1.detach(), rstd_out=rstd1, eps=LN_EPS)
             out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
         if need:
-            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf)
+            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf, rmf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
-            ctx.meta = (B, L, pad_value, H, drop_p, seeds)
+            ctx.meta = (B, L, pad_value, H, drop_p, seeds, fold)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2 = ctx.saved_tensors
+        x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2, rmf = ctx.saved_tensors
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1 = ctx.prm[:10]
-        B, L, pad_value, H, drop_p, seeds = ctx.meta
+        B, L, pad_value, H, drop_p, seeds, fold = ctx.meta
         d = x2.shape[1]
         P = Wo.shape[1]
         dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, ctx.prm[10:], drop_p, seeds[1], seeds[2])
@@ -637,7 +643,8 @@ class EncoderLastLayerFn(_Fn):
         (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
         hip.gemm_tn(dz, c_last, dWo, dbo)
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
-        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0])
+        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0],
+                                          rowmask=rmf if fold else None, bkv=bias_cat((bk, bv)) if fold else None)
         dkv2 = dkv.view(B * L, 2 * P)
         (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))    # same shared base as the full layer
         hip.gemm_tn(dq_last, x_last, dWqkv[:P], dbqkv[:P])

@@ -984,3 +984,39 @@ def test_attention_substitutes_bias_rows_for_unwritten_qkv(causal, drop_p):
     d0 = hip.attn_bwd(qkv, dctx, ref, lse_ref, ids, pad_value, causal, H, **kw)
     d1 = hip.attn_bwd(holes, dctx, got, lse, ids, pad_value, causal, H, bqkv=bias, **kw)
     assert torch.equal(d1, d0)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_attn_lastq_folds_the_padded_prefix(dt, drop_p):
+    """Single-query kernels with the first-live index + bias: the K / V rows of each sequence's padded prefix (bias rows
+    under the x_masked contract) are not fetched -- NaN there must not matter, results equal the unfolded kernels' up to
+    f32 summation order."""
+    from recguru_amd import hip
+    B, L, H, d = 9, 200, 4, 128
+    P = H * 32
+    g0 = torch.Generator().manual_seed(29)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 2
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids = ids.cuda()
+    rowmask = (ids != 0).float().view(-1)
+    M = B * L
+    x = ((torch.randn(B, L, d, generator=g0) * 0.8).cuda() * rowmask.view(B, L, 1)).to(dt).contiguous()
+    w = (torch.randn(2 * P, d, generator=g0) / d ** 0.5).to(dt).cuda()
+    bkv = (torch.randn(2 * P, generator=g0) * 0.3).cuda()
+    kv = hip.gemm_nt(x.view(M, d), w, bkv).view(B, L, 2 * P)
+    holes = kv.clone()
+    holes.view(M, 2 * P)[rowmask == 0] = float("nan")              # (left padding: the masked rows ARE the prefix)
+    q_last = (torch.randn(B, P, generator=g0) * 0.5).cuda().to(dt)
+    dctx = (torch.randn(B, P, generator=g0) * 0.5).cuda().to(dt)
+    c0 = hip.attn_lastq_fwd(q_last, kv, ids, 51, H, drop_p, 9)
+    c1 = hip.attn_lastq_fwd(q_last, holes, ids, 51, H, drop_p, 9, rowmask=rowmask, bkv=bkv)
+    t = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(c1.float(), c0.float(), **t)
+    dq0, dkv0 = hip.attn_lastq_bwd(q_last, kv, dctx, ids, 51, H, drop_p, 9)
+    dq1, dkv1 = hip.attn_lastq_bwd(q_last, holes, dctx, ids, 51, H, drop_p, 9, rowmask=rowmask, bkv=bkv)
+    torch.testing.assert_close(dq1.float(), dq0.float(), **t)
+    torch.testing.assert_close(dkv1.float(), dkv0.float(), **t)
