@@ -14,6 +14,7 @@
 // register axis, query on the lane) are exponentiated in place and fed straight back as the B
 // operand of O^T = V^T.P^T (rg_common.hip.h, stacked-accumulator mapping) -- P never touches LDS.
 #include <stdlib.h>
+#include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   // p == 0.5, bf16: the dropout mask is applied to the PACKED P fragment -- nibble of hash bits -> 4 x 16-bit masks from a
   // 16-entry table (2 VALU + 1 ds_read_b64 + 2 ANDs per 4 elements instead of a bit extract + AND per element), and the
   // f32 probabilities stay undropped, so the row sums come out of the ones-MFMA exactly as without dropout
-  constexpr bool PLUT = DM == 1 && sizeof(T) == 2 && !CAUSAL;
+  constexpr bool PLUT = DM == 1 && sizeof(T) == 2;
   constexpr bool MSUM = DM == 0 || PLUT;
   __shared__ __align__(8) unsigned int dlut[PLUT ? 32 : 2];
   __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
@@ -410,148 +411,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       if (q2 < L) load_frag(qnext, qsrc + (size_t)q2 * qld + 8 * lg);
       else frag_zero(qnext);
     }
-    // causal: a key tile that lies entirely in the future of every row of this query tile contributes exact zeros --
-    // unless a row is FULLY masked (no live key at or before it: uniform over all L keys, Q3), which can only happen
-    // for rows before the first live key
     f32x4 o[2];
     float sum, mx;
-    if constexpr (CAUSAL) {
-      const int nkq = (CAUSAL && qt * 16 >= klo) ? min(nkt, qt + 1) : nkt;
-      f32x4 s[NKT];
-      mx = -INFINITY;
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt) {
-        const bool kskip = ZKEYS && kt >= 1 && kt < nz;      // a copy of tile 0 (zero-input keys): folded in below
-        if (kt >= nkq || kskip) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (kt < nkq && !kskip) {
-          Frag<T> kf;
-          load_frag(kf, Ks + kofs(kt * 16 + li, lg));
-          float kb[4];
-          load4f(kb, kbias + kt * 16 + 4 * lg);
-          s[kt] = (f32x4){kb[0], kb[1], kb[2], kb[3]};     // the key bias rides in the accumulator: -2^100 + x == -2^100
-          mma(kf, qf, s[kt]);
-          if (CAUSAL && kt >= qt) {     // only the diagonal tile (and, for fully masked rows, the tiles above it) can hold a future key
-#pragma unroll
-            for (int r = 0; r < 4; ++r) s[kt][r] = (kt * 16 + r > qrel) ? fminf(s[kt][r], MASK_BIG) : s[kt][r];     // keeps -inf beyond L
-          }
-          mx = fmaxf(fmaxf(mx, s[kt][0]), s[kt][1]);
-          mx = fmaxf(fmaxf(mx, s[kt][2]), s[kt][3]);
-        }
-      }
-      ASTAMP(1);
-      mx = fmaxf(mx, __shfl_xor(mx, 16));
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      // exp2(s*c2 - mx*c2) as ONE fma: for a fully masked row every s and mx are the sentinel -2^100, whose products
-      // with c2 are exact, so the argument is exactly 0 (uniform row, Q3) -- no cancellation residue.
-      const float nmx = -mx * c2;
-      sum = 0.f;
-      f32x2 sum2 = (f32x2){0.f, 0.f};
-#pragma unroll
-      for (int kt = 0; kt < NKT; ++kt)
-        if (kt < nkq && !(ZKEYS && kt >= 1 && kt < nz)) {
-#pragma unroll
-          for (int r = 0; r < 4; r += 2) {        // pairs: the fma and the row-sum add as packed instructions
-            const f32x2 arg = (f32x2){s[kt][r], s[kt][r + 1]} * (f32x2){c2, c2} + (f32x2){nmx, nmx};
-            f32x2 p;
-            p.x = __builtin_amdgcn_exp2f(arg.x);
-            p.y = __builtin_amdgcn_exp2f(arg.y);
-            s[kt][r] = p.x;
-            s[kt][r + 1] = p.y;
-            if constexpr (DM != 0) sum2 += p;     // DM == 0: the row sum comes out of the MFMA below
-          }
-        }
-      // zero-input keys: p of key 0 (every key of tile 0 has it) stands for each of the nskip folded keys
-      const float pz = (ZKEYS && nskip) ? s[0][0] : 0.f;
-      const float pzr = (float)(T)pz;               // as the P operand of the MFMAs sees it (bf16 tier: rounded)
-      if constexpr (DM != 0) {
-        sum = sum2.x + sum2.y;
-        if (ZKEYS && nskip) sum += (float)(nskip >> 2) * pz;        // a quarter in each of the row's four lanes
-        sum += __shfl_xor(sum, 16);
-        sum += __shfl_xor(sum, 32);
-      }
-      float zcnt = (float)nskip;                    // folded keys that survive the attention-map dropout
-      if constexpr (DM == 1 && ZKEYS) {
-        if (nskip) {
-          int c = 0;
-#pragma unroll
-          for (int w = 0; w < NW; ++w) {
-            const int lo = max(16, 32 * w), hi = min(16 * nz, 32 * w + 32);      // folded keys covered by hash word w
-            if (lo < hi) {
-              const unsigned int m = (hi - 32 * w == 32 ? 0xFFFFFFFFu : ((1u << (hi - 32 * w)) - 1u)) & ~((1u << (lo - 32 * w)) - 1u);
-              c += __popc(dmask[w * LPK + min(q, L - 1)] & m);
-            }
-          }
-          zcnt = (float)c;
-        }
-      }
-      if constexpr (DM == 1) {   // nn.Dropout on the attention map (after softmax): the normaliser stays the undropped sum
-#pragma unroll
-        for (int kt = 0; kt < NKT; kt += 2)
-          if (kt < nkq) {           // skipped (future) key tiles hold zeros already
-            const unsigned int w = dmask[(kt >> 1) * LPK + q] >> (4 * lg);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              s[kt][r] = rg_and(s[kt][r], rg_bitmask(w, r));
-              if (kt + 1 < NKT) s[kt + 1][r] = rg_and(s[kt + 1][r], rg_bitmask(w, 16 + r));
-            }
-          }
-      } else if constexpr (DM == 2) {
-        const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lpad(L) + 4u * lg;
-#pragma unroll
-        for (int kt = 0; kt < NKT; kt += 2)       // NKT is even; rows start on a hash-word boundary
-          if (kt < nkq) {
-            float k0[4], k1[4];
-            rg_keep4_pair(drop, base + kt * 16, k0, k1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) { s[kt][r] *= k0[r]; if (kt + 1 < NKT) s[kt + 1][r] *= k1[r]; }
-          }
-      }
-      ASTAMP(2);
-
-      o[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};
-      Frag<T> ones;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
-#pragma unroll
-      for (int ks = 0; ks < NKT / 2; ++ks)
-        if (2 * ks < nkq && !(ZKEYS && 2 * ks >= 1 && 2 * ks + 1 < nz)) {     // a pair of folded tiles holds zeros only
-          Frag<T> pf;
-          acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
-#pragma unroll
-          for (int dt = 0; dt < 2; ++dt) {
-            Frag<T> vf;
-            VStage<T>::frag(vf, Vs, LDV, ks * 32, dt * 16, li, lg);
-            mma(vf, pf, o[dt]);
-          }
-          // row sums of P as a third product against a ones tile: every accumulator row of a lane is the
-          // complete sum over the keys (no per-element adds, no cross-lane reduction), and it is the sum of
-          // exactly the (rounded) P that multiplies V
-          if constexpr (DM == 0) mma(ones, pf, osum);
-        }
-      if constexpr (DM == 0) sum = osum[0] + (float)nskip * pzr;   // the MFMA row sum adds the ROUNDED P
-      if (ZKEYS && nskip) {                         // + (kept folded keys) x p_0 x bv: V row of key 0
-        const float wz = pzr * zcnt;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int dv = dt * 16 + 4 * lg + r;
-            o[dt][r] += wz * (float)(VT ? Vs[dv * LDV] : Vs[dv]);
-          }
-      }
-    } else {
-      // ---- non-causal: every query row sees every key.  Key tiles are taken in the fixed order 0, NKT-1, NKT-2, ..., 1
-      // (list entry j -> tile t(j), all compile-time), branch-free inside a region: the K fragment and bias of entry j + 1
-      // are read while the MFMA of entry j runs (a branch per tile kept every LDS round trip on the wave's critical path:
-      // 262 -> 220 us at the bench shape).  Zero-input keys (see above) sit at the FRONT of a left-padded sequence, i.e. at
-      // the END of the list: the list's tail is cut into NTR regions of 4 tiles with one scalar branch per region and
-      // loop, and a region whose tiles are all zero-input keys is skipped -- its 64 keys are (kept: popcount of the
-      // dropout bits) more copies of key 0.
-      constexpr int TR = 4, NTR = NKT >= 12 ? 2 : (NKT >= 8 ? 1 : 0), F = NKT - TR * NTR;
-      auto tile_of = [](int j) { return j == 0 ? 0 : NKT - j; };
-      const int nfr = min(NTR, (nz - 1) >> 2);            // folded regions (nz == 0: (nz - 1) >> 2 == -1 -> see nrun)
-      const int nrun = NTR - max(nfr, 0);                 // tail regions that are evaluated (region 0 always is)
+    {
+      // ---- Key tiles are taken as a LIST (entry j -> tile t(j), all compile-time) cut into regions with one scalar branch
+      // per region and loop, branch-free inside a region: the K fragment and bias of entry j + 1 are read while the MFMA of
+      // entry j runs (a branch per tile kept every LDS round trip on the wave's critical path: 262 -> 220 us at the bench
+      // shape).
+      //  * non-causal: every query row sees every key; order 0, NKT-1, NKT-2, ..., 1.  Zero-input keys (see above) sit at
+      //    the FRONT of a left-padded sequence, i.e. at the END of the list: its tail is cut into NTR regions of 4 tiles and
+      //    a region whose tiles are all zero-input keys is skipped -- its 64 keys are (kept: popcount of the dropout bits)
+      //    more copies of key 0.
+      //  * causal: ascending order, regions of 4; a region entirely in the future of every row of this query tile
+      //    contributes exact zeros and is skipped -- unless a row is FULLY masked (no live key at or before it: uniform
+      //    over all L keys, Q3), which can only happen for rows before the first live key (klo).  Inside the last evaluated
+      //    region the future keys are masked element-wise (its own instantiation of the region body).
+      constexpr int TR = 4;
+      constexpr int NTR = CAUSAL ? (NKT + TR - 1) / TR - 1 : (NKT >= 12 ? 2 : (NKT >= 8 ? 1 : 0));
+      constexpr int F = CAUSAL ? (NKT < TR ? NKT : TR) : NKT - TR * NTR;
+      auto tile_of = [](int j) { return CAUSAL ? j : (j == 0 ? 0 : NKT - j); };
+      const int nkq = (CAUSAL && qt * 16 >= klo) ? min(nkt, qt + 1) : nkt;       // causal: tiles 0 .. nkq-1 matter
+      const int nfr = CAUSAL ? 0 : min(NTR, (nz - 1) >> 2);     // folded regions (nz == 0: (nz - 1) >> 2 == -1 -> see nrun)
+      const int nrun = CAUSAL ? (nkq <= F ? 0 : (nkq - F + TR - 1) / TR) : NTR - max(nfr, 0);     // tail regions that are evaluated
       const int nskip = 16 * TR * max(nfr, 0);            // folded keys: tiles 1 .. TR * nfr
       f32x4 s[NKT];
       mx = -INFINITY;
@@ -566,20 +447,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
         for (int rg = 0; rg <= NTR; ++rg)
           if (rg <= nrun) {
-            const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = rg == 0 ? F : j0 + TR;
+            const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
+            auto finish = [&](int j, auto MK) {           // entry j's scores are complete: future keys masked (MK), row max
+              if constexpr (decltype(MK)::value) {
 #pragma unroll
-            for (int j = j0; j < j1; ++j) {
-              if (j + 1 < NKT) issue(j + 1, (j + 1) & 1);
-              s[j] = (f32x4){kbb[j & 1][0], kbb[j & 1][1], kbb[j & 1][2], kbb[j & 1][3]};   // the key bias rides in the accumulator
-              mma(kfb[j & 1], qf, s[j]);
-              if (j > j0) {
-                mx = fmaxf(fmaxf(mx, s[j - 1][0]), s[j - 1][1]);
-                mx = fmaxf(fmaxf(mx, s[j - 1][2]), s[j - 1][3]);
+                for (int r = 0; r < 4; ++r) s[j][r] = (j * 16 + r > qrel) ? fminf(s[j][r], MASK_BIG) : s[j][r];   // keeps -inf beyond L
               }
-              __builtin_amdgcn_sched_barrier(0);          // keeps the reads one entry ahead (hoisting them all costs a wave per SIMD)
-            }
-            mx = fmaxf(fmaxf(mx, s[j1 - 1][0]), s[j1 - 1][1]);
-            mx = fmaxf(fmaxf(mx, s[j1 - 1][2]), s[j1 - 1][3]);
+              mx = fmaxf(fmaxf(mx, s[j][0]), s[j][1]);
+              mx = fmaxf(fmaxf(mx, s[j][2]), s[j][3]);
+            };
+            auto body = [&](auto MK) {
+#pragma unroll
+              for (int j = j0; j < j1; ++j) {
+                if (j + 1 < NKT) issue(j + 1, (j + 1) & 1);
+                s[j] = (f32x4){kbb[j & 1][0], kbb[j & 1][1], kbb[j & 1][2], kbb[j & 1][3]};   // the key bias rides in the accumulator
+                mma(kfb[j & 1], qf, s[j]);
+                if (j > j0) finish(j - 1, MK);
+                __builtin_amdgcn_sched_barrier(0);        // keeps the reads one entry ahead (hoisting them all costs a wave per SIMD)
+              }
+              finish(j1 - 1, MK);
+            };
+            if (CAUSAL && j1 - 1 >= qt) body(std::true_type{});      // (uniform) the region reaches the diagonal or beyond
+            else body(std::false_type{});
           }
       }
       ASTAMP(1);
@@ -591,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
         if (rg <= nrun) {
-          const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = rg == 0 ? F : j0 + TR;
+          const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
           for (int j = j0; j < j1; ++j)
 #pragma unroll
@@ -630,23 +519,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
         }
       }
       // dropout on the f32 probabilities (f32 tier, generic p): s[j] holds tile t(j)
+      auto entry_of = [](int t) { return CAUSAL ? t : (t == 0 ? 0 : NKT - t); };       // inverse of tile_of
+      auto region_on = [&](int j) { return j < F || (j - F) / TR + 1 <= nrun; };        // (uniform) entry j was evaluated
       if constexpr (DM == 1 && !PLUT) {
 #pragma unroll
-        for (int j = 0; j < NKT; ++j) {
-          const int t = tile_of(j);
-          const unsigned int w = dmask[(t >> 1) * LPK + q] >> (4 * lg + 16 * (t & 1));
+        for (int j = 0; j < NKT; ++j)
+          if (!CAUSAL || region_on(j)) {
+            const int t = tile_of(j);
+            const unsigned int w = dmask[(t >> 1) * LPK + q] >> (4 * lg + 16 * (t & 1));
 #pragma unroll
-          for (int r = 0; r < 4; ++r) s[j][r] = rg_and(s[j][r], rg_bitmask(w, r));
-        }
+            for (int r = 0; r < 4; ++r) s[j][r] = rg_and(s[j][r], rg_bitmask(w, r));
+          }
       } else if constexpr (DM == 2) {
         const unsigned int base = (((unsigned int)b * a.H + h) * L + min(q, L - 1)) * rg_lpad(L) + 4u * lg;
 #pragma unroll
         for (int t = 0; t < NKT; t += 2) {            // hash words cover the key-tile pair (t, t + 1): list entries ja, jb
-          const int ja = t == 0 ? 0 : NKT - t, jb = NKT - (t + 1);
-          float k0[4], k1[4];
-          rg_keep4_pair(drop, base + t * 16, k0, k1);
+          const int ja = entry_of(t), jb = entry_of(t + 1);
+          if (!CAUSAL || region_on(ja)) {             // (causal: a pair never straddles two regions)
+            float k0[4], k1[4];
+            rg_keep4_pair(drop, base + t * 16, k0, k1);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) { s[ja][r] *= k0[r]; s[jb][r] *= k1[r]; }
+            for (int r = 0; r < 4; ++r) { s[ja][r] *= k0[r]; s[jb][r] *= k1[r]; }
+          }
           __builtin_amdgcn_sched_barrier(0);        // one pair's hashes at a time (all of them in flight cost a wave per SIMD)
         }
       }
@@ -659,9 +553,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
         if (rg <= nrun) {
-          const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = rg == 0 ? F : j0 + TR;
+          const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
-          for (int ks = j0 / 2; ks < j1 / 2; ++ks) {          // F and TR are even
+          for (int ks = j0 / 2; ks < j1 / 2; ++ks) {          // F, TR and NKT are even
             const int tA = tile_of(2 * ks), tB = tile_of(2 * ks + 1);
             Frag<T> pf;
             acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
