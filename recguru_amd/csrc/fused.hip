@@ -273,8 +273,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16):
   // 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
   // work tile is 64 live-ish rows wherever the padding sits).
-  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
-  int cur = (int)blockIdx.x;
+  LiveWalk lw;                              // list entries by v_readlane (one vector load per 16 tiles), see rg_common.hip.h
+  lw.init(a.live16, a.M);
+  const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
+  int cur = (int)blockIdx.x, kcur = 0;
   auto next_group = [&](int (&g)[4]) -> bool {
     if (cur >= nwork) {
 #pragma unroll
@@ -285,11 +287,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
     } else {
-      const int nlive = a.live16[0];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) g[rt] = 4 * cur + rt < nlive ? a.live16[1 + 4 * cur + rt] * 16 : a.M;
+      lw.group(kcur, g, a.M);
     }
     cur += gridDim.x;
+    ++kcur;
     return true;
   };
   auto prefetch_rows = [&](const int (&g)[4]) {         // rows >= M: clamped address, no branch (never stored)
@@ -662,8 +663,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
     for (int i = tid; i < FD; i += 256) { lnp[i] = a.ln_gamma[i]; lnp[FD + i] = a.ln_beta[i]; lnp[2 * FD + i] = 1.f / a.ln_gamma[i]; }
   }
 
-  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
-  int cur = (int)blockIdx.x;
+  LiveWalk lw;
+  lw.init(a.live16, a.M);
+  const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
+  int cur = (int)blockIdx.x, kcur = 0;
   auto next_group = [&](int (&g)[4]) -> bool {
     if (cur >= nwork) {
 #pragma unroll
@@ -674,11 +677,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
     } else {
-      const int nlive = a.live16[0];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) g[rt] = 4 * cur + rt < nlive ? a.live16[1 + 4 * cur + rt] * 16 : a.M;
+      lw.group(kcur, g, a.M);
     }
     cur += gridDim.x;
+    ++kcur;
     return true;
   };
   auto prefetch_h = [&](const int (&g)[4], int ch) {    // rows >= M: clamped address, never stored

@@ -51,15 +51,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // A work tile is 4 row tiles of 16 rows at rows mb[0..3] (>= M: absent): 64 consecutive rows, or -- with the list
   // of live 16-row tiles a.live16 (rg_live_tiles) -- 4 consecutive list entries; rows of the padded tiles are not read
   // and their rows of C are written as zeros at the end.  Thread tid stages chunk i = row 16 i + (tid >> 4).
-  const int nwork = a.live16 ? (a.live16[0] + 3) >> 2 : ntiles;
-  auto group = [&](int wt, int (&g)[4]) {
+  LiveWalk lw;
+  lw.init(a.live16, a.M);
+  const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
+  auto group = [&](int k, int (&g)[4]) {                 // k-th work tile of this workgroup
     if (!a.live16) {
+      const int wt = (int)blockIdx.x + k * (int)gridDim.x;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) g[rt] = wt * WS_M + 16 * rt;
     } else {
-      const int nl = a.live16[0];
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) g[rt] = (wt < nwork && 4 * wt + rt < nl) ? a.live16[1 + 4 * wt + rt] * 16 : a.M;
+      lw.group(k, g, a.M);
     }
   };
   // chunk (tile, kc) -> the tile's rows, columns kc*128.. of A ; each thread stages 4 x 16 bytes
@@ -82,15 +83,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
       load_frag(axn[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
     }
   };
-  int tile = blockIdx.x;
+  int tile = blockIdx.x, kt_ = 0;                         // kt_: index of `tile` among this workgroup's tiles
   int mb[4], mbn[4];
   if (tile < nwork) {
-    group(tile, mb);
+    group(0, mb);
     prefetch(mb, 0);
     if constexpr (AUX) aux_prefetch(mb, 0);
   }
-  for (; tile < nwork; tile += gridDim.x) {
-    group(tile + (int)gridDim.x, mbn);
+  for (; tile < nwork; tile += gridDim.x, ++kt_) {
+    group(kt_ + 1, mbn);
     f32x4 acc[2][4];
 #pragma unroll
     for (int kc = 0; kc < NKC; ++kc) {

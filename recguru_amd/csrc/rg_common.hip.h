@@ -306,6 +306,38 @@ static inline int rg_head_grid(int B, int H) {
 // counter, so every software-prefetched global load would be waited for at every barrier.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The work tiles of a persistent workgroup (k-th tile = blockIdx.x + k * gridDim.x) under a live-tile list
+// (rg_live_tiles): a work tile is 4 consecutive list entries.  The entries of 16 consecutive k's sit in ONE register
+// (lane 4 (k & 15) + rt), fetched by a single unconditional vector load per 16 tiles and handed out with v_readlane.
+// Read from memory tile by tile -- a dependent load and a wait per entry, behind per-entry branches -- the list cost five
+// L2 round trips per tile, each behind a vmcnt(0) that also drained the kernel's prefetches and waited for its stores.
+struct LiveWalk {
+  const int* list;
+  int nlive, cap, v, blk;
+  __device__ __forceinline__ void init(const int* live16, int M) {
+    list = live16;
+    nlive = live16 ? live16[0] : 0;
+    cap = ((M + 15) >> 4) - 1;          // last valid entry index (entries past nlive are never used)
+    v = 0;
+    blk = -1;
+  }
+  // first rows of the 4 row tiles of work tile `wt` = blockIdx.x + k * gridDim.x (>= M: absent)
+  __device__ __forceinline__ void group(int k, int (&g)[4], int M) {
+    const int wt = (int)blockIdx.x + k * (int)gridDim.x;
+    if ((k >> 4) != blk) {              // (uniform) next block of 16 tiles
+      blk = k >> 4;
+      const int lane = threadIdx.x & 63;
+      const long long idx = 4ll * ((long long)blockIdx.x + (long long)gridDim.x * (16 * blk + (lane >> 2))) + (lane & 3);
+      v = list[1 + (int)(idx < (long long)cap ? idx : (long long)cap)];
+    }
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      const int e = __builtin_amdgcn_readlane(v, 4 * (k & 15) + rt);
+      g[rt] = (4 * wt + rt < nlive) ? e * 16 : M;
+    }
+  }
+};
+
 #define RG_CHECK_LAUNCH()                                   \
   do {                                                      \
     hipError_t e__ = hipGetLastError();                     \
