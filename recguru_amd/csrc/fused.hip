@@ -219,7 +219,9 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 #endif
 
 // DM: dropout mode -- 0 none, 1 p == 0.5 (one hash bit per element), 2 generic p (16-bit hash fields)
-template <typename T, int DM>
+// CROSS: the decoder form (collapsed cross-attention stage between the two LayerNorms).  The encoder launches (three
+// quarters of them) run the instantiation without it: its loads and registers were what spilled under dropout.
+template <typename T, int DM, bool CROSS>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -326,7 +328,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       // 64 padded positions: the block's output is out * rowmask = 0 whatever the arithmetic gives, and no gradient
       // comes back through these rows -- write the zeros (and finite placeholders for what backward reads) and move on
       zero_to_hbm<T>(out, FD, 0, mb, a.M, tid);
-      const bool cross = a.o_bcast || a.cross_s;
+      const bool cross = CROSS;
       if (ysave) zero_to_hbm<T>(ysave, FD, 0, mb, a.M, tid);
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, mb, a.M, tid);
       if (h1save)
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     }
     regs_to_tile<T>(acc, Ay, n0, li, lg);
     STAMP(2);
-    if (a.o_bcast || a.cross_s) {
+    if constexpr (CROSS) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
       if (ysave) { lds_barrier(); tile_to_hbm<T, true>(Ay, ysave, FD, 0, mb, a.M, tid); }
       // o rows: the (uniform) dropout / no-dropout switch sits outside the loops and the loads of a row tile are
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     }
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
     {
-      const bool cross = a.o_bcast || a.cross_s;
+      constexpr bool cross = CROSS;
       if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T, true>(Ay, cross ? y2save : ysave, FD, 0, mb, a.M, tid);
     }
     STAMP(3);
@@ -553,7 +555,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     // the padded row tiles (listed from the far end of live16): out rows = 0 -- and zeros / finite placeholders in
     // everything a backward pass reads --, 4 row tiles per step
     const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
-    const bool cross = a.o_bcast || a.cross_s;
+    constexpr bool cross = CROSS;
     for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
       int md[4];
 #pragma unroll
@@ -599,10 +601,16 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
   if (grid > ntiles) grid = ntiles;
   const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
-#define RG_PA(T, DM)                                                                                                      \
+  const bool cross = a->o_bcast || a->cross_s;
+#define RG_PA2(T, DM, C)                                                                                                  \
   do {                                                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM>), dim3(grid), dim3(256), smem, s, *a);                                \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C>), dim3(grid), dim3(256), smem, s, *a);                             \
+  } while (0)
+#define RG_PA(T, DM)                 \
+  do {                               \
+    if (cross) RG_PA2(T, DM, true);  \
+    else RG_PA2(T, DM, false);       \
   } while (0)
 #define RG_PA_T(T)                   \
   do {                               \
@@ -615,6 +623,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   else return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: bad dtype");
 #undef RG_PA_T
 #undef RG_PA
+#undef RG_PA2
   RG_CHECK_LAUNCH();
   return 0;
 }
