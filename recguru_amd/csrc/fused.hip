@@ -221,7 +221,9 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // DM: dropout mode -- 0 none, 1 p == 0.5 (one hash bit per element), 2 generic p (16-bit hash fields)
 // CROSS: the decoder form (collapsed cross-attention stage between the two LayerNorms).  The encoder launches (three
 // quarters of them) run the instantiation without it: its loads and registers were what spilled under dropout.
-template <typename T, int DM, bool CROSS>
+// SAVE: a training launch (y / y2 / h1 / rstd* saved for the backward); inference launches (the critic phase's encoder
+// passes: most launches of a step) compile all of it away.
+template <typename T, int DM, bool CROSS, bool SAVE>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -251,9 +253,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const T* __restrict__ W1 = reinterpret_cast<const T*>(a.W1);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
-  T* __restrict__ ysave = reinterpret_cast<T*>(a.y_save);
-  T* __restrict__ y2save = reinterpret_cast<T*>(a.y2_save);
-  T* __restrict__ h1save = reinterpret_cast<T*>(a.h1_save);
+  T* __restrict__ ysave = SAVE ? reinterpret_cast<T*>(a.y_save) : nullptr;
+  T* __restrict__ y2save = SAVE ? reinterpret_cast<T*>(a.y2_save) : nullptr;
+  T* __restrict__ h1save = SAVE ? reinterpret_cast<T*>(a.h1_save) : nullptr;
+  float* __restrict__ rstd1o = SAVE ? a.rstd1 : nullptr;
+  float* __restrict__ rstd2o = SAVE ? a.rstd2 : nullptr;
+  float* __restrict__ rstdco = SAVE ? a.rstd_c : nullptr;
   const int n0 = wave * 32;                 // this wave's 32 output features of every 128-wide block
   const int ntiles = (a.M + FT_M - 1) / FT_M;
   const int nchunk = a.dff / FD;
@@ -334,9 +339,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       if (h1save)
         for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, mb, a.M, tid);
       if (tid < FT_M && mb[0] + tid < a.M) {            // plain tiles only: 64 consecutive rows
-        if (a.rstd1) a.rstd1[mb[0] + tid] = 0.f;
-        if (a.rstd2) a.rstd2[mb[0] + tid] = 0.f;
-        if (a.rstd_c) a.rstd_c[mb[0] + tid] = 0.f;
+        if (rstd1o) rstd1o[mb[0] + tid] = 0.f;
+        if (rstd2o) rstd2o[mb[0] + tid] = 0.f;
+        if (rstdco) rstdco[mb[0] + tid] = 0.f;
       }
       lds_barrier();                                    // the staged ctx / x tile of this iteration is dropped
       prefetch_rows(mbn);
@@ -365,10 +370,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     STAMP(1);
     float rstd[4];
     ln_regs(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
-    if (a.rstd1 && wave == 0 && lg == 0) {
+    if (rstd1o && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
-        if (mb[rt] + li < a.M) a.rstd1[mb[rt] + li] = rstd[rt];
+        if (mb[rt] + li < a.M) rstd1o[mb[rt] + li] = rstd[rt];
     }
     regs_to_tile<T>(acc, Ay, n0, li, lg);
     STAMP(2);
@@ -426,10 +431,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       }
       lds_barrier();                                    // ysave copy done before the tile is overwritten
       ln_regs(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
-      if (a.rstd_c && wave == 0 && lg == 0) {
+      if (rstdco && wave == 0 && lg == 0) {
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt)
-          if (mb[rt] + li < a.M) a.rstd_c[mb[rt] + li] = rstd[rt];
+          if (mb[rt] + li < a.M) rstdco[mb[rt] + li] = rstd[rt];
       }
       regs_to_tile<T>(acc, Ay, n0, li, lg);
     }
@@ -530,10 +535,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
       }
     ln_regs(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
-    if (a.rstd2 && wave == 0 && lg == 0) {
+    if (rstd2o && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
-        if (mb[rt] + li < a.M) a.rstd2[mb[rt] + li] = rstd[rt];
+        if (mb[rt] + li < a.M) rstd2o[mb[rt] + li] = rstd[rt];
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -569,9 +574,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       if (tid < FT_M) {
         const int m = md[tid >> 4] + (tid & 15);
         if (m < a.M) {
-          if (a.rstd1) a.rstd1[m] = 0.f;
-          if (a.rstd2) a.rstd2[m] = 0.f;
-          if (a.rstd_c) a.rstd_c[m] = 0.f;
+          if (rstd1o) rstd1o[m] = 0.f;
+          if (rstd2o) rstd2o[m] = 0.f;
+          if (rstdco) rstdco[m] = 0.f;
         }
       }
     }
@@ -602,15 +607,16 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   if (grid > ntiles) grid = ntiles;
   const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
   const bool cross = a->o_bcast || a->cross_s;
-#define RG_PA2(T, DM, C)                                                                                                  \
+  const bool save = a->y_save || a->y2_save || a->h1_save || a->rstd1 || a->rstd2 || a->rstd_c;
+#define RG_PA2(T, DM, C, S)                                                                                               \
   do {                                                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C>), dim3(grid), dim3(256), smem, s, *a);                             \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C, S>), dim3(grid), dim3(256), smem, s, *a);                          \
   } while (0)
-#define RG_PA(T, DM)                 \
-  do {                               \
-    if (cross) RG_PA2(T, DM, true);  \
-    else RG_PA2(T, DM, false);       \
+#define RG_PA(T, DM)                                  \
+  do {                                                \
+    if (cross) { if (save) RG_PA2(T, DM, true, true); else RG_PA2(T, DM, true, false); }      \
+    else { if (save) RG_PA2(T, DM, false, true); else RG_PA2(T, DM, false, false); }          \
   } while (0)
 #define RG_PA_T(T)                   \
   do {                               \
