@@ -444,6 +444,27 @@ typedef struct {
   float ln_drop_p; unsigned long long ln_drop_seed;
 } rg_ffn_bwd_args;
 size_t rg_ffn_bwd_ln_workspace(int M);
+
+/* ---- attention block, backward of its tail in one launch ----------------------------------------------
+ * y = LayerNorm(ctx . Wo^T + bo + x) (MultiHeadAttention tail, Transformer/transformer.py:160-161), backwards with respect
+ * to ctx:   dz = LayerNorm backward of dy (rg_ln_bwd's arithmetic, from the saved OUTPUT y; rows with rowmask == 0 get 0),
+ *           dctx = dz . Wo.
+ * dz [M,128] is written (it is the residual gradient and the Y operand of dWo += dz^T ctx), dctx [M,P=128] is written,
+ * dgamma / dbeta are accumulated through ln_partials (>= rg_attn_out_bwd_workspace(M) bytes) and a reduce launch.
+ * Wot = Wo^T [P,d] as the [out][in] operand, row-major or fragment-packed (w_packed).  d == P == 128.
+ * live16: rows of padded tiles of dz / dctx stay unwritten.  Replaces rg_ln_bwd + rg_gemm_nt (1.25 KB -> 1 KB per token,
+ * and the LayerNorm backward no longer runs as a launch of its own at 2.7 TB/s). */
+typedef struct {
+  const void* dy; const void* y; const float* rstd; const float* gamma; const float* beta;
+  const float* rowmask;      /* optional [M] */
+  const void* Wot;
+  void* dz; void* dctx;
+  float* dgamma; float* dbeta; float* ln_partials;
+  int M, d, P, w_packed;
+  const int* live16;
+} rg_attn_out_bwd_args;
+int rg_attn_out_bwd(const rg_attn_out_bwd_args* args /* host */, int dtype, void* stream);
+size_t rg_attn_out_bwd_workspace(int M);
 int rg_ffn_bwd_data(const rg_ffn_bwd_args* args /* host */, int dtype, void* stream);
 int rg_ffn_bwd_data_supported(int d, int dff);
 /* list [1 + 2*nt + 4], nt = ceil(M/16): list[0] = number of 16-row tiles holding a row with rowmask != 0, list[1..] their

@@ -938,3 +938,170 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
   RG_CHECK_LAUNCH();
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Attention block tail, backward (rg_attn_out_bwd): LayerNorm-1 backward on the staged rows (same staging layout and
+// arithmetic as rg_ln_bwd / the FFN kernel above) -> dz to LDS (A operand) and HBM -> dctx = dz . Wo with Wo^T stationary
+// in registers (one weight set, loaded once per workgroup).  HBM-bound: 2 tiles of LDS, ~100 VGPRs, 4 workgroups per CU.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn_out_bwd_kernel(rg_attn_out_bwd_args a) {
+  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
+  extern __shared__ __align__(16) unsigned char smem[];
+  T* Adz = reinterpret_cast<T*>(smem);
+  T* Aout = reinterpret_cast<T*>(smem + ACT_BYTES);
+  float* lnp = reinterpret_cast<float*>(smem + 2 * ACT_BYTES);      // gamma | beta | 1 / gamma
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+  const T* __restrict__ y = reinterpret_cast<const T*>(a.y);
+  T* __restrict__ dz = reinterpret_cast<T*>(a.dz);
+  T* __restrict__ dctx = reinterpret_cast<T*>(a.dctx);
+  const int n0 = wave * 32;
+  const int ntiles = (a.M + FT_M - 1) / FT_M;
+  for (int i = tid; i < FD; i += 256) { lnp[i] = a.gamma[i]; lnp[FD + i] = a.beta[i]; lnp[2 * FD + i] = 1.f / a.gamma[i]; }
+  WSet<T> w;
+  load_wset(w, reinterpret_cast<const T*>(a.Wot), FD, n0, 0, li, lg, a.w_packed);
+  Frag<T> cpre[4], xpre[4];
+  float rs_pre[4], rm_pre[4];
+  float dg[8], db[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { dg[j] = 0.f; db[j] = 0.f; }
+  LiveWalk lw;
+  lw.init(a.live16, a.M);
+  const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
+  int cur = (int)blockIdx.x, kcur = 0;
+  auto next_group = [&](int (&g)[4]) -> bool {
+    if (cur >= nwork) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = a.M;
+      return false;
+    }
+    if (!a.live16) {
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
+    } else {
+      lw.group(kcur, g, a.M);
+    }
+    cur += gridDim.x;
+    ++kcur;
+    return true;
+  };
+  auto prefetch_rows = [&](const int (&g)[4]) {         // unconditional loads from clamped rows
+    const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.rstd;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
+      load_frag(cpre[i], gofs(dy, (unsigned int)(m * FD + c8)));
+      load_frag(xpre[i], gofs(y, (unsigned int)(m * FD + c8)));
+      const float rv = rmp[m];
+      rs_pre[i] = a.rstd[m];
+      rm_pre[i] = a.rowmask ? rv : 1.f;
+    }
+  };
+  int mb[4], mbn[4];
+  bool have = next_group(mb);
+  if (have) prefetch_rows(mb);
+  __syncthreads();                                      // lnp
+  for (; have;) {
+    const bool have_next = next_group(mbn);
+    {
+      const int c8 = (tid & 15) * 8;
+      float gam[8], bet[8], igam[8];
+      load8(gam, lnp + c8);
+      load8(bet, lnp + FD + c8);
+      load8(igam, lnp + 2 * FD + c8);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int r = 16 * i + (tid >> 4), m = mb[i] + (tid >> 4);
+        const bool live = m < a.M;
+        const float rm = live ? rm_pre[i] : 0.f;
+        float g[8], xh[8], s1 = 0.f, s2 = 0.f;
+        if (rm != 0.f) {
+          const float irm = 1.f / rm;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float d = (float)cpre[i].v[j] * rm;
+            xh[j] = ((float)xpre[i].v[j] * irm - bet[j]) * igam[j];
+            g[j] = d * gam[j];
+            dg[j] += d * xh[j];
+            db[j] += d;
+            s1 += g[j];
+            s2 += g[j] * xh[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { g[j] = 0.f; xh[j] = 0.f; }
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float rstd = rm != 0.f ? rs_pre[i] : 0.f;
+        s1 *= 1.f / FD;
+        s2 *= 1.f / FD;
+        float o8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
+        store8(Adz + Tile<T>::off(r, c8), o8);
+        if (live) store8(gofs(dz, (unsigned int)(m * FD + c8)), o8);
+      }
+    }
+    prefetch_rows(mbn);                                 // next tile's rows: in flight under the product
+    lds_barrier();
+    f32x4 acc[2][4];
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+      for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    mma_wset<T>(acc, w, Adz, li, lg);                   // dctx = dz . Wot^T
+    regs_to_tile<T>(acc, Aout, n0, li, lg);
+    lds_barrier();
+    tile_to_hbm<T>(Aout, dctx, FD, 0, mb, a.M, tid);
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+    have = have_next;
+    // (the next iteration's stores to Adz come after this iteration's MFMA reads of it: every wave passed the second
+    // barrier after its reads; Aout is rewritten only after the next iteration's first barrier)
+  }
+  // dgamma / dbeta: lanes with the same feature octet -> waves -> this workgroup's slice of the partials
+#pragma unroll
+  for (int o = 16; o < 64; o <<= 1)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[j] += __shfl_xor(dg[j], o); db[j] += __shfl_xor(db[j], o); }
+  float* red = reinterpret_cast<float*>(smem);
+  __syncthreads();
+  if (lane < 16) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[(0 * 4 + wave) * FD + lane * 8 + j] = dg[j]; red[(1 * 4 + wave) * FD + lane * 8 + j] = db[j]; }
+  }
+  __syncthreads();
+  const int wsel = tid >> 7, n = tid & 127;
+  a.ln_partials[((size_t)blockIdx.x * 2 + wsel) * FD + n] = (red[(wsel * 4 + 0) * FD + n] + red[(wsel * 4 + 1) * FD + n]) + (red[(wsel * 4 + 2) * FD + n] + red[(wsel * 4 + 3) * FD + n]);
+}
+
+static int attn_out_bwd_grid(int M) {
+  const int ntiles = (M + FT_M - 1) / FT_M;
+  return ntiles < 512 ? ntiles : 512;                    // two persistent workgroups per CU (the LayerNorm state + weight set + prefetch need ~190 VGPRs)
+}
+extern "C" size_t rg_attn_out_bwd_workspace(int M) { return (size_t)(M <= 0 ? 0 : 1024) * 2 * FD * sizeof(float); }   // (grid <= 1024)
+
+extern "C" int rg_attn_out_bwd(const rg_attn_out_bwd_args* a, int dtype, void* stream) {
+  if (!a || a->M <= 0) return 0;
+  if (a->d != FD || a->P != FD) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_out_bwd: needs d_model == n_heads*32 == 128");
+  if (!a->dy || !a->y || !a->rstd || !a->gamma || !a->beta || !a->Wot || !a->dz || !a->dctx || !a->ln_partials)
+    return rg_set_error_msg(RG_ERR_INVALID, "attn_out_bwd: NULL operand");
+  if ((long long)a->M * FD * 4 >= (1ll << 32)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_out_bwd: M too large for 32-bit offsets");
+  hipStream_t s = (hipStream_t)stream;
+  const int esz = dtype == RG_BF16 ? 2 : 4;
+  const int smem = 2 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz + 3 * FD * 4;
+  const int grid = attn_out_bwd_grid(a->M);
+  if (dtype == RG_BF16) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_bwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL((attn_out_bwd_kernel<__bf16>), dim3(grid), dim3(256), smem, s, *a);
+  } else if (dtype == RG_F32) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL((attn_out_bwd_kernel<float>), dim3(grid), dim3(256), smem, s, *a);
+  } else return rg_set_error_msg(RG_ERR_INVALID, "attn_out_bwd: bad dtype");
+  if (a->dgamma || a->dbeta)
+    hipLaunchKernelGGL(ffn_bwd_ln_reduce_kernel, dim3(grid < 32 ? grid : 32), dim3(256), 0, s, a->ln_partials, grid, a->dgamma, a->dbeta);
+  RG_CHECK_LAUNCH();
+  return 0;
+}

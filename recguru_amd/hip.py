@@ -68,6 +68,12 @@ class FfnBwdArgs(ctypes.Structure):
                 ("ln_drop_p", c_f), ("ln_drop_seed", c_u64)]
 
 
+class AttnOutBwdArgs(ctypes.Structure):
+    _fields_ = [("dy", c_p), ("y", c_p), ("rstd", c_p), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p), ("Wot", c_p),
+                ("dz", c_p), ("dctx", c_p), ("dgamma", c_p), ("dbeta", c_p), ("ln_partials", c_p),
+                ("M", c_i), ("d", c_i), ("P", c_i), ("w_packed", c_i), ("live16", c_p)]
+
+
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
            "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
@@ -78,7 +84,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
-           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live"]
+           "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live",
+           "rg_attn_out_bwd", "rg_attn_out_bwd_workspace"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -710,6 +717,27 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     return out, sv
 
 
+def attn_out_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, Wot, live=None, w_packed=False):
+    """Backward of the attention block's tail y = LayerNorm(ctx Wo^T + bo + x) with respect to ctx, in one launch
+    (rg_attn_out_bwd): returns (dz [M,d], dctx [M,P]); dgamma / dbeta accumulated in place.  Wot = Wo^T [P,d] (operand
+    copy, fragment-packed when w_packed).  With a live-tile list the padded tiles' rows of dz / dctx stay unwritten."""
+    M, d = dy.shape
+    P = d
+    assert dy.is_contiguous() and y.is_contiguous() and dy.dtype == y.dtype
+    dz = torch.empty_like(dy)
+    dctx = torch.empty(M, P, device=dy.device, dtype=dy.dtype)
+    if POISON_UNWRITTEN and live is not None:
+        dz.fill_(float("nan"))
+        dctx.fill_(float("nan"))
+    fn = lib().rg_attn_out_bwd_workspace
+    fn.restype = ctypes.c_size_t
+    ws = _tn_workspace(dy.device, int(fn(M)), "attn_out_ln")
+    a = AttnOutBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(Wot), _p(dz), _p(dctx),
+                       _p(dgamma), _p(dbeta), _p(ws), M, d, P, 1 if w_packed else 0, _p(live))
+    _check(lib().rg_attn_out_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_attn_out_bwd")
+    return dz, dctx
+
+
 def ffn_bwd_data_supported(d, dff):
     return bool(lib().rg_ffn_bwd_data_supported(int(d), int(dff)))
 
@@ -869,7 +897,7 @@ def _work_ffn_bwd(dl2, dz, h1, *a, **k):
 
 _WORK = {"ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
 
 

@@ -395,6 +395,7 @@ def _fusable(x2, Wo, W1):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
+FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
 LASTQ_FOLD_PREFIX = True
 
 
@@ -460,10 +461,16 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     # rowmask here only lets the kernel skip the padded rows (their dy is already zero; the mask values are 0 / 1)
     live = _live(rowmask, dy.shape[0], d == 128 and P == 128)
     # every consumer of dz below is list-driven: the padded tiles' rows of dz are never written nor read
-    dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
-    hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
-    dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
+    if FUSE_ATTN_OUT_BWD and d == 128 and P == 128:
+        # LayerNorm backward + dctx = dz Wo in ONE launch (dz is read back only by the weight-gradient product)
+        dz, dctx = hip.attn_out_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe,
+                                    shadow(Wo, transpose=True, pack=True), live=live, w_packed=True)
+        hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
+    else:
+        dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
+        hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
+        dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
     # the forward's decision (same inputs; x_masked == 2: it was the fused block's forward): were the padded tiles' rows of
     # qkv left unwritten?
     sub = QKV_BIAS_ROWS_IN_ATTENTION and x_masked == 2 and _zero_rows_live(rowmask, x2.shape[0], True, d, 3 * P) is not None

@@ -1020,3 +1020,47 @@ def test_attn_lastq_folds_the_padded_prefix(dt, drop_p):
     dq1, dkv1 = hip.attn_lastq_bwd(q_last, holes, dctx, ids, 51, H, drop_p, 9, rowmask=rowmask, bkv=bkv)
     torch.testing.assert_close(dq1.float(), dq0.float(), **t)
     torch.testing.assert_close(dkv1.float(), dkv0.float(), **t)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("M,listed", [(203, False), (64, False), (9000, True), (9000, False)])
+def test_attn_out_bwd_equals_ln_bwd_plus_projection(dt, M, listed):
+    """rg_attn_out_bwd == rg_ln_bwd followed by the dctx = dz Wo product: dz bit-identical (same arithmetic), dctx and the
+    accumulated dgamma / dbeta to rounding; with a list the padded tiles' rows stay untouched."""
+    from recguru_amd import hip
+    if listed and dt == torch.float32:
+        pytest.skip("the list-driven GEMM this is compared with is a bf16-tier kernel")
+    d = 128
+    f32 = torch.float32
+    g, be = 1 + 0.1 * rnd(d, dt=f32, seed=1), 0.1 * rnd(d, dt=f32, seed=2)
+    mask = _pad_mask(M // 120, 120, M) if listed else (torch.arange(M) % 5 != 1).float().cuda()
+    live = hip.live_tiles(mask, M) if listed else None
+    z = rnd(M, d, dt=f32, seed=3)
+    rstd = 1 / torch.sqrt(z.var(1, unbiased=False) + 1e-8)
+    y = torch.nn.functional.layer_norm(z, (d,), g, be, 1e-8).to(dt)
+    dy = rnd(M, d, dt=dt, seed=4) * mask[:, None].to(dt)
+    Wo = rnd(d, d, dt=f32, scale=d ** -0.5, seed=5)
+    Wot = hip.cast(Wo, dt, transpose=hip.CAST_TRANSPOSE)
+    Wotp = hip.cast(Wo, dt, transpose=hip.CAST_TRANSPOSE | hip.CAST_PACK)
+    dg0, db0 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dz0 = hip.ln_bwd(dy, y, rstd, g, be, mask, dg0, db0, live=live)
+    dctx0 = hip.gemm_nt(dz0, Wot, live=live, skip_dead_fill=True)
+    dg1, db1 = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    hip.POISON_UNWRITTEN = listed
+    try:
+        dz1, dctx1 = hip.attn_out_bwd(dy, y, rstd, g, be, mask, dg1, db1, Wotp, live=live, w_packed=True)
+    finally:
+        hip.POISON_UNWRITTEN = False
+    rows = torch.ones(M, dtype=torch.bool, device="cuda")
+    if listed:
+        r16 = torch.zeros((M + 15) // 16 * 16, device="cuda")
+        r16[:M] = mask
+        rows = r16.view(-1, 16).amax(1).repeat_interleave(16)[:M] != 0
+        assert bool(torch.isnan(dz1[~rows].float()).all()) and bool(torch.isnan(dctx1[~rows].float()).all())
+    assert torch.equal(dz1[rows], dz0[rows])
+    t = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(dctx1[rows].float(), dctx0[rows].float(), **t)
+    torch.testing.assert_close(dg1, dg0, rtol=2e-4, atol=2e-4 * float(dg0.abs().max()))
+    torch.testing.assert_close(db1, db0, rtol=2e-4, atol=2e-4 * float(db0.abs().max()))
+    dz2, dctx2 = hip.attn_out_bwd(dy, y, rstd, g, be, mask, None, None, Wot, live=live, w_packed=False)      # row-major weights
+    assert torch.equal(dctx2[rows], dctx1[rows])
