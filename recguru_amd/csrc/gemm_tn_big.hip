@@ -205,7 +205,7 @@ template <int NPER, int K> __device__ __forceinline__ void wait_chunks(int k) { 
 }
 
 template <int N1, int N2> struct TnDma {
-  static constexpr int CT = 32;
+  static constexpr int CT = (N1 + N2 <= 384) ? 64 : 32;     // tokens per chunk: two k-steps per barrier at the narrow shapes
   static constexpr int YB = CT * N1 * 2, XB = CT * N2 * 2, STG = YB + XB;
   static constexpr int KY = YB / 8192, KX = XB / 8192, NPER = KY + KX;
   static constexpr int NSTF = (159 * 1024) / STG;
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;      // n1 tiles per wave
   constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;      // n2 tiles per wave
   constexpr int CT = C::CT, KY = C::KY, NPER = C::NPER, NST = C::NST, STG = C::STG;
+  constexpr int EPC = CT / 16, KS = CT / 32;            // list entries (16-row tiles) and MFMA k-steps per chunk
   static_assert(NST >= 3 && (NST - 1) * NPER < 64, "ring depth / vmcnt range");
   extern __shared__ __align__(16) unsigned char smem_td[];                       // the ONLY LDS object (hipcc waits vmcnt(0) before reads otherwise)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,14 +230,14 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   const int m1 = SPLIT1 ? wave * MT * 16 : 0;
   const int m2 = SPLIT1 ? 0 : wave * NT * 16;
   const int nlive = a.live16 ? a.live16[0] : 0;
-  const int nchunks = a.live16 ? (nlive + 1) >> 1 : (a.T + CT - 1) / CT;
+  const int nchunks = a.live16 ? (nlive + EPC - 1) / EPC : (a.T + CT - 1) / CT;
   const int per = (nchunks + gridDim.x - 1) / gridDim.x;
   const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
   if (c_beg >= c_end) return;
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
 
   // per-lane source of DMA instruction k: row r of the chunk (r >> 4: which of its two 16-row tiles), swizzled 16-byte chunk
-  int srow[NPER];                   // row inside the chunk (0 .. 31)
+  int srow[NPER];                   // row inside the chunk (0 .. CT-1)
   unsigned int scb[NPER];           // byte offset of the (swizzled) 16-byte chunk inside the row
 #pragma unroll
   for (int k = 0; k < NPER; ++k) {
@@ -249,10 +250,10 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   }
   // This workgroup's slice of the live-tile list goes to LDS once, BEFORE the first DMA: beside LDS-DMAs in flight hipcc
   // waits vmcnt(0) for any ordinary (register-destination) global load, i.e. a list read per chunk drained the ring
-  int* lst = reinterpret_cast<int*>(smem_td + NST * STG);           // [2 * (c_end - c_beg)] first rows (>= T: absent)
+  int* lst = reinterpret_cast<int*>(smem_td + NST * STG);           // [EPC * (c_end - c_beg)] first rows (>= T: absent)
   if (a.live16) {
-    for (int i = tid; i < 2 * (c_end - c_beg); i += 512) {
-      const int e = 2 * c_beg + i;
+    for (int i = tid; i < EPC * (c_end - c_beg); i += 512) {
+      const int e = EPC * c_beg + i;
       lst[i] = e < nlive ? a.live16[1 + min(e, nlive - 1)] * 16 : a.T;
     }
     __syncthreads();
@@ -260,28 +261,39 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   // LDS reads inside the chunk loop are inline asm: for an LDS read it can see, hipcc waits until EVERY LDS-DMA issued
   // before it has completed (it cannot tell the stages of the ring apart) -- vmcnt(0) in front of each chunk's fragments.
   // Ordering is by hand instead: counted vmcnt + barrier before a stage is read (above), lgkmcnt(0) before use.
-  auto bases = [&](int chunk, int& b0, int& b1) {        // first rows of the chunk's two 16-row tiles (>= T: absent)
+  auto bases = [&](int chunk, int (&bb)[EPC]) {          // first rows of the chunk's 16-row tiles (>= T: absent)
     if (a.live16) {
-      long long v;
-      const unsigned int ad = (unsigned int)(size_t)(lst + 2 * (chunk - c_beg));
-      asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad) : "memory");
-      b0 = (int)(v & 0xFFFFFFFFll);
-      b1 = (int)(v >> 32);
+      const unsigned int ad = (unsigned int)(size_t)(lst + EPC * (chunk - c_beg));
+      if constexpr (EPC == 2) {
+        long long v;
+        asm volatile("ds_read_b64 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad) : "memory");
+        bb[0] = (int)(v & 0xFFFFFFFFll);
+        bb[1] = (int)(v >> 32);
+      } else {
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        i32x4 v;
+        asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ad) : "memory");
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) bb[e] = v[e];
+      }
     } else {
-      b0 = chunk * CT;
-      b1 = chunk * CT + 16;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) bb[e] = chunk * CT + 16 * e;
     }
   };
   auto issue = [&](int chunk) {
-    int b0, b1;
-    bases(chunk, b0, b1);
+    int bb[EPC];
+    bases(chunk, bb);
     unsigned char* stage = smem_td + (chunk % NST) * STG;
 #pragma unroll
     for (int k = 0; k < NPER; ++k) {
       const bool isy = k < KY;
       const unsigned int ld2 = (unsigned int)(isy ? a.ldy : a.ldx) * 2u;
       // rows past the end: clamped to the last row (finite data; their Y rows are zeroed before use)
-      const int row = min((srow[k] >= 16 ? b1 : b0) + (srow[k] & 15), a.T - 1);
+      int bsel = bb[0];
+#pragma unroll
+      for (int e = 1; e < EPC; ++e) bsel = (srow[k] >> 4) == e ? bb[e] : bsel;
+      const int row = min(bsel + (srow[k] & 15), a.T - 1);
       const char* src = (isy ? Y : X) + (size_t)(unsigned int)row * ld2 + scb[k];
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(stage + (isy ? 0 : C::YB) + (wave + 8 * (isy ? k : k - KY)) * 1024),
@@ -334,32 +346,38 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
     if (chunk + NST - 1 < c_end) issue(chunk + NST - 1);
     unsigned char* stage = smem_td + (chunk % NST) * STG;
     if (chunk == nchunks - 1) {                       // only the kernel's last chunk can hold rows that do not exist
-      int b0, b1;
-      bases(chunk, b0, b1);
-      b0 = __builtin_amdgcn_readfirstlane(b0);
-      b1 = __builtin_amdgcn_readfirstlane(b1);
-      if (b0 + 16 > a.T || b1 + 16 > a.T) {           // zero their Y rows
+      int bb[EPC];
+      bases(chunk, bb);
+      bool partial = false;
+#pragma unroll
+      for (int e = 0; e < EPC; ++e) { bb[e] = __builtin_amdgcn_readfirstlane(bb[e]); partial = partial || bb[e] + 16 > a.T; }
+      if (partial) {                                  // zero their Y rows
         for (int i = tid; i < CT * N1 / 8; i += 512) {
           const int r = i / (N1 / 8);
-          const int row = (r < 16 ? b0 : b1) + (r & 15);
+          int bsel = bb[0];
+#pragma unroll
+          for (int e = 1; e < EPC; ++e) bsel = (r >> 4) == e ? bb[e] : bsel;
+          const int row = bsel + (r & 15);
           if (row >= a.T) *reinterpret_cast<uint4*>(stage + i * 16) = make_uint4(0u, 0u, 0u, 0u);
         }
         lds_barrier();
       }
     }
-    const unsigned int sofs = (unsigned int)((chunk % NST) * STG);
+    const unsigned int sofs0 = (unsigned int)((chunk % NST) * STG);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {                   // k-steps of 32 tokens
     // Y fragments and the first X fragment up front; X fragment j + 1 is read while the MFMAs of fragment j run.  LDS reads
     // return in order: with the two reads of fragment j + 1 outstanding, lgkmcnt(2) says everything before them has landed.
     // The registers pass through the wait statements, so no MFMA moves above the wait that covers its operands.
     i64 ya[MT][2], xb[NT][2];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) rd_y(ya[i][0], ya[i][1], sofs, (m1 >> 4) + i);
-    rd_x(xb[0][0], xb[0][1], sofs, m2 >> 4);
+    for (int i = 0; i < MT; ++i) rd_y(ya[i][0], ya[i][1], sofs0 + ks * 32 * 2 * N1, (m1 >> 4) + i);
+    rd_x(xb[0][0], xb[0][1], sofs0 + ks * 32 * 2 * N2, m2 >> 4);
     Frag<T> af[MT];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (j + 1 < NT) {
-        rd_x(xb[j + 1][0], xb[j + 1][1], sofs, (m2 >> 4) + j + 1);
+        rd_x(xb[j + 1][0], xb[j + 1][1], sofs0 + ks * 32 * 2 * N2, (m2 >> 4) + j + 1);
         asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
       } else {
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb[j][0]), "+v"(xb[j][1]));
@@ -376,6 +394,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
       to_frag(bf, xb[j][0], xb[j][1], GELU_X);
 #pragma unroll
       for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
+    }
     }
   }
   float* __restrict__ part = a.partials ? a.partials + (size_t)blockIdx.x * (N1 * N2) + tid : nullptr;
@@ -438,7 +457,7 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   const int nchunks = (a.T + ct - 1) / ct;
   int grid = nchunks < 256 ? nchunks : 256;
   const int per = (nchunks + grid - 1) / grid;
-  const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + 2 * per * 4 : TB_T * (N1 + 8 + N2 + 8) * 2;
+  const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + (TnDma<N1, N2>::CT / 16) * per * 4 : TB_T * (N1 + 8 + N2 + 8) * 2;
 #define RG_TNB(KERN)                                                                                                     \
   do {                                                                                                                    \
     hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, smem);           \
