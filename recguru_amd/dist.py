@@ -52,13 +52,28 @@ class DataParallel(object):
         dist.all_reduce(y, op=dist.ReduceOp.SUM, group=self.group)
         return y[0] / self.world
 
+    def begin_sync(self, params):
+        """Start the SUM all-reduce of the LARGE gradients among `params` now (asynchronously, on the backend's own
+        stream) -- for gradients that are already final while more backward work follows (a domain's embedding table
+        after that domain's backward: its 51 MB exchange then runs under the other domain's backward instead of after
+        it).  The matching sync_grads() skips them and waits for them."""
+        self._pending = getattr(self, "_pending", [])
+        for p in params:
+            g = p.grad
+            if g is None or g.numel() < self.big_elems or not g.is_contiguous() or getattr(p, "_rg_gbase", None) is not None:
+                continue
+            work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            self._pending.append((g.data_ptr(), g.numel(), work))
+
     def sync_grads(self, params):
         """SUM all-reduce of every present gradient.  Large contiguous gradients (the embedding tables: 51 MB each at the
         bench catalogue) are reduced IN PLACE, one collective each -- no staging copy; the many small ones travel in flat
         buckets (few large collectives: xGMI links are point-to-point, so per-collective latency matters more than on a
         switch) and come back with one multi-tensor copy.  Gradients that are row slices of one shared buffer (the fused
         Q/K/V gradient base of ops._gt_cat) are reduced once, as that buffer."""
-        seen, big, small = set(), [], []
+        pending = getattr(self, "_pending", [])
+        self._pending = []
+        seen, big, small = set((ptr, n) for ptr, n, _ in pending), [], []
         for p in params:
             g = p.grad
             if g is None:
@@ -82,6 +97,8 @@ class DataParallel(object):
             size += g.numel()
         if bucket:
             self._reduce(bucket)
+        for _, _, work in pending:                          # exchanges started by begin_sync()
+            work.wait()
 
     def _reduce(self, bucket):
         if len(bucket) == 1 and bucket[0].is_contiguous():

@@ -154,6 +154,22 @@ class _NoDP(object):
     def sync_grads(self, params):
         pass
 
+    def begin_sync(self, params):
+        pass
+
+
+def _domain_only_params(netG, domain):
+    """Large parameters that only domain `domain`'s passes touch (its embedding table): their gradients are final as
+    soon as that domain's backward has run."""
+    cache = getattr(netG, "_rg_domain_params", None)
+    if cache is None:
+        cache = {}
+        for dom in ("a", "b"):
+            cache[dom] = [p for n, p in _unwrap(netG).named_parameters()
+                          if p.numel() >= (1 << 20) and n.split(".")[0].endswith("_" + dom)]
+        netG._rg_domain_params = cache
+    return cache[domain]
+
 
 def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True, loss_type="s_soft", opt_type="org",
                   dp=None, log_every=50, verbose=True):
@@ -387,6 +403,7 @@ def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, 
     mask_b = get_pad_mask(dout_b, param.pad_index, device)
     loss_recon_b = loss_ae(netG, in_b, din_b, dout_b, n_b, True, bs, sl, param, mask_b, device, domain="b")
     loss_recon_a.backward()
+    dp.begin_sync(_domain_only_params(netG, "a"))      # domain a's table: exchanged under domain b's backward
     loss_recon_b.backward()
     dp.sync_grads(g_params if g_params is not None else list(netG.parameters()))
     opt_g.step()
