@@ -74,3 +74,38 @@ def test_dp2_matches_full_batch():
             continue                                          # rounding-noise gradients
         scale = max(np.abs(ref[k]).max(), 1e-12)
         np.testing.assert_allclose(got[k], ref[k], rtol=1e-4, atol=1e-5 * scale + 1e-7, err_msg=k)
+
+
+def _worker_async(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from recguru_amd import dist as rdist
+    dp = rdist.init_from_env("gloo")
+    dp.big_elems = 64                                   # "large" = 64 elements in this test
+    g0 = torch.Generator().manual_seed(11)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (256, 7, 100, 33)]
+    for i, p in enumerate(ps):
+        p.grad = torch.randn(p.numel(), generator=g0) * (rank + 1) + i
+    want = [p.grad.clone() * 0 for p in ps]
+    for r in range(world):                              # what the SUM over ranks is
+        g1 = torch.Generator().manual_seed(11)
+        for i, p in enumerate(ps):
+            want[i] += torch.randn(p.numel(), generator=g1) * (r + 1) + i
+    dp.begin_sync([ps[0], ps[1]])                       # the large one starts now (the small one is left to sync_grads)
+    assert len(dp._pending) == 1
+    ps[2].grad += 0.0                                   # "more backward work"
+    dp.sync_grads(ps)                                   # skips ps[0], reduces the rest, waits for ps[0]
+    assert dp._pending == []
+    if rank == 0:
+        ret["ok"] = all(torch.allclose(p.grad, w, rtol=1e-6, atol=1e-6) for p, w in zip(ps, want))
+    dp.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_begin_sync_reduces_each_gradient_exactly_once():
+    """DataParallel.begin_sync starts the exchange of gradients that are already final; the following sync_grads must
+    neither reduce them a second time nor return before they have arrived."""
+    with mp.Manager() as mgr:
+        ret = mgr.dict()
+        mp.spawn(_worker_async, args=(2, _free_port(), ret), nprocs=2, join=True)
+        assert ret["ok"]
