@@ -979,7 +979,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     for (int i = 0; i < NKT; ++i) { dq1[i][0] = (f32x4){0.f, 0.f, 0.f, 0.f}; dq1[i][1] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
   }
   // ---------------------------------------------------------------- phase 1: dK^T, dV^T
-  for (int kt = wave; kt < nt; kt += 4) {
+  const int nkeyt = (L + 15) >> 4;                  // key tiles that hold a key (nt rounds up to a pair: at L = 200 the 14th
+                                                    // tile is keys 208 .. 223 -- nothing to differentiate)
+  for (int kt = wave; kt < nkeyt; kt += 4) {
     const int key = kt * 16 + li;                   // this lane's key (column of S)
     Frag<T> kf, vf;
     load_frag(kf, Ks + key * LDR + 8 * lg);
