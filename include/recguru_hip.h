@@ -335,6 +335,21 @@ int rg_item_loss_bwd(const rg_item_loss_args* args /* host */, int dtype, void* 
 size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long table_rows);
 int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long table_rows, void* workspace,
                             size_t workspace_bytes, int dtype, void* stream);
+/* Training form (replaces rg_item_loss_fwd + the rows pass of rg_item_loss_bwd_binned when a gradient will be asked
+ * for): ONE walk over the 1+k rows of every position yields the loss sum and, for an upstream gradient of 1, the
+ * coefficients coef[t*(1+k)+j] = dloss/dlogit_j * mask_t / sums[1] and dh = sum_j coef_j E[j].  sums[1] must hold
+ * the mask count ON ENTRY (rg_sum over mask; under data parallelism the all-reduced count); sums[0] += sum mask*loss.
+ * aux_tok, gout, dE are not used.  Supported: d in {64,128,256} and 1+k rows that fit four register batches
+ * (rg_item_loss_train_supported).  The backward is rg_scale_dev(dh, gout) + rg_item_loss_scatter_binned, which adds
+ * gout[0] * (table gradient of coef) to dE by the same counting sort + LDS accumulation as rg_item_loss_bwd_binned
+ * (same workspace size).  Results equal those of the two-call form bit for bit when gout == 1. */
+int rg_item_loss_train_supported(int k, int d);
+int rg_item_loss_train(const rg_item_loss_args* args /* host */, float* coef, int dtype, void* stream);
+int rg_item_loss_scatter_binned(const rg_item_loss_args* args /* host */, const float* coef, long long table_rows,
+                                void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* x[0..n) *= s[0] with s on the device; no memory traffic when s[0] == 1.  n % 8 == 0. */
+int rg_scale_dev(void* x, long long n, const float* s /* device */, int dtype, void* stream);
+
 
 /* ---- dropout pieces of the block paths that are not fused (widths other than d_model = 128) ---------------
  * rg_dropout: x [M,N] *= keep(seed, m*N + c) / (1-p) in place (nn.Dropout; the mask is a stateless hash, the same

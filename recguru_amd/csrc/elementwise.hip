@@ -998,6 +998,32 @@ extern "C" int rg_gp_penalty(const float* g, void* dg, float* gp, long long B, i
              "gp_penalty")
 }
 
+// x *= s[0], s on the device; every workgroup leaves at once when s[0] == 1 (the upstream gradient of a plain
+// loss.backward()), so the common case costs one launch and no memory traffic.  n % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void scale_dev_kernel(T* __restrict__ x, long long n8, const float* __restrict__ sp) {
+  const float s = sp[0];
+  if (s == 1.f) return;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n8; i += (long long)gridDim.x * EW_BLOCK) {
+    float v[8];
+    load8(v, x + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= s;
+    store8(x + 8 * i, v);
+  }
+}
+
+extern "C" int rg_scale_dev(void* x, long long n, const float* s, int dtype, void* stream) {
+  if (n <= 0) return 0;
+  if (n % 8 || !s) return rg_set_error_msg(RG_ERR_INVALID, "scale_dev: n must be a multiple of 8 and s non-null");
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = ew_grid(n / 8, EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(scale_dev_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, st, (__bf16*)x, n / 8, s),
+             hipLaunchKernelGGL(scale_dev_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, st, (float*)x, n / 8, s),
+             "scale_dev")
+}
+
 extern "C" int rg_sum(const float* x, float* out, long long n, float scale, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sum_kernel, dim3(ew_grid(n, EW_BLOCK * 4)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, out, n, scale);

@@ -298,6 +298,115 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
   }
 }
 
+// Training form (grad mode): the forward and the rows pass of the backward are ONE walk over the 1+k rows.
+// The rows stay in registers between the log-sum-exp and the coefficient pass, so they are gathered once
+// instead of twice (the second gather was the whole cost of K1 above).  The upstream gradient is not known yet:
+// c and dh are produced for gout = 1 (w = mask_t / sums[1], sums[1] = the mask count, which the caller supplies
+// BEFORE the launch) and the backward scales them (bin_fill multiplies c by gout, rg_scale_dev does dh; both
+// are exact no-ops for gout == 1, the value a plain loss.backward() sends).  NIT batches of G * RG_U rows.
+template <typename T, int LPR, int NIT>
+__global__ __launch_bounds__(64 * LW) void item_loss_train_rows_kernel(rg_item_loss_args a, float* __restrict__ cbuf) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const T* __restrict__ E = reinterpret_cast<const T*>(a.table);
+  T* __restrict__ dH = reinterpret_cast<T*>(a.dh);
+  const int d = a.d, k = a.k, n = a.k + 1;
+  const float gs = 1.f / a.sums[1];
+  float lsum = 0.f;
+  for (long long t = (long long)blockIdx.x * LW + wave; t < a.ntok; t += (long long)gridDim.x * LW) {
+    const float m = a.mask[t];
+    float dh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dh[j] = 0.f;
+    if (m != 0.f) {
+      float h[8];
+      load8(h, H + (size_t)t * d + 8 * li);
+      const long long pos = a.pos[t];
+      long long item[NIT][RG_U];
+      float e[NIT][RG_U][8], dot[NIT][RG_U];
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int idx = (it * RG_U + u) * G + gi;
+          item[it][u] = (idx == 0 || idx >= n) ? pos : a.neg[t * k + idx - 1];
+        }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) load8(e[it][u], E + (size_t)item[it][u] * d + 8 * li);
+      float mx = -INFINITY, sm = 0.f, ns = 0.f, l0 = 0.f;      // per row group
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int idx = (it * RG_U + u) * G + gi;
+          float s = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s += e[it][u][j] * h[j];
+          s = group_sum<LPR>(s);
+          dot[it][u] = s;
+          if (idx < n) {
+            if (idx == 0) l0 = s;
+            if (a.mode == RG_LOSS_SAMPLED_CE) {
+              const float nm = fmaxf(mx, s);
+              sm = sm * __expf(mx - nm) + __expf(s - nm);
+              mx = nm;
+            } else if (idx > 0) ns += s;
+          }
+        }
+      l0 = __shfl(l0, 0);
+      float loss, aux;
+      if (a.mode == RG_LOSS_SAMPLED_CE) {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) {
+          const float omx = __shfl_xor(mx, o), osm = __shfl_xor(sm, o);
+          const float nm = fmaxf(mx, omx);
+          sm = (mx == -INFINITY ? 0.f : sm * __expf(mx - nm)) + (omx == -INFINITY ? 0.f : osm * __expf(omx - nm));
+          mx = nm;
+        }
+        aux = mx + __logf(sm);
+        loss = aux - l0;
+      } else {
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1) ns += __shfl_xor(ns, o);
+        bpr_value(a.mode, l0, ns / (float)k, loss, aux);
+      }
+      lsum += loss * m;
+      const float w = m * gs;
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int idx = (it * RG_U + u) * G + gi;
+          float c;
+          if (a.mode == RG_LOSS_SAMPLED_CE) c = (__expf(dot[it][u] - aux) - (idx == 0 ? 1.f : 0.f)) * w;
+          else c = bpr_coef(a.mode, idx, aux, l0, k) * w;
+          if (idx >= n) c = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dh[j] += c * e[it][u][j];
+          if (idx < n && li == 0) cbuf[t * n + idx] = c;
+        }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dh[j] += __shfl_xor(dh[j], o);
+    }
+    if (gi == 0) store8(dH + (size_t)t * d + 8 * li, dh);
+  }
+  __shared__ float red[LW];
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f;
+    for (int w = 0; w < LW; ++w) s0 += red[w];
+    if (s0 != 0.f) atomicAdd(a.sums, s0);
+  }
+}
+
+
 template <typename T>
 static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
   long long g = (a.ntok + LW - 1) / LW;
@@ -349,6 +458,7 @@ struct BinWs {
   float* c; int* hist; int* start; int* cursor; int* chunk_start;
   uint2* ent;        // sorted entries: x = (position << RG_RPB_LOG) | row-in-bin, y = c as bits  (one 8-byte store / load)
   int nbins;
+  const float* cscale;  // non-null: the c values are for gout = 1 and bin_fill multiplies them by cscale[0]
 };
 
 // The items of pairs p, p+256, p+512, p+768 (-1: masked position, skip row, or p >= p1).  Branch-free: clamped
@@ -418,6 +528,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
   int* base = lh + w.nbins;
   const int n = a.k + 1;
   const long long npairs = a.ntok * n;
+  const float gsc = w.cscale ? w.cscale[0] : 1.f;
   for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
   __syncthreads();
   const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
@@ -440,7 +551,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
     float cv[RG_PB];
     pair_items4(a, p, p1, n, it);
 #pragma unroll
-    for (int u = 0; u < RG_PB; ++u) cv[u] = w.c[min(p + 256 * u, p1 - 1)];
+    for (int u = 0; u < RG_PB; ++u) cv[u] = w.c[min(p + 256 * u, p1 - 1)] * gsc;
 #pragma unroll
     for (int u = 0; u < RG_PB; ++u) {
       if (it[u] < 0) continue;
@@ -560,7 +671,7 @@ extern "C" size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d
 }
 
 template <typename T>
-static int launch_binned(const rg_item_loss_args& a, void* ws, size_t ws_bytes, long long table_rows, hipStream_t s) {
+static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws, size_t ws_bytes, long long table_rows, hipStream_t s) {
   const int n = a.k + 1;
   const long long npairs = a.ntok * n;
   const size_t need = rg_item_loss_bwd_binned_workspace(a.ntok, a.k, a.d, table_rows);
@@ -569,7 +680,8 @@ static int launch_binned(const rg_item_loss_args& a, void* ws, size_t ws_bytes, 
   BinWs w;
   w.nbins = (int)((table_rows + RG_RPB - 1) / RG_RPB);
   char* p = reinterpret_cast<char*>(ws);
-  w.c = reinterpret_cast<float*>(p); p += align256(npairs * 4);
+  w.c = coef ? const_cast<float*>(coef) : reinterpret_cast<float*>(p); p += align256(npairs * 4);
+  w.cscale = coef ? a.gout : nullptr;
   w.ent = reinterpret_cast<uint2*>(p); p += align256(npairs * 8);
   const size_t ib = align256((size_t)(w.nbins + 1) * 4);
   w.hist = reinterpret_cast<int*>(p); p += ib;
@@ -578,10 +690,11 @@ static int launch_binned(const rg_item_loss_args& a, void* ws, size_t ws_bytes, 
   w.chunk_start = reinterpret_cast<int*>(p);
   hipError_t e = hipMemsetAsync(w.hist, 0, ib, s);
   if (e != hipSuccess) return rg_set_error(e, "item_loss_bwd_binned(memset)");
-  // K1: dh and c
+  // K1: dh and c (not when rg_item_loss_train already made them)
   long long g = (a.ntok + LW - 1) / LW;
   if (g > 256 * 32) g = 256 * 32;
-  if (a.d == 64) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 8, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
+  if (coef) {}
+  else if (a.d == 64) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 8, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   else if (a.d == 128) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 16, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   else hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 32, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   // K2..K4
@@ -612,9 +725,60 @@ static int launch_binned(const rg_item_loss_args& a, void* ws, size_t ws_bytes, 
 extern "C" int rg_item_loss_bwd_binned(const rg_item_loss_args* a, long long table_rows, void* workspace, size_t workspace_bytes,
                                        int dtype, void* stream) {
   if (!a || a->ntok <= 0) return 0;
-  if (dtype == RG_BF16) return launch_binned<__bf16>(*a, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
-  if (dtype == RG_F32) return launch_binned<float>(*a, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  if (dtype == RG_BF16) return launch_binned<__bf16>(*a, nullptr, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_binned<float>(*a, nullptr, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "item_loss_bwd_binned: bad dtype");
+}
+
+// ---- training form: rg_item_loss_train (forward, c and dh for gout = 1) + rg_item_loss_scatter_binned (backward) ----
+static int train_nit(int k, int d) {           // row batches the kernel keeps in registers; 0 = not supported
+  if (!(d == 64 || d == 128 || d == 256)) return 0;
+  const int per = (64 / (d / 8)) * RG_U, n = k + 1;
+  return n <= per ? 1 : (n <= 2 * per ? 2 : (n <= 4 * per ? 4 : 0));
+}
+extern "C" int rg_item_loss_train_supported(int k, int d) { return train_nit(k, d) != 0; }
+
+template <typename T>
+static int launch_train(const rg_item_loss_args& a, float* coef, hipStream_t s) {
+  const int nit = train_nit(a.k, a.d);
+  if (!nit) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_train: needs d in {64,128,256} and 1+k <= 4 row batches (32 rows at d=256, 64 at 128, 128 at 64)");
+  if (!coef || !a.dh || !a.sums) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_train: coef, dh and sums are required");
+  long long g = (a.ntok + LW - 1) / LW;
+  if (g > 256 * 32) g = 256 * 32;
+  dim3 grid((int)g), block(64 * LW);
+#define RG_TR(LPR)                                                                                           \
+  do {                                                                                                       \
+    if (nit == 1) hipLaunchKernelGGL((item_loss_train_rows_kernel<T, LPR, 1>), grid, block, 0, s, a, coef);  \
+    else if (nit == 2) hipLaunchKernelGGL((item_loss_train_rows_kernel<T, LPR, 2>), grid, block, 0, s, a, coef); \
+    else hipLaunchKernelGGL((item_loss_train_rows_kernel<T, LPR, 4>), grid, block, 0, s, a, coef);           \
+  } while (0)
+  if (a.d == 64) RG_TR(8);
+  else if (a.d == 128) RG_TR(16);
+  else RG_TR(32);
+#undef RG_TR
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
+// sums[1] must hold the mask count on entry (the divisor of the masked mean; under data parallelism the GLOBAL
+// count); sums[0] += sum_t mask*loss_t.  coef [ntok*(1+k)] f32 and dh [ntok,d] come out for an upstream gradient
+// of 1; aux_tok / gout / dE are not used.
+extern "C" int rg_item_loss_train(const rg_item_loss_args* a, float* coef, int dtype, void* stream) {
+  if (!a || a->ntok <= 0) return 0;
+  if (dtype == RG_BF16) return launch_train<__bf16>(*a, coef, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_train<float>(*a, coef, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "item_loss_train: bad dtype");
+}
+
+// dE += gout[0] * (table gradient of the coefficients rg_item_loss_train left in coef): K2..K5 of the binned
+// backward; dh is not touched (scale the saved one with rg_scale_dev).
+extern "C" int rg_item_loss_scatter_binned(const rg_item_loss_args* a, const float* coef, long long table_rows, void* workspace,
+                                           size_t workspace_bytes, int dtype, void* stream) {
+  if (!a || a->ntok <= 0) return 0;
+  if (!coef || !a->gout) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_scatter_binned: coef and gout are required");
+  if (dtype == RG_BF16) return launch_binned<__bf16>(*a, coef, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_binned<float>(*a, coef, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "item_loss_scatter_binned: bad dtype");
 }
 
 // ------------------------------------------------------------------------------------------------

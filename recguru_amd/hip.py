@@ -85,7 +85,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
            "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live",
-           "rg_attn_out_bwd", "rg_attn_out_bwd_workspace"]
+           "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
+           "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -560,6 +561,47 @@ def item_loss_bwd_binned(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE,
     _check(lib().rg_item_loss_bwd_binned(ctypes.byref(a), c_ll(table.shape[0]), _vp(ws), ctypes.c_size_t(need),
                                          dt_of(h), _stream()), "rg_item_loss_bwd_binned")
     return dh
+
+
+def item_loss_train_supported(k, d):
+    return bool(lib().rg_item_loss_train_supported(int(k), int(d)))
+
+
+def item_loss_train(h, table, pos, neg, mask, k, mode, sums):
+    """Loss sum into sums[0] (sums[1] = the mask count, set by the caller) plus, for an upstream gradient of 1,
+    the coefficients [ntok*(1+k)] f32 and dh [ntok,d]: one gather of the rows instead of two."""
+    ntok, d = h.shape
+    assert h.is_contiguous() and table.is_contiguous() and table.dtype == h.dtype
+    assert pos.dtype == torch.int64 and neg.dtype == torch.int64 and pos.numel() == ntok and neg.numel() == ntok * k
+    coef = torch.empty(ntok * (k + 1), device=h.device, dtype=torch.float32)
+    dh = torch.empty_like(h)
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), None, _p(sums), None, _p(dh), None, ntok, d, k,
+                     mode, -1)
+    _check(lib().rg_item_loss_train(ctypes.byref(a), _vp(coef), dt_of(h), _stream()), "rg_item_loss_train")
+    return coef, dh
+
+
+def item_loss_scatter_binned(h, table_rows, pos, neg, mask, k, coef, gout, dE, skip_row=-1):
+    """dE += gout * (table gradient of coef), the K2..K5 half of item_loss_bwd_binned."""
+    ntok, d = h.shape
+    need = item_loss_bwd_binned_supported(ntok, k, d, table_rows)
+    if not need:
+        raise RuntimeError("item_loss_scatter_binned: unsupported shape (d=%d, rows=%d, k=%d)" % (d, table_rows, k))
+    ws = _BIN_WS.get(h.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=h.device, dtype=torch.uint8)
+        _BIN_WS[h.device] = ws
+    a = ItemLossArgs(_p(h), None, _p(pos), _p(neg), _p(mask), None, None, _p(gout), None, _p(dE), ntok, d, k, 0,
+                     skip_row)
+    _check(lib().rg_item_loss_scatter_binned(ctypes.byref(a), _vp(coef), c_ll(table_rows), _vp(ws), ctypes.c_size_t(need),
+                                             dt_of(h), _stream()), "rg_item_loss_scatter_binned")
+
+
+def scale_dev(x, s):
+    """x *= s[0] in place (s: device f32 scalar); free when s[0] == 1."""
+    assert x.is_contiguous() and s.dtype == torch.float32 and x.numel() % 8 == 0
+    _check(lib().rg_scale_dev(_vp(x), c_ll(x.numel()), _vp(s), dt_of(x), _stream()), "rg_scale_dev")
+    return x
 
 
 def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_row=-1):

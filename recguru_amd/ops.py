@@ -395,6 +395,7 @@ def _fusable(x2, Wo, W1):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
+FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
 LASTQ_FOLD_PREFIX = True
 
@@ -776,25 +777,48 @@ class ItemLoss(_Fn):
         neg = neg.contiguous().view(-1)
         mask = mask.reshape(-1).contiguous()
         tab = shadow(table)
+        ctx.table = table
+        ctx.meta = (k, mode, skip_row, h.shape)
+        # large batches: counting-sort + LDS accumulation of the table gradient (the atomic form is bound by the
+        # chip-wide float-atomic rate); small ones: one atomic row per (position, item) pair
+        ntok = h2.shape[0]
+        ctx.binned = ntok >= 65536 and bool(hip.item_loss_bwd_binned_supported(ntok, k, d, table.shape[0]))
+        ctx.fused = (FUSE_ITEM_LOSS_TRAIN and _needs_grad(ctx) and ctx.binned and hip.item_loss_train_supported(k, d))
+        if ctx.fused:
+            # one gather of the 1+k rows serves the loss, the coefficients and dh (for gout = 1; backward scales)
+            sums = torch.zeros(2, device=h2.device, dtype=torch.float32)
+            hip.sum_into(mask, sums[1:2])
+            if _DP is not None and _DP.world > 1:
+                _DP.global_count(sums[1:2])
+            coef, dh1 = hip.item_loss_train(h2, tab, pos, neg, mask, k, mode, sums)
+            ctx.save_for_backward(h2, pos, neg, mask, coef, dh1, sums)
+            ctx.consumed = False
+            return sums[0] / sums[1]
         sums, aux = hip.item_loss_fwd(h2, tab, pos, neg, mask, k, mode)
         if _DP is not None and _DP.world > 1:
             _DP.global_count(sums[1:2])          # Q12: sum(l*m) / GLOBAL sum(m); grads are SUM-reduced
         ctx.save_for_backward(h2, pos, neg, mask, aux, sums)
-        ctx.table = table
-        ctx.meta = (k, mode, skip_row, h.shape)
         return sums[0] / sums[1]
 
     @staticmethod
     def backward(ctx, gout):
-        h2, pos, neg, mask, aux, sums = ctx.saved_tensors
         table = ctx.table
         k, mode, skip_row, shape = ctx.meta
         dE, ret = _gt(table)
         g1 = gout.reshape(1).to(torch.float32).contiguous()
-        # large batches: counting-sort + LDS accumulation of the table gradient (the atomic form is bound by the
-        # chip-wide float-atomic rate); small ones: one atomic row per (position, item) pair
-        binned = h2.shape[0] >= 65536 and hip.item_loss_bwd_binned_supported(h2.shape[0], k, h2.shape[1], table.shape[0])
-        fn = hip.item_loss_bwd_binned if binned else hip.item_loss_bwd
+        if ctx.fused:
+            h2, pos, neg, mask, coef, dh1, sums = ctx.saved_tensors
+            if not ctx.consumed:
+                ctx.consumed = True                  # dh1 is scaled in place: it serves ONE backward
+                hip.item_loss_scatter_binned(h2, table.shape[0], pos, neg, mask, k, coef, g1, dE, skip_row)
+                return hip.scale_dev(dh1, g1).view(shape), ret, None, None, None, None, None, None
+            # a second backward through a retained graph: the two-call form, from scratch
+            cnt = sums[1:2].clone()
+            sums, aux = hip.item_loss_fwd(h2, shadow(table), pos, neg, mask, k, mode)
+            sums[1:2] = cnt
+        else:
+            h2, pos, neg, mask, aux, sums = ctx.saved_tensors
+        fn = hip.item_loss_bwd_binned if ctx.binned else hip.item_loss_bwd
         dh = fn(h2, shadow(table), pos, neg, mask, k, mode, aux, sums, g1, dE, skip_row)
         return dh.view(shape), ret, None, None, None, None, None, None
 

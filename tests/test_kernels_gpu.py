@@ -379,6 +379,72 @@ def test_item_loss_bwd_binned_large(V, ntok, k):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d,k,mode,gv", [(128, 30, 0, 1.0), (128, 30, 0, 0.7), (64, 30, 2, 1.0), (256, 31, 0, 1.3), (128, 5, 1, 1.0),
+                                         (64, 100, 0, 1.0), (128, 63, 2, 0.5)])
+def test_item_loss_train_form(dt, d, k, mode, gv):
+    """rg_item_loss_train + rg_scale_dev + rg_item_loss_scatter_binned against the two-call form (forward, binned
+    backward): the loss, dh and the table gradient; bit-equal coefficients and dh when the upstream gradient is 1."""
+    from recguru_amd import hip
+    ntok, V = 3001, 1500
+    g0 = torch.Generator().manual_seed(d + k)
+    h = rnd(ntok, d, dt=dt, scale=0.3, seed=1)
+    table = rnd(V + 2, d, dt=dt, seed=2)
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.4).float().cuda()
+    assert hip.item_loss_train_supported(k, d) and hip.item_loss_bwd_binned_supported(ntok, k, d, V + 2)
+    sums, aux = hip.item_loss_fwd(h, table, pos, neg, mask, k, mode)
+    gout = torch.full((1,), gv, device="cuda")
+    dE1, dE2 = torch.zeros(V + 2, d, device="cuda"), torch.zeros(V + 2, d, device="cuda")
+    dh1 = hip.item_loss_bwd_binned(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE1, skip_row=3)
+    s2 = torch.zeros(2, device="cuda")
+    hip.sum_into(mask, s2[1:2])
+    assert float(s2[1]) == float(sums[1])
+    coef, dh2 = hip.item_loss_train(h, table, pos, neg, mask, k, mode, s2)
+    torch.testing.assert_close(s2[0] / s2[1], sums[0] / sums[1], rtol=1e-5, atol=1e-6)
+    hip.scale_dev(dh2, gout)
+    hip.item_loss_scatter_binned(h, V + 2, pos, neg, mask, k, coef, gout, dE2, skip_row=3)
+    assert float(dE2[3].abs().max()) == 0.0
+    if gv == 1.0:
+        torch.testing.assert_close(dh2.float(), dh1.float(), rtol=0, atol=0)
+        torch.testing.assert_close(dE2, dE1, rtol=1e-5, atol=1e-7)
+    else:
+        t = dict(rtol=1e-5, atol=1e-7) if dt == torch.float32 else dict(rtol=2e-2, atol=1e-5)
+        torch.testing.assert_close(dh2.float(), dh1.float(), **t)
+        torch.testing.assert_close(dE2, dE1, rtol=1e-4, atol=1e-7)
+
+
+def test_item_loss_autograd_train_form_matches_two_call_form():
+    """ops.ItemLoss with the training form on and off: same loss, same gradients (upstream gradient 1 and 0.3), and a
+    second backward through a retained graph still gives the right answer."""
+    from recguru_amd import ops
+    ntok, V, d, k = 70000, 3000, 128, 30
+    g0 = torch.Generator().manual_seed(5)
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.4).float().cuda()
+    res = {}
+    for fused in (True, False):
+        ops.FUSE_ITEM_LOSS_TRAIN = fused
+        try:
+            h = rnd(ntok, d, dt=torch.bfloat16, scale=0.3, seed=1).requires_grad_(True)
+            table = rnd(V + 2, d, dt=torch.float32, seed=2).requires_grad_(True)
+            loss = ops.sampled_softmax_loss(h, table, pos, neg, mask, k, skip_row=0)
+            (loss * 0.3).backward(retain_graph=True)
+            g1 = (h.grad.float().clone(), table.grad.clone())
+            h.grad = None
+            table.grad = None
+            loss.backward()
+            res[fused] = (loss.detach().clone(), g1, (h.grad.float().clone(), table.grad.clone()))
+        finally:
+            ops.FUSE_ITEM_LOSS_TRAIN = True
+    torch.testing.assert_close(res[True][0], res[False][0], rtol=1e-5, atol=1e-6)
+    for i in (1, 2):
+        torch.testing.assert_close(res[True][i][0], res[False][i][0], rtol=2e-2, atol=1e-7)
+        torch.testing.assert_close(res[True][i][1], res[False][i][1], rtol=1e-4, atol=1e-7)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,dff,cross,save", [(64, 128, False, False), (203, 512, False, True), (131, 512, True, True),
                                                (1000, 256, True, False)])
 def test_post_attn_fused_vs_unfused(dt, M, dff, cross, save):

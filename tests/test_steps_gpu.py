@@ -452,15 +452,16 @@ def test_large_batch_bf16_composition_vs_oracle(capsys):
     cb = tuple(t.cuda() for t in bt)
     mask = T.get_pad_mask(cb[2], 0, "cuda")
     seen = []
-    real_binned = hip.item_loss_bwd_binned
-    hip.item_loss_bwd_binned = lambda *a, **kw: (seen.append("binned"), real_binned(*a, **kw))[1]
+    real_train, real_scatter = hip.item_loss_train, hip.item_loss_scatter_binned
+    hip.item_loss_train = lambda *a, **kw: (seen.append("train"), real_train(*a, **kw))[1]
+    hip.item_loss_scatter_binned = lambda *a, **kw: (seen.append("binned"), real_scatter(*a, **kw))[1]
     try:
         la = T.loss_ae(G, *cb, True, B, L, param, mask, "cuda", domain="a")
         la.backward()
     finally:
-        hip.item_loss_bwd_binned = real_binned
+        hip.item_loss_train, hip.item_loss_scatter_binned = real_train, real_scatter
     torch.cuda.synchronize()
-    assert seen == ["binned"]                                   # the counting-sort table gradient was the one that ran
+    assert seen == ["train", "binned"]     # the one-gather training form and the counting-sort table gradient ran
     l_rel = abs(float(la) - float(la_ref)) / float(la_ref)
     worst = {}
     for name in ("encoder.layers.0.pos_ffn.l1.weight", "encoder.layers.2.enc_self_attn.WV.weight",
