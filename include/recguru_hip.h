@@ -500,6 +500,29 @@ int rg_attn_lastq_fwd(const void* qlast, const void* kv, const int64_t* key_ids,
 int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const int64_t* key_ids, int64_t pad_value,
                       void* dq, void* dkv, int B, int L, int H, float scale, float drop_p, unsigned long long seed,
                       int dtype, void* stream, const float* bkv, const int* first_live);
+
+/* Single-query attention of the last encoder layer straight from the layer input x (no K / V projection: WK is
+ * absorbed into the query, WV into the output -- csrc/attention_lastq_x.hip).  Same results as rg_gemm_nt(x, [WK;WV])
+ * + rg_attn_lastq_fwd/bwd up to operand rounding.  bf16, d_model = H*32 = 128, L <= 256 (rg_attn_lastq_x_supported).
+ * qlast = WQ x[:, L-1] + bQ [B,128]; wk / wv [128,128] bf16 row-major [out,in]; first_live[b] (or NULL) = first row of
+ * sequence b that is not a zero row of x (rows before it are not read).
+ * Backward outputs: dx [B,L,128] (every row written; the caller adds the query path's dx of row L-1), dq [B,128], and
+ * the operands of the two weight-gradient products over T = B*4 rows (row b*4+h):
+ *   dWV += ym_v^T xbar,  dWK += ym_q^T dqp      (rg_gemm_tn; ym_* = dctx / qlast with the other heads' blocks zeroed)
+ * dbv [128] is ACCUMULATED (dbK is exactly zero: a constant added to every score of a softmax row). */
+typedef struct {
+  const void* x; const void* qlast; const void* wk; const void* wv;
+  const float* bk; const float* bv;
+  const int64_t* key_ids; int64_t pad_value;
+  const int* first_live;
+  void* ctx;                                   /* forward out [B,128] */
+  const void* dctx;                            /* backward in [B,128] */
+  void* dx; void* dq; void* ym_v; void* ym_q; void* xbar; void* dqp; float* dbv;
+  int B, L; float scale; float drop_p; unsigned long long seed;
+} rg_lastq_x_args;
+int rg_attn_lastq_x_supported(int d, int P, int H, int L, int dtype);
+int rg_attn_lastq_x_fwd(const rg_lastq_x_args* args /* host */, void* stream);
+int rg_attn_lastq_x_bwd(const rg_lastq_x_args* args /* host */, void* stream);
 /* bkv [2*H*32] f32 (K | V bias) + first_live [B] (rg_first_live), both optional (NULL): the caller guarantees that the
  * K / V rows before a sequence's first live position are the bias rows (x_masked contract of rg_attn_args): the kernels
  * then do not fetch them (one score, one probability mass for the whole padded prefix). */

@@ -86,7 +86,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
            "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live",
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
-           "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev"]
+           "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
+           "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -677,6 +678,52 @@ def attn_lastq_bwd(q_last, kv, dctx, key_ids, pad_value, H, drop_p=0.0, seed=0, 
                                    *_lastq_fold(rowmask, bkv, B, L)),
            "rg_attn_lastq_bwd")
     return dq, dkv
+
+
+class LastqXArgs(ctypes.Structure):
+    _fields_ = [("x", c_p), ("qlast", c_p), ("wk", c_p), ("wv", c_p), ("bk", c_p), ("bv", c_p), ("key_ids", c_p),
+                ("pad_value", ctypes.c_int64), ("first_live", c_p), ("ctx", c_p), ("dctx", c_p), ("dx", c_p), ("dq", c_p),
+                ("ym_v", c_p), ("ym_q", c_p), ("xbar", c_p), ("dqp", c_p), ("dbv", c_p),
+                ("B", c_i), ("L", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64)]
+
+
+def attn_lastq_x_supported(d, P, H, L, dtype):
+    return bool(lib().rg_attn_lastq_x_supported(int(d), int(P), int(H), int(L), BF16 if dtype == torch.bfloat16 else F32))
+
+
+def _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, rowmask):
+    B, L, d = x.shape
+    assert x.is_contiguous() and q_last.is_contiguous() and wk.is_contiguous() and wv.is_contiguous() and key_ids.is_contiguous()
+    assert wk.dtype == x.dtype and wv.dtype == x.dtype and bk.dtype == torch.float32 and bv.dtype == torch.float32
+    fl = first_live(rowmask, B, L) if rowmask is not None else None
+    a = LastqXArgs(_p(x), _p(q_last), _p(wk), _p(wv), _p(bk), _p(bv), _p(key_ids), int(pad_value), _p(fl))
+    a.B, a.L, a.scale, a.drop_p, a.seed = B, L, 32 ** -0.5, drop_p, seed
+    return a, fl
+
+
+def attn_lastq_x_fwd(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p=0.0, seed=0, rowmask=None):
+    """Row L-1 of the attention from the layer input x [B,L,128] (K / V never formed): q_last [B,128] = WQ x[:, -1] + bQ,
+    wk / wv [128,128] operand tier, bk / bv f32.  rowmask [B*L]: rows before a sequence's first live one are zero rows of
+    x (x_masked contract) and are not read."""
+    a, keep = _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, rowmask)
+    ctx = torch.empty_like(q_last)
+    a.ctx = _p(ctx)
+    _check(lib().rg_attn_lastq_x_fwd(ctypes.byref(a), _stream()), "rg_attn_lastq_x_fwd")
+    return ctx
+
+
+def attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, key_ids, pad_value, dbv, drop_p=0.0, seed=0, rowmask=None):
+    """-> (dx [B,L,128], dq [B,128], ym_v, xbar, ym_q, dqp [B*4,128]): dWV += ym_v^T xbar, dWK += ym_q^T dqp; dbv accumulated."""
+    a, keep = _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, rowmask)
+    B, L, d = x.shape
+    assert dctx.is_contiguous() and dctx.dtype == x.dtype and dbv.dtype == torch.float32
+    dx = torch.empty_like(x)
+    dq = torch.empty_like(q_last)
+    ops4 = torch.empty(4, B * 4, d, device=x.device, dtype=x.dtype)
+    a.dctx, a.dx, a.dq, a.dbv = _p(dctx), _p(dx), _p(dq), _p(dbv)
+    a.ym_v, a.xbar, a.ym_q, a.dqp = _p(ops4[0]), _p(ops4[1]), _p(ops4[2]), _p(ops4[3])
+    _check(lib().rg_attn_lastq_x_bwd(ctypes.byref(a), _stream()), "rg_attn_lastq_x_bwd")
+    return dx, dq, ops4[0], ops4[1], ops4[2], ops4[3]
 
 
 def post_attn_supported(d, P, dff):

@@ -397,6 +397,7 @@ def _fusable(x2, Wo, W1):
 QKV_BIAS_ROWS_IN_ATTENTION = True
 FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
+LASTQ_FROM_X = True          # rg_attn_lastq_x_*: the last layer's single-query attention straight from x (no K / V)
 LASTQ_FOLD_PREFIX = True
 
 
@@ -612,14 +613,23 @@ class EncoderLastLayerFn(_Fn):
         x_last, rm_last = hip.last_rows(x, rmf)
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         bkv = bias_cat((bk, bv))
-        kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bkv,
-                         live=_zero_rows_live(rmf, B * L, _X_MASKED, d, 2 * Wk.shape[0]), skip_dead_fill=2)
+        P = Wk.shape[0]
         q_last = hip.gemm_nt(x_last, shadow(Wq), bq.detach())
         # inside the model stacks (x_masked) the K / V rows of a sequence's padded prefix are the bias rows: the
         # single-query kernels then score and weigh the whole prefix once instead of fetching it
         fold = bool(_X_MASKED) and LASTQ_FOLD_PREFIX
-        c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0],
-                                    rowmask=rmf if fold else None, bkv=bkv if fold else None)
+        from_x = LASTQ_FROM_X and hip.attn_lastq_x_supported(d, P, H, L, x.dtype)
+        if from_x:
+            # K and V are never formed: WK is absorbed into the query, WV into the output (attention_lastq_x.hip)
+            wkv = shadow_cat((Wk, Wv))
+            kv = None
+            c_last = hip.attn_lastq_x_fwd(x, q_last, wkv[:P], wkv[P:], bkv[:P], bkv[P:], key_ids, pad_value, drop_p, seeds[0],
+                                          rowmask=rmf if _X_MASKED else None)
+        else:
+            kv = hip.gemm_nt(x2, shadow_cat((Wk, Wv)), bkv,
+                             live=_zero_rows_live(rmf, B * L, _X_MASKED, d, 2 * P), skip_dead_fill=2)
+            c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0],
+                                        rowmask=rmf if fold else None, bkv=bkv if fold else None)
         if _fusable(x_last, Wo, W1):
             out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
@@ -635,14 +645,14 @@ class EncoderLastLayerFn(_Fn):
         if need:
             ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf, rmf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
-            ctx.meta = (B, L, pad_value, H, drop_p, seeds, fold)
+            ctx.meta = (B, L, pad_value, H, drop_p, seeds, fold, from_x, bool(_X_MASKED))
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2, rmf = ctx.saved_tensors
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1 = ctx.prm[:10]
-        B, L, pad_value, H, drop_p, seeds, fold = ctx.meta
+        B, L, pad_value, H, drop_p, seeds, fold, from_x, xm = ctx.meta
         d = x2.shape[1]
         P = Wo.shape[1]
         dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, ctx.prm[10:], drop_p, seeds[1], seeds[2])
@@ -651,13 +661,21 @@ class EncoderLastLayerFn(_Fn):
         (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
         hip.gemm_tn(dz, c_last, dWo, dbo)
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True))
-        dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0],
-                                          rowmask=rmf if fold else None, bkv=bias_cat((bk, bv)) if fold else None)
-        dkv2 = dkv.view(B * L, 2 * P)
         (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))    # same shared base as the full layer
+        if from_x:
+            wkv, bkv = shadow_cat((Wk, Wv)), bias_cat((bk, bv))
+            dx, dq_last, ym_v, xbar, ym_q, dqp = hip.attn_lastq_x_bwd(
+                x2.view(B, L, d), q_last, dctx, wkv[:P], wkv[P:], bkv[:P], bkv[P:], key_ids, pad_value, dbqkv[2 * P:],
+                drop_p, seeds[0], rowmask=rmf if xm else None)
+            hip.gemm_tn(ym_q, dqp, dWqkv[P:2 * P])           # dWK = sum_b q_h (x) dq'_h, heads on the block diagonal
+            hip.gemm_tn(ym_v, xbar, dWqkv[2 * P:])           # dWV = sum_b dctx_h (x) xbar_h      (dbK is exactly zero)
+        else:
+            dq_last, dkv = hip.attn_lastq_bwd(q_last, kv.view(B, L, -1), dctx, key_ids, pad_value, H, drop_p, seeds[0],
+                                              rowmask=rmf if fold else None, bkv=bias_cat((bk, bv)) if fold else None)
+            dkv2 = dkv.view(B * L, 2 * P)
+            hip.gemm_tn(dkv2, x2, dWqkv[P:], dbqkv[P:])
+            dx = hip.gemm_nt(dkv2, shadow_cat((Wk, Wv), transpose=True)).view(B, L, d)
         hip.gemm_tn(dq_last, x_last, dWqkv[:P], dbqkv[:P])
-        hip.gemm_tn(dkv2, x2, dWqkv[P:], dbqkv[P:])
-        dx = hip.gemm_nt(dkv2, shadow_cat((Wk, Wv), transpose=True)).view(B, L, d)
         dx_last = hip.gemm_nt(dq_last, shadow(Wq, transpose=True), epilogue=hip.EPI_ADD, aux=dz)
         dx[:, -1, :] += dx_last
         return ((dx, None, None, None, None, None, rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg1, rbe1)

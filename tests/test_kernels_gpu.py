@@ -1088,6 +1088,79 @@ def test_attn_lastq_folds_the_padded_prefix(dt, drop_p):
     torch.testing.assert_close(dkv1.float(), dkv0.float(), **t)
 
 
+@pytest.mark.parametrize("L,drop_p,masked,pad_value", [(200, 0.0, True, 51), (200, 0.5, True, 51), (200, 0.5, True, 0),
+                                                       (77, 0.0, False, 7), (256, 0.5, True, 51), (16, 0.0, True, 0),
+                                                       (5, 0.5, False, 51)])
+def test_attn_lastq_x_matches_projection_plus_single_query(L, drop_p, masked, pad_value):
+    """rg_attn_lastq_x_fwd / bwd (K and V never formed) against an f64 evaluation of the same attention row from x (no
+    dropout) and against the K/V projection + single-query kernels (same dropout masks): context, dx, dq, dWK, dWV, dbV."""
+    from recguru_amd import hip
+    B, H, d, dt = 41, 4, 128, torch.bfloat16
+    P = H * 32
+    g0 = torch.Generator().manual_seed(L + int(drop_p * 10) + pad_value)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 1
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids[2, :] = pad_value                                          # every key replaced: uniform row, no gradient to q / k
+    ids[3, L - 1] = pad_value
+    ids = ids.cuda()
+    rowmask = (ids != 0).float().view(-1).contiguous()
+    M = B * L
+    x = (torch.randn(B, L, d, generator=g0) * 0.8).cuda()
+    if masked:
+        x = x * rowmask.view(B, L, 1)
+    x = x.to(dt).contiguous()
+    w = (torch.randn(2 * P, d, generator=g0) / d ** 0.5).to(dt).cuda()
+    bkv = (torch.randn(2 * P, generator=g0) * 0.3).cuda()
+    wk, wv, bk, bv = w[:P].contiguous(), w[P:].contiguous(), bkv[:P].contiguous(), bkv[P:].contiguous()
+    q_last = (torch.randn(B, P, generator=g0) * 0.7).cuda().to(dt)
+    dctx = (torch.randn(B, P, generator=g0) * 0.5).cuda().to(dt)
+    rm = rowmask if masked else None
+    # ---- the two-kernel path
+    kv = hip.gemm_nt(x.view(M, d), w, bkv).view(B, L, 2 * P)
+    c_old = hip.attn_lastq_fwd(q_last, kv, ids, pad_value, H, drop_p, 9)
+    dq_old, dkv_old = hip.attn_lastq_bwd(q_last, kv, dctx, ids, pad_value, H, drop_p, 9)
+    dkv2 = dkv_old.view(M, 2 * P).float()
+    dx_old = dkv2 @ w.float()
+    dW_old = dkv2.t() @ x.view(M, d).float()
+    dbv_old = dkv2[:, P:].sum(0)
+    # ---- one kernel from x
+    c_new = hip.attn_lastq_x_fwd(x, q_last, wk, wv, bk, bv, ids, pad_value, drop_p, 9, rowmask=rm)
+    dbv = torch.zeros(P, device="cuda")
+    dx, dq, ym_v, xbar, ym_q, dqp = hip.attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, ids, pad_value, dbv, drop_p, 9, rowmask=rm)
+    dWv = ym_v.float().t() @ xbar.float()
+    dWk = ym_q.float().t() @ dqp.float()
+
+    def close(a, b, frac, what):
+        err = float((a.float() - b.float()).abs().max())
+        ref = float(b.float().abs().max())
+        assert err <= frac * ref + 1e-6, "%s: max err %.3g of max %.3g" % (what, err, ref)
+
+    close(c_new, c_old, 0.02, "context")
+    close(dq, dq_old, 0.03, "dq")
+    # the rows the x_masked contract pins to zero: their gradient is never used (the producer of x multiplies what comes
+    # back by the same mask); the tiles before a sequence's first live row are written as zeros
+    rows = rowmask.bool() if masked else torch.ones(M, dtype=torch.bool, device="cuda")
+    close(dx.view(M, d)[rows], dx_old[rows], 0.03, "dx")
+    assert bool(torch.isfinite(dx.float()).all())
+    close(dWv, dW_old[P:], 0.03, "dWV")
+    close(dWk, dW_old[:P], 0.04, "dWK")
+    close(dbv, dbv_old, 0.02, "dbV")
+    if drop_p == 0.0:                                              # f64 from the same bf16 inputs: the new path is the closer one
+        xd, wd = x.double(), w.double()
+        qd = q_last.double().view(B, H, 32)
+        kvd = (xd.view(M, d) @ wd.t() + bkv.double()).view(B, L, 2, H, 32)
+        s = torch.einsum("bhc,blhc->bhl", qd, kvd[:, :, 0]) * 32 ** -0.5
+        s = s.masked_fill((ids == pad_value)[:, None, :], -1e9)
+        pr = torch.softmax(s, -1)
+        ref = torch.einsum("bhl,blhc->bhc", pr, kvd[:, :, 1]).reshape(B, P)
+        e_new = float((c_new.double() - ref).abs().max())
+        e_old = float((c_old.double() - ref).abs().max())
+        assert e_new <= max(e_old, 2 ** -8 * float(ref.abs().max())) * 1.05, (e_new, e_old)
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,listed", [(203, False), (64, False), (9000, True), (9000, False)])
 def test_attn_out_bwd_equals_ln_bwd_plus_projection(dt, M, listed):

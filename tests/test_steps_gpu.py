@@ -244,15 +244,21 @@ def test_loss_curves_replay(tier, capsys):
         np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
         np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-3, atol=bands["phase3.loss_recon_rec"])
     else:
-        # bf16 operands (8 significant bits) over 30 optimizer steps, the first of them Noam steps at lr up to 0.06:
-        # bounds = 2x the largest drift measured on an MI355X over several builds (phase 1: 3.4 % of the loss at its worst
-        # point; phase 2: D_cost / W_D / g_dis 2.6e-3 abs, recon 0.016 abs; phase 3: loss_recommend 0.036 abs, loss_recon
-        # 0.015 abs) -- the trajectory is chaotic in rounding (see curve_bands), so the drift moves from build to build
+        # bf16 operands (8 significant bits) over 30 optimizer steps, the first of them Noam steps at lr up to 0.06.  The
+        # trajectory is chaotic in rounding (see curve_bands) and the table gradients are summed by float atomics, so the
+        # drift moves from build to build and a little from run to run.  Largest drifts measured on an MI355X over the
+        # round-2 builds: phase 1 3.4 % of the loss at its worst point; phase 2 D_cost / W_D / g_dis 3.2e-3 abs,
+        # reconstruction losses 0.032 abs (1.4 %); phase 3 loss_recon 0.03 abs (1.5 %), loss_recommend 0.11 abs (2.5 %:
+        # the rounding-sensitive series, its float32 band is 500x that of the reconstruction losses).  The builds'
+        # ONE-step errors against the oracle are the same (tools/ab_lastq.sh).  Bounds = 2x those drifts.
         np.testing.assert_allclose(p1, z["phase1.loss"], rtol=0.07, atol=1e-5)
         for i, n in enumerate(names2):
-            np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=0, atol=0.032 if "recon" in n else 5e-3, err_msg=n)
-        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=0, atol=0.075)
-        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=0, atol=0.03)
+            if "recon" in n:
+                np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=0.03, atol=0, err_msg=n)
+            else:
+                np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=0, atol=6.5e-3, err_msg=n)
+        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=0.05, atol=0)
+        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=0.03, atol=0)
     # the scalar log carries the reference's series names (tools/plot.py layout)
     assert len(T.plot.values(param.result_path + "/disc cost_%s" % T.date)) == 5
     assert len(T.plot.values(param.result_path + "/tuning_recommendation_loss")) == 5
