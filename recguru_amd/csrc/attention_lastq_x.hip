@@ -40,6 +40,31 @@ __device__ __forceinline__ unsigned int pack_bf(float a, float b) {
 }
 __device__ __forceinline__ float bcast(float v, int l) { return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), l)); }
 
+// wave reductions by DPP (row-local steps, then row_bcast15 / row_bcast31 into the last lane): 6 VALU operations and a
+// v_readlane instead of 6 dependent ds_bpermute round trips -- the four reductions of a sequence sit on its critical path
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_move(float idle, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(idle), __float_as_int(v), CTRL, ROWS, 0xf, false));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+  v += dpp_move<0xB1, 0xf>(0.f, v);          // quad_perm [1,0,3,2]
+  v += dpp_move<0x4E, 0xf>(0.f, v);          // quad_perm [2,3,0,1]
+  v += dpp_move<0x141, 0xf>(0.f, v);         // row_half_mirror
+  v += dpp_move<0x140, 0xf>(0.f, v);         // row_mirror: every lane holds its row's sum
+  v += dpp_move<0x142, 0xa>(0.f, v);         // row_bcast15 into rows 1 and 3
+  v += dpp_move<0x143, 0xc>(0.f, v);         // row_bcast31 into rows 2 and 3
+  return bcast(v, 63);
+}
+__device__ __forceinline__ float wave_max_dpp(float v) {
+  v = fmaxf(v, dpp_move<0xB1, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x4E, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x141, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x140, 0xf>(v, v));
+  v = fmaxf(v, dpp_move<0x142, 0xa>(v, v));
+  v = fmaxf(v, dpp_move<0x143, 0xc>(v, v));
+  return bcast(v, 63);
+}
+
 // sum over the 64 lanes of 32 per-lane values; lane l ends up with the total of value index l >> 1 (5 halving
 // exchanges of 16, 8, 4, 2, 1 values and a last pair sum: 32 cross-lane moves instead of 32 x 6)
 template <int W>
@@ -64,6 +89,7 @@ struct Smem {
   float* dp;           // [4][SLD]      backward: x . dxbar
   float* cf;           // [LT*16][8]    backward: (p~, ds) per head
   float* vec;          // [8][128]      backward: dxbar_h, q'_h (f32)
+  float* xb;           // [8][128]      weighted row sums of all heads (forward: 4 rows used)
 };
 
 // x rows [rs, SLD) of sequence b into LDS by LDS-DMA (no staging registers, every row in flight at once): one wave
@@ -103,6 +129,31 @@ __device__ __forceinline__ f32x4 tile_product(const Smem& sm, int t, const Frag<
     mma(a, bq[ks], acc);
   }
   return acc;
+}
+
+// B operand of a weighted row sum: slots (g, jj) = rows j0 + 8g + jj of feature 16 ft + (lane & 15), straight from the
+// swizzled row-major image by two transposing reads (4 rows x 16 features per 16 lanes each)
+__device__ __forceinline__ void x_rows_frag(Frag<__bf16>& f, const Smem& sm, int j0, int ft, int lane) {
+  typedef __attribute__((ext_vector_type(4))) short s16x4;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+  const int r0 = 8 * g + q, ch = 2 * ft + (pp >> 1);
+  const unsigned char* base = reinterpret_cast<const unsigned char*>(sm.xs) + ((pp & 1) << 3);
+  const unsigned char* p0 = base + (j0 + r0) * 256 + ((ch ^ (r0 & 15)) << 4);
+  const unsigned char* p1 = base + (j0 + r0 + 4) * 256 + ((ch ^ ((r0 + 4) & 15)) << 4);
+  union { s16x4 s; bf16x4_t b; } u0, u1;
+  u0.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p0);
+  u1.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p1);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
+}
+// A operand rows from f32 weights w[0..7] (this lane's 8 slots): bf16 high part where `hi`, low part where `lo`, else 0
+__device__ __forceinline__ void weights_frag(Frag<__bf16>& f, const float (&w)[8], bool hi, bool lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float h = (float)(__bf16)w[j];
+    f.v[j] = (__bf16)(hi ? h : (lo ? w[j] - h : 0.f));
+  }
 }
 
 struct Head {                       // what wave h keeps for the whole launch
@@ -159,12 +210,12 @@ __device__ __forceinline__ void softmax_keys(const Smem& sm, int SLD, int h, int
     s[i] = j < L ? (msk[i] ? LX_MASK_BIG : raw) : -INFINITY;
     mx = fmaxf(mx, s[i]);
   }
-  mx = wave_max(mx);
+  mx = wave_max_dpp(mx);
   full = mx < 0.5f * LX_MASK_BIG;
   float sum = 0.f;
 #pragma unroll
   for (int i = 0; i < LX_KPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
-  sum = wave_sum(sum);
+  sum = wave_sum_dpp(sum);
   const float inv = 1.f / sum;
 #pragma unroll
   for (int i = 0; i < LX_KPL; ++i) {
@@ -179,11 +230,12 @@ __device__ __forceinline__ void softmax_keys(const Smem& sm, int SLD, int h, int
 __global__ __launch_bounds__(256, 2) void attn_lastq_x_fwd_kernel(rg_lastq_x_args a) {
   extern __shared__ __align__(16) unsigned char lx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = a.L, LT = (L + 15) >> 4, SLD = LT * 16;
+  const int L = a.L, LT = (L + 15) >> 4, SLD = ((L + 31) >> 5) << 5;      // rows held in LDS: whole 32-row k-steps
   Smem sm;
   sm.xs = reinterpret_cast<unsigned int*>(lx_smem);
   sm.qs = reinterpret_cast<__bf16*>(sm.xs + SLD * 64);
   sm.ss = reinterpret_cast<float*>(sm.qs + 16 * LX_QLD);
+  sm.xb = sm.ss + 4 * SLD;
   for (int i = tid; i < 16 * LX_QLD / 2; i += 256) reinterpret_cast<unsigned int*>(sm.qs)[i] = 0u;
   Head hd;
   load_head(hd, a, h, lane);
@@ -191,17 +243,29 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_fwd_kernel(rg_lastq_x_arg
   const __bf16* __restrict__ X = reinterpret_cast<const __bf16*>(a.x);
   const __bf16* __restrict__ Q = reinterpret_cast<const __bf16*>(a.qlast);
   __bf16* __restrict__ C = reinterpret_cast<__bf16*>(a.ctx);
+  // the x rows of a sequence are requested as soon as the previous sequence's last reader of the LDS image is done (one
+  // barrier before its epilogue), so the HBM latency runs under the epilogue and the next query's projection
+  auto first_row = [&](int b) { return (a.first_live ? min(a.first_live[b], L - 1) : 0) & ~31; };
+  // ... and what the next sequence needs from global memory BEFORE its rows land (query, first row) is fetched one stage
+  // earlier still and pinned in registers ahead of the request: a load issued after the LDS-DMAs could only be waited
+  // for together with them (vmcnt counts in order)
+  // (raw values: any arithmetic on them would make the compiler wait for the load where it is issued)
+  const unsigned short* Qr = reinterpret_cast<const unsigned short*>(a.qlast) + h * LX_DK + (lane & 31);
+  auto as_q = [&](unsigned int raw) { return lane < 32 ? __uint_as_float(raw << 16) : 0.f; };
+  int rs = blockIdx.x < a.B ? first_row(blockIdx.x) : 0;
+  float ql_next = blockIdx.x < a.B ? as_q(Qr[(size_t)blockIdx.x * LX_D]) : 0.f;
+  asm volatile("" : "+v"(ql_next));
+  pin_head(hd);                                                 // (the weight loads are waited for HERE, not at the loop head)
+  __syncthreads();                                              // (qs zeroed)
+  if (blockIdx.x < a.B) stage_x(sm, X + (size_t)blockIdx.x * L * LX_D, rs, L, SLD, h, lane);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const int first = a.first_live ? min(a.first_live[b], L - 1) : 0;
-    const int rs = first & ~15;
     pin_head(hd);
-    __syncthreads();                                            // the previous sequence is done with the LDS
-    stage_x(sm, X + (size_t)b * L * LX_D, rs, L, SLD, h, lane);
-    const float ql = lane < 32 ? (float)Q[(size_t)b * LX_D + h * LX_DK + lane] : 0.f;
+    const float ql = ql_next;
+    const int nb = b + gridDim.x;
     float q0, q1;
     vec_times_rows(hd.wk, ql, q0, q1);
     q0 *= a.scale; q1 *= a.scale;
-    const float qb = wave_sum(ql * hd.bk) * a.scale;
+    const float qb = wave_sum_dpp(ql * hd.bk) * a.scale;
     put_cols(sm, h, 4 + h, q0, q1, lane);
     stage_wait();
     __syncthreads();
@@ -215,12 +279,15 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_fwd_kernel(rg_lastq_x_arg
         const f32x4 acc = tile_product(sm, t, bq, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[r] + __shfl_down(acc[r], 4);
+          const float v = acc[r] + dpp_move<0x104, 0xf>(0.f, acc[r]);          // row_shl:4: column n + 4 (the low parts)
           if (n < 4) sm.ss[n * SLD + 16 * t + 4 * g + r] = v;
         }
       }
     }
     __syncthreads();
+    const int nbc = min(nb, a.B - 1);
+    int first_raw = a.first_live ? a.first_live[nbc] : 0;       // in flight under the softmax and the row sums
+    unsigned int q_raw = Qr[(size_t)nbc * LX_D];
     float p[LX_KPL], kp[LX_KPL];
     bool msk[LX_KPL], full;
     const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
@@ -233,19 +300,37 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_fwd_kernel(rg_lastq_x_arg
       sp += pd;
       if (j < SLD) sm.ss[h * SLD + j] = pd;                    // this wave's own row: no barrier needed
     }
-    sp = wave_sum(sp);
-    float a0 = 0.f, a1 = 0.f;
-#pragma unroll 2
-    for (int j = rs; j < SLD; j += 4) {
-      const float4 pw = *reinterpret_cast<const float4*>(sm.ss + h * SLD + j);
-      const float pv[4] = {pw.x, pw.y, pw.z, pw.w};
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const unsigned int xw = x_pair(sm, j + u, lane);
-        a0 += pv[u] * bf_lo(xw);
-        a1 += pv[u] * bf_hi(xw);
+    sp = wave_sum_dpp(sp);
+    __syncthreads();                                            // p~ of every head is in place
+    {                                                           // xbar[h][f] = sum_j p~[h][j] x[j][f]: wave w makes features 32w .. 32w+31
+      const int i = lane & 15, g = lane >> 4;
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 1
+      for (int j0 = rs; j0 < SLD; j0 += 32) {
+        const float* src = sm.ss + (i & 3) * SLD + j0 + 8 * g;
+        const float4 w0 = *reinterpret_cast<const float4*>(src), w1 = *reinterpret_cast<const float4*>(src + 4);
+        const float w[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        Frag<__bf16> af, b0, b1;
+        weights_frag(af, w, i < 4, i >= 4 && i < 8);
+        x_rows_frag(b0, sm, j0, 2 * h, lane);
+        x_rows_frag(b1, sm, j0, 2 * h + 1, lane);
+        mma(af, b0, acc[0]);
+        mma(af, b1, acc[1]);
       }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                           // rows 0-3: high parts, rows 4-7 (lanes 16-31): low parts
+          const float v = acc[t][r] + __shfl_down(acc[t][r], 16);
+          if (g == 0) sm.xb[r * LX_D + 16 * (2 * h + t) + i] = v;
+        }
     }
+    __syncthreads();                                            // xb complete; nobody reads the x image any more
+    const float2 xp = reinterpret_cast<const float2*>(sm.xb + h * LX_D)[lane];
+    const float a0 = xp.x, a1 = xp.y;
+    asm volatile("" : "+v"(q_raw), "+v"(first_raw));             // both have arrived: nothing after the request waits on them
+    ql_next = as_q(q_raw);
+    if (nb < a.B) { rs = __builtin_amdgcn_readfirstlane(min(first_raw, L - 1) & ~31); stage_x(sm, X + (size_t)nb * L * LX_D, rs, L, SLD, h, lane); }
     const float o = rows_times_vec(hd.wv, a0, a1, lane);
     const float bvl = __shfl(hd.bv, lane >> 1);
     if (!(lane & 1)) C[(size_t)b * LX_D + h * LX_DK + (lane >> 1)] = (__bf16)(o + bvl * sp);
@@ -255,14 +340,15 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_fwd_kernel(rg_lastq_x_arg
 __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_args a) {
   extern __shared__ __align__(16) unsigned char lx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int L = a.L, LT = (L + 15) >> 4, SLD = LT * 16;
+  const int L = a.L, LT = (L + 15) >> 4, SLD = ((L + 31) >> 5) << 5;      // rows held in LDS: whole 32-row k-steps
   Smem sm;
   sm.xs = reinterpret_cast<unsigned int*>(lx_smem);
   sm.qs = reinterpret_cast<__bf16*>(sm.xs + SLD * 64);
   sm.ss = reinterpret_cast<float*>(sm.qs + 16 * LX_QLD);
   sm.dp = sm.ss + 4 * SLD;
-  sm.cf = sm.dp + 4 * SLD;
+  sm.cf = sm.ss + (8 * SLD > 8 * LX_D ? 8 * SLD : 8 * LX_D);
   sm.vec = sm.cf + SLD * 8;
+  sm.xb = sm.ss;                                                // [8][128] <= ss | dp: both dead once cf is written
   Head hd;
   load_head(hd, a, h, lane);
   const DropCfg drop = make_drop(a.drop_p, a.seed);
@@ -276,32 +362,41 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
   unsigned int* __restrict__ XB = reinterpret_cast<unsigned int*>(a.xbar);
   unsigned int* __restrict__ DP = reinterpret_cast<unsigned int*>(a.dqp);
   float dbv = 0.f;
+  auto first_row = [&](int b) { return (a.first_live ? min(a.first_live[b], L - 1) : 0) & ~31; };
+  const unsigned short* Qr = reinterpret_cast<const unsigned short*>(a.qlast) + h * LX_DK + (lane & 31);
+  const unsigned short* Gr = reinterpret_cast<const unsigned short*>(a.dctx) + h * LX_DK + (lane & 31);
+  auto as_q = [&](unsigned int raw) { return lane < 32 ? __uint_as_float(raw << 16) : 0.f; };
+  int rs_next = blockIdx.x < a.B ? first_row(blockIdx.x) : 0;
+  float ql_next = blockIdx.x < a.B ? as_q(Qr[(size_t)blockIdx.x * LX_D]) : 0.f;
+  float gl_next = blockIdx.x < a.B ? as_q(Gr[(size_t)blockIdx.x * LX_D]) : 0.f;
+  asm volatile("" : "+v"(ql_next), "+v"(gl_next));
+  pin_head(hd);
+  if (blockIdx.x < a.B) stage_x(sm, X + (size_t)blockIdx.x * L * LX_D, rs_next, L, SLD, h, lane);
   for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
-    const int first = a.first_live ? min(a.first_live[b], L - 1) : 0;
-    const int rs = first & ~15;
+    const int rs = rs_next;
+    const int nb = b + gridDim.x;
     pin_head(hd);
-    __syncthreads();
-    stage_x(sm, X + (size_t)b * L * LX_D, rs, L, SLD, h, lane);
-    const float ql = lane < 32 ? (float)Q[(size_t)b * LX_D + h * LX_DK + lane] : 0.f;
-    const float gl = lane < 32 ? (float)G[(size_t)b * LX_D + h * LX_DK + lane] : 0.f;
+    __syncthreads();                                            // the previous sequence's dx stage is done with cf / vec
+    const float ql = ql_next, gl = gl_next;
     float q0, q1, d0, d1;
     vec_times_rows(hd.wk, ql, q0, q1);
     q0 *= a.scale; q1 *= a.scale;
     __builtin_amdgcn_sched_barrier(0);                          // one matrix unpacked at a time
     vec_times_rows(hd.wv, gl, d0, d1);                          // dxbar_h
     __builtin_amdgcn_sched_barrier(0);
-    const float qb = wave_sum(ql * hd.bk) * a.scale;
-    const float dsp = wave_sum(gl * hd.bv);                     // d(sum of p~)
+    const float qb = wave_sum_dpp(ql * hd.bk) * a.scale;
+    const float dsp = wave_sum_dpp(gl * hd.bv);                     // d(sum of p~)
     put_cols(sm, h, 4 + h, q0, q1, lane);
     put_cols(sm, 8 + h, 12 + h, d0, d1, lane);
     reinterpret_cast<float2*>(sm.vec + h * LX_D)[lane] = make_float2(d0, d1);
     reinterpret_cast<float2*>(sm.vec + (4 + h) * LX_D)[lane] = make_float2(q0, q1);
     {                                                           // the operands of the dWV / dWK products: other heads' blocks zero
-      const int owner = lane >> 4;                              // features (2*lane, 2*lane+1) belong to head lane >> 4
-      const unsigned int gq = reinterpret_cast<const unsigned int*>(G + (size_t)b * LX_D)[lane];
-      const unsigned int qq = reinterpret_cast<const unsigned int*>(Q + (size_t)b * LX_D)[lane];
-      YV[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = owner == h ? gq : 0u;
-      YQ[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = owner == h ? qq : 0u;
+      const bool own = (lane >> 4) == h;                        // features (2*lane, 2*lane+1) belong to head lane >> 4
+      const int c = (2 * lane) & 31;                            // ... and are elements c, c+1 of this head's 32 (held by lanes c, c+1)
+      const unsigned int gq = pack_bf(__shfl(gl, c), __shfl(gl, c + 1));      // (exact: the values came from bf16)
+      const unsigned int qq = pack_bf(__shfl(ql, c), __shfl(ql, c + 1));
+      YV[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? gq : 0u;
+      YQ[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? qq : 0u;
     }
     stage_wait();
     __syncthreads();
@@ -315,13 +410,16 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
         const f32x4 acc = tile_product(sm, t, bq, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float v = acc[r] + __shfl_down(acc[r], 4);
+          const float v = acc[r] + dpp_move<0x104, 0xf>(0.f, acc[r]);          // row_shl:4: column n + 4 (the low parts)
           if (n < 4) sm.ss[n * SLD + 16 * t + 4 * g + r] = v;
           else if (n >= 8 && n < 12) sm.dp[(n - 8) * SLD + 16 * t + 4 * g + r] = v;
         }
       }
     }
     __syncthreads();
+    const int nbc = min(nb, a.B - 1);
+    int first_raw = a.first_live ? a.first_live[nbc] : 0;       // (raw: see the forward kernel)
+    unsigned int q_raw = Qr[(size_t)nbc * LX_D], g_raw = Gr[(size_t)nbc * LX_D];
     float p[LX_KPL], kp[LX_KPL];
     bool msk[LX_KPL], full;
     const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
@@ -336,26 +434,47 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
       delta += p[i] * dpk[i];
       sp += p[i] * kp[i];
     }
-    delta = wave_sum(delta);
-    sp = wave_sum(sp);
+    delta = wave_sum_dpp(delta);
+    sp = wave_sum_dpp(sp);
 #pragma unroll
     for (int i = 0; i < LX_KPL; ++i) {
       const int j = lane + 64 * i;
       const float ds = (full || msk[i]) ? 0.f : p[i] * (dpk[i] - delta);
       if (j < SLD) *reinterpret_cast<float2*>(sm.cf + j * 8 + 2 * h) = make_float2(p[i] * kp[i], ds);
     }
-    float a0 = 0.f, a1 = 0.f, g0 = 0.f, g1 = 0.f;               // xbar_h and dq'_h (before the scale)
-#pragma unroll 2
-    for (int j = rs; j < SLD; j += 4) {
+    __syncthreads();                                            // cf of every head is in place; scores / dp are dead
+    {                                                           // xbar[h][f] = sum_j p~ x, dq'[h][f] = sum_j ds x: wave w makes features 32w .. 32w+31
+      const int i = lane & 15, g = lane >> 4;
+      f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+      const float* src = sm.cf + 2 * (i & 3) + (i >> 3);        // operand rows: p~ high, p~ low, ds high, ds low (4 heads each)
+#pragma unroll 1
+      for (int j0 = rs; j0 < SLD; j0 += 32) {
+        float w[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float2 c = *reinterpret_cast<const float2*>(sm.cf + (j + u) * 8 + 2 * h);
-        const unsigned int xw = x_pair(sm, j + u, lane);
-        const float x0 = bf_lo(xw), x1 = bf_hi(xw);
-        a0 += c.x * x0; a1 += c.x * x1;
-        g0 += c.y * x0; g1 += c.y * x1;
+        for (int jj = 0; jj < 8; ++jj) w[jj] = src[(j0 + 8 * g + jj) * 8];
+        Frag<__bf16> af, b0, b1;
+        weights_frag(af, w, !(i & 4), (i & 4) != 0);
+        x_rows_frag(b0, sm, j0, 2 * h, lane);
+        x_rows_frag(b1, sm, j0, 2 * h + 1, lane);
+        mma(af, b0, acc[0]);
+        mma(af, b1, acc[1]);
       }
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {                           // lanes 0-15: xbar (high + low rows), lanes 32-47: dq'
+          const float v = acc[t][r] + __shfl_down(acc[t][r], 16);
+          if (!(g & 1)) sm.xb[((g >> 1) * 4 + r) * LX_D + 16 * (2 * h + t) + i] = v;
+        }
     }
+    __syncthreads();                                            // xb complete; nobody reads the x image any more
+    asm volatile("" : "+v"(q_raw), "+v"(g_raw), "+v"(first_raw));
+    ql_next = as_q(q_raw); gl_next = as_q(g_raw);
+    if (nb < a.B) { rs_next = __builtin_amdgcn_readfirstlane(min(first_raw, L - 1) & ~31); stage_x(sm, X + (size_t)nb * L * LX_D, rs_next, L, SLD, h, lane); }   // in flight under the dx stage
+    const float2 xp = reinterpret_cast<const float2*>(sm.xb + h * LX_D)[lane];
+    const float2 gp = reinterpret_cast<const float2*>(sm.xb + (4 + h) * LX_D)[lane];
+    const float a0 = xp.x, a1 = xp.y;
+    float g0 = gp.x, g1 = gp.y;
     g0 *= a.scale; g1 *= a.scale;
     XB[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = pack_bf(a0, a1);
     DP[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = pack_bf(g0, g1);
@@ -364,7 +483,6 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
     const float dq = rows_times_vec(hd.wk, g0, g1, lane);
     if (!(lane & 1)) DQ[(size_t)b * LX_D + h * LX_DK + (lane >> 1)] = (__bf16)dq;
     dbv += gl * sp;
-    __syncthreads();                                            // cf of every head is in place
     {                                                           // dx rows: wave w takes rows rs + w, rs + w + 4, ...
       float2 vd[4], vq[4];
 #pragma unroll
@@ -393,9 +511,11 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
 }
 
 static size_t lx_smem_bytes(int L, bool bwd) {
-  const size_t SLD = (size_t)((L + 15) >> 4) * 16;
-  size_t n = SLD * 256 + 16 * LX_QLD * 2 + 4 * SLD * 4;
-  if (bwd) n += 4 * SLD * 4 + SLD * 8 * 4 + 8 * LX_D * 4;
+  const size_t SLD = (size_t)((L + 31) >> 5) * 32;
+  const size_t sc = 4 * SLD * 4;                                  // one [4][SLD] f32 image
+  size_t n = SLD * 256 + 16 * LX_QLD * 2;
+  if (!bwd) n += sc + 8 * LX_D * 4;                               // ss | xb
+  else n += (2 * sc > 8 * LX_D * 4 ? 2 * sc : 8 * LX_D * 4) + SLD * 8 * 4 + 8 * LX_D * 4;   // ss | dp (xb aliases them) | cf | vec
   return n;
 }
 
