@@ -168,6 +168,13 @@ int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, cons
                     long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
 int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
                          long long skip_row, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* Same result as rg_embed_scatter_bwd with the gradient rows summed per 64-row bin of the table in LDS (counting sort of
+ * the positions by bin, csrc/loss.hip) instead of one atomic row per live position.  table_rows = rows of dE.
+ * workspace >= rg_embed_scatter_binned_workspace() bytes (0: shape not supported -- d not in {64,128,256}, > 8192 bins). */
+size_t rg_embed_scatter_binned_workspace(long long ntok, int d, long long table_rows);
+int rg_embed_scatter_bwd_binned(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
+                                long long table_rows, long long skip_row, float drop_p, unsigned long long seed,
+                                void* workspace, size_t workspace_bytes, int dtype, void* stream);
 /* drop_p / seed: nn.Dropout of PositionalEncoding.forward (transformer.py:106); the mask is a stateless
  * hash of (seed, element index), regenerated by the backward.  drop_p = 0 disables it. */
 

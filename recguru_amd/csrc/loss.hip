@@ -450,12 +450,15 @@ static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 #define RG_RPB 64            // table rows per bin
 #define RG_RPB_LOG 6
-#define RG_CHUNK 2048        // entries per accumulate work item
+#define RG_CHUNK 2048        // entries per accumulate work item (item loss)
+#define RG_CHUNK_EMB 512     // ... embedding scatter: a hot item's thousands of positions spread over many workgroups
 #define RG_MAXBINS 8192
 #define RG_PPW 8192          // (position, item) pairs per workgroup in count / fill
 
 struct BinWs {
   float* c; int* hist; int* start; int* cursor; int* chunk_start;
+  int* chunk_bin;    // [chunks] the bin of each accumulate work item (written by the scan: no search per work item)
+  int chunk;         // entries per accumulate work item
   uint2* ent;        // sorted entries: x = (position << RG_RPB_LOG) | row-in-bin, y = c as bits  (one 8-byte store / load)
   int nbins;
   const float* cscale;  // non-null: the c values are for gout = 1 and bin_fill multiplies them by cscale[0]
@@ -502,24 +505,30 @@ __global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, Bin
 
 // one workgroup: start[b] = exclusive prefix of hist, cursor = start, chunk_start = exclusive prefix of ceil(hist/CHUNK)
 __global__ __launch_bounds__(1024) void bin_scan_kernel(BinWs w) {
-  __shared__ int part[1024], partc[1024];
-  const int tid = threadIdx.x;
+  __shared__ int wt[16], wtc[16];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int per = (w.nbins + 1023) / 1024;
   const int b0 = tid * per, b1 = min(b0 + per, w.nbins);
   int s = 0, sc = 0;
-  for (int b = b0; b < b1; ++b) { s += w.hist[b]; sc += (w.hist[b] + RG_CHUNK - 1) / RG_CHUNK; }
-  part[tid] = s; partc[tid] = sc;
-  __syncthreads();
-  if (tid == 0) {
-    int acc = 0, accc = 0;
-    for (int i = 0; i < 1024; ++i) { const int v = part[i], vc = partc[i]; part[i] = acc; partc[i] = accc; acc += v; accc += vc; }
-    w.start[w.nbins] = acc; w.chunk_start[w.nbins] = accc;
+  for (int b = b0; b < b1; ++b) { s += w.hist[b]; sc += (w.hist[b] + w.chunk - 1) / w.chunk; }
+  // exclusive scan of (s, sc) over the 1024 threads: shuffles inside a wave, 16 wave totals through LDS
+  int is = s, isc = sc;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(is, o), uc = __shfl_up(isc, o);
+    if (lane >= o) { is += u; isc += uc; }
   }
+  if (lane == 63) { wt[wv] = is; wtc[wv] = isc; }
   __syncthreads();
-  s = part[tid]; sc = partc[tid];
+  int base = 0, basec = 0;
+  for (int i = 0; i < wv; ++i) { base += wt[i]; basec += wtc[i]; }
+  if (tid == 1023) { w.start[w.nbins] = base + is; w.chunk_start[w.nbins] = basec + isc; }
+  s = base + is - s; sc = basec + isc - sc;
   for (int b = b0; b < b1; ++b) {
     w.start[b] = s; w.cursor[b] = s; w.chunk_start[b] = sc;
-    s += w.hist[b]; sc += (w.hist[b] + RG_CHUNK - 1) / RG_CHUNK;
+    const int nc = (w.hist[b] + w.chunk - 1) / w.chunk;
+    for (int j = 0; j < nc; ++j) w.chunk_bin[sc + j] = b;
+    s += w.hist[b]; sc += nc;
   }
 }
 
@@ -569,26 +578,30 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
 // then owns whole rows, sums c * h[t] for a row in registers (LPR lanes per entry, G entries per wave
 // instruction, U per lane group in flight), reduces the G lane groups by shuffles and parks the row in an LDS
 // tile that is flushed once, coalesced, with 256-byte-shaped global atomics.
-template <typename T, int LPR>
-__global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a, BinWs w, long long table_rows) {
-  constexpr int G = 64 / LPR, D = LPR * 8, U = 4, EPT = RG_CHUNK / 256;
-  extern __shared__ float sm[];                     // acc [RG_RPB][D] | sorted t [RG_CHUNK] | sorted c [RG_CHUNK]
+// DROP (the embedding scatter below): the rows are the gradient of an embedding output -- sparse bins, and under dropout
+// element (t, e) of h is multiplied by the dropout multiplier of index t*D + e, regenerated here.
+template <typename T, int LPR, bool DROP>
+__global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a, BinWs w, long long table_rows, DropCfg drop) {
+  constexpr int CH = DROP ? RG_CHUNK_EMB : RG_CHUNK;
+  constexpr int G = 64 / LPR, D = LPR * 8, U = 4, EPT = CH / 256;
+  extern __shared__ float sm[];                     // acc [RG_RPB][D] | sorted t [CH] | sorted c [CH]
   float* acc = sm;
   int* st = reinterpret_cast<int*>(sm + RG_RPB * D);
-  float* sc = reinterpret_cast<float*>(st + RG_CHUNK);
+  float* sc = reinterpret_cast<float*>(st + CH);
   __shared__ int cnt[RG_RPB], rstart[RG_RPB + 1];
-  __shared__ int s_bin, s_lo, s_hi;
+  __shared__ int s_bin, s_lo, s_hi, s_alone;
+  __shared__ float part[DROP ? 4 * D : 1];          // hot rows: one partial row per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gi = lane / LPR, li = lane % LPR;
   const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
   const int nchunks = w.chunk_start[w.nbins];
   for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
     if (tid == 0) {
-      int lo = 0, hi = w.nbins;                     // last bin with chunk_start[bin] <= ch
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (w.chunk_start[mid] <= ch) lo = mid; else hi = mid; }
+      const int lo = w.chunk_bin[ch];               // (a binary search over chunk_start here: 11 dependent L2 round trips per work item)
       const int bs = w.start[lo], be = w.start[lo + 1];
-      const int e0 = bs + (ch - w.chunk_start[lo]) * RG_CHUNK;
-      s_bin = lo; s_lo = e0; s_hi = min(e0 + RG_CHUNK, be);
+      const int e0 = bs + (ch - w.chunk_start[lo]) * CH;
+      s_bin = lo; s_lo = e0; s_hi = min(e0 + CH, be);
+      s_alone = be - bs <= CH;                // the bin's only work item: its rows belong to this workgroup alone
     }
     if (tid < RG_RPB) cnt[tid] = 0;
     __syncthreads();
@@ -621,9 +634,94 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
     for (int i = 0; i < EPT; ++i)
       if (myr[i] >= 0) { const int p = rstart[myr[i]] + myp[i]; st[p] = myt[i]; sc[p] = myc[i]; }
     __syncthreads();
-    // ---- each wave sums whole rows
+    // ---- sparse bins (the embedding scatter: a few entries per row, some hot rows): rows of up to CAP entries are summed
+    // by ONE LANE GROUP each, G rows of a wave in flight together and nothing reduced across groups (a row per wave made
+    // 16 dependent gather rounds per chunk); longer rows take the wave-per-row loop below
+    constexpr int CAP = 2 * U;
+    if (DROP) {
+      for (int r = wave * G + gi; r < RG_RPB; r += 4 * G) {
+        const int lo = rstart[r], hi = rstart[r + 1];
+        float s8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = 0.f;
+        const bool mine = hi - lo <= CAP;
+#pragma unroll
+        for (int it = 0; it < CAP / U; ++it) {
+          const int eb = lo + it * U;
+          int t[U];
+          float c[U], h[U][8];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int e = max(min(eb + u, hi - 1), 0);
+            t[u] = st[e];
+            c[u] = (mine && eb + u < hi) ? sc[e] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (drop.thresh) {
+              float kp[8];
+              rg_keep8(drop, (unsigned int)t[u] * (unsigned int)D + 8u * (unsigned int)li, kp);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s8[j] += c[u] * kp[j] * h[u][j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+            }
+          }
+        }
+        if (mine) store8(acc + r * D + 8 * li, s8);
+      }
+    }
+    // ---- hot rows of the embedding scatter (a popular item: up to the whole work item is ONE row): all four waves share
+    // the row's entries and their partial sums meet in LDS (a single wave walked them 16 at a time)
+    constexpr int HOT = 64;
+    if (DROP) {
+      for (int r = 0; r < RG_RPB; ++r) {                     // (uniform over the workgroup)
+        const int lo = rstart[r], hi = rstart[r + 1];
+        if (hi - lo <= HOT) continue;
+        float s8[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] = 0.f;
+        for (int eb = lo + (wave * G + gi) * U; eb < hi; eb += 4 * G * U) {
+          int t[U];
+          float c[U], h[U][8];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            const int e = min(eb + u, hi - 1);
+            t[u] = st[e];
+            c[u] = (eb + u < hi) ? sc[e] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if (drop.thresh) {
+              float kp[8];
+              rg_keep8(drop, (unsigned int)t[u] * (unsigned int)D + 8u * (unsigned int)li, kp);
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s8[j] += c[u] * kp[j] * h[u][j];
+            } else {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+            }
+          }
+        }
+#pragma unroll
+        for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s8[j] += __shfl_xor(s8[j], o);
+        if (gi == 0) store8(part + wave * D + 8 * li, s8);
+        __syncthreads();
+        if (tid < D) acc[r * D + tid] = part[tid] + part[D + tid] + part[2 * D + tid] + part[3 * D + tid];
+        __syncthreads();
+      }
+    }
+    // ---- dense bins (the item loss) and the mid-length rows of sparse ones: each wave sums whole rows
     for (int r = wave; r < RG_RPB; r += 4) {
       const int lo = rstart[r], hi = rstart[r + 1];
+      if (DROP && (hi - lo <= CAP || hi - lo > HOT)) continue;
       float s8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s8[j] = 0.f;
@@ -639,9 +737,17 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
 #pragma unroll
         for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
 #pragma unroll
-        for (int u = 0; u < U; ++u)
+        for (int u = 0; u < U; ++u) {
+          if (DROP && drop.thresh) {
+            float kp[8];
+            rg_keep8(drop, (unsigned int)t[u] * (unsigned int)D + 8u * (unsigned int)li, kp);
 #pragma unroll
-          for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+            for (int j = 0; j < 8; ++j) s8[j] += c[u] * kp[j] * h[u][j];
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+          }
+        }
       }
 #pragma unroll
       for (int o = LPR; o < 64; o <<= 1)
@@ -650,10 +756,18 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
       if (gi == 0) store8(acc + r * D + 8 * li, s8);
     }
     __syncthreads();
-    for (int i = tid; i < RG_RPB * D; i += 256) {
-      const long long row = (long long)bin * RG_RPB + i / D;
-      const float v = acc[i];
-      if (row < table_rows && v != 0.f) atomicAdd(a.dE + row * D + (i % D), v);
+    if (s_alone) {                                   // plain read-modify-write: no other work item of this launch adds to these rows
+      for (int i = tid; i < RG_RPB * D; i += 256) {
+        const long long row = (long long)bin * RG_RPB + i / D;
+        const float v = acc[i];
+        if (row < table_rows && v != 0.f) a.dE[row * D + (i % D)] += v;
+      }
+    } else {
+      for (int i = tid; i < RG_RPB * D; i += 256) {
+        const long long row = (long long)bin * RG_RPB + i / D;
+        const float v = acc[i];
+        if (row < table_rows && v != 0.f) atomicAdd(a.dE + row * D + (i % D), v);
+      }
     }
     __syncthreads();
   }
@@ -667,11 +781,12 @@ extern "C" size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d
   const long long npairs = ntok * (k + 1);
   if (!(d == 64 || d == 128 || d == 256) || nbins > RG_MAXBINS || npairs >= (1LL << 31) || ntok <= 0 ||
       ntok >= (1LL << (32 - RG_RPB_LOG))) return 0;
-  return align256(npairs * 4) + align256(npairs * 8) + align256((nbins + 1) * 4) * 4;
+  return align256(npairs * 4) + align256(npairs * 8) + align256((nbins + 1) * 4) * 4 + align256((nbins + npairs / RG_CHUNK_EMB + 1) * 4);
 }
 
 template <typename T>
-static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws, size_t ws_bytes, long long table_rows, hipStream_t s) {
+static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws, size_t ws_bytes, long long table_rows, hipStream_t s,
+                         const DropCfg* drop = nullptr) {
   const int n = a.k + 1;
   const long long npairs = a.ntok * n;
   const size_t need = rg_item_loss_bwd_binned_workspace(a.ntok, a.k, a.d, table_rows);
@@ -682,12 +797,14 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   char* p = reinterpret_cast<char*>(ws);
   w.c = coef ? const_cast<float*>(coef) : reinterpret_cast<float*>(p); p += align256(npairs * 4);
   w.cscale = coef ? a.gout : nullptr;
+  w.chunk = drop ? RG_CHUNK_EMB : RG_CHUNK;
   w.ent = reinterpret_cast<uint2*>(p); p += align256(npairs * 8);
   const size_t ib = align256((size_t)(w.nbins + 1) * 4);
   w.hist = reinterpret_cast<int*>(p); p += ib;
   w.start = reinterpret_cast<int*>(p); p += ib;
   w.cursor = reinterpret_cast<int*>(p); p += ib;
-  w.chunk_start = reinterpret_cast<int*>(p);
+  w.chunk_start = reinterpret_cast<int*>(p); p += ib;
+  w.chunk_bin = reinterpret_cast<int*>(p);
   hipError_t e = hipMemsetAsync(w.hist, 0, ib, s);
   if (e != hipSuccess) return rg_set_error(e, "item_loss_bwd_binned(memset)");
   // K1: dh and c (not when rg_item_loss_train already made them)
@@ -704,16 +821,19 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w.nbins * 8);
   hipLaunchKernelGGL(bin_fill_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 8, s, a, w);
   // K5
-  const size_t smem = (size_t)RG_RPB * a.d * 4 + (size_t)RG_CHUNK * 8;
+  const size_t smem = (size_t)RG_RPB * a.d * 4 + (size_t)(drop ? RG_CHUNK_EMB : RG_CHUNK) * 8;
   const int ga = 256 * (int)(smem <= 40 * 1024 ? 4 : (smem <= 52 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1)));
-#define RG_ACC(LPR)                                                                                                 \
+#define RG_ACC1(LPR, DR)                                                                                            \
   do {                                                                                                              \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(bin_accumulate_kernel<T, LPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
-    hipLaunchKernelGGL((bin_accumulate_kernel<T, LPR>), dim3(ga), dim3(256), smem, s, a, w, table_rows);             \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bin_accumulate_kernel<T, LPR, DR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem); \
+    hipLaunchKernelGGL((bin_accumulate_kernel<T, LPR, DR>), dim3(ga), dim3(256), smem, s, a, w, table_rows, dc);      \
   } while (0)
+#define RG_ACC(LPR) do { if (drop) RG_ACC1(LPR, true); else RG_ACC1(LPR, false); } while (0)
+  const DropCfg dc = drop ? *drop : make_drop(0.f, 0);
   if (a.d == 64) RG_ACC(8);
   else if (a.d == 128) RG_ACC(16);
   else RG_ACC(32);
+#undef RG_ACC1
 #undef RG_ACC
   RG_CHECK_LAUNCH();
   return 0;
@@ -779,6 +899,26 @@ extern "C" int rg_item_loss_scatter_binned(const rg_item_loss_args* a, const flo
   if (dtype == RG_BF16) return launch_binned<__bf16>(*a, coef, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
   if (dtype == RG_F32) return launch_binned<float>(*a, coef, workspace, workspace_bytes, table_rows, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "item_loss_scatter_binned: bad dtype");
+}
+
+// ---- embedding backward through the same bins: dE[ids[t]] += dx[t] * mask[t] * dropout multipliers ----
+// (elementwise.hip's rg_embed_scatter_bwd sends one atomic row per live position: 235 MB of float atomics per launch at
+// the bench shape, bound by the chip-wide atomic rate; here a position is an entry with coefficient mask[t], and the
+// rows of a bin are summed in LDS and flushed once)
+extern "C" size_t rg_embed_scatter_binned_workspace(long long ntok, int d, long long table_rows) {
+  return rg_item_loss_bwd_binned_workspace(ntok, 0, d, table_rows);
+}
+extern "C" int rg_embed_scatter_bwd_binned(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
+                                           long long table_rows, long long skip_row, float drop_p, unsigned long long seed,
+                                           void* workspace, size_t workspace_bytes, int dtype, void* stream) {
+  if (ntok <= 0) return 0;
+  if (!dx || !ids || !mask || !dE) return rg_set_error_msg(RG_ERR_INVALID, "embed_scatter_bwd_binned: dx, ids, mask and dE are required");
+  rg_item_loss_args a = {};
+  a.h = dx; a.pos = ids; a.mask = mask; a.dE = dE; a.ntok = ntok; a.d = d; a.k = 0; a.skip_row = skip_row;
+  const DropCfg drop = make_drop(drop_p, seed);
+  if (dtype == RG_BF16) return launch_binned<__bf16>(a, mask, workspace, workspace_bytes, table_rows, (hipStream_t)stream, &drop);
+  if (dtype == RG_F32) return launch_binned<float>(a, mask, workspace, workspace_bytes, table_rows, (hipStream_t)stream, &drop);
+  return rg_set_error_msg(RG_ERR_INVALID, "embed_scatter_bwd_binned: bad dtype");
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -87,7 +87,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live",
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
-           "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd"]
+           "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
+           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -283,6 +284,30 @@ def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     assert dx.is_contiguous() and dE.dtype == torch.float32 and dE.is_contiguous()
     _check(lib().rg_embed_scatter_bwd(_vp(dx), _vp(ids), _vp(mask), _vp(dE), c_ll(ntok), d, c_ll(skip_row),
                                       c_f(drop_p), c_u64(seed), dt_of(dx), _stream()), "rg_embed_scatter_bwd")
+    return dE
+
+
+def embed_scatter_binned_supported(ntok, d, table_rows):
+    fn = lib().rg_embed_scatter_binned_workspace
+    fn.restype = ctypes.c_size_t
+    return int(fn(c_ll(ntok), int(d), c_ll(table_rows)))
+
+
+def embed_scatter_bwd_binned(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
+    """embed_scatter_bwd with the rows summed per table bin in LDS (large batches: the atomic form is bound by the float
+    atomic rate).  Shares the item loss's scratch buffer."""
+    ntok, d = ids.numel(), dx.shape[-1]
+    need = embed_scatter_binned_supported(ntok, d, dE.shape[0])
+    if not need:
+        raise RuntimeError("embed_scatter_bwd_binned: unsupported shape (d=%d, rows=%d)" % (d, dE.shape[0]))
+    assert dx.is_contiguous() and dE.dtype == torch.float32 and dE.is_contiguous() and mask.dtype == torch.float32
+    ws = _BIN_WS.get(dx.device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=dx.device, dtype=torch.uint8)
+        _BIN_WS[dx.device] = ws
+    _check(lib().rg_embed_scatter_bwd_binned(_vp(dx), _vp(ids), _vp(mask), _vp(dE), c_ll(ntok), d, c_ll(dE.shape[0]),
+                                             c_ll(skip_row), c_f(drop_p), c_u64(seed), _vp(ws), ctypes.c_size_t(need),
+                                             dt_of(dx), _stream()), "rg_embed_scatter_bwd_binned")
     return dE
 
 

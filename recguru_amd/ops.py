@@ -379,7 +379,11 @@ class EmbedPE(_Fn):
         ids, mask = ctx.saved_tensors
         skip_row, drop_p, seed = ctx.meta
         dE, ret = _gt(ctx.table)
-        hip.embed_scatter_bwd(dx.contiguous().view(-1, dx.shape[-1]), ids, mask, dE, skip_row, drop_p, seed)
+        dx2 = dx.contiguous().view(-1, dx.shape[-1])
+        # large batches: rows summed per table bin in LDS; small ones: one atomic row per live position
+        binned = (EMBED_SCATTER_BINNED and dx2.shape[0] >= 65536
+                  and hip.embed_scatter_binned_supported(dx2.shape[0], dx2.shape[1], dE.shape[0]))
+        (hip.embed_scatter_bwd_binned if binned else hip.embed_scatter_bwd)(dx2, ids, mask, dE, skip_row, drop_p, seed)
         return ret, None, None, None, None, None
 
 
@@ -395,6 +399,7 @@ def _fusable(x2, Wo, W1):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
+EMBED_SCATTER_BINNED = True  # rg_embed_scatter_bwd_binned at >= 65536 positions
 FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
 LASTQ_FROM_X = True          # rg_attn_lastq_x_*: the last layer's single-query attention straight from x (no K / V)

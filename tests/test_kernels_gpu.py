@@ -379,6 +379,29 @@ def test_item_loss_bwd_binned_large(V, ntok, k):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("V,ntok,d,drop_p", [(1000, 5000, 128, 0.0), (70000, 30000, 128, 0.5), (3000, 70000, 64, 0.5),
+                                             (500, 9000, 256, 0.3)])
+def test_embed_scatter_binned_equals_atomic_form(dt, V, ntok, d, drop_p):
+    """rg_embed_scatter_bwd_binned == rg_embed_scatter_bwd: skewed ids (several chunks in the hot bins), masked positions,
+    a skip row, the dropout multipliers of the forward regenerated per element."""
+    from recguru_amd import hip
+    g0 = torch.Generator().manual_seed(V + d)
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64)
+    ids = (torch.multinomial(w, ntok, replacement=True, generator=g0) + 1).cuda()
+    ids[::17] = 0
+    mask = (torch.rand(ntok, generator=g0) > 0.35).float().cuda()
+    dx = rnd(ntok, d, dt=dt, scale=0.5, seed=3)
+    assert hip.embed_scatter_binned_supported(ntok, d, V + 2)
+    dE1, dE2 = torch.zeros(V + 2, d, device="cuda"), torch.zeros(V + 2, d, device="cuda")
+    hip.embed_scatter_bwd(dx, ids, mask, dE1, skip_row=0, drop_p=drop_p, seed=77)
+    hip.embed_scatter_bwd_binned(dx, ids, mask, dE2, skip_row=0, drop_p=drop_p, seed=77)
+    assert float(dE2[0].abs().max()) == 0.0
+    torch.testing.assert_close(dE2, dE1, rtol=1e-4, atol=1e-5)
+    hip.embed_scatter_bwd_binned(dx, ids, mask, dE2, skip_row=0, drop_p=drop_p, seed=77)      # accumulates
+    torch.testing.assert_close(dE2, 2 * dE1, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("d,k,mode,gv", [(128, 30, 0, 1.0), (128, 30, 0, 0.7), (64, 30, 2, 1.0), (256, 31, 0, 1.3), (128, 5, 1, 1.0),
                                          (64, 100, 0, 1.0), (128, 63, 2, 0.5)])
 def test_item_loss_train_form(dt, d, k, mode, gv):
