@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
   float* sc = reinterpret_cast<float*>(st + CH);
   __shared__ int cnt[RG_RPB], rstart[RG_RPB + 1];
   __shared__ int s_bin, s_lo, s_hi, s_alone;
-  __shared__ float part[DROP ? 4 * D : 1];          // hot rows: one partial row per wave
+  __shared__ float part[4 * D];                     // hot rows: one partial row per wave
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int gi = lane / LPR, li = lane % LPR;
   const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
@@ -674,10 +674,10 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
         if (mine) store8(acc + r * D + 8 * li, s8);
       }
     }
-    // ---- hot rows of the embedding scatter (a popular item: up to the whole work item is ONE row): all four waves share
+    // ---- hot rows (a popular item: up to the whole work item is ONE row): all four waves share
     // the row's entries and their partial sums meet in LDS (a single wave walked them 16 at a time)
-    constexpr int HOT = 64;
-    if (DROP) {
+    constexpr int HOT = DROP ? 64 : 512;
+    {
       for (int r = 0; r < RG_RPB; ++r) {                     // (uniform over the workgroup)
         const int lo = rstart[r], hi = rstart[r + 1];
         if (hi - lo <= HOT) continue;
@@ -697,7 +697,7 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
           for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
 #pragma unroll
           for (int u = 0; u < U; ++u) {
-            if (drop.thresh) {
+            if (DROP && drop.thresh) {
               float kp[8];
               rg_keep8(drop, (unsigned int)t[u] * (unsigned int)D + 8u * (unsigned int)li, kp);
 #pragma unroll
@@ -721,7 +721,7 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
     // ---- dense bins (the item loss) and the mid-length rows of sparse ones: each wave sums whole rows
     for (int r = wave; r < RG_RPB; r += 4) {
       const int lo = rstart[r], hi = rstart[r + 1];
-      if (DROP && (hi - lo <= CAP || hi - lo > HOT)) continue;
+      if ((DROP && hi - lo <= CAP) || hi - lo > HOT) continue;
       float s8[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s8[j] = 0.f;

@@ -27,6 +27,9 @@ timeout 300 python3 tools/kb_attn.py > $O/kb_attention.txt 2>&1
 timeout 300 python3 tools/kb_tn.py > $O/kb_weight_gradient_gemms.txt 2>&1
 RG_TN_REGSTAGE=1 timeout 300 python3 tools/kb_tn.py > $O/kb_weight_gradient_gemms_register_staged.txt 2>&1
 timeout 300 python3 tools/kb_ffn_bwd.py > $O/kb_ffn_backward.txt 2>&1
+timeout 300 python3 tools/kb_item_loss.py > $O/kb_item_loss.txt 2>&1
+timeout 300 python3 tools/kb_lastq.py > $O/kb_lastq.txt 2>&1
+timeout 300 python3 tools/kb_embed_scatter.py > $O/kb_embed_scatter.txt 2>&1
 bash tools/pmc_pa.sh train > $O/sq_post_attn.txt 2>&1
 bash tools/pmc_attn.sh 0.5 > $O/sq_attention.txt 2>&1
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
