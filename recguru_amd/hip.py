@@ -1009,10 +1009,29 @@ def _work_ffn_bwd(dl2, dz, h1, *a, **k):
             M * ((4 if k.get("ln") is not None else 3) * d + 2 * dff) * _esize(src))
 
 
-_WORK = {"ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
+def _work_lastq_x_fwd(x, q_last, *a, **k):
+    B, L, d = x.shape
+    return "attn_lastq_x_fwd_kernel", B * (4 * 2.0 * L * d * 2 + 4 * 2.0 * 32 * d * 2), B * L * d * _esize(x) + 2 * B * d * _esize(x)
+
+
+def _work_lastq_x_bwd(x, q_last, *a, **k):
+    B, L, d = x.shape
+    return "attn_lastq_x_bwd_kernel", B * (4 * 2.0 * L * d * 5 + 4 * 2.0 * 32 * d * 3), 2 * B * L * d * _esize(x) + 11 * B * d * _esize(x)
+
+
+def _work_item_loss_train(h, table, pos, neg, mask, k, mode, *a, **kw):
+    n, d = h.shape
+    nl = float(mask.sum())                  # masked positions are skipped by definition of the loss, not by a list
+    return ("item_loss_train_rows_kernel", 4.0 * nl * (k + 1) * d,
+            nl * (k + 2) * d * _esize(table) + n * d * _esize(table) + nl * (k + 1) * 12 + n * 4)
+
+
+_WORK = {"attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
+         "ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
-          "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum"]
+          "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
+          "item_loss_scatter_binned", "embed_scatter_bwd_binned", "scale_dev"]
 
 
 def start_profile():
