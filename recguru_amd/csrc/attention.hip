@@ -171,7 +171,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   const int nqt = (L + 15) / 16;
   DropCfg drop = make_drop(a.drop_p, a.seed);
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
-  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   if (tid == 0) { klo_s = L; zpre_s = L; }
   if (PLUT && tid < 16) {
     dlut[2 * tid] = ((tid & 1) ? 0xFFFFu : 0u) | ((tid & 2) ? 0xFFFF0000u : 0u);
@@ -215,6 +214,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       rmk_r[i] = rmp2[a.rowmask ? (size_t)b * L + min(key, L - 1) : 0];
     }
   }
+  // the head's dropout words: hashed HERE, under the latency of the mask / key-id loads above (at the top of the kernel,
+  // with nothing in flight, the fill was exposed time: 1 us per head)
+  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
 #pragma unroll
   for (int rd = 0; rd < NRD; ++rd) {
@@ -860,7 +862,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
   const unsigned int lp4 = rg_lpad(L);
-  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
   QLive<NKT> ql;
   const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.lse;
   ql.load(a.rowmask, rmp, b, L, tid); // consumed after the staging loads below are in flight
@@ -912,6 +913,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
         rmr[i] = a.rowmask ? x : 1.f;
       }
     }
+    // the head's dropout words are hashed under the latency of the staging loads just issued
+    if constexpr (DM == 1) { if (i0 == 0) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid); }
     // dctx rows with rowmask == 0 are zero by contract (rg_attn_bwd_args.rowmask) and are TAKEN as zero whatever the
     // buffer holds: its producer may leave the rows of padded 16-row tiles unwritten (rg_gemm_nt_args.skip_dead_fill).
     // The qkv / ctx rows of such positions are real data (a padded position is still a key unless its id is pad_value).
