@@ -1175,23 +1175,35 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     // sums and stores a quarter of them
     float* red = reinterpret_cast<float*>(QKVG);
     constexpr int HT = NKT / 2;                     // tiles per round
+    // a query tile of padded positions only never entered a step: its partial sums are exact zeros in every wave, so it
+    // is neither parked nor summed (its rows are written as zeros) -- 39 % of the tiles at the bench's lengths, and with
+    // left padding the whole first round
 #pragma unroll
     for (int rnd = 0; rnd < 2; ++rnd) {
-      __syncthreads();                              // round 0: every wave is done with Q / K / V / dO; round 1: readers done
+      const unsigned int lm = (qmask >> (rnd * HT)) & ((1u << HT) - 1u);      // (scalar) live tiles of this round
+      if (lm) {
+        __syncthreads();                            // first executed round: every wave is done with Q / K / V / dO; then: readers done
 #pragma unroll
-      for (int i = 0; i < HT; ++i)
+        for (int i = 0; i < HT; ++i)
+          if ((lm >> i) & 1u) {
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          *reinterpret_cast<f32x4*>(red + (((wave * HT + i) * 2 + dt) * 64 + lane) * 4) = dq1[rnd * HT + i][dt];
-      __syncthreads();
+            for (int dt = 0; dt < 2; ++dt)
+              *reinterpret_cast<f32x4*>(red + (((wave * HT + i) * 2 + dt) * 64 + lane) * 4) = dq1[rnd * HT + i][dt];
+          }
+        __syncthreads();
+      }
       for (int i = wave; i < HT; i += 4) {
         const int qt = rnd * HT + i, q = qt * 16 + li;
         if (qt >= nt || q >= L) continue;
+        const bool livet = (lm >> i) & 1u;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          f32x4 sacc = *reinterpret_cast<const f32x4*>(red + (((0 * HT + i) * 2 + dt) * 64 + lane) * 4);
+          f32x4 sacc = (f32x4){0.f, 0.f, 0.f, 0.f};
+          if (livet) {
+            sacc = *reinterpret_cast<const f32x4*>(red + (((0 * HT + i) * 2 + dt) * 64 + lane) * 4);
 #pragma unroll
-          for (int w = 1; w < 4; ++w) sacc += *reinterpret_cast<const f32x4*>(red + (((w * HT + i) * 2 + dt) * 64 + lane) * 4);
+            for (int w = 1; w < 4; ++w) sacc += *reinterpret_cast<const f32x4*>(red + (((w * HT + i) * 2 + dt) * 64 + lane) * 4);
+          }
           float v[4] = {sacc[0] * a.scale, sacc[1] * a.scale, sacc[2] * a.scale, sacc[3] * a.scale};
           store4(dqkv + (size_t)q * ld + h * DK + dt * 16 + 4 * lg, v);
         }
