@@ -1184,6 +1184,52 @@ def test_attn_lastq_x_matches_projection_plus_single_query(L, drop_p, masked, pa
         assert e_new <= max(e_old, 2 ** -8 * float(ref.abs().max())) * 1.05, (e_new, e_old)
 
 
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+@pytest.mark.parametrize("pad_value", [0, 77])
+def test_last_encoder_layer_from_x_equals_kv_path_through_autograd(drop_p, pad_value):
+    """EncoderM(last_only=True) with the last layer's attention taken straight from x (ops.LASTQ_FROM_X) and through
+    K / V: same dropout seeds -> same masks; the user embedding and EVERY parameter gradient of the stack agree to
+    bf16 rounding (pad_value 77: padded positions are live keys, quirk Q2; 0: they are masked keys)."""
+    from recguru_amd import blocks, ops
+    B, L, d, H, dff = 24, 200, 128, 4, 512
+    g0 = torch.Generator().manual_seed(11 + pad_value)
+    ids = torch.randint(1, 60, (B, L), generator=g0)
+    lens = torch.randint(2, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 1
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids = ids.cuda()
+    mask = (ids != 0).float()
+    torch.manual_seed(3)
+    enc = blocks.EncoderM(d, dff, 32, 32, H, 2, 0, "cuda", drop_p).cuda()
+    enc.train()
+    x0 = (torch.randn(B, L, d, generator=g0).cuda() * 0.7 * mask.unsqueeze(-1))
+    w = torch.linspace(-1, 1, B * d, device="cuda").view(B, d)
+    res = {}
+    for from_x in (True, False):
+        ops.LASTQ_FROM_X = from_x
+        try:
+            ops.manual_seed(17)
+            enc.zero_grad(set_to_none=True)
+            x = x0.to(torch.bfloat16).requires_grad_(True)
+            u = enc(x, ids, pad_value, mask, last_only=True)
+            (u.float() * w).sum().backward()
+            res[from_x] = (u.detach().float().clone(), x.grad.float().clone(),
+                           {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None})
+        finally:
+            ops.LASTQ_FROM_X = True
+    (u1, dx1, g1), (u0, dx0, g0_) = res[True], res[False]
+    assert float((u1 - u0).abs().max()) <= 0.03 * float(u0.abs().max())
+    lv = (mask != 0).unsqueeze(-1).expand_as(dx0)
+    assert float((dx1 - dx0)[lv].abs().max()) <= 0.04 * float(dx0[lv].abs().max())
+    assert set(g1) == set(g0_)
+    for k in g0_:
+        if k.endswith("WK.bias"):            # structurally gradient-free (a constant per softmax row): noise vs exact zero
+            continue
+        scale = float(g0_[k].abs().max())
+        assert float((g1[k] - g0_[k]).abs().max()) <= 0.04 * scale + 1e-6, k
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("M,listed", [(203, False), (64, False), (9000, True), (9000, False)])
 def test_attn_out_bwd_equals_ln_bwd_plus_projection(dt, M, listed):
