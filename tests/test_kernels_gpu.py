@@ -1185,6 +1185,36 @@ def test_attn_lastq_x_matches_projection_plus_single_query(L, drop_p, masked, pa
 
 
 @pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_embed_pe_autograd_binned_equals_atomic_scatter(drop_p):
+    """ops.embed_pe backward above 65536 positions (binned scatter) against the atomic form: same seeds, same table gradient."""
+    from recguru_amd import ops
+    B, L, d, V = 400, 200, 128, 5000
+    g0 = torch.Generator().manual_seed(23)
+    w = 1.0 / torch.arange(1, V + 1, dtype=torch.float64)
+    ids = (torch.multinomial(w, B * L, replacement=True, generator=g0) + 1).view(B, L)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids = ids.cuda()
+    mask = (ids != 0).float()
+    pe = torch.randn(L, d, generator=g0).cuda() * 0.1
+    gout = torch.randn(B, L, d, generator=g0).cuda().to(torch.bfloat16)
+    grads = {}
+    for binned in (True, False):
+        ops.EMBED_SCATTER_BINNED = binned
+        try:
+            ops.manual_seed(5)
+            table = (torch.randn(V + 2, d, generator=torch.Generator().manual_seed(1)) * 0.3).cuda().requires_grad_(True)
+            out = ops.embed_pe(table, pe, ids, mask, skip_row=0, drop_p=drop_p)
+            out.backward(gout)
+            grads[binned] = table.grad.clone()
+        finally:
+            ops.EMBED_SCATTER_BINNED = True
+    assert float(grads[True][0].abs().max()) == 0.0
+    torch.testing.assert_close(grads[True], grads[False], rtol=1e-4, atol=1e-4 * float(grads[False].abs().max()))
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
 @pytest.mark.parametrize("pad_value", [0, 77])
 def test_last_encoder_layer_from_x_equals_kv_path_through_autograd(drop_p, pad_value):
     """EncoderM(last_only=True) with the last layer's attention taken straight from x (ops.LASTQ_FROM_X) and through
