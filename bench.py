@@ -9,9 +9,11 @@ sequences from the loaders; value = 12*B*N / t  (SURVEY.md 8d).  Workload = BASE
 configs[2] ("cross-domain RecGURU, two 100k-item domains, 1xMI355X") at the metric's shape
 seq_len=200 / hidden=128 / batch=4096 per GPU; per-GPU work is fixed as N grows (weak scaling).
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W            (N > 1 without a launcher: bench.py starts the N rank
+                                                             processes itself, before anything touches a GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+  python bench.py --mode ae                                 (the AE step alone: one train_recon_x iteration, 2*B sequences)
 
 Prints ONE JSON line on rank 0.  The `roofline` object is measured live in this process with HIP
 events on the launch stream around every launch of the dominant kernel (an instrumented pass of the
@@ -19,8 +21,11 @@ same step after the timed region); `cpu_baseline` times the CPU oracle (oracle/r
 a port of the reference arithmetic) on a bounded sample of the same workload on the host cores.
 """
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -32,7 +37,11 @@ sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense
 HBM_PEAK_GBS = 8000.0
 MFMA_KERNELS = ("gemm", "attn", "post_attn")           # kernels priced against the MFMA peak; the rest against HBM
-PMC_FILES = [os.path.join(ROOT, "profiles", "r02", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "pmc_traffic.json")]
+# counter passes of the newest round first (profiles/rNN/pmc_traffic.json, written by tools/profile_round.sh rNN);
+# RG_PMC_TRAFFIC=<file> overrides
+PMC_FILES = ([os.environ["RG_PMC_TRAFFIC"]] if os.environ.get("RG_PMC_TRAFFIC") else []) + \
+    sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9]*", "pmc_traffic.json")), reverse=True) + \
+    [os.path.join(ROOT, "profiles", "pmc_traffic.json")]
 
 
 def pmc_traffic(kernel):
@@ -55,6 +64,13 @@ def pmc_traffic(kernel):
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--mode", choices=["gan", "ae"], default="gan",
+                    help="gan: the AE+GAN step = one phase-2 iteration of train_gan_all (BASELINE.json's metric); "
+                         "ae: the AE step = one train_recon_x iteration (SURVEY 8d (i))")
+    ap.add_argument("--ae_steps", type=int, default=5, help="gan mode: AE steps timed after the main region for the "
+                    "`ae_step` object of the line (0: skip)")
+    ap.add_argument("--full_length_steps", type=int, default=4, help="gan mode: steps timed with full-length users (no "
+                    "padding to skip) for `value_full_length` (0: skip)")
     ap.add_argument("--device_sampler", action="store_true",
                     help="loaders included: assemble every batch and draw fresh negatives on the GPU (recguru_amd.sampler) "
                          "instead of iterating pre-staged tensors")
@@ -69,6 +85,9 @@ def parse():
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--n_negs", type=int, default=30)
     ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--residual", choices=["bf16", "split"], default="bf16",
+                    help="bf16 tier: residual stream between kernels as one bf16 tensor, or split into a bf16 pair hi + lo "
+                         "(ops.set_residual_dtype(torch.float32): ~16 significant bits, DESIGN.md 2)")
     ap.add_argument("--dropout", type=float, default=0.5,
                     help="transformer dropout (reference config_auto4rec.py:225: 0.5); the discriminator's 0.2 is active too")
     ap.add_argument("--batches_per_domain", type=int, default=2, help="distinct synthetic batches cycled")
@@ -80,8 +99,29 @@ def parse():
     return ap.parse_args()
 
 
+def make_loaders(args, device, rank, min_len):
+    """Every rank synthesises ITS OWN shard of users (seeded by rank): same per-GPU work and the same statistics as
+    sharding one big stream rank::world, without each of the N processes building all N shards on the host."""
+    from recguru_amd import synthetic
+    n_users = args.batch * args.batches_per_domain
+    loaders = []
+    for i, seed in enumerate((1, 2)):
+        seed = seed + 1000 * rank
+        if args.device_sampler:
+            # loaders INCLUDED in the step: batches assembled and fresh negatives drawn on the GPU for every draw
+            from recguru_amd import sampler
+            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed, min_len=min_len)
+            dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
+            loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
+                                                args.seq_len * args.n_negs, seed=seed, shuffle=False))
+        else:
+            dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed, min_len=min_len)
+            loaders.append(synthetic.TensorLoader(dom, args.batch, device))
+    return loaders
+
+
 def build(args, device, rank, world):
-    from recguru_amd import config, models, optim, synthetic
+    from recguru_amd import blocks, config, models, optim
     a = argparse.Namespace(date="bench", d_model=args.d_model, n_head=args.n_head, d_ff=512, n_negs=args.n_negs,
                            decoder_neg=True, fix_enc=True, lr=0.01, batch_size=args.batch, batch_size_val=256,
                            dataset_pick=1, run=1, target_domain="a", cross="True", sas="False",
@@ -98,26 +138,13 @@ def build(args, device, rank, world):
         D.eval()
     opt_g = optim.Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:128
     opt_d = optim.Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))           # train_gan.py:134
-    # every rank synthesises ITS OWN shard of users (seeded by rank): same per-GPU work and the same statistics as
-    # sharding one big stream rank::world, without each of the N processes building all N shards on the host
-    n_users = args.batch * args.batches_per_domain
-    loaders = []
-    for i, seed in enumerate((1, 2)):
-        seed = seed + 1000 * rank
-        if args.device_sampler:
-            # loaders INCLUDED in the step: batches assembled and fresh negatives drawn on the GPU for every draw
-            from recguru_amd import sampler
-            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed, min_len=args.min_len)
-            dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
-            loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
-                                                args.seq_len * args.n_negs, seed=seed, shuffle=False))
-        else:
-            dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed, min_len=args.min_len)
-            loaders.append(synthetic.TensorLoader(dom, args.batch, device))
-    return param, G, D, opt_g, opt_d, loaders
+    opt_rec = blocks.ScheduledOptim(optim.Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-09), 1.0, param.d_model,
+                                    param.n_warmup_steps)                     # train_gan.py:126-127
+    return param, G, D, opt_g, opt_d, opt_rec, make_loaders(args, device, rank, args.min_len)
 
 
 def make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args):
+    """The AE+GAN step: one phase-2 iteration through the shipped training.critic_phase + generator_iteration."""
     from recguru_amd import training as T
     a_iter, b_iter = T._Cycler(loaders[0]), T._Cycler(loaders[1])
     g_params = list(G.parameters())
@@ -132,6 +159,45 @@ def make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args):
                                                 g_params)
         return d_cost, w_d, g_dis, lra, lrb
     return step
+
+
+def make_ae_step(param, G, opt_rec, loaders, device, dp):
+    """The AE step: one iteration of train_recon_x (gan_training.py:839-866) through the shipped training.recon_step --
+    reconstruction loss of both domains (encoder + decoder + sampled softmax), backward, Noam-Adam."""
+    from recguru_amd import training as T
+    a_iter, b_iter = T._Cycler(loaders[0]), T._Cycler(loaders[1])
+    g_params = list(G.parameters())
+    ndp = dp or T._NoDP()
+
+    def step(overlap=True):
+        ba = a_iter.next(device)
+        bb = b_iter.next(device)
+        return T.recon_step(G, opt_rec, ba[:4], bb[:4], param, device, ndp, g_params, True, "s_soft", "schedule")
+    return step
+
+
+def timed(step, warmup, steps, dp, device):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize on both sides; the time is the
+    MAX over ranks.  Returns (seconds, host seconds to enqueue the steps, the last step's outputs)."""
+    out = None
+    for _ in range(warmup):
+        out = step()
+    if dp:
+        dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    t_host = time.perf_counter() - t0          # host time to ENQUEUE the steps (== dt when the host is the bottleneck)
+    torch.cuda.synchronize()
+    if dp:
+        dp.barrier()
+    dt = time.perf_counter() - t0
+    if dp:
+        t = torch.tensor([dt], device=device)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t[0])
+    return dt, t_host, out
 
 
 def cpu_baseline(args):
@@ -177,15 +243,21 @@ def cpu_baseline(args):
     doms = [synthetic.make_domain(B, V, L, k, seed=s, min_len=args.min_len) for s in (1, 2)]
     bt = [tuple(torch.as_tensor(dm[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items")) for dm in doms]
 
+    ae = args.mode == "ae"
+    per_step = (2 if ae else 12) * B
+
     def iteration(drop, drop_d):
         O.DROPOUT, O.DROPOUT_D = drop, drop_d
         pG, pD = build()
         opt_g = O.Adam({k_: v for k_, v in pG.items() if v.requires_grad}, 1e-4, (0.5, 0.9))
         opt_d = O.Adam(pD, 1e-4, (0.5, 0.9))
         t0 = time.perf_counter()
-        for _ in range(O.CRITIC_ITERS):
-            O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
-        O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
+        if ae:
+            O.recon_step(pG, cfg, bt[0], bt[1], opt_g, lr=O.noam_lr(1, d, 4000))
+        else:
+            for _ in range(O.CRITIC_ITERS):
+                O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
+            O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
         return time.perf_counter() - t0
     try:
         dt = iteration(args.dropout, 0.2 if args.dropout > 0 else 0.0)
@@ -193,22 +265,77 @@ def cpu_baseline(args):
         dt0 = dt if args.dropout == 0 else (iteration(0.0, 0.0) if dt < 60.0 else None)
     finally:
         O.DROPOUT, O.DROPOUT_D = 0.0, 0.0
-    return {"value": 12 * B / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "value_dropout0": (12 * B / dt0) if dt0 else None,
-            "sample": "1 AE+GAN iteration (5 critic + 1 generator), B=%d users/domain/draw, L=%d d=%d H=%d N=%d V=%d k=%d, fp32, "
+    return {"value": per_step / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "value_dropout0": (per_step / dt0) if dt0 else None,
+            "sample": "1 %s, B=%d users/domain/draw, L=%d d=%d H=%d N=%d V=%d k=%d, fp32, "
                       "torch %s CPU kernels: dropout %g (D: %g) %.1f s = `value`; dropout 0 %s s = `value_dropout0`"
-                      % (B, L, d, H, N, V, k, torch.__version__, args.dropout, 0.2 if args.dropout > 0 else 0.0, dt,
+                      % ("AE step (train_recon_x iteration)" if ae else "AE+GAN iteration (5 critic + 1 generator)",
+                         B, L, d, H, N, V, k, torch.__version__, args.dropout, 0.2 if args.dropout > 0 else 0.0, dt,
                          ("%.1f" % dt0) if dt0 else "skipped")}
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` without an outer launcher: start the N rank processes here -- the parent never touches
+    a GPU (torch.cuda.device_count() does not initialise one), the children are fresh interpreters -- relay rank 0's JSON
+    line and return non-zero if any rank fails.  The reference scales from one command too (nn.DataParallel,
+    train_gan.py:124-133)."""
+    n = args.gpus
+    single = bool(os.environ.get("RG_BENCH_SINGLE_DEVICE"))
+    have = torch.cuda.device_count()
+    if have < n and not single:
+        sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible (RG_BENCH_SINGLE_DEVICE=1 RG_BENCH_BACKEND=gloo "
+                         "runs every rank on GPU 0 for debugging)\n" % (n, have))
+        return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+        # rank 0's stdout carries the one JSON line; the other ranks' stdout goes to this process's stderr
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            if any(c not in (None, 0) for c in codes):
+                rc = next(c for c in codes if c not in (None, 0))
+                break
+            if all(c == 0 for c in codes):
+                break
+            time.sleep(0.2)
+            if codes[0] is None:
+                continue
+    finally:
+        if rc != 0:                              # a rank died: the others would wait in a collective for ever
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            t_end = time.time() + 10
+            for p in procs:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with code %s\n" % rc)
+    return rc if rc >= 0 else 1
 
 
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs `python -m torch.distributed.run --nproc-per-node %d ...`"
-                     % (args.gpus, args.gpus))
+    if world == 1 and args.gpus > 1:
+        sys.exit(launch_ranks(args))           # before any GPU call in this process
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible -- the HIP path has no CPU fallback")
     from recguru_amd import dist as rdist, hip, ops
@@ -218,28 +345,18 @@ def main():
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_residual_dtype(torch.float32 if args.residual == "split" else torch.bfloat16)
     ops.set_data_parallel(dp)
     ops.manual_seed(0, rank)                  # independent dropout streams per rank
-    param, G, D, opt_g, opt_d, loaders = build(args, device, rank, world)
-    step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args)
+    param, G, D, opt_g, opt_d, opt_rec, loaders = build(args, device, rank, world)
+    ae = args.mode == "ae"
+    per_step = (2 if ae else 12) * args.batch * world           # user sequences one step draws, all ranks
+    if ae:
+        step = make_ae_step(param, G, opt_rec, loaders, device, dp)
+    else:
+        step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args)
 
-    for _ in range(args.warmup):
-        out = step()
-    if dp:
-        dp.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    t_host = time.perf_counter() - t0          # host time to ENQUEUE the steps (== dt when the host is the bottleneck)
-    torch.cuda.synchronize()
-    if dp:
-        dp.barrier()
-    dt = time.perf_counter() - t0
-    if dp:
-        t = torch.tensor([dt], device=device)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t[0])
+    dt, t_host, out = timed(step, args.warmup, args.steps, dp, device)
     losses = [float(x) for x in out]
 
     roof = None
@@ -257,24 +374,24 @@ def main():
         def roofline_of(name, a):
             """One kernel's roofline entry: algorithmic flops and bytes of its launches / summed HIP-event time.
             The binding roofline is the one that gives the larger lower bound on the time (arithmetic intensity
-            against the ridge point peak_flops / peak_bandwidth); both achieved rates are reported."""
+            against the ridge point peak_flops / peak_bandwidth).  `achieved` / `frac` price the work of the 16-row
+            tiles the kernel really processed (padded tiles are skipped: nothing reads them); `achieved_nominal` /
+            `frac_nominal` price every row, as the reference computes it."""
             sec = a["ms"] * 1e-3
             tf, gbs = a["flops"] / sec / 1e12, a["bytes"] / sec / 1e9
             tf_x, gbs_x = a["flops_exec"] / sec / 1e12, a["bytes_exec"] / sec / 1e9
             mfma = name.startswith(MFMA_KERNELS) and a["flops"] / (peak_tf * 1e12) >= a["bytes"] / (HBM_PEAK_GBS * 1e9)
             if mfma:
-                r = {"bound": "mfma", "kernel": name, "achieved": round(tf, 2), "peak": peak_tf, "unit": "TFLOP/s",
-                     "frac": round(tf / peak_tf, 4)}
+                r = {"bound": "mfma", "kernel": name, "achieved": round(tf_x, 2), "peak": peak_tf, "unit": "TFLOP/s",
+                     "frac": round(tf_x / peak_tf, 4), "achieved_nominal": round(tf, 2), "frac_nominal": round(tf / peak_tf, 4)}
             else:
-                r = {"bound": "hbm", "kernel": name, "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(gbs / HBM_PEAK_GBS, 4)}
-            # `achieved` / `frac` price the NOMINAL work of a launch (every row, as the reference computes it); the
-            # *_executed fields price only the 16-row tiles the kernel really processed (padded tiles are skipped)
-            r.update({"frac_executed": round((tf_x / peak_tf) if mfma else (gbs_x / HBM_PEAK_GBS), 4),
+                r = {"bound": "hbm", "kernel": name, "achieved": round(gbs_x, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(gbs_x / HBM_PEAK_GBS, 4), "achieved_nominal": round(gbs, 1),
+                     "frac_nominal": round(gbs / HBM_PEAK_GBS, 4)}
+            r.update({"executed_share_of_nominal_work": round(a["flops_exec"] / a["flops"], 3) if a["flops"] else
+                      (round(a["bytes_exec"] / a["bytes"], 3) if a["bytes"] else 1.0),
                       "tflops_executed": round(tf_x, 2), "hbm_gbs_executed": round(gbs_x, 1),
-                      "executed_share_of_nominal_work": round(a["flops_exec"] / a["flops"], 3) if a["flops"] else
-                      (round(a["bytes_exec"] / a["bytes"], 3) if a["bytes"] else 1.0)})
-            r.update({"tflops": round(tf, 2), "hbm_gbs": round(gbs, 1), "launches_per_step": a["launches"],
+                      "tflops_nominal": round(tf, 2), "hbm_gbs_nominal": round(gbs, 1), "launches_per_step": a["launches"],
                       "avg_launch_us": round(a["ms"] * 1e3 / a["launches"], 2),
                       "share_of_kernel_time": round(a["ms"] / total_ms, 3)})
             return r
@@ -290,30 +407,64 @@ def main():
     if dp:
         dp.barrier()
 
+    # the same step with FULL-LENGTH users (no padded position anywhere: nothing for the live-tile lists to skip) and the
+    # AE step, a few steps each, so that the default line carries them
+    full = ae_line = None
+    if not ae and args.full_length_steps > 0 and args.min_len < args.seq_len - 1:
+        del step, loaders
+        torch.cuda.empty_cache()
+        loaders = make_loaders(args, device, rank, args.seq_len - 1)
+        step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args)
+        dtf, _, _ = timed(step, 1, args.full_length_steps, dp, device)
+        full = {"value": round(per_step * args.full_length_steps / dtf, 1), "ms_per_step": round(dtf / args.full_length_steps * 1e3, 3),
+                "steps": args.full_length_steps, "user_lengths": "U{%d..%d}" % (args.seq_len - 1, args.seq_len + 20)}
+    if not ae and args.ae_steps > 0:
+        if full is not None:                    # back to the default length distribution
+            del step, loaders
+            torch.cuda.empty_cache()
+            loaders = make_loaders(args, device, rank, args.min_len)
+        step = make_ae_step(param, G, opt_rec, loaders, device, dp)
+        dta, _, outa = timed(step, 2, args.ae_steps, dp, device)
+        ae_line = {"metric": "user-sequences/sec (AE step)", "value": round(2 * args.batch * world * args.ae_steps / dta, 1),
+                   "ms_per_step": round(dta / args.ae_steps * 1e3, 3), "steps": args.ae_steps,
+                   "sequences_per_step": 2 * args.batch * world,
+                   "workload": "one train_recon_x iteration (gan_training.py:839-866): reconstruction loss of both domains, "
+                               "backward, Noam-Adam", "last_step": {"recon_a": float(outa[0]), "recon_b": float(outa[1])}}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(args)
 
     if rank == 0:
         B = args.batch
+        names = ("recon_a", "recon_b") if ae else ("D_cost", "Wasserstein_D", "g_dis", "recon_a", "recon_b")
         line = {
-            "metric": "user-sequences/sec (AE+GAN step)", "value": round(12 * B * world * args.steps / dt, 1),
+            "metric": "user-sequences/sec (%s step)" % ("AE" if ae else "AE+GAN"),
+            "value": round(per_step * args.steps / dt, 1),
             "unit": "user-sequences/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic" + (", batches assembled + negatives sampled on device each draw" if args.device_sampler else ""),
-            "config": {"workload": "cross-domain RecGURU AE+GAN phase-2 iteration (5 critic + 1 generator update), "
-                                   "two %d-item domains" % args.items,
+            "vs_baseline": None, "dtype": args.dtype, "residual_stream": (
+                "bf16 pair hi + lo" if (args.residual == "split" and args.dtype == "bf16") else args.dtype), "data": "synthetic" + (", batches assembled + negatives sampled on device each draw" if args.device_sampler else ""),
+            "config": {"workload": ("cross-domain RecGURU AE step (one train_recon_x iteration: both domains' reconstruction "
+                                    "loss, backward, Noam-Adam), " if ae else
+                                    "cross-domain RecGURU AE+GAN phase-2 iteration (5 critic + 1 generator update), ")
+                                   + "two %d-item domains" % args.items,
                        "per_gpu_batch": B, "seq_len": args.seq_len, "d_model": args.d_model, "n_head": args.n_head,
                        "n_blocks": args.n_blocks, "d_ff": 512, "n_negs": args.n_negs, "dropout": args.dropout,
                        "user_lengths": "U{%d..%d}" % (min(args.min_len, args.seq_len + 20), args.seq_len + 20),
                        "discriminator_dropout": 0.2 if args.dropout > 0 else 0.0,
-                       "sequences_per_step": 12 * B * world, "generator_step_sequences_per_sec":
-                           round(2 * B * world * args.steps / dt, 1),
+                       "sequences_per_step": per_step,
                        "parallelism": "dp%d" % world, "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 2),
-                       "last_step": dict(zip(("D_cost", "Wasserstein_D", "g_dis", "recon_a", "recon_b"), losses))},
+                       "last_step": dict(zip(names, losses))},
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if not ae:
+            line["config"]["generator_step_sequences_per_sec"] = round(2 * B * world * args.steps / dt, 1)
+            line["value_full_length"] = full["value"] if full else None
+            line["full_length_users"] = full
+            line["ae_step"] = ae_line
         print(json.dumps(line))
+        sys.stdout.flush()
     if dp:
         torch.distributed.destroy_process_group()
 

@@ -166,6 +166,11 @@ int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream
  * dE[rows,d]; skip_row (e.g. padding_idx 0 of AutoEnc4Rec.py:153) receives nothing (-1 = none). */
 int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
                     long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* Split-residual form (bf16 tier, see rg_post_attn_args.x_lo): the rows are gathered from the F32 MASTER table
+ * (table_f32 [rows,d]; the embedding feeds the residual stream directly, so rounding the table to bf16 first would cap its
+ * precision at 8 bits) and leave as the pair out = bf16(v), out_lo = bf16(v - out). */
+int rg_embed_pe_fwd_split(const float* table_f32, const float* pe, const int64_t* ids, const float* mask, void* out,
+                          void* out_lo, long long ntok, int L, int d, float drop_p, unsigned long long seed, void* stream);
 int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,
                          long long skip_row, float drop_p, unsigned long long seed, int dtype, void* stream);
 /* Same result as rg_embed_scatter_bwd with the gradient rows summed per 64-row bin of the table in LDS (counting sort of
@@ -429,6 +434,14 @@ typedef struct {
   int skip_dead_saves;   /* with live16: 1 = leave the padded tiles' rows of the *_save / rstd* buffers untouched (every
                             consumer is list-driven as well), 0 = write zeros / finite placeholders there */
   int w_packed;          /* 1: Wo, W1, W2 are fragment-packed copies (rg_cast RG_CAST_PACK: contiguous 1 KB operand fragments) */
+  /* Split residual stream (bf16 tier only; both or neither): the layer input and output travel through HBM as a bf16
+   * PAIR  value = hi + lo  (hi = bf16(value): the tensor every MFMA-operand consumer reads; lo = bf16(value - hi): read
+   * only here, as part of the residual addend) -- ~16 significant bits for the residual stream at 2 x 2 bytes, where one
+   * bf16 tensor carries 8 (SURVEY.md 7 "keep the residual stream fp32, feed bf16 only to MFMA operands").  Inside the
+   * kernel the LayerNorm outputs that serve as residuals (y, y2) are kept as hi + lo tiles as well.
+   * x_lo [M,d] : lo part of x (NULL: x is exact);  out_lo [M,d] : receives the lo part of out (NULL: not produced). */
+  const void* x_lo;
+  void* out_lo;
 } rg_post_attn_args;
 int rg_post_attn_fwd(const rg_post_attn_args* args /* host */, int dtype, void* stream);
 

@@ -158,13 +158,17 @@ class EncoderM(nn.Module):
         """last_only=True returns enc_outputs[:, -1, :] ([B, d]) without computing the other rows of
         the last layer (identical values and gradients)."""
         n = len(self.layers)
-        # x comes from the embedding stage `(E[ids] + pe) * pad_mask` (transformer.py:105) and every layer output is
-        # multiplied by the same pad_mask (:594): rows at padded positions are exactly zero (ops.masked_input)
-        with ops.masked_input():
-            for i, layer in enumerate(self.layers):
+        # Every layer output is multiplied by pad_mask (:594), so from the second layer on the layer input has exactly-zero
+        # rows at padded positions (ops.masked_input: the Q / K / V projection may then use the bias row for them).  The
+        # FIRST layer's input only when it provably is the embedding stage `(E[ids] + pe) * pad_mask` of this very mask
+        # (transformer.py:105; ops.masked_by) -- an arbitrary caller-supplied x is taken as it is, like the reference does.
+        masked = ops.masked_by(x, pad_mask)
+        for i, layer in enumerate(self.layers):
+            with ops.masked_input(masked):
                 if last_only and i == n - 1:
                     return layer.forward_last(x, key_ids, pad_value, pad_mask)
                 x = layer(x, key_ids, pad_value, pad_mask)
+            masked = True
         return x[:, -1, :] if last_only else x
 
 
@@ -183,7 +187,9 @@ class DecoderM(nn.Module):
     def forward(self, x, u, dec_ids, enc_ids, pad_m):
         """enc_ids: the encoder input ids; their (== 0) positions are the masked keys of the
         decoder-encoder attention (AutoEnc4Rec_cross.py:134) -- only needed when dropout is active."""
-        with ops.masked_input():            # same contract as EncoderM: x rows are zero wherever pad_m is (transformer.py:539)
-            for layer in self.layers:
+        masked = ops.masked_by(x, pad_m)     # same contract as EncoderM (layer outputs: transformer.py:539)
+        for layer in self.layers:
+            with ops.masked_input(masked):
                 x = layer(x, u, dec_ids, enc_ids, pad_m)
+            masked = True
         return x

@@ -49,6 +49,43 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
   }
 }
 
+// Split-residual form: f32 master rows in, value = hi + lo out as two bf16 tensors (rg_embed_pe_fwd_split).
+__global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_split_kernel(const float* __restrict__ table, const float* __restrict__ pe,
+                                                                     const int64_t* __restrict__ ids,
+                                                                     const float* __restrict__ mask, __bf16* __restrict__ out,
+                                                                     __bf16* __restrict__ out_lo, long long ntok, int L, int d,
+                                                                     DropCfg drop) {
+  const int cpr = d >> 3;
+  const long long total = ntok * cpr;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const long long tok = i / cpr;
+    const int c8 = (int)(i - tok * cpr) * 8;
+    const float m = mask[tok];
+    const int64_t id = ids[tok];
+    float v[8], lo[8];
+    if (m != 0.f) {
+      float p[8];
+      load8(v, table + (size_t)id * d + c8);
+      load8(p, pe + (size_t)(tok % L) * d + c8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = (v[j] + p[j]) * m;
+      if (drop.thresh) {
+        float k8[8];
+        rg_keep8(drop, (unsigned int)tok * (unsigned int)d + (unsigned int)c8, k8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= k8[j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) lo[j] = v[j] - (float)(__bf16)v[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { v[j] = 0.f; lo[j] = 0.f; }
+    }
+    store8(out + (size_t)tok * d + c8, v);
+    store8(out_lo + (size_t)tok * d + c8, lo);
+  }
+}
+
 // dE[ids[b,t],:] += dx[b,t,:] * mask[b,t]  -- one wave per token row, 256 contiguous bytes per
 // atomic wave-instruction (the shape the memory-side f32 atomic unit runs at full rate).
 // Item popularity is heavy-tailed (the head item of a Zipf(1) catalogue is ~8 % of all tokens), and memory-side
@@ -878,6 +915,20 @@ extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t
              hipLaunchKernelGGL(embed_pe_fwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)table, pe, ids, mask, (__bf16*)out, ntok, L, d, drop),
              hipLaunchKernelGGL(embed_pe_fwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)table, pe, ids, mask, (float*)out, ntok, L, d, drop),
              "embed_pe_fwd")
+}
+
+extern "C" int rg_embed_pe_fwd_split(const float* table_f32, const float* pe, const int64_t* ids, const float* mask, void* out,
+                                     void* out_lo, long long ntok, int L, int d, float drop_p, unsigned long long seed,
+                                     void* stream) {
+  const DropCfg drop = make_drop(drop_p, seed);
+  if (ntok <= 0) return 0;
+  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd_split: d must be a multiple of 8");
+  if (!table_f32 || !out || !out_lo) return rg_set_error_msg(RG_ERR_INVALID, "embed_pe_fwd_split: table_f32, out and out_lo are required");
+  const int grid = ew_grid(ntok * (d >> 3), EW_BLOCK);
+  hipLaunchKernelGGL(embed_pe_fwd_split_kernel, dim3(grid), dim3(EW_BLOCK), 0, (hipStream_t)stream, table_f32, pe, ids, mask,
+                     (__bf16*)out, (__bf16*)out_lo, ntok, L, d, drop);
+  RG_CHECK_LAUNCH();
+  return 0;
 }
 
 extern "C" int rg_embed_scatter_bwd(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,

@@ -182,6 +182,34 @@ __device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restri
     }
 }
 
+// the part of the registers that rounding to T loses: v - T(v), as a second tile (split residual stream, rg_post_attn_args.x_lo)
+template <typename T>
+__device__ __forceinline__ void regs_to_tile_lo(const f32x4 (&v)[2][4], T* __restrict__ tile, int n0, int li, int lg) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float t[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) t[r] = v[ct][rt][r] - (float)(T)v[ct][rt][r];
+      store4(tile + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg), t);
+    }
+}
+
+// acc += tile (this lane's own 8 x 4 positions)
+template <typename T>
+__device__ __forceinline__ void add_tile(f32x4 (&acc)[2][4], const T* __restrict__ tile, int n0, int li, int lg) {
+#pragma unroll
+  for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+    for (int rt = 0; rt < 4; ++rt) {
+      float r4[4];
+      load4t(r4, tile + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[ct][rt][r] += r4[r];
+    }
+}
+
 // A work tile is 4 row tiles of 16 consecutive rows each, at rows mb[0..3] (mb[rt] >= M marks an absent one): the 64
 // rows of a plain tile (mb[rt] = m0 + 16 rt), or the next 4 LIVE row tiles of the workgroup's range when padded row
 // tiles are compacted away.  Thread tid stages chunk i of the tile = row 16 i + (tid >> 4), columns 8 (tid & 15)..
@@ -223,7 +251,9 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // quarters of them) run the instantiation without it: its loads and registers were what spilled under dropout.
 // SAVE: a training launch (y / y2 / h1 / rstd* saved for the backward); inference launches (the critic phase's encoder
 // passes: most launches of a step) compile all of it away.
-template <typename T, int DM, bool CROSS, bool SAVE>
+// RES: split residual stream (x = x + x_lo in, out / out_lo out; the LayerNorm outputs y / y2 keep their lo part in a free
+// tile: y_lo parks in the ctx tile during the FFN, x_lo arrives in the y tile, out_lo leaves through the g-chunk tile).
+template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -253,6 +283,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const T* __restrict__ W1 = reinterpret_cast<const T*>(a.W1);
   const T* __restrict__ W2 = reinterpret_cast<const T*>(a.W2);
   T* __restrict__ out = reinterpret_cast<T*>(a.out);
+  const T* __restrict__ xlo = RES ? reinterpret_cast<const T*>(a.x_lo) : nullptr;
+  T* __restrict__ outlo = RES ? reinterpret_cast<T*>(a.out_lo) : nullptr;
   T* __restrict__ ysave = SAVE ? reinterpret_cast<T*>(a.y_save) : nullptr;
   T* __restrict__ y2save = SAVE ? reinterpret_cast<T*>(a.y2_save) : nullptr;
   T* __restrict__ h1save = SAVE ? reinterpret_cast<T*>(a.h1_save) : nullptr;
@@ -276,6 +308,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 
   WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
   Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
+  Frag<T> xlpre[RES ? 4 : 1];               // ... and the lo part of x
 
   // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16):
   // 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
@@ -306,6 +339,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
       load_frag(cpre[i], gofs(ctx, (unsigned int)(m * FD + c8)));
       load_frag(xpre[i], gofs(x, (unsigned int)(m * FD + c8)));
+      if constexpr (RES) load_frag(xlpre[i], gofs(xlo, (unsigned int)(m * FD + c8)));
     }
   };
   int mb[4], mbn[4];
@@ -322,6 +356,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
       *reinterpret_cast<Frag<T>*>(Actx + Tile<T>::off(r, c8)) = cpre[i];
       *reinterpret_cast<Frag<T>*>(Ag + Tile<T>::off(r, c8)) = xpre[i];
+      if constexpr (RES) *reinterpret_cast<Frag<T>*>(Ay + Tile<T>::off(r, c8)) = xlpre[i];     // the y tile is free until LayerNorm 1
     }
     float rm4[4];
 #pragma unroll
@@ -333,6 +368,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       // 64 padded positions: the block's output is out * rowmask = 0 whatever the arithmetic gives, and no gradient
       // comes back through these rows -- write the zeros (and finite placeholders for what backward reads) and move on
       zero_to_hbm<T>(out, FD, 0, mb, a.M, tid);
+      if constexpr (RES) zero_to_hbm<T>(outlo, FD, 0, mb, a.M, tid);
       const bool cross = CROSS;
       if (ysave) zero_to_hbm<T>(ysave, FD, 0, mb, a.M, tid);
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, mb, a.M, tid);
@@ -358,18 +394,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     mma_wset<T>(acc, wp, Actx, li, lg);
     load_wset(wp, W1, FD, n0, 0, li, lg, a.w_packed);   // prefetch FFN chunk 0 (hidden behind LN1)
     // + residual x (from LDS), LayerNorm 1 on the registers
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        float r4[4];
-        load4t(r4, Ag + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[ct][rt][r] += r4[r];
-      }
+    add_tile<T>(acc, Ag, n0, li, lg);
+    if constexpr (RES) add_tile<T>(acc, Ay, n0, li, lg);          // x_lo
     STAMP(1);
     float rstd[4];
     ln_regs(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
+    // (past the barrier inside ln_regs every wave is done with the ctx tile, x and x_lo)
+    if constexpr (RES) regs_to_tile_lo<T>(acc, Actx, n0, li, lg);   // y_lo parks in the ctx tile (each lane: its own positions)
     if (rstd1o && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt)
@@ -404,6 +435,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           for (int ct = 0; ct < 2; ++ct) {
             float y4[4];
             load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
+            if constexpr (RES) {
+              float yl[4];
+              load4t(yl, Actx + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) y4[r] += yl[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               float o = bo4[ct][r];
@@ -425,6 +462,12 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           for (int ct = 0; ct < 2; ++ct) {
             float y4[4];
             load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+            if constexpr (RES) {
+              float yl[4];
+              load4t(yl, Actx + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+#pragma unroll
+              for (int r = 0; r < 4; ++r) y4[r] += yl[r];
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ct][rt][r] = y4[r] + o4[rt][ct][r];
           }
@@ -437,6 +480,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           if (mb[rt] + li < a.M) rstdco[mb[rt] + li] = rstd[rt];
       }
       regs_to_tile<T>(acc, Ay, n0, li, lg);
+      if constexpr (RES) regs_to_tile_lo<T>(acc, Actx, n0, li, lg);
     }
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
     {
@@ -525,15 +569,8 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       }
     }
     // ---- + residual y (LDS), LayerNorm 2 on the registers, * rowmask, out via the (free) ctx tile
-#pragma unroll
-    for (int ct = 0; ct < 2; ++ct)
-#pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
-        float r4[4];
-        load4t(r4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
-      }
+    add_tile<T>(acc2, Ay, n0, li, lg);
+    if constexpr (RES) add_tile<T>(acc2, Actx, n0, li, lg);       // y_lo
     ln_regs(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
     if (rstd2o && wave == 0 && lg == 0) {
 #pragma unroll
@@ -547,9 +584,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= rm4[rt];
     regs_to_tile<T>(acc2, Actx, n0, li, lg);
+    if constexpr (RES) regs_to_tile_lo<T>(acc2, Ag, n0, li, lg);  // (the barrier inside ln_regs: the last g chunk has been consumed)
     STAMP(9);
     lds_barrier();
     tile_to_hbm<T>(Actx, out, FD, 0, mb, a.M, tid);
+    if constexpr (RES) tile_to_hbm<T>(Ag, outlo, FD, 0, mb, a.M, tid);
     lds_barrier();                                      // before the next tile overwrites Actx / Ag / Ay
     STAMP(10);
 #pragma unroll
@@ -566,6 +605,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
       zero_to_hbm<T>(out, FD, 0, md, a.M, tid);
+      if constexpr (RES) zero_to_hbm<T>(outlo, FD, 0, md, a.M, tid);
       if (a.skip_dead_saves) continue;      // the backward is list-driven too: it never reads the padded tiles' saves
       if (ysave) zero_to_hbm<T>(ysave, FD, 0, md, a.M, tid);
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, md, a.M, tid);
@@ -608,10 +648,18 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
   const bool cross = a->o_bcast || a->cross_s;
   const bool save = a->y_save || a->y2_save || a->h1_save || a->rstd1 || a->rstd2 || a->rstd_c;
-#define RG_PA2(T, DM, C, S)                                                                                               \
+  const bool res = a->x_lo || a->out_lo;
+  if (res && (!a->x_lo || !a->out_lo || dtype != RG_BF16))
+    return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: the split residual stream needs x_lo AND out_lo, bf16 tier");
+#define RG_PA3(T, DM, C, S, R)                                                                                            \
   do {                                                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C, S>), dim3(grid), dim3(256), smem, s, *a);                          \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S, R>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C, S, R>), dim3(grid), dim3(256), smem, s, *a);                       \
+  } while (0)
+#define RG_PA2(T, DM, C, S)                                                                       \
+  do {                                                                                            \
+    if constexpr (sizeof(T) == 2) { if (res) RG_PA3(T, DM, C, S, true); else RG_PA3(T, DM, C, S, false); } \
+    else RG_PA3(T, DM, C, S, false);                                                              \
   } while (0)
 #define RG_PA(T, DM)                                  \
   do {                                                \
@@ -630,6 +678,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 #undef RG_PA_T
 #undef RG_PA
 #undef RG_PA2
+#undef RG_PA3
   RG_CHECK_LAUNCH();
   return 0;
 }

@@ -38,6 +38,7 @@ class DataParallel(object):
         self.rank = dist.get_rank(group)
         self.bucket_elems = bucket_bytes // 4
         self.big_elems = 1 << 20                    # gradients of >= 4 MB are all-reduced in place, on their own
+        self._pending = []                          # (data_ptr, numel, work) of exchanges started by begin_sync()
 
     def scale_mean(self, loss):
         return loss / self.world
@@ -57,7 +58,6 @@ class DataParallel(object):
         stream) -- for gradients that are already final while more backward work follows (a domain's embedding table
         after that domain's backward: its 51 MB exchange then runs under the other domain's backward instead of after
         it).  The matching sync_grads() skips them and waits for them."""
-        self._pending = getattr(self, "_pending", [])
         for p in params:
             g = p.grad
             if g is None or g.numel() < self.big_elems or not g.is_contiguous() or getattr(p, "_rg_gbase", None) is not None:
@@ -71,8 +71,7 @@ class DataParallel(object):
         buckets (few large collectives: xGMI links are point-to-point, so per-collective latency matters more than on a
         switch) and come back with one multi-tensor copy.  Gradients that are row slices of one shared buffer (the fused
         Q/K/V gradient base of ops._gt_cat) are reduced once, as that buffer."""
-        pending = getattr(self, "_pending", [])
-        self._pending = []
+        pending, self._pending = self._pending, []
         seen, big, small = set((ptr, n) for ptr, n, _ in pending), [], []
         for p in params:
             g = p.grad
@@ -86,18 +85,27 @@ class DataParallel(object):
                 continue
             seen.add(key)
             (big if (g.numel() >= self.big_elems and g.is_contiguous()) else small).append(g)
-        for g in big:
-            dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
-        bucket, size = [], 0
-        for g in small:
-            if bucket and size + g.numel() > self.bucket_elems:
+        try:
+            for g in big:
+                dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
+            bucket, size = [], 0
+            for g in small:
+                if bucket and size + g.numel() > self.bucket_elems:
+                    self._reduce(bucket)
+                    bucket, size = [], 0
+                bucket.append(g)
+                size += g.numel()
+            if bucket:
                 self._reduce(bucket)
-                bucket, size = [], 0
-            bucket.append(g)
-            size += g.numel()
-        if bucket:
-            self._reduce(bucket)
-        for _, _, work in pending:                          # exchanges started by begin_sync()
+        finally:
+            for _, _, work in pending:                      # exchanges started by begin_sync(): always waited for
+                work.wait()
+
+    def discard_pending(self):
+        """Wait for and forget exchanges started by begin_sync() whose sync_grads() never came (an exception between the
+        two): the next step must not skip those gradients nor wait on stale work."""
+        pending, self._pending = self._pending, []
+        for _, _, work in pending:
             work.wait()
 
     def _reduce(self, bucket):

@@ -57,7 +57,7 @@ class PostAttnArgs(ctypes.Structure):
                 ("M", c_i), ("d", c_i), ("P", c_i), ("dff", c_i), ("eps", c_f),
                 ("drop_p", c_f), ("seed_h1", c_u64), ("seed_out", c_u64),
                 ("cross_s", c_p), ("cross_oh", c_p), ("cross_bo", c_p), ("H", c_i), ("live16", c_p),
-                ("skip_dead_saves", c_i), ("w_packed", c_i)]
+                ("skip_dead_saves", c_i), ("w_packed", c_i), ("x_lo", c_p), ("out_lo", c_p)]
 
 
 class FfnBwdArgs(ctypes.Structure):
@@ -88,7 +88,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
-           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned"]
+           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -277,6 +277,19 @@ def embed_pe_fwd(table, pe, ids, mask, L, drop_p=0.0, seed=0):
     _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, c_f(drop_p),
                                  c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd")
     return out
+
+
+def embed_pe_fwd_split(table_f32, pe, ids, mask, L, drop_p=0.0, seed=0):
+    """Split-residual form (rg_embed_pe_fwd_split): rows from the f32 master table, value = hi + lo as two bf16 tensors."""
+    ntok, d = ids.numel(), table_f32.shape[1]
+    assert ids.dtype == torch.int64 and ids.is_contiguous() and mask.dtype == torch.float32 and mask.numel() == ntok
+    assert pe.dtype == torch.float32 and pe.shape[1] == d and pe.is_contiguous()
+    assert table_f32.dtype == torch.float32 and table_f32.is_contiguous()
+    out = torch.empty(ntok, d, device=table_f32.device, dtype=torch.bfloat16)
+    lo = torch.empty_like(out)
+    _check(lib().rg_embed_pe_fwd_split(_vp(table_f32), _vp(pe), _vp(ids), _vp(mask), _vp(out), _vp(lo), c_ll(ntok), L, d,
+                                       c_f(drop_p), c_u64(seed), _stream()), "rg_embed_pe_fwd_split")
+    return out, lo
 
 
 def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
@@ -794,10 +807,13 @@ def first_live(rowmask, B, L):
 
 
 def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, save=False, cross=None, L=0, eps=1e-8,
-                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True, skip_dead_saves=False, w_packed=False):
+                  drop_p=0.0, seed_h1=0, seed_out=0, cross_drop=None, compact=True, skip_dead_saves=False, w_packed=False,
+                  x_lo=None):
     """Fused MHA tail [+ collapsed cross-attention] + FFN + row mask.  cross = (o [B,d] f32, gamma, beta);
     under dropout cross = (None, gamma, beta) and cross_drop = (s [M,H], oh [B,H,d] f32, bo [d], H).
-    Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save."""
+    Returns (out, saved) with saved = dict(y, rstd1, h1, rstd2[, y2, rstd_c]) when save.
+    x_lo [M,d] (bf16 tier): split residual stream -- the residual is x + x_lo and saved["out_lo"] receives the part of the
+    output that rounding `out` to bf16 lost (rg_post_attn_args.x_lo)."""
     M, P = ctx.shape
     d = x.shape[1]
     dff = W1.shape[0]
@@ -822,11 +838,16 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
                 t.fill_(float("nan"))
     o, gc, bec = cross if cross is not None else (None, None, None)
     cs, coh, cbo, cH = cross_drop if cross_drop is not None else (None, None, None, 0)
+    out_lo = None
+    if x_lo is not None:
+        assert x_lo.shape == x.shape and x_lo.dtype == x.dtype == torch.bfloat16 and x_lo.is_contiguous()
+        out_lo = sv["out_lo"] = torch.empty_like(out)
     a = PostAttnArgs(_p(ctx), _p(x), _p(Wo), _p(bo), _p(g1), _p(be1), _p(o), _p(gc), _p(bec), L,
                      _p(W1), _p(b1), _p(W2), _p(b2), _p(g2), _p(be2), _p(rowmask), _p(out),
                      _p(sv.get("y")), _p(sv.get("rstd1")), _p(sv.get("y2")), _p(sv.get("rstd_c")), _p(sv.get("h1")),
                      _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH,
-                     _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0, 1 if w_packed else 0)
+                     _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0, 1 if w_packed else 0,
+                     _p(x_lo), _p(out_lo))
     _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 

@@ -30,6 +30,30 @@ def compute_dtype():
     return _COMPUTE
 
 
+# Residual stream of the bf16 tier: torch.bfloat16 = one bf16 tensor per layer input / output (8 significant bits);
+# torch.float32 = SPLIT form, value = hi + lo as a pair of bf16 tensors (~16 bits, SURVEY.md 7: "keep the residual stream
+# fp32, feed bf16 only to MFMA operands"): `hi` is the tensor every existing consumer reads (projections, attention,
+# weight-gradient operands, the item loss), `lo` rides along as the attribute _rg_lo and is read only by the fused block's
+# residual add; the embedding rows are gathered from the f32 master table; the LayerNorm outputs inside the fused block keep
+# their lo part on chip; the user embedding [B, d] leaves as an f32 tensor.  Fused path only (d_model = 128, d_ff % 128 = 0);
+# the gradient stream stays bf16.  DESIGN.md 2 has the measured error / cost of both settings.
+_RESID = torch.bfloat16
+
+
+def set_residual_dtype(dt):
+    global _RESID
+    assert dt in (torch.float32, torch.bfloat16)
+    _RESID = dt
+
+
+def residual_dtype():
+    return _RESID
+
+
+def _split_resid():
+    return _RESID == torch.float32 and _COMPUTE == torch.bfloat16
+
+
 # ------------------------------------------------------------------------------------------------
 # shadow weights
 # ------------------------------------------------------------------------------------------------
@@ -318,10 +342,14 @@ def _inv_keep(p):
 # K1: embedding + positional encoding + mask (+ dropout)
 # ------------------------------------------------------------------------------------------------
 _GRAD_MODE = True
+_LO_IN = None          # the lo part of the layer input of the _Fn.run() call in progress (split residual stream)
+_LO_OUT = None         # set by that call's forward: the lo part of its output
 FUSE_QKV_INFERENCE = False  # True: no-grad layer passes project Q / K / V inside the attention kernel (rg_attn_fwd x-input
                             # form).  Correct (tests) but SLOWER at the bench shape: 467 us against 254 + 122 us -- the per-head
                             # projection needs 252 row-strided fragment loads per workgroup and the vector L1 / TA becomes the
                             # bound at four workgroups per CU
+import os as _os
+_DEBUG = bool(_os.environ.get("RG_DEBUG"))
 _X_MASKED = False      # set by masked_input(): the layer functions' input rows are zero wherever their row mask is
 
 
@@ -330,9 +358,12 @@ class masked_input(object):
     x[row] == 0 wherever rowmask[row] == 0 (the embedding and each layer output were multiplied by that mask), which
     lets the Q / K / V projections fill padded tiles with the bias row instead of computing them."""
 
+    def __init__(self, on=True):
+        self.on = bool(on)
+
     def __enter__(self):
         global _X_MASKED
-        self.prev, _X_MASKED = _X_MASKED, True
+        self.prev, _X_MASKED = _X_MASKED, self.on
 
     def __exit__(self, *a):
         global _X_MASKED
@@ -347,12 +378,20 @@ class _Fn(torch.autograd.Function):
 
     @classmethod
     def run(cls, *args):
-        global _GRAD_MODE
-        prev, _GRAD_MODE = _GRAD_MODE, torch.is_grad_enabled()
+        """Split residual stream: the lo part of the first argument (a layer input produced by embed_pe or another layer)
+        reaches forward() as _LO_IN, and the lo part forward() leaves in _LO_OUT is attached to the output tensor."""
+        global _GRAD_MODE, _LO_IN, _LO_OUT
+        prev = (_GRAD_MODE, _LO_IN, _LO_OUT)
+        _GRAD_MODE = torch.is_grad_enabled()
+        _LO_IN = getattr(args[0], "_rg_lo", None) if (args and torch.is_tensor(args[0]) and _split_resid()) else None
+        _LO_OUT = None
         try:
-            return cls.apply(*args)
+            out = cls.apply(*args)
+            if _LO_OUT is not None:
+                out._rg_lo = _LO_OUT
+            return out
         finally:
-            _GRAD_MODE = prev
+            _GRAD_MODE, _LO_IN, _LO_OUT = prev
 
 
 def _needs_grad(ctx):
@@ -368,7 +407,12 @@ class EmbedPE(_Fn):
         ids = ids.contiguous()
         mask = mask.reshape(-1).contiguous()
         seed = _draw() if drop_p > 0 else 0
-        out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L, drop_p, seed)
+        if _split_resid():
+            global _LO_OUT
+            out, lo = hip.embed_pe_fwd_split(table.detach(), pe, ids, mask, L, drop_p, seed)
+            _LO_OUT = lo.view(B, L, -1)
+        else:
+            out = hip.embed_pe_fwd(shadow(table), pe, ids, mask, L, drop_p, seed)
         ctx.save_for_backward(ids, mask)
         ctx.table = table
         ctx.meta = (skip_row, drop_p, seed)
@@ -387,8 +431,26 @@ class EmbedPE(_Fn):
         return ret, None, None, None, None, None
 
 
+def _mask_tag(mask):
+    return (mask.data_ptr(), mask._version, mask.numel())
+
+
 def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
-    return EmbedPE.run(table, pe, ids, mask, skip_row, float(drop_p))
+    out = EmbedPE.run(table, pe, ids, mask, skip_row, float(drop_p))
+    out._rg_masked = _mask_tag(mask)        # rows of `out` are exactly zero wherever this very mask is (masked_by())
+    return out
+
+
+def masked_by(x, rowmask):
+    """True when x is known to have exactly-zero rows wherever rowmask is 0: it came out of embed_pe() with this very mask
+    tensor (same storage, not written since).  What lets the model stacks enter masked_input() from their FIRST layer on;
+    a caller's arbitrary x (the reference's EncoderM / DecoderM accept any, transformer.py:587,:520) is not assumed to be.
+    RG_DEBUG=1 verifies the claim on the device."""
+    ok = rowmask is not None and getattr(x, "_rg_masked", None) == _mask_tag(rowmask)
+    if ok and _DEBUG:
+        m = rowmask.reshape(x.shape[0], x.shape[1], 1).to(x.dtype)
+        assert float((x.detach() * (1 - m)).abs().max()) == 0.0, "masked_by: a padded row of x is not zero"
+    return ok
 
 
 # ------------------------------------------------------------------------------------------------
@@ -396,6 +458,26 @@ def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
 # ------------------------------------------------------------------------------------------------
 def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
+
+
+def _lo_in(x2, rows=None):
+    """The lo part of the layer input of the call in progress as an [M, d] matrix (zeros when the caller's x carries none:
+    its value is then exactly x), or None when the residual stream is not split.  rows: a slicing function for the
+    single-row forms."""
+    if not _split_resid():
+        return None
+    lo = _LO_IN
+    if lo is None:
+        return torch.zeros_like(x2)
+    lo = rows(lo) if rows is not None else lo
+    return lo.contiguous().view(x2.shape)
+
+
+def _lo_out(sv, shape):
+    global _LO_OUT
+    lo = sv.pop("out_lo", None)
+    if lo is not None:
+        _LO_OUT = lo.view(shape)
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
@@ -573,7 +655,8 @@ class EncoderLayerFn(_Fn):
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
                                         be2.detach(),
                                         rowmask, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
-                                        skip_dead_saves=_lists_everywhere(W1, B * L))
+                                        skip_dead_saves=_lists_everywhere(W1, B * L), x_lo=_lo_in(x2))
+            _lo_out(sv, (B, L, d))
             if need:
                 y, sa, sf = sv["y"], (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
         else:
@@ -635,11 +718,14 @@ class EncoderLastLayerFn(_Fn):
                              live=_zero_rows_live(rmf, B * L, _X_MASKED, d, 2 * P), skip_dead_fill=2)
             c_last = hip.attn_lastq_fwd(q_last, kv.view(B, L, -1), key_ids, pad_value, H, drop_p, seeds[0],
                                         rowmask=rmf if fold else None, bkv=bkv if fold else None)
+        out_lo = None
         if _fusable(x_last, Wo, W1):
             out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
                                         be2.detach(),
-                                        rm_last, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2])
+                                        rm_last, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
+                                        x_lo=_lo_in(x_last, rows=lambda t: t.reshape(B, L, d)[:, -1, :]))
+            out_lo = sv.pop("out_lo", None)
             if need:
                 y, rstd1, sf = sv["y"], sv["rstd1"], (sv["h1"], sv["rstd2"])
         else:
@@ -651,6 +737,9 @@ class EncoderLastLayerFn(_Fn):
             ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf, rmf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, pad_value, H, drop_p, seeds, fold, from_x, bool(_X_MASKED))
+        if out_lo is not None:
+            # split residual stream: the user embedding leaves as ONE f32 tensor (hi + lo); `out` (hi) stays the saved tensor
+            return out.to(torch.float32) + out_lo.to(torch.float32)
         return out
 
     @staticmethod
@@ -660,7 +749,7 @@ class EncoderLastLayerFn(_Fn):
         B, L, pad_value, H, drop_p, seeds, fold, from_x, xm = ctx.meta
         d = x2.shape[1]
         P = Wo.shape[1]
-        dy, gf = _ffn_block_bwd(dout.contiguous(), y, out, (h1, rstd2), rm_last, ctx.prm[10:], drop_p, seeds[1], seeds[2])
+        dy, gf = _ffn_block_bwd(dout.to(out.dtype).contiguous(), y, out, (h1, rstd2), rm_last, ctx.prm[10:], drop_p, seeds[1], seeds[2])
         (dg1, rg1), (dbe1, rbe1) = _gt(g1), _gt(be1)
         dz = hip.ln_bwd(dy, y, rstd1, g1.detach(), be1.detach(), None, dg1, dbe1)
         (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
@@ -704,7 +793,8 @@ class DecoderLayerFn(_Fn):
         x2 = x.contiguous().view(B * L, d)
         key_ids = key_ids.contiguous()
         rowmask = rowmask.reshape(-1).contiguous()
-        u = u.contiguous()
+        ctx.u_dtype = u.dtype
+        u = u.to(x.dtype).contiguous()           # (split residual stream: the user embedding arrives f32; operand here)
         seeds = (_draw(), _draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0, 0)
         P = cWv.shape[0]
         c = hip.gemm_nt(u, shadow(cWv), cbv.detach())                        # [B, P]
@@ -727,7 +817,8 @@ class DecoderLayerFn(_Fn):
                                         shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
                                         be2.detach(),
                                         rowmask, w_packed=True, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
-                                        seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1, B * L), **cross_kw)
+                                        seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1, B * L), x_lo=_lo_in(x2), **cross_kw)
+            _lo_out(sv, (B, L, d))
             if need:
                 y1, y2, rstd_c = sv["y"], sv["y2"], sv["rstd_c"]
                 sa, sf = (qkv, ctx_, lse, sv["rstd1"]), (sv["h1"], sv["rstd2"])
@@ -785,7 +876,7 @@ class DecoderLayerFn(_Fn):
         du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
         dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
                                  ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
-        return ((dx.view(B, L, d), du, None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
+        return ((dx.view(B, L, d), du.to(ctx.u_dtype), None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -157,18 +157,54 @@ class _NoDP(object):
     def begin_sync(self, params):
         pass
 
+    def discard_pending(self):
+        pass
 
-def _domain_only_params(netG, domain):
+
+def _domain_only_params(netG, domain, dp=None):
     """Large parameters that only domain `domain`'s passes touch (its embedding table): their gradients are final as
-    soon as that domain's backward has run."""
+    soon as that domain's backward has run.  "Large" is the data-parallel object's in-place threshold (dist.big_elems)."""
+    thr = getattr(dp, "big_elems", 1 << 20)
     cache = getattr(netG, "_rg_domain_params", None)
-    if cache is None:
-        cache = {}
+    if cache is None or cache.get("thr") != thr:
+        cache = {"thr": thr}
         for dom in ("a", "b"):
             cache[dom] = [p for n, p in _unwrap(netG).named_parameters()
-                          if p.numel() >= (1 << 20) and n.split(".")[0].endswith("_" + dom)]
+                          if p.numel() >= thr and n.split(".")[0].endswith("_" + dom)]
         netG._rg_domain_params = cache
     return cache[domain]
+
+
+def recon_step(model_train, opt, batch_a, batch_b, param, device, dp, params, neg_sample=True, loss_type="s_soft",
+               opt_type="org"):
+    """One phase-1 step (the loop body of train_recon_x, gan_training.py:843-866): the reconstruction (or BPR) loss of both
+    domains, their backward passes, the gradient exchange and the optimizer step.  batch = (enc_in, dec_in, dec_out,
+    n_items); returns the two losses as device scalars."""
+    enc_a, din_a, dout_a, n_a = batch_a
+    enc_b, din_b, dout_b, n_b = batch_b
+    bs, sl = dout_a.shape[0], dout_a.shape[1]
+    mask_a = get_pad_mask(dout_a, param.pad_index, device)
+    mask_b = get_pad_mask(dout_b, param.pad_index, device)
+    dp.discard_pending()
+    opt.zero_grad()
+    if loss_type == "s_soft":
+        loss_a = loss_ae(model_train, enc_a, din_a, dout_a, n_a, neg_sample, bs, sl, param, mask_a, device, "a")
+        loss_b = loss_ae(model_train, enc_b, din_b, dout_b, n_b, neg_sample, bs, sl, param, mask_b, device, "b")
+    elif loss_type == "bpr":
+        loss_a = loss_bpr_func(model_train, enc_a, din_a, dout_a, n_a, mask_a, "a", param)
+        loss_b = loss_bpr_func(model_train, enc_b, din_b, dout_b, n_b, mask_b, "b", param)
+    else:
+        print("loss configuration error")
+        sys.exit()
+    loss_a.backward()
+    dp.begin_sync(_domain_only_params(model_train, "a", dp))      # domain a's table: exchanged under domain b's backward
+    loss_b.backward()
+    dp.sync_grads(params)
+    if opt_type == "org":
+        opt.step()
+    else:
+        opt.step_and_update_lr()
+    return loss_a.detach(), loss_b.detach()
 
 
 def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True, loss_type="s_soft", opt_type="org",
@@ -177,33 +213,15 @@ def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True,
     dp = dp or _NoDP()
     model_train.train()
     it_a, it_b = iter(data[0]), iter(data[1])
-    seqs, _, _, _ = next(it_a)                                  # the reference consumes one a-batch here (:837)
-    bs, sl = seqs[2].shape[0], seqs[2].shape[1]
+    next(it_a)                                                  # the reference consumes one a-batch here (:837)
     params = [p for p in model_train.parameters()]
     losses = []
     for i in range(steps):
         enc_a, din_a, dout_a, n_a, it_a = load_batch_data(it_a, data[0], device)
         enc_b, din_b, dout_b, n_b, it_b = load_batch_data(it_b, data[1], device)
-        mask_a = get_pad_mask(dout_a, param.pad_index, device)
-        mask_b = get_pad_mask(dout_b, param.pad_index, device)
-        opt.zero_grad()
-        if loss_type == "s_soft":
-            loss_a = loss_ae(model_train, enc_a, din_a, dout_a, n_a, neg_sample, bs, sl, param, mask_a, device, "a")
-            loss_b = loss_ae(model_train, enc_b, din_b, dout_b, n_b, neg_sample, bs, sl, param, mask_b, device, "b")
-        elif loss_type == "bpr":
-            loss_a = loss_bpr_func(model_train, enc_a, din_a, dout_a, n_a, mask_a, "a", param)
-            loss_b = loss_bpr_func(model_train, enc_b, din_b, dout_b, n_b, mask_b, "b", param)
-        else:
-            print("loss configuration error")
-            sys.exit()
-        loss_a.backward()
-        loss_b.backward()
-        dp.sync_grads(params)
-        if opt_type == "org":
-            opt.step()
-        else:
-            opt.step_and_update_lr()
-        losses.append((loss_a.detach(), loss_b.detach()))
+        loss_a, loss_b = recon_step(model_train, opt, (enc_a, din_a, dout_a, n_a), (enc_b, din_b, dout_b, n_b), param,
+                                    device, dp, params, neg_sample, loss_type, opt_type)
+        losses.append((loss_a, loss_b))
         if log_every and i % log_every == log_every - 1:
             la, lb = float(loss_a), float(loss_b)
             if verbose:
@@ -386,6 +404,7 @@ def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, 
     plus the reconstruction loss of both domains; batch = (enc_in, dec_in, dec_out, n_items, bs, sl)."""
     for p in netD.parameters():
         p.requires_grad = False
+    dp.discard_pending()                         # exchanges an interrupted earlier step may have left behind
     opt_g.zero_grad()
     in_a, din_a, dout_a, n_a, bs, sl = batch_a
     in_b, din_b, dout_b, n_b, bs, sl = batch_b
@@ -403,7 +422,7 @@ def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, 
     mask_b = get_pad_mask(dout_b, param.pad_index, device)
     loss_recon_b = loss_ae(netG, in_b, din_b, dout_b, n_b, True, bs, sl, param, mask_b, device, domain="b")
     loss_recon_a.backward()
-    dp.begin_sync(_domain_only_params(netG, "a"))      # domain a's table: exchanged under domain b's backward
+    dp.begin_sync(_domain_only_params(netG, "a", dp))      # domain a's table: exchanged under domain b's backward
     loss_recon_b.backward()
     dp.sync_grads(g_params if g_params is not None else list(netG.parameters()))
     opt_g.step()

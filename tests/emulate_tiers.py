@@ -1,0 +1,102 @@
+"""CPU emulation of the operand / storage roundings of the HIP tiers, against the f32 oracle at the bench shape.
+
+Not a test and not product code: a decision aid for DESIGN.md 2 (which roundings cost how much of the user-embedding
+error), run here on the CPU.  It restates the ENCODER path (embedding -> N layers -> last position) with
+
+  * every GEMM / attention operand rounded to bf16 (what v_mfma_f32_16x16x32_bf16 consumes), f32 accumulation,
+  * the tensors that travel through HBM between kernels stored in `resid` (bf16: today's tier; f32: VERDICT r2 item 2),
+  * optionally the intra-kernel intermediates (LayerNorm-1 output as the FFN's residual) kept f32.
+
+  python tests/emulate_tiers.py [B]
+"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import recguru_oracle as O          # noqa: E402
+
+
+def r(x):
+    return x.to(torch.bfloat16).to(torch.float32)
+
+
+def lin(x, W, b):
+    return r(x) @ r(W).T + b
+
+
+def encoder_last(p, cfg, enc_in, domain, mask, resid, y_f32, stores=("emb", "qkv", "p", "ctx", "y", "g", "out"), table_f32=False):
+    st = (lambda t, name: r(t) if name in stores else t)
+    keep = (lambda t: t) if resid == "f32" else r
+    emb = p["src_emb_%s.weight" % domain] if table_f32 else r(p["src_emb_%s.weight" % domain])
+    pe = p["pos_emb_%s.pe" % domain][0]
+    L = enc_in.shape[1]
+    x = keep((emb[enc_in] + pe[:L].unsqueeze(0)) * mask.unsqueeze(2)) if "emb" in stores else (emb[enc_in] + pe[:L].unsqueeze(0)) * mask.unsqueeze(2)
+    pad_value = cfg.vocab_size_a if domain == "a" else cfg.vocab_size_b
+    masked = O.pad_key_mask(enc_in, pad_value, L)
+    B, H, dk = x.shape[0], cfg.n_heads, cfg.d_k
+    for i in range(cfg.n_layers):
+        pre = "encoder.layers.%d.enc_self_attn." % i
+        q = st(lin(x, p[pre + "WQ.weight"], p[pre + "WQ.bias"]), "qkv").view(B, L, H, dk).transpose(1, 2)
+        k = st(lin(x, p[pre + "WK.weight"], p[pre + "WK.bias"]), "qkv").view(B, L, H, dk).transpose(1, 2)
+        v = st(lin(x, p[pre + "WV.weight"], p[pre + "WV.bias"]), "qkv").view(B, L, H, dk).transpose(1, 2)
+        s = (q @ k.transpose(-1, -2)) / math.sqrt(dk)
+        s = s.masked_fill(masked.unsqueeze(1), O.MASK_FILL)
+        e = torch.exp(s - s.max(-1, keepdim=True).values)
+        e = st(e, "p")                                    # P operand of the PV product; its row sum is of the rounded P
+        ctx = st((e @ v) / e.sum(-1, keepdim=True), "ctx").transpose(1, 2).reshape(B, L, H * dk)
+        z = lin(ctx, p[pre + "linear.weight"], p[pre + "linear.bias"]) + x
+        y = O.layer_norm(z, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"])
+        yres = y if y_f32 else st(y, "y")
+        pre = "encoder.layers.%d.pos_ffn." % i
+        h1 = lin(y, p[pre + "l1.weight"], p[pre + "l1.bias"])
+        g = st(O.gelu_tanh(h1), "g")
+        o = lin(g, p[pre + "l2.weight"], p[pre + "l2.bias"]) + yres
+        x = O.layer_norm(o, p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"]) * mask.unsqueeze(2)
+        x = keep(x) if "out" in stores else x
+    return x[:, -1, :]
+
+
+def main():
+    from recguru_amd import synthetic
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    L, d, H, N, V, k = 200, 128, 4, 3, 100000, 30
+    cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
+    torch.manual_seed(0)
+    p = {"src_emb_a.weight": torch.randn(V + 2, d), "pos_emb_a.pe": O.positional_table(5000, d).unsqueeze(0)}
+    P = H * 32
+    for i in range(N):
+        pre = "encoder.layers.%d.enc_self_attn." % i
+        for nm, (o, c) in (("WQ", (P, d)), ("WK", (P, d)), ("WV", (P, d)), ("linear", (d, P))):
+            p[pre + nm + ".weight"] = (torch.rand(o, c) * 2 - 1) / c ** 0.5
+            p[pre + nm + ".bias"] = (torch.rand(o) * 2 - 1) / c ** 0.5
+        p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+        pre = "encoder.layers.%d.pos_ffn." % i
+        for nm, (o, c) in (("l1", (512, d)), ("l2", (d, 512))):
+            p[pre + nm + ".weight"] = (torch.rand(o, c) * 2 - 1) / c ** 0.5
+            p[pre + nm + ".bias"] = (torch.rand(o) * 2 - 1) / c ** 0.5
+        p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
+    dom = synthetic.make_domain(B, V, L, k, seed=1)
+    enc = torch.as_tensor(dom["enc_in"])
+    mask = O.nonpad(enc)
+    with torch.no_grad():
+        ref = O.cross_get_seq_embed(p, cfg, enc, "a", mask)[:, -1, :].double()
+        full = ("emb", "qkv", "p", "ctx", "y", "g", "out")
+        rows = [("bf16 tier as shipped (operands, qkv/ctx, residual stream bf16)", dict(resid="bf16", y_f32=False, stores=full)),
+                ("  + LayerNorm-1 output kept f32 as the FFN residual (in-kernel)", dict(resid="bf16", y_f32=True, stores=full)),
+                ("f32 residual stream in HBM (x, layer outputs), operands bf16", dict(resid="f32", y_f32=True, stores=full)),
+                ("  ... f32 residual stream AND the embedding rows gathered from the f32 master table", dict(resid="f32", y_f32=True, stores=full, table_f32=True)),
+                ("  ... and q/k/v, P, ctx, gelu kept f32 too: ONLY weights + GEMM inputs rounded", dict(resid="f32", y_f32=True, stores=())),
+                ]
+        for name, kw in rows:
+            got = encoder_last(p, cfg, enc, "a", mask, **kw).double()
+            e = (got - ref).abs()
+            print("%-82s max err / max |value| = %.2e   rms err / rms value = %.2e" % (
+                name, float(e.max() / ref.abs().max()), float(e.pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())))
+
+
+if __name__ == "__main__":
+    main()

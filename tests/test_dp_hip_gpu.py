@@ -1,8 +1,15 @@
-"""Data parallelism THROUGH THE HIP PATH: two fresh processes on the one GPU of the box, gloo between
-them, each running the shipped training.critic_update + training.generator_iteration on its rank::2 shard of a golden
-case with ops.set_data_parallel installed (global mask count inside ItemLoss, pre-divided means, SUM all-reduce of the
-in-place p.grad buffers -- including the row slices of the shared QKV gradient base).  Rank 0's post-sync gradients must
-equal the single-process full-batch gradients."""
+"""Data parallelism THROUGH THE HIP PATH: fresh rank processes, each running the shipped step functions
+(training.critic_update / generator_iteration / recon_step) on its rank::world shard with ops.set_data_parallel installed
+(global mask count inside ItemLoss, pre-divided means, SUM all-reduce of the in-place p.grad buffers -- including the row
+slices of the shared QKV gradient base, the >= 4 MB in-place path and begin_sync's asynchronous exchange).
+
+  * gloo, both ranks on the box's one GPU: gradients of a golden case (f32 tier) and of the BENCH SHAPE in the bf16 tier
+    (V = 100k: both tables take the big-gradient path) equal the single-process full-batch gradients; a 20-step phase-1
+    + 3-iteration phase-2 loss curve, dropout 0, is the same with 1 and with 2 ranks.
+  * nccl (RCCL), one GPU per rank: the same gradient check and `python bench.py --gpus 2` with no outer launcher --
+    skipped on boxes with fewer than two GPUs.
+"""
+import json
 import os
 import socket
 import subprocess
@@ -15,6 +22,7 @@ from golden_util import load_case
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
 NOISE = ("dec_enc_attn.WQ", "dec_enc_attn.WK", "WK.bias")
 
 
@@ -26,40 +34,168 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name", ["case1"])
-def test_dp2_hip_matches_full_batch(name, tmp_path):
-    import torch
-    from dp_worker import run_steps
-    out = os.path.join(str(tmp_path), "rank0.npz")
+def _run_ranks(argv, world=2, backend="gloo", extra_env=None, timeout=900):
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py"), name, out], env=env,
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank if backend == "nccl" else 0), WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RG_DP_BACKEND=backend)
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.join(HERE, "dp_worker.py")] + argv, env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=600)
+            o, _ = p.communicate(timeout=timeout)
         except subprocess.TimeoutExpired:
             p.kill()
             o, _ = p.communicate()
         logs.append(o.decode()[-3000:])
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
-    got = dict(np.load(out))
-    # single process, full batch, same code path without a DataParallel
-    from recguru_amd import ops
-    gD, gG, sc = run_steps(load_case(name), 0, 1, None)
-    ops.set_data_parallel(None)
-    ops.set_compute_dtype(torch.bfloat16)
+
+
+def _compare_grads(got, gD, gG, rtol, atol_of_max):
     n = 0
     for pre, ref in (("D.", gD), ("G.", gG)):
         for k, g in ref.items():
             if any(s in k for s in NOISE):
                 continue
             scale = max(float(np.abs(g).max()), 1e-12)
-            np.testing.assert_allclose(got[pre + k], g, rtol=1e-4, atol=2e-5 * scale + 1e-7, err_msg=pre + k)
+            np.testing.assert_allclose(got[pre + k], g, rtol=rtol, atol=atol_of_max * scale + 1e-7, err_msg=pre + k)
             n += 1
-    assert n > 40
+    return n
+
+
+def _reset_ops():
+    import torch
+    from recguru_amd import ops
+    ops.set_data_parallel(None)
+    ops.set_compute_dtype(torch.bfloat16)
+
+
+@pytest.mark.parametrize("name", ["case1"])
+def test_dp2_hip_matches_full_batch(name, tmp_path):
+    from dp_worker import run_steps
+    out = os.path.join(str(tmp_path), "rank0.npz")
+    _run_ranks(["grads", name, out])
+    got = dict(np.load(out))
+    # single process, full batch, same code path without a DataParallel
+    gD, gG, sc = run_steps(load_case(name), 0, 1, None)
+    _reset_ops()
+    assert _compare_grads(got, gD, gG, 1e-4, 2e-5) > 40
     # rank 0 logs its own shard's losses (means over DIFFERENT users), so only finiteness is checked on them
     assert np.isfinite(got["scalars"]).all() and np.isfinite(sc).all()
+
+
+@pytest.mark.parametrize("tier", ["bf16", "f32"])
+def test_dp2_hip_bench_shape(tier, tmp_path, capsys):
+    """The measured tier under DP at the bench shape (L=200, d=128, N=3, V=100k, k=30; B=16 split 2 x 8): the two 51 MB
+    embedding-table gradients go through DataParallel.begin_sync (asynchronous, under the other domain's backward) and the
+    in-place big-gradient all-reduce on GPU buffers, everything else through the flat bucket.  Per sequence the
+    arithmetic of a shard is that of the full batch (no batch-coupled op), so the summed gradients differ from the
+    full-batch ones only by the order of f32 accumulation (atomics, bucket sums)."""
+    from dp_worker import run_steps
+    out = os.path.join(str(tmp_path), "rank0.npz")
+    _run_ranks(["grads", "bench", out], extra_env={"RG_DP_TIER": tier})
+    got = dict(np.load(out))
+    os.environ["RG_DP_TIER"] = tier
+    try:
+        gD, gG, sc = run_steps("bench", 0, 1, None)
+    finally:
+        del os.environ["RG_DP_TIER"]
+        _reset_ops()
+    worst = []
+    for pre, ref in (("D.", gD), ("G.", gG)):
+        for k, g in ref.items():
+            if not any(s in k for s in NOISE):
+                worst.append((float(np.abs(got[pre + k] - g).max() / max(np.abs(g).max(), 1e-12)), pre + k))
+    worst.sort(reverse=True)
+    with capsys.disabled():
+        print("\n[DP x2, bench shape, %s tier] worst gradient difference / max |gradient|: %s" % (
+            tier, ", ".join("%s %.2g" % (k, v) for v, k in worst[:4])))
+    assert "G.src_emb_a.weight" in got and got["G.src_emb_a.weight"].size >= (1 << 20)     # the big-gradient path ran
+    assert _compare_grads(got, gD, gG, 1e-3 if tier == "bf16" else 1e-4, 1e-4 if tier == "bf16" else 2e-5) > 40
+
+
+def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
+    """"1 vs 2 ranks, same global batch, 20-step loss curve equal within fp32 tolerance (dropout 0)" -- 20
+    steps of train_recon_x's body and 3 phase-2 iterations (15 critic updates + 3 generator updates) of the shipped
+    functions on the loss-curve fixture's batches, f32 tier."""
+    from dp_worker import run_curve
+    out = os.path.join(str(tmp_path), "curve.npz")
+    _run_ranks(["curve", "curves1", out])
+    got = dict(np.load(out))
+    p1, p2, keep = run_curve(load_case("curves1"), 0, 1, None)
+    _reset_ops()
+    e1 = float(np.abs(got["p1"] / p1 - 1).max())
+    e2 = np.abs(got["p2"] - p2).max(0)
+    with capsys.disabled():
+        print("\n[DP x2 vs 1 rank, f32 tier] phase-1 max rel diff %.3g over %d steps | phase-2 max abs diff "
+              "(D_cost, W_D, g_dis, recon_a, recon_b) %s" % (e1, p1.shape[0], np.array2string(e2, precision=2)))
+    assert p1.shape == (20, 2) and p2.shape == (3, 5)
+    np.testing.assert_allclose(got["p1"], p1, rtol=2e-5, atol=1e-6)
+    # phase 2: the gradient penalty goes through ReLU masks [h > 0] and Adam turns rounding-level gradients into +-lr
+    # steps, so two f32 summation orders drift apart a little more than rounding (DESIGN.md 2, "loss curves")
+    np.testing.assert_allclose(got["p2"][:, 3:], p2[:, 3:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["p2"][:, :3], p2[:, :3], rtol=0, atol=2e-4)
+    for k, w in keep.items():
+        np.testing.assert_allclose(got["w." + k], w, rtol=0, atol=2e-3 * float(np.abs(w).max()), err_msg=k)
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.device_count() >= 2
+
+
+def test_dp2_rccl_matches_full_batch(tmp_path):
+    """backend="nccl" (RCCL over xGMI), one GPU per rank."""
+    if not _two_gpus():
+        pytest.skip("needs two GPUs")
+    from dp_worker import run_steps
+    out = os.path.join(str(tmp_path), "rank0.npz")
+    _run_ranks(["grads", "bench", out], backend="nccl", extra_env={"RG_DP_TIER": "bf16"})
+    got = dict(np.load(out))
+    os.environ["RG_DP_TIER"] = "bf16"
+    try:
+        gD, gG, sc = run_steps("bench", 0, 1, None)
+    finally:
+        del os.environ["RG_DP_TIER"]
+        _reset_ops()
+    assert _compare_grads(got, gD, gG, 1e-3, 1e-4) > 40
+
+
+def _bench(args, env=None, timeout=1200):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})),
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    return json.loads(lines[0])
+
+
+SMALL = ["--batch", "64", "--items", "5000", "--steps", "2", "--warmup", "1", "--no_cpu_baseline", "--batches_per_domain", "1"]
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` with NO outer launcher starts its own rank processes (before any GPU call in the parent),
+    prints one JSON line with n_gpus = 2 and exits 0.  On a 1-GPU box both ranks share GPU 0 over gloo (the debug knobs);
+    with two GPUs the same command runs over RCCL."""
+    env = {} if _two_gpus() else {"RG_BENCH_SINGLE_DEVICE": "1", "RG_BENCH_BACKEND": "gloo"}
+    line = _bench(["--gpus", "2"] + SMALL, env)
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["value"] > 0
+    assert line["config"]["sequences_per_step"] == 12 * 64 * 2
+    assert line["ae_step"]["sequences_per_step"] == 2 * 64 * 2 and line["value_full_length"] > 0
+    assert all(np.isfinite(v) for v in line["config"]["last_step"].values())
+
+
+def test_bench_line_contract_single_gpu():
+    """The default line: BASELINE.json's metric, roofline (frac = executed rows, frac_nominal beside it), the AE-step
+    object and the full-length-users value; --mode ae reports the AE step as the metric."""
+    line = _bench(["--gpus", "1"] + SMALL)
+    assert line["metric"] == "user-sequences/sec (AE+GAN step)" and line["n_gpus"] == 1
+    r = line["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= r["frac_nominal"] + 1e-9
+    assert line["ae_step"]["value"] > 0 and line["value_full_length"] > 0
+    ae = _bench(["--gpus", "1", "--mode", "ae"] + SMALL)
+    assert ae["metric"] == "user-sequences/sec (AE step)" and ae["config"]["sequences_per_step"] == 2 * 64
+    assert "ae_step" not in ae and ae["value"] > 0

@@ -511,6 +511,56 @@ def test_post_attn_fused_vs_unfused(dt, M, dff, cross, save):
             torch.testing.assert_close(sv["rstd_c"], 1 / torch.sqrt(zc.var(1, unbiased=False) + 1e-8), rtol=2e-2 if dt != torch.float32 else 1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("cross", [False, True])
+@pytest.mark.parametrize("save", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_post_attn_split_residual(cross, save, drop_p):
+    """Split residual stream (rg_post_attn_args.x_lo / out_lo): with x = hi + lo the block's out + out_lo reproduces a
+    reference in which NOTHING but the MFMA operands is rounded (ctx, y as the W1 operand, gelu as the W2 operand, weights),
+    to a few 1e-3 -- where the single-tensor form also rounds x, both LayerNorm outputs as residuals, and out itself.  And:
+    the hi part, the saves and the dropout masks are those of a plain launch whose residual input is the f32 x rounded once."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    M, d, dff, L = 64 * 5 + 16, 128, 512, 7
+    P = d
+    x32 = rnd(M, d, dt=torch.float32, seed=2)
+    hi = x32.to(dt)
+    lo = (x32 - hi.float()).to(dt)
+    ctx = rnd(M, P, dt=dt, seed=1)
+    Wo, W1, W2 = rnd(d, P, dt=dt, scale=P ** -0.5, seed=3), rnd(dff, d, dt=dt, scale=d ** -0.5, seed=4), \
+        rnd(d, dff, dt=dt, scale=dff ** -0.5, seed=5)
+    bo, b1, b2 = (0.1 * rnd(n, dt=torch.float32, seed=6 + i) for i, n in enumerate((d, dff, d)))
+    g1, g2, gc = (1 + 0.1 * rnd(d, dt=torch.float32, seed=10 + i) for i in range(3))
+    be1, be2, bec = (0.1 * rnd(d, dt=torch.float32, seed=20 + i) for i in range(3))
+    rm = (torch.arange(M) % 5 != 2).float().cuda()
+    nb = (M + L - 1) // L
+    o = rnd(nb, d, dt=torch.float32, seed=30) if cross else None
+    kw = dict(save=save, cross=(o, gc, bec) if cross else None, L=L, drop_p=drop_p, seed_h1=77, seed_out=78)
+    out, sv = hip.post_attn_fwd(ctx, hi, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rm, x_lo=lo, **kw)
+    out_lo = sv["out_lo"]
+    plain, svp = hip.post_attn_fwd(ctx, hi, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rm, **kw)
+    both = out.float() + out_lo.float()
+    assert float(out_lo.float().abs().max()) <= float(out.float().abs().max()) * 2.0 ** -8      # lo is a rounding residue
+    assert float(both[rm == 0].abs().max()) == 0.0
+    if drop_p == 0.0:
+        F = torch.nn.functional
+        y = F.layer_norm(ctx.float() @ Wo.float().T + bo + x32, (d,), g1, be1, 1e-8)
+        if cross:
+            y = F.layer_norm(y + o.repeat_interleave(L, 0)[:M], (d,), gc, bec, 1e-8)
+        h1 = y.to(dt).float() @ W1.float().T + b1
+        ref = F.layer_norm(gelu_tanh(h1).to(dt).float() @ W2.float().T + b2 + y, (d,), g2, be2, 1e-8) * rm[:, None]
+        e_split = float((both - ref).abs().max() / ref.abs().max())
+        e_plain = float((plain.float() - ref).abs().max() / ref.abs().max())
+        assert e_split < 2.5e-3 and e_split < 0.5 * e_plain, (e_split, e_plain)
+    else:
+        # same dropout masks as the plain launch: the outputs agree to the rounding of the residual stream
+        assert float((both - plain.float()).abs().max()) < 6e-2
+        assert float(((both != 0) != (plain.float() != 0)).float().mean()) < 1e-3
+    if save:
+        for k in ("h1", "y"):
+            assert float((sv[k].float() - svp[k].float()).abs().max()) < 6e-2
+
+
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (128, 512), (384, 128), (512, 128)])
 @pytest.mark.parametrize("epi", ["none", "add", "gelu_grad", "posmask", "relu"])
 def test_gemm_ws_matches_generic(K, N, epi):

@@ -123,3 +123,37 @@ def test_qkv_bias_fill_for_padded_tiles_is_exact():
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5)         # the loss sums are f32 atomics
     for k_, g in res[1][2].items():
         torch.testing.assert_close(res[0][2][k_], g, rtol=1e-5, atol=1e-7, msg=k_)     # f32 atomics arrive in any order
+
+
+def test_encoder_stack_takes_an_arbitrary_input():
+    """EncoderM / DecoderM accept ANY x, like the reference's (transformer.py:587,:520 only mask the layer OUTPUTS): rows of
+    a caller-supplied x at padded positions need not be zero, and such a position is still a key (quirk Q2).  The
+    bias-row shortcut for padded tiles (ops.masked_input) may therefore be taken for the first layer only when x provably
+    is the embedding stage of the same mask (ops.masked_by).  bf16 tier at a size where the shortcut engages (M >= 16384)
+    against the f32 tier (which has no such shortcut) on the same unmasked x."""
+    from recguru_amd import blocks, ops
+    torch.manual_seed(5)
+    B, L, d, H = 96, 200, 128, 4
+    enc = blocks.EncoderM(d, 512, 32, 32, H, 2, 0, "cuda", 0.0).to(torch.float32).cuda()
+    dec = blocks.DecoderM(d, 512, 32, 32, H, 2, 0, "cuda", 0.0).to(torch.float32).cuda()
+    enc.eval()
+    dec.eval()
+    ids = torch.randint(1, 50, (B, L), device="cuda")
+    lens = torch.randint(5, L, (B,), device="cuda")
+    ids[torch.arange(L, device="cuda")[None, :] < (L - lens)[:, None]] = 0                    # left padding
+    mask = (ids != 0).to(torch.float32)
+    x32 = torch.randn(B, L, d, device="cuda")                                                  # NOT multiplied by the mask
+    u32 = torch.randn(B, d, device="cuda")
+    out = {}
+    try:
+        for tier in (torch.float32, torch.bfloat16):
+            ops.set_compute_dtype(tier)
+            x = x32.to(tier)
+            assert not ops.masked_by(x, mask)
+            with torch.no_grad():
+                out[tier] = (enc(x, ids, 77, mask).float(), dec(x, u32.to(tier), ids, ids, mask).float())
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+    for a, b in zip(out[torch.float32], out[torch.bfloat16]):
+        err = float((a - b).abs().max() / a.abs().max())
+        assert err < 4e-2, err          # bf16 rounding of two layers; the shortcut taken wrongly gives O(1) differences
