@@ -114,6 +114,14 @@ def make_loaders(args, device, rank, min_len):
             dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
             loaders.append(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
                                                 args.seq_len * args.n_negs, seed=seed, shuffle=False))
+        elif n_users * args.seq_len * args.n_negs * 8 > (2 << 30):
+            # large negative blocks (config-5: k = 1024 -> 13 GB of ids per batch): drawn ONCE by the device sampler at
+            # start-up and pre-staged like the host-built ones (the host generator rejects per user in numpy: minutes)
+            from recguru_amd import sampler
+            seqs, val, test, _ = synthetic.make_users(n_users, args.items, args.seq_len, seed=seed, min_len=min_len)
+            dom = sampler.DeviceDomain(seqs, val, test, args.items, device)
+            loaders.append(list(sampler.DeviceLoader(dom, args.batch, args.seq_len, args.seq_len, args.items + 1,
+                                                     args.seq_len * args.n_negs, seed=seed, shuffle=False)))
         else:
             dom = synthetic.make_domain(n_users, args.items, args.seq_len, args.n_negs, seed=seed, min_len=min_len)
             loaders.append(synthetic.TensorLoader(dom, args.batch, device))

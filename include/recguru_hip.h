@@ -354,7 +354,11 @@ int rg_item_loss_bwd_binned(const rg_item_loss_args* args /* host */, long long 
  * aux_tok, gout, dE are not used.  Supported: d in {64,128,256} and 1+k rows that fit four register batches
  * (rg_item_loss_train_supported).  The backward is rg_scale_dev(dh, gout) + rg_item_loss_scatter_binned, which adds
  * gout[0] * (table gradient of coef) to dE by the same counting sort + LDS accumulation as rg_item_loss_bwd_binned
- * (same workspace size).  Results equal those of the two-call form bit for bit when gout == 1. */
+ * (same workspace size).  Results equal those of the two-call form bit for bit when gout == 1.
+ * rg_item_loss_train_supported: 1 = that register form; 2 = the ONLINE form (any k, sampled softmax only, e.g. config-5's
+ * k = 1024): running max / sum / sum_j exp(l_j - max) E[j] per position, rows still gathered once; it needs aux_tok [ntok]
+ * (receives the log-sum-exp) and leaves the RAW logits in coef; rg_item_loss_scatter_binned given the same aux_tok and sums
+ * turns them into the coefficients while it sorts the pairs. */
 int rg_item_loss_train_supported(int k, int d);
 int rg_item_loss_train(const rg_item_loss_args* args /* host */, float* coef, int dtype, void* stream);
 int rg_item_loss_scatter_binned(const rg_item_loss_args* args /* host */, const float* coef, long long table_rows,

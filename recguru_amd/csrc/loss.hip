@@ -407,6 +407,107 @@ __global__ __launch_bounds__(64 * LW) void item_loss_train_rows_kernel(rg_item_l
 }
 
 
+// Training form for ANY k (sampled softmax, mode RG_LOSS_SAMPLED_CE; config-5: k = 1024 rows of 512 B per position): the
+// 1 + k rows cannot wait in registers, so the softmax is taken ONLINE -- per lane group a running maximum, a running sum and a
+// running vector  A = sum_j exp(l_j - max) E[j]  that is rescaled whenever the maximum moves (the flash-attention
+// recurrence with the item rows as V) -- and the rows are still gathered exactly ONCE per position:
+//   loss_t = lse - l_0,    dh_t = (A / sum - E[pos]) * mask_t / count      (d loss / d h for label 0).
+// The coefficients of the table gradient need the final lse, which is not known while the rows pass by: the kernel leaves
+// the RAW logits in cbuf and lse in aux_tok, and the binned scatter (bin_fill) forms c = (exp(l - lse) - [j == 0]) mask / count
+// from them while it sorts the pairs anyway.  The two-call form gathers the rows twice (0.47 TB each at config-5).
+template <typename T, int LPR>
+__global__ __launch_bounds__(64 * LW) void item_loss_train_online_kernel(rg_item_loss_args a, float* __restrict__ cbuf) {
+  constexpr int G = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const T* __restrict__ E = reinterpret_cast<const T*>(a.table);
+  T* __restrict__ dH = reinterpret_cast<T*>(a.dh);
+  const int d = a.d, k = a.k, n = a.k + 1;
+  const float gs = 1.f / a.sums[1];
+  float lsum = 0.f;
+  for (long long t = (long long)blockIdx.x * LW + wave; t < a.ntok; t += (long long)gridDim.x * LW) {
+    const float m = a.mask[t];
+    float dh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dh[j] = 0.f;
+    if (m != 0.f) {
+      float h[8], e0[8], A[8];
+      load8(h, H + (size_t)t * d + 8 * li);
+      const long long pos = a.pos[t];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { A[j] = 0.f; e0[j] = 0.f; }
+      float mx = -INFINITY, sm = 0.f, l0 = 0.f;          // per row group
+      for (int i0 = 0; i0 < n; i0 += G * RG_U) {
+        long long item[RG_U];
+        float e[RG_U][8];
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int idx = i0 + u * G + gi;
+          item[u] = (idx == 0 || idx >= n) ? pos : a.neg[t * k + idx - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) load8(e[u], E + (size_t)item[u] * d + 8 * li);
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int idx = i0 + u * G + gi;
+          float dot = 0.f;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) dot += e[u][j] * h[j];
+          dot = group_sum<LPR>(dot);
+          if (idx < n) {
+            if (idx == 0) {
+              l0 = dot;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) e0[j] = e[u][j];
+            }
+            if (li == 0) cbuf[t * n + idx] = dot;
+            const float nm = fmaxf(mx, dot);
+            const float r = __expf(mx - nm), p = __expf(dot - nm);     // (mx == -inf: r = 0, sm and A are still 0)
+            sm = sm * r + p;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) A[j] = A[j] * r + p * e[u][j];
+            mx = nm;
+          }
+        }
+      }
+      // combine the G row groups (a group that saw no row has mx = -inf and weight 0)
+      float M = mx;
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
+      const float wg = mx == -INFINITY ? 0.f : __expf(mx - M);
+      sm *= wg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) A[j] *= wg;
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        sm += __shfl_xor(sm, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A[j] += __shfl_xor(A[j], o);
+      }
+      l0 = __shfl(l0, 0);
+      const float lse = M + __logf(sm);
+      lsum += (lse - l0) * m;
+      if (lane == 0) a.aux_tok[t] = lse;
+      const float w = m * gs, inv = 1.f / sm;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dh[j] = (A[j] * inv - e0[j]) * w;       // e0 lives in group 0, which is the group that stores
+    } else if (lane == 0) {
+      a.aux_tok[t] = 0.f;
+    }
+    if (gi == 0) store8(dH + (size_t)t * d + 8 * li, dh);
+  }
+  __shared__ float red[LW];
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f;
+    for (int w = 0; w < LW; ++w) s0 += red[w];
+    if (s0 != 0.f) atomicAdd(a.sums, s0);
+  }
+}
+
+
 template <typename T>
 static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
   long long g = (a.ntok + LW - 1) / LW;
@@ -461,7 +562,10 @@ struct BinWs {
   int chunk;         // entries per accumulate work item
   uint2* ent;        // sorted entries: x = (position << RG_RPB_LOG) | row-in-bin, y = c as bits  (one 8-byte store / load)
   int nbins;
+  int bin_log;       // log2 of the table rows per bin: RG_RPB_LOG (64 rows), or RG_WIDE_LOG (256 rows) for catalogues beyond RG_MAXBINS * 64 rows
   const float* cscale;  // non-null: the c values are for gout = 1 and bin_fill multiplies them by cscale[0]
+  const float* lse;     // non-null (rg_item_loss_train's online form): c holds RAW logits; bin_fill forms
+  const float* count;   //   c = (exp(l - lse[t]) - [j == 0]) * mask[t] / count[0]
 };
 
 // The items of pairs p, p+256, p+512, p+768 (-1: masked position, skip row, or p >= p1).  Branch-free: clamped
@@ -496,7 +600,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, Bin
     pair_items4(a, p, p1, n, it);
 #pragma unroll
     for (int u = 0; u < RG_PB; ++u)
-      if (it[u] >= 0) atomicAdd(&lh[it[u] >> RG_RPB_LOG], 1);
+      if (it[u] >= 0) atomicAdd(&lh[it[u] >> w.bin_log], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < w.nbins; i += 256)
@@ -546,7 +650,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
     pair_items4(a, p, p1, n, it);
 #pragma unroll
     for (int u = 0; u < RG_PB; ++u)
-      if (it[u] >= 0) atomicAdd(&lh[it[u] >> RG_RPB_LOG], 1);
+      if (it[u] >= 0) atomicAdd(&lh[it[u] >> w.bin_log], 1);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < w.nbins; i += 256) {
@@ -560,14 +664,25 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
     float cv[RG_PB];
     pair_items4(a, p, p1, n, it);
 #pragma unroll
-    for (int u = 0; u < RG_PB; ++u) cv[u] = w.c[min(p + 256 * u, p1 - 1)] * gsc;
+    for (int u = 0; u < RG_PB; ++u) cv[u] = w.c[min(p + 256 * u, p1 - 1)];
+    if (w.lse) {          // raw logits -> softmax coefficients (uniform branch)
+      const float ic = 1.f / w.count[0];
+#pragma unroll
+      for (int u = 0; u < RG_PB; ++u) {
+        const long long pc = min(p + 256 * u, p1 - 1);
+        const long long t = pc / n;
+        cv[u] = (__expf(cv[u] - w.lse[t]) - (pc - t * n == 0 ? 1.f : 0.f)) * a.mask[t] * ic;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < RG_PB; ++u) cv[u] *= gsc;
 #pragma unroll
     for (int u = 0; u < RG_PB; ++u) {
       if (it[u] < 0) continue;
       const long long pu = p + 256 * u;
-      const int b = (int)(it[u] >> RG_RPB_LOG);
+      const int b = (int)(it[u] >> w.bin_log);
       const int e = base[b] + atomicAdd(&lh[b], 1);
-      w.ent[e] = make_uint2(((unsigned int)(pu / n) << RG_RPB_LOG) | (unsigned int)(it[u] & (RG_RPB - 1)), __float_as_uint(cv[u]));
+      w.ent[e] = make_uint2(((unsigned int)(pu / n) << w.bin_log) | (unsigned int)(it[u] & ((1 << w.bin_log) - 1)), __float_as_uint(cv[u]));
     }
   }
 }
@@ -773,14 +888,127 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
   }
 }
 
+// Large catalogues (table_rows > RG_MAXBINS * 64, e.g. 2 M items): bins of RG_WIDE_RPB = 256 rows keep the bin histograms of
+// count / fill inside LDS, and a [256][D] f32 accumulation tile would not fit -- so a work item is a LONGER run of one bin's
+// entries (RG_CHUNK_WIDE: ~32 entries per row at a uniform draw), counting-sorted by row inside LDS in two passes over the
+// entries (no per-thread arrays), and every row's sum leaves straight from the wave that formed it: through a per-wave LDS
+// row (so that the global adds are one dword per lane, 256 contiguous bytes per instruction: the shape the memory-side
+// float-atomic unit takes at full rate).  Per (position, item) pair the table gradient then costs one gather of h[t]
+// (2 bytes per element) plus 1 / (entries per row and chunk) of a 4-byte atomic per element.
+#define RG_WIDE_LOG 8
+#define RG_WIDE_RPB 256
+#define RG_CHUNK_WIDE 8192
+template <typename T, int LPR>
+__global__ __launch_bounds__(256) void bin_accumulate_wide_kernel(rg_item_loss_args a, BinWs w, long long table_rows) {
+  constexpr int CH = RG_CHUNK_WIDE, RB = RG_WIDE_RPB;
+  constexpr int G = 64 / LPR, D = LPR * 8, U = 4;
+  extern __shared__ float sm[];                     // sorted t [CH] | sorted c [CH] | row buffers [4][D]
+  int* st = reinterpret_cast<int*>(sm);
+  float* sc = sm + CH;
+  float* rowbuf = sm + 2 * CH;
+  __shared__ int cnt[RB], rstart[RB + 1], wsum[4];
+  __shared__ int s_bin, s_lo, s_hi, s_alone;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const int nchunks = w.chunk_start[w.nbins];
+  for (int ch = blockIdx.x; ch < nchunks; ch += gridDim.x) {
+    if (tid == 0) {
+      const int lo = w.chunk_bin[ch];
+      const int bs = w.start[lo], be = w.start[lo + 1];
+      const int e0 = bs + (ch - w.chunk_start[lo]) * CH;
+      s_bin = lo; s_lo = e0; s_hi = min(e0 + CH, be);
+      s_alone = be - bs <= CH;
+    }
+    cnt[tid] = 0;                                    // RB == 256 == blockDim
+    __syncthreads();
+    const int e0 = s_lo, e1 = s_hi, bin = s_bin;
+    const bool alone = s_alone != 0;
+    // ---- counting sort of the run by row-in-bin: histogram, scan, placement (the second read of the entries hits L2)
+    for (int e = e0 + tid; e < e1; e += 256) atomicAdd(&cnt[w.ent[e].x & (RB - 1)], 1);
+    __syncthreads();
+    {
+      const int v = cnt[tid];
+      int incl = v;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) { const int up = __shfl_up(incl, o); if (lane >= o) incl += up; }
+      if (lane == 63) wsum[wave] = incl;
+      __syncthreads();
+      int base = 0;
+      for (int i = 0; i < wave; ++i) base += wsum[i];
+      rstart[tid] = base + incl - v;
+      if (tid == 255) rstart[RB] = base + incl;
+      cnt[tid] = 0;
+    }
+    __syncthreads();
+    for (int e = e0 + tid; e < e1; e += 256) {
+      const uint2 en = w.ent[e];
+      const int r = (int)(en.x & (RB - 1));
+      const int p = rstart[r] + atomicAdd(&cnt[r], 1);
+      st[p] = (int)(en.x >> RG_WIDE_LOG);
+      sc[p] = __uint_as_float(en.y);
+    }
+    __syncthreads();
+    // ---- each wave sums whole rows in registers and sends them off itself
+    float* myrow = rowbuf + wave * D;
+    for (int r = wave; r < RB; r += 4) {
+      const int lo = rstart[r], hi = rstart[r + 1];
+      if (hi == lo) continue;
+      float s8[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s8[j] = 0.f;
+      for (int eb = lo + gi * U; eb < hi; eb += G * U) {
+        int t[U];
+        float c[U], h[U][8];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int e = min(eb + u, hi - 1);
+          t[u] = st[e];
+          c[u] = (eb + u < hi) ? sc[e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) load8(h[u], H + (size_t)t[u] * D + 8 * li);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s8[j] += c[u] * h[u][j];
+      }
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s8[j] += __shfl_xor(s8[j], o);
+      if (gi == 0) store8(myrow + 8 * li, s8);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");     // (same wave: LDS operations complete in order)
+      __builtin_amdgcn_wave_barrier();
+      const long long row = (long long)bin * RB + r;
+      if (row < table_rows) {
+        float* __restrict__ dst = a.dE + row * D;
+#pragma unroll
+        for (int i = 0; i < D / 64; ++i) {
+          const float v = myrow[lane + 64 * i];
+          if (v != 0.f) { if (alone) dst[lane + 64 * i] += v; else atomicAdd(dst + lane + 64 * i, v); }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+  }
+}
+
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 // bytes of workspace rg_item_loss_bwd_binned needs; 0 if the shape is not supported by the binned path
+static int bin_log_of(long long table_rows) {      // rows per bin: 64, or 256 for catalogues of more than RG_MAXBINS * 64 rows; 0: too large
+  if ((table_rows + RG_RPB - 1) / RG_RPB <= RG_MAXBINS) return RG_RPB_LOG;
+  if ((table_rows + RG_WIDE_RPB - 1) / RG_WIDE_RPB <= RG_MAXBINS) return RG_WIDE_LOG;
+  return 0;
+}
 extern "C" size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long table_rows) {
-  const long long nbins = (table_rows + RG_RPB - 1) / RG_RPB;
+  const int bl = bin_log_of(table_rows);
+  if (!bl) return 0;
+  const long long nbins = (table_rows + (1LL << bl) - 1) >> bl;
   const long long npairs = ntok * (k + 1);
-  if (!(d == 64 || d == 128 || d == 256) || nbins > RG_MAXBINS || npairs >= (1LL << 31) || ntok <= 0 ||
-      ntok >= (1LL << (32 - RG_RPB_LOG))) return 0;
+  if (!(d == 64 || d == 128 || d == 256) || npairs >= (1LL << 31) || ntok <= 0 || ntok >= (1LL << (32 - bl))) return 0;
   return align256(npairs * 4) + align256(npairs * 8) + align256((nbins + 1) * 4) * 4 + align256((nbins + npairs / RG_CHUNK_EMB + 1) * 4);
 }
 
@@ -790,14 +1018,20 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   const int n = a.k + 1;
   const long long npairs = a.ntok * n;
   const size_t need = rg_item_loss_bwd_binned_workspace(a.ntok, a.k, a.d, table_rows);
-  if (!need) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_bwd_binned: needs d in {64,128,256}, <= 8192 bins of 64 rows, < 2^31 pairs, < 2^26 positions");
+  if (!need) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_bwd_binned: needs d in {64,128,256}, <= 8192 bins of 64 (or 256) rows, < 2^31 pairs, < 2^26 (2^24) positions");
   if (!ws || ws_bytes < need) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_bwd_binned: workspace too small");
   BinWs w;
-  w.nbins = (int)((table_rows + RG_RPB - 1) / RG_RPB);
+  w.bin_log = bin_log_of(table_rows);
+  const bool wide = w.bin_log == RG_WIDE_LOG;
+  if (wide && drop) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_scatter_bwd_binned: tables of more than 524288 rows take the atomic form");
+  w.nbins = (int)((table_rows + (1LL << w.bin_log) - 1) >> w.bin_log);
   char* p = reinterpret_cast<char*>(ws);
   w.c = coef ? const_cast<float*>(coef) : reinterpret_cast<float*>(p); p += align256(npairs * 4);
   w.cscale = coef ? a.gout : nullptr;
-  w.chunk = drop ? RG_CHUNK_EMB : RG_CHUNK;
+  w.lse = coef ? a.aux_tok : nullptr;           // rg_item_loss_scatter_binned after the online training form
+  w.count = a.sums;
+  if (w.lse && !w.count) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_scatter_binned: aux_tok (lse of raw logits) needs sums");
+  w.chunk = drop ? RG_CHUNK_EMB : (wide ? RG_CHUNK_WIDE : RG_CHUNK);
   w.ent = reinterpret_cast<uint2*>(p); p += align256(npairs * 8);
   const size_t ib = align256((size_t)(w.nbins + 1) * 4);
   w.hist = reinterpret_cast<int*>(p); p += ib;
@@ -821,6 +1055,20 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w.nbins * 8);
   hipLaunchKernelGGL(bin_fill_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 8, s, a, w);
   // K5
+  if (wide) {
+    const size_t smw = (size_t)RG_CHUNK_WIDE * 8 + (size_t)4 * a.d * 4;
+#define RG_ACCW(LPR)                                                                                                 \
+  do {                                                                                                               \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(bin_accumulate_wide_kernel<T, LPR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smw); \
+    hipLaunchKernelGGL((bin_accumulate_wide_kernel<T, LPR>), dim3(256 * 2), dim3(256), smw, s, a, w, table_rows);      \
+  } while (0)
+    if (a.d == 64) RG_ACCW(8);
+    else if (a.d == 128) RG_ACCW(16);
+    else RG_ACCW(32);
+#undef RG_ACCW
+    RG_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t smem = (size_t)RG_RPB * a.d * 4 + (size_t)(drop ? RG_CHUNK_EMB : RG_CHUNK) * 8;
   const int ga = 256 * (int)(smem <= 40 * 1024 ? 4 : (smem <= 52 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1)));
 #define RG_ACC1(LPR, DR)                                                                                            \
@@ -856,16 +1104,29 @@ static int train_nit(int k, int d) {           // row batches the kernel keeps i
   const int per = (64 / (d / 8)) * RG_U, n = k + 1;
   return n <= per ? 1 : (n <= 2 * per ? 2 : (n <= 4 * per ? 4 : 0));
 }
-extern "C" int rg_item_loss_train_supported(int k, int d) { return train_nit(k, d) != 0; }
+// 1: the register form; 2: the online form (any k; sampled softmax only); 0: neither
+extern "C" int rg_item_loss_train_supported(int k, int d) {
+  if (!(d == 64 || d == 128 || d == 256)) return 0;
+  return train_nit(k, d) != 0 ? 1 : 2;
+}
 
 template <typename T>
 static int launch_train(const rg_item_loss_args& a, float* coef, hipStream_t s) {
   const int nit = train_nit(a.k, a.d);
-  if (!nit) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_train: needs d in {64,128,256} and 1+k <= 4 row batches (32 rows at d=256, 64 at 128, 128 at 64)");
+  if (!(a.d == 64 || a.d == 128 || a.d == 256)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_train: needs d in {64,128,256}");
   if (!coef || !a.dh || !a.sums) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_train: coef, dh and sums are required");
   long long g = (a.ntok + LW - 1) / LW;
   if (g > 256 * 32) g = 256 * 32;
   dim3 grid((int)g), block(64 * LW);
+  if (!nit) {       // more rows than four register batches: the online form
+    if (a.mode != RG_LOSS_SAMPLED_CE || !a.aux_tok)
+      return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_train: 1+k beyond 4 row batches takes the online form: sampled softmax only, aux_tok [ntok] required");
+    if (a.d == 64) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 8>), grid, block, 0, s, a, coef);
+    else if (a.d == 128) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 16>), grid, block, 0, s, a, coef);
+    else hipLaunchKernelGGL((item_loss_train_online_kernel<T, 32>), grid, block, 0, s, a, coef);
+    RG_CHECK_LAUNCH();
+    return 0;
+  }
 #define RG_TR(LPR)                                                                                           \
   do {                                                                                                       \
     if (nit == 1) hipLaunchKernelGGL((item_loss_train_rows_kernel<T, LPR, 1>), grid, block, 0, s, a, coef);  \
@@ -906,6 +1167,7 @@ extern "C" int rg_item_loss_scatter_binned(const rg_item_loss_args* a, const flo
 // the bench shape, bound by the chip-wide atomic rate; here a position is an entry with coefficient mask[t], and the
 // rows of a bin are summed in LDS and flushed once)
 extern "C" size_t rg_embed_scatter_binned_workspace(long long ntok, int d, long long table_rows) {
+  if (bin_log_of(table_rows) != RG_RPB_LOG) return 0;       // wide bins: item loss only (the atomic scatter serves large tables)
   return rg_item_loss_bwd_binned_workspace(ntok, 0, d, table_rows);
 }
 extern "C" int rg_embed_scatter_bwd_binned(const void* dx, const int64_t* ids, const float* mask, float* dE, long long ntok, int d,

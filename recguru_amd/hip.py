@@ -603,25 +603,29 @@ def item_loss_bwd_binned(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE,
 
 
 def item_loss_train_supported(k, d):
-    return bool(lib().rg_item_loss_train_supported(int(k), int(d)))
+    """0: no training form; 1: the register form; 2: the online form (any k, sampled softmax only; needs lse)."""
+    return int(lib().rg_item_loss_train_supported(int(k), int(d)))
 
 
-def item_loss_train(h, table, pos, neg, mask, k, mode, sums):
+def item_loss_train(h, table, pos, neg, mask, k, mode, sums, lse=None):
     """Loss sum into sums[0] (sums[1] = the mask count, set by the caller) plus, for an upstream gradient of 1,
-    the coefficients [ntok*(1+k)] f32 and dh [ntok,d]: one gather of the rows instead of two."""
+    the coefficients [ntok*(1+k)] f32 and dh [ntok,d]: one gather of the rows instead of two.
+    lse [ntok] f32 (the online form, item_loss_train_supported() == 2): receives the log-sum-exp; coef then holds the RAW
+    logits, which item_loss_scatter_binned(..., lse=, sums=) converts."""
     ntok, d = h.shape
     assert h.is_contiguous() and table.is_contiguous() and table.dtype == h.dtype
     assert pos.dtype == torch.int64 and neg.dtype == torch.int64 and pos.numel() == ntok and neg.numel() == ntok * k
     coef = torch.empty(ntok * (k + 1), device=h.device, dtype=torch.float32)
     dh = torch.empty_like(h)
-    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), None, _p(sums), None, _p(dh), None, ntok, d, k,
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(lse), _p(sums), None, _p(dh), None, ntok, d, k,
                      mode, -1)
     _check(lib().rg_item_loss_train(ctypes.byref(a), _vp(coef), dt_of(h), _stream()), "rg_item_loss_train")
     return coef, dh
 
 
-def item_loss_scatter_binned(h, table_rows, pos, neg, mask, k, coef, gout, dE, skip_row=-1):
-    """dE += gout * (table gradient of coef), the K2..K5 half of item_loss_bwd_binned."""
+def item_loss_scatter_binned(h, table_rows, pos, neg, mask, k, coef, gout, dE, skip_row=-1, lse=None, sums=None):
+    """dE += gout * (table gradient of coef), the K2..K5 half of item_loss_bwd_binned.  lse / sums: coef holds raw logits
+    (the online training form)."""
     ntok, d = h.shape
     need = item_loss_bwd_binned_supported(ntok, k, d, table_rows)
     if not need:
@@ -630,7 +634,7 @@ def item_loss_scatter_binned(h, table_rows, pos, neg, mask, k, coef, gout, dE, s
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, device=h.device, dtype=torch.uint8)
         _BIN_WS[h.device] = ws
-    a = ItemLossArgs(_p(h), None, _p(pos), _p(neg), _p(mask), None, None, _p(gout), None, _p(dE), ntok, d, k, 0,
+    a = ItemLossArgs(_p(h), None, _p(pos), _p(neg), _p(mask), _p(lse), _p(sums), _p(gout), None, _p(dE), ntok, d, k, 0,
                      skip_row)
     _check(lib().rg_item_loss_scatter_binned(ctypes.byref(a), _vp(coef), c_ll(table_rows), _vp(ws), ctypes.c_size_t(need),
                                              dt_of(h), _stream()), "rg_item_loss_scatter_binned")

@@ -897,14 +897,20 @@ class ItemLoss(_Fn):
         # chip-wide float-atomic rate); small ones: one atomic row per (position, item) pair
         ntok = h2.shape[0]
         ctx.binned = ntok >= 65536 and bool(hip.item_loss_bwd_binned_supported(ntok, k, d, table.shape[0]))
-        ctx.fused = (FUSE_ITEM_LOSS_TRAIN and _needs_grad(ctx) and ctx.binned and hip.item_loss_train_supported(k, d))
+        form = hip.item_loss_train_supported(k, d) if (FUSE_ITEM_LOSS_TRAIN and _needs_grad(ctx) and ctx.binned) else 0
+        ctx.fused = form == 1 or (form == 2 and mode == hip.LOSS_SAMPLED_CE)
+        ctx.lse = None
         if ctx.fused:
-            # one gather of the 1+k rows serves the loss, the coefficients and dh (for gout = 1; backward scales)
+            # one gather of the 1+k rows serves the loss, the coefficients and dh (for gout = 1; backward scales); beyond four
+            # register batches of rows (config-5: k = 1024) the ONLINE form: coef then holds raw logits and lse their
+            # log-sum-exp, which the scatter turns into coefficients
             sums = torch.zeros(2, device=h2.device, dtype=torch.float32)
             hip.sum_into(mask, sums[1:2])
             if _DP is not None and _DP.world > 1:
                 _DP.global_count(sums[1:2])
-            coef, dh1 = hip.item_loss_train(h2, tab, pos, neg, mask, k, mode, sums)
+            if form == 2:
+                ctx.lse = torch.empty(ntok, device=h2.device, dtype=torch.float32)
+            coef, dh1 = hip.item_loss_train(h2, tab, pos, neg, mask, k, mode, sums, lse=ctx.lse)
             ctx.save_for_backward(h2, pos, neg, mask, coef, dh1, sums)
             ctx.consumed = False
             return sums[0] / sums[1]
@@ -924,7 +930,8 @@ class ItemLoss(_Fn):
             h2, pos, neg, mask, coef, dh1, sums = ctx.saved_tensors
             if not ctx.consumed:
                 ctx.consumed = True                  # dh1 is scaled in place: it serves ONE backward
-                hip.item_loss_scatter_binned(h2, table.shape[0], pos, neg, mask, k, coef, g1, dE, skip_row)
+                hip.item_loss_scatter_binned(h2, table.shape[0], pos, neg, mask, k, coef, g1, dE, skip_row,
+                                             lse=ctx.lse, sums=sums if ctx.lse is not None else None)
                 return hip.scale_dev(dh1, g1).view(shape), ret, None, None, None, None, None, None
             # a second backward through a retained graph: the two-call form, from scratch
             cnt = sums[1:2].clone()

@@ -356,11 +356,14 @@ def test_item_loss(dt, d, k, mode):
         torch.testing.assert_close(dE2, dE, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("V,ntok,k", [(1000, 5000, 30), (70000, 20000, 7)])
-def test_item_loss_bwd_binned_large(V, ntok, k):
-    """Many bins, several chunks per bin, skewed positives, a skip row: binned == atomic table gradient."""
+@pytest.mark.parametrize("V,ntok,k,d", [(1000, 5000, 30, 128), (70000, 20000, 7, 128),
+                                        (600000, 3000, 200, 256), (2000000, 1500, 1024, 256), (530000, 40000, 3, 64)])
+def test_item_loss_bwd_binned_large(V, ntok, k, d):
+    """Many bins, several chunks per bin, skewed positives, a skip row: binned == atomic table gradient.  Catalogues beyond
+    8192 x 64 rows (config-5: 2 M items, d = 256, k = 1024) take the 256-row bins (bin_accumulate_wide_kernel)."""
     from recguru_amd import hip
-    d, dt = 128, torch.bfloat16
+    dt = torch.bfloat16
+    assert hip.item_loss_bwd_binned_supported(ntok, k, d, V + 2)
     g0 = torch.Generator().manual_seed(V)
     h = rnd(ntok, d, dt=dt, scale=0.3, seed=1)
     table = rnd(V + 2, d, dt=dt, seed=2)
@@ -399,6 +402,43 @@ def test_embed_scatter_binned_equals_atomic_form(dt, V, ntok, d, drop_p):
     torch.testing.assert_close(dE2, dE1, rtol=1e-4, atol=1e-5)
     hip.embed_scatter_bwd_binned(dx, ids, mask, dE2, skip_row=0, drop_p=drop_p, seed=77)      # accumulates
     torch.testing.assert_close(dE2, 2 * dE1, rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d,k,gv,V", [(256, 200, 1.0, 1500), (128, 300, 0.7, 900), (64, 1024, 1.0, 5000), (256, 1024, 1.0, 600000)])
+def test_item_loss_train_online_form(dt, d, k, gv, V):
+    """Sampled softmax with more rows than the register form holds (config-5: k = 1024): rg_item_loss_train's ONLINE form
+    (running max / sum / weighted row sum; raw logits + lse out) + rg_item_loss_scatter_binned(lse=, sums=) against the
+    two-call form -- loss, dh and the table gradient -- and the logits / lse against torch."""
+    from recguru_amd import hip
+    ntok = 700
+    g0 = torch.Generator().manual_seed(d + k)
+    h = rnd(ntok, d, dt=dt, scale=0.3, seed=1)
+    table = rnd(V + 2, d, dt=dt, seed=2)
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok, k), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.4).float().cuda()
+    assert hip.item_loss_train_supported(k, d) == 2 and hip.item_loss_bwd_binned_supported(ntok, k, d, V + 2)
+    sums, aux = hip.item_loss_fwd(h, table, pos, neg, mask, k, 0)
+    gout = torch.full((1,), gv, device="cuda")
+    dE1, dE2 = torch.zeros(V + 2, d, device="cuda"), torch.zeros(V + 2, d, device="cuda")
+    dh1 = hip.item_loss_bwd_binned(h, table, pos, neg, mask, k, 0, aux, sums, gout, dE1, skip_row=3)
+    s2 = torch.zeros(2, device="cuda")
+    hip.sum_into(mask, s2[1:2])
+    lse = torch.empty(ntok, device="cuda")
+    logits, dh2 = hip.item_loss_train(h, table, pos, neg, mask, k, 0, s2, lse=lse)
+    torch.testing.assert_close(s2[0] / s2[1], sums[0] / sums[1], rtol=1e-5, atol=1e-6)
+    live = mask != 0
+    ref_l = torch.einsum("td,tkd->tk", h.float(), table[torch.cat([pos[:, None], neg], 1)].float())
+    torch.testing.assert_close(logits.view(ntok, k + 1)[live], ref_l[live], rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(lse[live], torch.logsumexp(ref_l, 1)[live], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(lse[live], aux[live], rtol=1e-5, atol=1e-5)
+    hip.scale_dev(dh2, gout)
+    hip.item_loss_scatter_binned(h, V + 2, pos, neg, mask, k, logits, gout, dE2, skip_row=3, lse=lse, sums=s2)
+    assert float(dE2[3].abs().max()) == 0.0 and float(dh2[~live].float().abs().max()) == 0.0
+    t = dict(rtol=1e-4, atol=1e-7) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-6)
+    torch.testing.assert_close(dh2.float(), dh1.float(), **t)
+    torch.testing.assert_close(dE2, dE1, rtol=2e-4, atol=1e-7)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
