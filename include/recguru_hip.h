@@ -70,6 +70,12 @@ typedef struct {
                                  (epilogue NONE) -- exact when the caller guarantees that those rows of A are all zero: the
                                  padded positions of a layer input (transformer.py:594 / :539 multiply every layer output by
                                  the pad mask, and the embedding by it, :105), whose Q / K / V rows are the biases */
+  /* c_hm_L > 0 (weight-stationary path only: bf16, N % 128 == 0, M = B * c_hm_L): C is written HEAD-MAJOR, as N / 128 tensors
+   * [B][4][c_hm_L][32] one after the other -- the 128-column block cb of row m = b * L + l goes to
+   * ((cb * B + b) * 4 + head) * L * 32 + l * 32, head = column / 32.  For the fused Q / K / V projection (N = 384) this is
+   * q | k | v [B, H = 4, L, 32]: a head's K (V, Q) tile is ONE contiguous run of L * 64 bytes, which the attention kernels
+   * stage by LDS-DMA (rg_attn_args.qkv_hm).  ldc is ignored. */
+  int c_hm_L;
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 
@@ -139,6 +145,13 @@ typedef struct {
    * are hot, and the data replaced by the bias rows) -- unwritten rows are cold lines, reading them cost more than the
    * projection saved by not writing them. */
   const int* first_live;
+  /* qkv_hm = 1 (bf16, qkv form, d_model = 128 / H = 4 not required): qkv is the head-major triple q | k | v, each [B, H, L, 32]
+   * (rg_gemm_nt_args.c_hm_L).  pad_rows (required then): [3 * H + 1][32] elements of the tier dtype -- row h: the Q bias of
+   * head h, row H + h: its K bias, row 2 H + h: its V bias, row 3 H: zeros.  Rows the kernel must not read from qkv
+   * (x_masked == 2: positions before first_live; rows >= L of the padded key range) are fetched from there instead: the
+   * K / V tiles are filled by LDS-DMA (one contiguous 1 KB per wave instruction), with nothing staged through registers. */
+  int qkv_hm;
+  const void* pad_rows;
 } rg_attn_args;
 int rg_attn_fwd(const rg_attn_args* args /* host */, int dtype, void* stream);
 int rg_attn_fwd_x_supported(int d, int dtype, float drop_p);

@@ -60,6 +60,25 @@ template <> struct VStage<__bf16> {
     for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
   }
 };
+// Head-major form (rg_attn_args.qkv_hm): the V tile is filled by LDS-DMA, which writes 1 KB per wave instruction CONTIGUOUSLY --
+// no row pad.  Rows of exactly 64 bytes with the 16-byte chunks XOR-swizzled by 2 * ((row >> 2) & 1): the 32 lanes of a
+// ds_read_b64_tr_b16 service group cover 8 consecutive rows x 2 chunks, and rows r, r + 4 (same banks unswizzled) then use
+// disjoint chunk pairs.  The swizzle is applied to the DMA's per-lane SOURCE address and to these reads.
+struct VStageHM {
+  static __device__ __forceinline__ int off(int row, int col) {       // element offset of (row, col); col % 4 == 0
+    return row * DK + ((((col >> 3) ^ (((row >> 2) & 1) << 1)) & 3) << 3) + (col & 7);
+  }
+  static __device__ __forceinline__ void frag2(Frag<__bf16>& f, const __bf16* V, int kA, int kB, int dv0, int li, int lg) {
+    typedef __attribute__((ext_vector_type(4))) short s16x4;
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+    const int q = li >> 2, p = li & 3;
+    union { s16x4 s; bf16x4_t b; } u0, u1;
+    u0.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(V + off(kA + 4 * lg + q, dv0 + 4 * p)));
+    u1.s = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(V + off(kB + 4 * lg + q, dv0 + 4 * p)));
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
+  }
+};
 template <> struct VStage<float> {
   static constexpr bool TRANSPOSED = true;
   static __device__ __forceinline__ void frag(Frag<float>& f, const float* Vt, int ldv, int k0, int dv0, int li, int lg) {
@@ -131,7 +150,8 @@ __device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, con
 // the separate Q/K/V GEMM, its [M, 3P] write and this kernel's read of it disappear (the matrix pipe is idle > 90 % of
 // this kernel's time, so the 24 extra MFMAs per 16-key tile are free).  A Q tile goes to the wave's own rows of the ctx
 // output (which it overwrites with the context later) and comes back through the same prefetch that read qkv.
-template <typename T, int NKT, bool CAUSAL, int DM, bool XIN = false>
+// HM: head-major qkv (rg_attn_args.qkv_hm; bf16): a head's K / V / Q tiles are contiguous runs, K and V arrive by LDS-DMA.
+template <typename T, int NKT, bool CAUSAL, int DM, bool XIN = false, bool HM = false>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #ifdef RG_STAMP
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -145,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   constexpr int LDK = sizeof(T) == 2 ? DK : DK + 8;
   auto kofs = [](int row, int chunk) { return sizeof(T) == 2 ? row * DK + ((chunk ^ ((-(row >> 2)) & 3)) << 3) : row * (DK + 8) + chunk * 8; };
   constexpr bool VT = VStage<T>::TRANSPOSED;
-  constexpr int LDV = VT ? LPK + 8 : DK + 8;
+  static_assert(!HM || (sizeof(T) == 2 && !XIN), "head-major staging: bf16 qkv form");
+  constexpr int LDV = VT ? LPK + 8 : (HM ? DK : DK + 8);
   constexpr int VELEMS = VT ? DK * LDV : LPK * LDV;
   __shared__ __align__(16) T Ks[LPK * LDK];
   __shared__ __align__(16) T Vs[VELEMS];
@@ -160,18 +181,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   __shared__ __align__(8) unsigned int dlut[PLUT ? 32 : 2];
   __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
   __shared__ int zpre_s;              // ZKEYS: length of the leading run of zero-input keys (L if all of them are)
+  __shared__ int fix_s;               // HM: a row with rowmask == 0 at or behind first_live (not a left-padded sequence)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   int b, h;
   if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
-  const T* __restrict__ qkv = XIN ? nullptr : reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  const T* __restrict__ qkv = XIN ? nullptr : reinterpret_cast<const T*>(a.qkv) + (HM ? (size_t)0 : (size_t)b * L * ld);
+  // head-major: tensor w of head (b, h) starts at ((w * B + b) * H + h) * L * 32
+  const size_t hm_head = ((size_t)b * a.H + h) * L * DK, hm_tensor = (size_t)a.B * a.H * L * DK;
+  int first_hm = 0;                    // HM + x_masked == 2: rows before it are bias rows (loaded FIRST: the DMA addresses need it)
+  if constexpr (HM) {
+    if (a.x_masked == 2 && a.rowmask != nullptr && a.first_live) first_hm = min(a.first_live[b], L);
+  }
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
   const int nqt = (L + 15) / 16;
   DropCfg drop = make_drop(a.drop_p, a.seed);
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
-  if (tid == 0) { klo_s = L; zpre_s = L; }
+  if (tid == 0) { klo_s = L; zpre_s = L; fix_s = 0; }
   if (PLUT && tid < 16) {
     dlut[2 * tid] = ((tid & 1) ? 0xFFFFu : 0u) | ((tid & 2) ? 0xFFFF0000u : 0u);
     dlut[2 * tid + 1] = ((tid & 4) ? 0xFFFFu : 0u) | ((tid & 8) ? 0xFFFF0000u : 0u);
@@ -209,9 +237,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const int64_t kid = a.key_ids[(size_t)b * L + min(key, L - 1)];
     padk_r[i] = key < L && kid == a.pad_value;
     rmk_r[i] = 1.f;
-    if constexpr (ZKEYS) {
+    if constexpr (ZKEYS || HM) {
       const float* __restrict__ rmp2 = a.rowmask ? a.rowmask : reinterpret_cast<const float*>(a.qkv);
       rmk_r[i] = rmp2[a.rowmask ? (size_t)b * L + min(key, L - 1) : 0];
+    }
+  }
+  if constexpr (HM) {
+    // ---- K and V tiles of this head by LDS-DMA: 16 rows (1 KB, contiguous in LDS) per wave instruction, the chunk
+    // swizzles of the two images applied to the per-lane SOURCE address.  Rows the kernel must not read from qkv come from
+    // pad_rows instead: before first_live (x_masked == 2: such rows may be unwritten) the head's bias row, beyond L zeros.
+    const T* __restrict__ padr = reinterpret_cast<const T*>(a.pad_rows);
+    const T* __restrict__ kh = qkv + hm_tensor + hm_head;
+    const T* __restrict__ vh = qkv + 2 * hm_tensor + hm_head;
+    const T* __restrict__ kb_row = padr + (a.H + h) * DK;
+    const T* __restrict__ vb_row = padr + (2 * a.H + h) * DK;
+    const T* __restrict__ z_row = padr + 3 * a.H * DK;
+#pragma unroll
+    for (int j0 = 0; j0 < NKT; j0 += 4) {
+      const int j = j0 + wave;                       // 16-row piece of the tiles (wave-uniform)
+      if (j < NKT) {
+        const int row = j * 16 + (lane >> 2), cp = lane & 3;
+        const int ck = cp ^ ((-(row >> 2)) & 3), cv = cp ^ (((row >> 2) & 1) << 1);
+        const T* ksrc = row >= L ? z_row : (row < first_hm ? kb_row : kh + (size_t)row * DK);
+        const T* vsrc = row >= L ? z_row : (row < first_hm ? vb_row : vh + (size_t)row * DK);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + 8 * ck),
+                                         (__attribute__((address_space(3))) void*)(Ks + j * 16 * DK), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + 8 * cv),
+                                         (__attribute__((address_space(3))) void*)(Vs + j * 16 * DK), 16, 0, 0);
+      }
     }
   }
   // the head's dropout words: hashed HERE, under the latency of the mask / key-id loads above (at the top of the kernel,
@@ -316,7 +369,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       // the Q rows are read back by this same wave (global memory, its own rows of ctx): stores complete first
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-  } else {
+  } else if constexpr (!HM) {
   // ---- stage K and V of this head (raw 16/32-byte copies) and the key bias row
   // all of a batch's global loads are issued before its first LDS store: one HBM latency per batch of 4 chunks
   // per thread, not one per chunk (the rolled copy loop spent as long staging as computing)
@@ -382,11 +435,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     kbias[key] = key >= L ? -INFINITY : (pad ? MASK_BIG : 0.f);
     if (CAUSAL && key < L && !pad) atomicMin(&klo_s, key);
     if (ZKEYS && key < L && (pad || rmk_r[i] != 0.f)) atomicMin(&zpre_s, key);      // the prefix ends at the first other key
+    if (HM && a.x_masked == 2 && a.rowmask != nullptr && key < L && key >= first_hm && rmk_r[i] == 0.f) fix_s = 1;
   }
   // first live tile's Q fragment: in flight across the barrier.  Q rows: columns h*32.. of qkv, or (XIN) this wave's
   // own rows of ctx
-  const T* __restrict__ qsrc = XIN ? reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK : qkv + h * DK;
-  const int qld = XIN ? P : ld;
+  const T* __restrict__ qsrc = XIN ? reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK
+                                   : (HM ? qkv + hm_head : qkv + h * DK);
+  const int qld = XIN ? P : (HM ? DK : ld);
   Frag<T> qnext;
   frag_zero(qnext);
   if (wl) {
@@ -394,7 +449,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     if (q < L) load_frag(qnext, qsrc + (size_t)q * qld + 8 * lg);
   }
   const unsigned int wl0 = wl;
+  if constexpr (HM) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed
   lds_barrier();
+  if constexpr (HM) {
+    if (fix_s) {
+      // rare: rowmask == 0 at or behind first_live (not a left-padded sequence) -- those rows of qkv may be unwritten too:
+      // the bias rows are written over what the DMA brought
+      const T* __restrict__ padr = reinterpret_cast<const T*>(a.pad_rows);
+      for (int c = tid; c < L * 4; c += 256) {
+        const int row = c >> 2, ch = c & 3;
+        if (row >= first_hm && a.rowmask[(size_t)b * L + row] == 0.f) {
+          *reinterpret_cast<Frag<T>*>(Ks + kofs(row, ch)) = *reinterpret_cast<const Frag<T>*>(padr + (a.H + h) * DK + 8 * ch);
+          *reinterpret_cast<Frag<T>*>(Vs + VStageHM::off(row, 8 * ch)) = *reinterpret_cast<const Frag<T>*>(padr + (2 * a.H + h) * DK + 8 * ch);
+        }
+      }
+      lds_barrier();
+    }
+  }
   const int klo = klo_s;
   const int nz = zkeys ? (__builtin_amdgcn_readfirstlane(zpre_s) >> 4) : 0;        // leading key tiles made of zero-input keys only
   const int nskip = nz >= 2 ? (nz - 1) * 16 : 0;   // keys of tiles 1 .. nz-1, folded into key 0
@@ -577,7 +648,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
               Frag<T> vf;
-              VStage<T>::frag2(vf, Vs, LDV, tA * 16, tB * 16, dt * 16, li, lg);
+              if constexpr (HM) VStageHM::frag2(vf, Vs, tA * 16, tB * 16, dt * 16, li, lg);
+              else VStage<T>::frag2(vf, Vs, LDV, tA * 16, tB * 16, dt * 16, li, lg);
               mma(vf, pf, o[dt]);
             }
           }
@@ -1239,6 +1311,34 @@ static int launch_fwd_x(const rg_attn_args& a, hipStream_t s) {
   return 0;
 }
 
+// head-major qkv (bf16): K / V tiles by LDS-DMA
+static int launch_fwd_hm(const rg_attn_args& a, hipStream_t s) {
+  const int nkt = (a.L + 31) / 32 * 2;
+  dim3 grid(rg_head_grid(a.B, a.H)), block(256);
+  const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+#define RG_FWDH2(N, C)                                                                                          \
+  do {                                                                                                          \
+    if (dm == 0) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, N, C, 0, false, true>), grid, block, 0, s, a);     \
+    else if (dm == 1) hipLaunchKernelGGL((attn_fwd_kernel<__bf16, N, C, 1, false, true>), grid, block, 0, s, a); \
+    else hipLaunchKernelGGL((attn_fwd_kernel<__bf16, N, C, 2, false, true>), grid, block, 0, s, a);             \
+  } while (0)
+#define RG_FWDH(N)                       \
+  do {                                   \
+    if (a.causal) RG_FWDH2(N, true);     \
+    else RG_FWDH2(N, false);             \
+  } while (0)
+  if (nkt <= 4) RG_FWDH(4);
+  else if (nkt <= 8) RG_FWDH(8);
+  else if (nkt <= 14) RG_FWDH(14);
+  else if (nkt <= 16) RG_FWDH(16);
+  else if (nkt <= 26) RG_FWDH(26);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: L > 416 not supported yet");
+#undef RG_FWDH
+#undef RG_FWDH2
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+
 extern "C" int rg_attn_fwd_x_supported(int d, int dtype, float drop_p) {
   return dtype == RG_BF16 && d == 128 && (drop_p <= 0.f || drop_p == 0.5f);
 }
@@ -1326,6 +1426,10 @@ extern "C" int rg_attn_fwd(const rg_attn_args* a, int dtype, void* stream) {
       return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: the x-input form needs bf16, d_model 128, dropout 0 or 0.5, wqkv and bqkv");
     if (a->lse) return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: the x-input form is inference only (lse must be NULL)");
     return launch_fwd_x(*a, (hipStream_t)stream);
+  }
+  if (a->qkv_hm) {
+    if (dtype != RG_BF16 || !a->pad_rows) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_fwd: qkv_hm is a bf16 form and needs pad_rows");
+    return launch_fwd_hm(*a, (hipStream_t)stream);
   }
   if (dtype == RG_BF16) return launch_fwd<__bf16>(*a, (hipStream_t)stream);
   if (dtype == RG_F32) return launch_fwd<float>(*a, (hipStream_t)stream);

@@ -33,6 +33,16 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   T* __restrict__ C = reinterpret_cast<T*>(a.C);
   const int n0 = wave * 32;
   const int ntiles = (a.M + WS_M - 1) / WS_M;
+  // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: block cb
+  // = tensor cb of [B][4][L][32], head = c8 / 32 -- four consecutive rows of one head are 256 contiguous bytes)
+  const int hmL = a.c_hm_L, hmB = hmL > 0 ? a.M / hmL : 0;
+  auto c_off = [&](int m, int cb, int c8) -> size_t {
+    if (hmL > 0) {
+      const int bb = m / hmL, l = m - bb * hmL;
+      return ((size_t)((cb * hmB + bb) * 4 + (c8 >> 5)) * hmL + l) * 32 + (c8 & 31);
+    }
+    return (size_t)m * a.ldc + cb * 128 + c8;
+  };
 
   // ---- stationary weights: w[cb][kc][ks][ct]
   Frag<T> w[NCB][NKC][4][2];
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8;
             const int m = mb[i] + (tid >> 4);
             if (m < a.M) {
-              const size_t off = (size_t)m * a.ldc + cb * 128 + c8;
+              const size_t off = c_off(m, cb, c8);
               if constexpr (!AUX) {
                 if (a.epilogue == RG_EPI_NONE) {
                   *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
           if (m < a.M) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              *reinterpret_cast<Frag<T>*>(C + (size_t)m * a.ldc + cb * 128 + (tid & 15) * 8) = z[cb];
+              *reinterpret_cast<Frag<T>*>(C + c_off(m, cb, (tid & 15) * 8)) = z[cb];
           }
         }
       }
@@ -246,6 +256,7 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;   // dropout-after-ReLU lives in the generic kernel
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
   if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
+  if (a->c_hm_L > 0 && (a->M % a->c_hm_L) != 0) return 0;
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;

@@ -1029,7 +1029,7 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   w.c = coef ? const_cast<float*>(coef) : reinterpret_cast<float*>(p); p += align256(npairs * 4);
   w.cscale = coef ? a.gout : nullptr;
   w.lse = coef ? a.aux_tok : nullptr;           // rg_item_loss_scatter_binned after the online training form
-  w.count = a.sums;
+  w.count = a.sums ? a.sums + 1 : nullptr;      // sums[1]: the mask count
   if (w.lse && !w.count) return rg_set_error_msg(RG_ERR_INVALID, "item_loss_scatter_binned: aux_tok (lse of raw logits) needs sums");
   w.chunk = drop ? RG_CHUNK_EMB : (wide ? RG_CHUNK_WIDE : RG_CHUNK);
   w.ent = reinterpret_cast<uint2*>(p); p += align256(npairs * 8);

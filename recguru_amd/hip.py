@@ -27,7 +27,7 @@ class GemmNtArgs(ctypes.Structure):
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
                 ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p),
-                ("skip_dead_fill", c_i)]
+                ("skip_dead_fill", c_i), ("c_hm_L", c_i)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -39,7 +39,8 @@ class GemmTnArgs(ctypes.Structure):
 class AttnArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("key_ids", c_p), ("pad_value", c_l), ("causal", c_i), ("ctx", c_p), ("lse", c_p),
                 ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f), ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p),
-                ("x", c_p), ("wqkv", c_p), ("bqkv", c_p), ("d", c_i), ("x_masked", c_i), ("first_live", c_p)]
+                ("x", c_p), ("wqkv", c_p), ("bqkv", c_p), ("d", c_i), ("x_masked", c_i), ("first_live", c_p),
+                ("qkv_hm", c_i), ("pad_rows", c_p)]
 
 
 class AttnBwdArgs(ctypes.Structure):
@@ -155,11 +156,13 @@ POISON_UNWRITTEN = False
 
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
             gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
-            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False):
+            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False, headmajor_L=0):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N].  live: list of live 16-row tiles
     (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill=True
     (only for outputs whose consumers are all list- or rowmask-driven), or come out as the bias row with
-    skip_dead_fill=2 (exact when those rows of A are zero)."""
+    skip_dead_fill=2 (exact when those rows of A are zero).
+    headmajor_L = L > 0 (weight-stationary shapes only): C comes out head-major, as N / 128 tensors [M / L, 4, L, 32]
+    (rg_gemm_nt_args.c_hm_L) -- returned as a [N / 128, M / L, 4, L, 32] tensor."""
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.dtype == A.dtype
@@ -169,14 +172,18 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
             out.fill_(float("nan"))
     if M == 0:
         return out
+    if headmajor_L:
+        assert N % 128 == 0 and M % headmajor_L == 0 and out.is_contiguous() and not out_f32
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0)
+                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L))
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
+    if headmajor_L:
+        return out.view(N // 128, M // headmajor_L, 4, headmajor_L, 32)
     return out
 
 
@@ -218,18 +225,28 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     return dW
 
 
-def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False, bqkv=None):
+def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False, bqkv=None,
+             pad_rows=None):
     """qkv [B,L,3*H*32] -> ctx [B,L,H*32], lse [B,H,L] (f32).  x_masked: the K / V rows at positions with rowmask == 0
     are all identical (the projection of an all-zero input row = the bias): a leading run of such keys is folded into one.
-    bqkv (with x_masked): those rows of qkv may be UNWRITTEN -- the kernel substitutes the bias rows [3*H*32] f32."""
-    B, L, P3 = qkv.shape
-    assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
+    bqkv (with x_masked): those rows of qkv may be UNWRITTEN -- the kernel substitutes the bias rows [3*H*32] f32.
+    Head-major form: qkv [3,B,H,L,32] (gemm_nt(headmajor_L=L)) with pad_rows [3*H+1,32] (bias rows of q | k | v per head
+    and a zero row, tier dtype): K / V tiles staged by LDS-DMA (rg_attn_args.qkv_hm)."""
+    hm = qkv.dim() == 5
+    if hm:
+        _, B, Hq, L, dk = qkv.shape
+        assert Hq == H and dk == 32 and pad_rows is not None and pad_rows.shape == (3 * H + 1, 32) and pad_rows.dtype == qkv.dtype
+        assert qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
+    else:
+        B, L, P3 = qkv.shape
+        assert P3 == 3 * H * 32 and qkv.is_contiguous() and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=qkv.device, dtype=qkv.dtype)
     lse = torch.empty(B, H, L, device=qkv.device, dtype=torch.float32) if need_lse else None
     a = AttnArgs(_p(qkv), _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), _p(lse), B, L, H, 32,
                  1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), None, None, _p(bqkv) if x_masked else None, 0,
                  (2 if bqkv is not None else 1) if (x_masked and rowmask is not None) else 0,
-                 _p(first_live(rowmask, B, L)) if (x_masked and rowmask is not None and bqkv is not None) else None)
+                 _p(first_live(rowmask, B, L)) if (x_masked and rowmask is not None and bqkv is not None) else None,
+                 1 if hm else 0, _p(pad_rows) if hm else None)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 
@@ -246,7 +263,7 @@ def attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=0.0, seed=0,
     assert bqkv.dtype == torch.float32 and bqkv.numel() == 3 * H * 32 and key_ids.dtype == torch.int64 and key_ids.is_contiguous()
     ctx = torch.empty(B, L, H * 32, device=x.device, dtype=x.dtype)
     a = AttnArgs(None, _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), None, B, L, H, 32,
-                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)), None)
+                 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)), None, 0, None)
     _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(x), _stream()), "rg_attn_fwd")
     return ctx
 

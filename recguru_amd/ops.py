@@ -118,6 +118,19 @@ def bias_cat(ps):
     return ent[1]
 
 
+def pad_rows_cat(ps, H):
+    """[3 * H + 1, 32] operand-tier rows for the head-major attention form (rg_attn_args.pad_rows): the bias of head h of
+    q | k | v as rows h, H + h, 2 H + h, and a zero row; cached per parameter version like bias_cat."""
+    key = (tuple(id(p) for p in ps), _COMPUTE, "pad_rows")
+    ver = tuple(_ver(p) for p in ps)
+    ent = _SHADOWS.get(key)
+    if ent is None or ent[0] != ver or any(r() is not p for r, p in zip(ent[2], ps)):
+        b = torch.cat([p.detach().reshape(H, 32) for p in ps] + [torch.zeros(1, 32, device=ps[0].device)], 0)
+        ent = (ver, b.to(_COMPUTE).contiguous(), tuple(weakref.ref(p) for p in ps))
+        _SHADOWS[key] = ent
+    return ent[1]
+
+
 def refresh_shadows(params):
     """Rebuild every cached shadow that involves one of `params` in ONE launch (rg_cast_multi) -- called by the
     optimizer right after its update, on the stream the update ran on, so that no forward pass pays a cast launch per
@@ -131,7 +144,7 @@ def refresh_shadows(params):
         if any(p is None for p in ps):
             dead.append(key)                            # its parameters are gone: drop the copy
             continue
-        if key[-1] == "bias_cat":                       # f32 concatenations: rebuilt lazily (bias_cat)
+        if key[-1] in ("bias_cat", "pad_rows"):         # small concatenations: rebuilt lazily (bias_cat, pad_rows_cat)
             continue
         if key[2] != _COMPUTE or not any(id(p) in ids for p in ps) or ps[0].dim() != 2 or not ps[0].is_cuda:
             continue
@@ -481,6 +494,7 @@ def _lo_out(sv, shape):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
+QKV_HEAD_MAJOR = True        # inference passes: head-major q | k | v + LDS-DMA staging in the attention forward
 EMBED_SCATTER_BINNED = True  # rg_embed_scatter_bwd_binned at >= 65536 positions
 FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
@@ -521,6 +535,14 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     # (allow_unwritten: the caller's consumer of ctx is list-driven too -- the fused block; the rows of ctx in padded
     # tiles are then placeholders computed from unwritten Q rows)
     sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten
+    if (QKV_HEAD_MAJOR and not need_grad and _COMPUTE == torch.bfloat16 and H == 4 and x2.shape[1] == 128
+            and x2.shape[0] >= 4096):
+        # inference passes (nothing saved for a backward): the projection writes q | k | v HEAD-MAJOR ([3, B, H, L, 32]: a head's
+        # K / V tile is one contiguous run) and the attention kernel fills its LDS tiles by LDS-DMA
+        qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2, headmajor_L=L)
+        ctx_, _ = hip.attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=False, drop_p=drop_p, seed=seed, rowmask=rowmask,
+                               x_masked=x_masked, bqkv=bqkv if sub else None, pad_rows=pad_rows_cat((bq, bk, bv), H))
+        return None, ctx_, None
     qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
                              rowmask=rowmask, x_masked=x_masked, bqkv=bqkv if sub else None)

@@ -1165,6 +1165,54 @@ def test_attention_substitutes_bias_rows_for_unwritten_qkv(causal, drop_p):
     assert torch.equal(d1, d0)
 
 
+@pytest.mark.parametrize("causal", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.5, 0.3])
+@pytest.mark.parametrize("L,interior", [(200, False), (200, True), (50, False), (120, True), (400, False)])
+def test_attention_head_major_equals_token_major(causal, drop_p, L, interior):
+    """Head-major q | k | v ([3, B, H, L, 32], written by the weight-stationary projection with c_hm_L) + LDS-DMA staging in the
+    attention forward: the same arithmetic on the same values as the token-major form -- bit-identical context rows.  With a
+    live-tile list the padded tiles stay UNWRITTEN (NaN here): rows before first_live come from pad_rows; `interior` puts
+    rowmask == 0 rows behind first_live too (the fix-up pass)."""
+    from recguru_amd import hip, ops
+    dt = torch.bfloat16
+    H, d = 4, 128
+    B = max(6, (16384 + L - 1) // L + 1)
+    P = H * 32
+    g0 = torch.Generator().manual_seed(L + int(causal))
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 3
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    if interior:
+        ids[torch.rand(B, L, generator=g0) < 0.03] = 0
+    ids = ids.cuda()
+    pad_value = 0 if causal else 51
+    rowmask = (ids != 0).float().view(-1).contiguous()
+    M = B * L
+    x = ((torch.randn(M, d, generator=g0) * 0.8).cuda() * rowmask.view(M, 1)).to(dt).contiguous()
+    w = (torch.randn(3 * P, d, generator=g0) / d ** 0.5).to(dt).cuda()
+    bias = (torch.randn(3 * P, generator=g0) * 0.3).cuda()
+    pad_rows = torch.cat([bias.view(3 * H, 32), torch.zeros(1, 32, device="cuda")], 0).to(dt).contiguous()
+    live = hip.live_tiles(rowmask, M)
+    kw = dict(drop_p=drop_p, seed=5, rowmask=rowmask)
+    for fill in (2, 1):                 # padded tiles filled with the bias row by the projection / left unwritten
+        tm = torch.full((M, 3 * P), float("nan"), device="cuda", dtype=dt)
+        hm = torch.full((M, 3 * P), float("nan"), device="cuda", dtype=dt)
+        hip.gemm_nt(x, w, bias, out=tm, live=live, skip_dead_fill=fill)
+        qh = hip.gemm_nt(x, w, bias, out=hm, live=live, skip_dead_fill=fill, headmajor_L=L)
+        assert qh.shape == (3, B, H, L, 32)
+        back = qh.permute(1, 3, 0, 2, 4).reshape(M, 3 * P)             # [B, L, 3, H, 32]
+        same = (back == tm) | (torch.isnan(back.float()) & torch.isnan(tm.float()))
+        assert bool(same.all())
+        sub = dict(x_masked=True, bqkv=bias) if fill == 1 else dict(x_masked=True)
+        ref, _ = hip.attn_fwd(tm.view(B, L, 3 * P), ids, pad_value, causal, H, need_lse=False, **sub, **kw)
+        got, _ = hip.attn_fwd(qh, ids, pad_value, causal, H, need_lse=False, pad_rows=pad_rows, **sub, **kw)
+        lv = rowmask.view(B, L) != 0
+        assert torch.isfinite(ref[lv].float()).all()
+        assert torch.equal(got[lv], ref[lv])
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("drop_p", [0.0, 0.5])
 def test_attn_lastq_folds_the_padded_prefix(dt, drop_p):
