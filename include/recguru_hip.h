@@ -376,6 +376,10 @@ int rg_item_loss_train_supported(int k, int d);
 int rg_item_loss_train(const rg_item_loss_args* args /* host */, float* coef, int dtype, void* stream);
 int rg_item_loss_scatter_binned(const rg_item_loss_args* args /* host */, const float* coef, long long table_rows,
                                 void* workspace, size_t workspace_bytes, int dtype, void* stream);
+/* nn.MSELoss()(a, b) (the overlapped-user term of the generator update, GURU/gan_training.py:28-35,:494-507) and its gradient
+ * in one pass: out[0] += mean((a - b)^2); da = 2 (a - b) / n = -db for an upstream gradient of 1 (either may be NULL).
+ * a, b, da, db: [n] of dtype, n % 8 == 0. */
+int rg_mse(const void* a, const void* b, float* out, void* da, void* db, long long n, int dtype, void* stream);
 /* x[0..n) *= s[0] with s on the device; no memory traffic when s[0] == 1.  n % 8 == 0. */
 int rg_scale_dev(void* x, long long n, const float* s /* device */, int dtype, void* stream);
 

@@ -452,14 +452,19 @@ def critic_step(pG, pD, cfg, seq_a, seq_b, opt_d, alpha):
     return d_cost.detach(), w_d.detach(), gp.detach()
 
 
-def generator_step(pG, pD, cfg, batch_a, batch_b, opt_g, collapsed=False):
-    """Generator update, gan_training.py:451-523 with overlap=False (main_2, :1010)."""
+def generator_step(pG, pD, cfg, batch_a, batch_b, opt_g, collapsed=False, overlap_pair=None):
+    """Generator update, gan_training.py:451-523.  overlap_pair = (enc_in_a, enc_in_b) of overlapped users: the MSE between
+    their two user embeddings (l2_constraint.forward_2 = nn.MSELoss, :28-35, :494-507; main_2 runs with overlap=False, :1010)."""
     opt_g.zero_grad()
     pDf = {k: v.detach() for k, v in pD.items()}          # p.requires_grad = False (:455-456)
     ae = get_user_embed(pG, cfg, batch_a[0], "a")
     be = get_user_embed(pG, cfg, batch_b[0], "b")
     g_dis = discriminator(pDf, ae).mean() - discriminator(pDf, be).mean()
     g_dis.backward()
+    if overlap_pair is not None:
+        oa = get_user_embed(pG, cfg, overlap_pair[0], "a")
+        ob = get_user_embed(pG, cfg, overlap_pair[1], "b")
+        ((oa - ob) ** 2).mean().backward()
     la = loss_ae_cross(pG, cfg, *batch_a, domain="a", collapsed=collapsed)
     lb = loss_ae_cross(pG, cfg, *batch_b, domain="b", collapsed=collapsed)
     la.backward()
@@ -511,8 +516,9 @@ def train_recon_x(pG, cfg, steps, data, warmup, betas=(0.9, 0.98), eps=1e-9, col
     return out, opt
 
 
-def train_gan_all(pG, pD, cfg, gan_loader, rec_loaders, iterations, domain="a", collapsed=False):
-    """gan_training.py:353-587 with overlap=False and no evaluation point inside the run: phase 2 for
+def train_gan_all(pG, pD, cfg, gan_loader, rec_loaders, iterations, domain="a", collapsed=False, train_overlap=None):
+    """gan_training.py:353-587 (train_overlap: the overlap=True form -- a list of ((enc_in, ...)_a, (enc_in, ...)_b) batches of
+    overlapped users, cycled as :494-499) with no evaluation point inside the run: phase 2 for
     iteration < int(0.6 * iterations) (CRITIC_ITERS critic updates, alpha = torch.rand(B, 1) from the CPU default
     generator as :39, then the generator update), phase 3 after that (opt_final_rec = Adam(1e-3, (0.9, 0.98)), :359;
     the rec iterator restarts from rec_loaders[1] once iteration > int(0.8 * iterations), :531-537).
@@ -525,18 +531,47 @@ def train_gan_all(pG, pD, cfg, gan_loader, rec_loaders, iterations, domain="a", 
     rec_task = _Loader(rec_loaders[0])
     rec_it = _Loader(gan_loader[0] if domain == "a" else gan_loader[1])
     p2, p3 = [], []
+    over_it = iter(train_overlap) if train_overlap is not None else None
     for iteration in range(int(iterations * 1.2)):
         if iteration < int(iterations * 0.6):
             for _ in range(CRITIC_ITERS):
                 sa, sb = a_it.next()[0], b_it.next()[0]
                 d_cost, w_d, _ = critic_step(pG, pD, cfg, sa, sb, opt_d, torch.rand(sa.shape[0], 1))
-            g_dis, la, lb = generator_step(pG, pD, cfg, a_it.next(), b_it.next(), opt_g, collapsed)
+            ba, bb = a_it.next(), b_it.next()
+            pair = None
+            if over_it is not None:
+                try:
+                    oa, ob = next(over_it)
+                except StopIteration:
+                    over_it = iter(train_overlap)
+                    oa, ob = next(over_it)
+                pair = (oa[0], ob[0])
+            g_dis, la, lb = generator_step(pG, pD, cfg, ba, bb, opt_g, collapsed, overlap_pair=pair)
             p2.append([float(d_cost), float(w_d), float(la), float(lb), float(g_dis)])
         else:
             rb = rec_task.next(restart=rec_loaders[1] if iteration > int(iterations * 0.8) else rec_loaders[0])
             l_bpr, l_rec = phase3_step(pG, cfg, rb, rec_it.next(), opt_final, domain, True, collapsed)
             p3.append([float(l_bpr), float(l_rec)])
     return p2, p3
+
+
+def recommendation_tune(pG, cfg, rec_loader, steps, domain="a", collapsed=False):
+    """gan_training.py:895-969 without its evaluation points: `steps` BPR steps on the recommender decoder of `domain` with
+    Adam(lr=0.006, betas=(0.9, 0.9)) over every generator parameter (:920), mask = (dec_in != pad) (:934-936 -- phase 3 of
+    train_gan_all uses dec_out), encoder state detached (fixed_enc); on exhaustion the iterator restarts from rec_loader[1]
+    only for domain "b" past half of the steps (:927-931).  Returns the loss of every step."""
+    opt = Adam({k: v for k, v in pG.items() if v.requires_grad}, 0.006, (0.9, 0.9))
+    it = _Loader(rec_loader[0])
+    out = []
+    for i in range(steps):
+        enc_in, dec_in, dec_out, n_items = it.next(restart=rec_loader[1] if (domain == "b" and i > int(steps / 2)) else rec_loader[0])
+        mask = nonpad(dec_in, cfg.pad_index).view(-1)
+        opt.zero_grad()
+        loss = loss_bpr_cross(pG, cfg, enc_in, dec_in, dec_out, n_items, mask, domain, True, collapsed)
+        loss.backward()
+        opt.step()
+        out.append(float(loss.detach()))
+    return out
 
 
 # ----------------------------------------------------------------------------------------------

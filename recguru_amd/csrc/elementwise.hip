@@ -1075,6 +1075,49 @@ extern "C" int rg_scale_dev(void* x, long long n, const float* s, int dtype, voi
              "scale_dev")
 }
 
+// nn.MSELoss()(a, b) of the overlapped-user term (gan_training.py:28-35,:494-507) with its gradient in the same pass:
+// out[0] += scale * sum (a - b)^2 / n ;  da = 2 scale (a - b) / n = -db  (for an upstream gradient of 1).  n % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void mse_kernel(const T* __restrict__ a, const T* __restrict__ b, float* __restrict__ out,
+                                                     T* __restrict__ da, T* __restrict__ db, long long n8, float inv_n) {
+  float acc = 0.f;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n8; i += (long long)gridDim.x * EW_BLOCK) {
+    float x[8], y[8], g[8];
+    load8(x, a + 8 * i);
+    load8(y, b + 8 * i);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = x[j] - y[j]; acc += d * d; g[j] = 2.f * inv_n * d; }
+    if (da) store8(da + 8 * i, g);
+    if (db) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) g[j] = -g[j];
+      store8(db + 8 * i, g);
+    }
+  }
+  acc = wave_sum(acc);
+  __shared__ float red[EW_BLOCK / 64];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < EW_BLOCK / 64; ++w) t += red[w];
+    atomicAdd(out, t * inv_n);
+  }
+}
+
+extern "C" int rg_mse(const void* a, const void* b, float* out, void* da, void* db, long long n, int dtype, void* stream) {
+  if (n <= 0) return 0;
+  if (n % 8 || !a || !b || !out) return rg_set_error_msg(RG_ERR_INVALID, "mse: n must be a multiple of 8; a, b and out non-null");
+  hipStream_t st = (hipStream_t)stream;
+  int grid = ew_grid(n / 8, EW_BLOCK);
+  if (grid > 1024) grid = 1024;
+  const float inv_n = 1.f / (float)n;
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL(mse_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, st, (const __bf16*)a, (const __bf16*)b, out, (__bf16*)da, (__bf16*)db, n / 8, inv_n),
+             hipLaunchKernelGGL(mse_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, st, (const float*)a, (const float*)b, out, (float*)da, (float*)db, n / 8, inv_n),
+             "mse")
+}
+
 extern "C" int rg_sum(const float* x, float* out, long long n, float scale, void* stream) {
   if (n <= 0) return 0;
   hipLaunchKernelGGL(sum_kernel, dim3(ew_grid(n, EW_BLOCK * 4)), dim3(EW_BLOCK), 0, (hipStream_t)stream, x, out, n, scale);

@@ -89,7 +89,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
-           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split"]
+           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -657,6 +657,16 @@ def item_loss_scatter_binned(h, table_rows, pos, neg, mask, k, coef, gout, dE, s
                                              dt_of(h), _stream()), "rg_item_loss_scatter_binned")
 
 
+def mse(a, b, want_grads=True):
+    """mean((a - b)^2) as a [1] f32 device tensor and (da, db) for an upstream gradient of 1 (rg_mse)."""
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous() and a.numel() % 8 == 0
+    out = torch.zeros(1, device=a.device, dtype=torch.float32)
+    da = torch.empty_like(a) if want_grads else None
+    db = torch.empty_like(b) if want_grads else None
+    _check(lib().rg_mse(_vp(a), _vp(b), _vp(out), _vp(da), _vp(db), c_ll(a.numel()), dt_of(a), _stream()), "rg_mse")
+    return out, da, db
+
+
 def scale_dev(x, s):
     """x *= s[0] in place (s: device f32 scalar); free when s[0] == 1."""
     assert x.is_contiguous() and s.dtype == torch.float32 and x.numel() % 8 == 0
@@ -1007,7 +1017,10 @@ def _work_gemm_tn(Y, X, *a, **k):
 
 
 def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, *a, **k):
-    B, L, P3 = qkv.shape
+    if qkv.dim() == 5:                  # head-major [3, B, H, L, 32]
+        B, L, P3 = qkv.shape[1], qkv.shape[3], 3 * qkv.shape[2] * 32
+    else:
+        B, L, P3 = qkv.shape
     return ("attn_fwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 4.0 * B * H * L * L * 32,
             B * L * (P3 + P3 // 3) * _esize(qkv))
 

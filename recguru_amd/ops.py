@@ -976,6 +976,30 @@ def bpr_loss(h, table, pos, neg, mask, k, skip_row=-1, sas=False):
 
 
 # ------------------------------------------------------------------------------------------------
+# K12: MSE between the embeddings of overlapped users (gan_training.py:28-35, :494-507)
+# ------------------------------------------------------------------------------------------------
+class MseLossFn(_Fn):
+    @staticmethod
+    def forward(ctx, a, b):
+        dt = torch.float32 if (a.dtype == torch.float32 or b.dtype == torch.float32) else a.dtype
+        a_, b_ = a.detach().to(dt).contiguous(), b.detach().to(dt).contiguous()
+        out, da, db = hip.mse(a_, b_, want_grads=_needs_grad(ctx))
+        ctx.g = (da, db, a.dtype, b.dtype)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        da, db, ta, tb = ctx.g
+        return ((da * gout).to(ta) if ctx.needs_input_grad[0] else None,
+                (db * gout).to(tb) if ctx.needs_input_grad[1] else None)
+
+
+def mse_loss(a, b):
+    """nn.MSELoss()(a, b) -- l2_constraint.forward_2 of the reference."""
+    return MseLossFn.run(a, b)
+
+
+# ------------------------------------------------------------------------------------------------
 # K9-K11: discriminator MLP and the W-GAN gradient penalty
 # ------------------------------------------------------------------------------------------------
 def _disc_fwd(x, W1, b1, W2, b2, W3, b3, W4, b4, drop_p=0.0, seeds=(0, 0, 0)):

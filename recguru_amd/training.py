@@ -399,9 +399,10 @@ def critic_phase(netG, netD, batches, opt_d, param, device, dp, overlap=True):
     return out
 
 
-def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, g_params=None):
-    """Generator update (gan_training.py:455-523, overlap=False): W-loss through D into the encoder,
-    plus the reconstruction loss of both domains; batch = (enc_in, dec_in, dec_out, n_items, bs, sl)."""
+def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, g_params=None, overlap_pair=None):
+    """Generator update (gan_training.py:455-523): W-loss through D into the encoder, [the MSE between the embeddings of the
+    overlapped users' two domains, :494-507, when overlap_pair = (enc_in_a, enc_in_b) is given,] plus the reconstruction
+    loss of both domains; batch = (enc_in, dec_in, dec_out, n_items, bs, sl)."""
     for p in netD.parameters():
         p.requires_grad = False
     dp.discard_pending()                         # exchanges an interrupted earlier step may have left behind
@@ -417,6 +418,12 @@ def generator_iteration(netG, netD, batch_a, batch_b, opt_g, param, device, dp, 
     else:
         g_dis_loss = mean(netD(ae)) - mean(netD(be))
     dp.scale_mean(g_dis_loss).backward()
+    if overlap_pair is not None:
+        over_ae = get_user_embed(netG, overlap_pair[0], "a", param, device, 0)
+        over_be = get_user_embed(netG, overlap_pair[1], "b", param, device, 0)
+        overlap_loss = ops.mse_loss(over_ae, over_be)                   # l2_func.forward_2 (:28-35)
+        dp.scale_mean(overlap_loss).backward()
+        generator_iteration.last_overlap_loss = overlap_loss.detach()
     mask_a = get_pad_mask(dout_a, param.pad_index, device)
     loss_recon_a = loss_ae(netG, in_a, din_a, dout_a, n_a, True, bs, sl, param, mask_a, device, domain="a")
     mask_b = get_pad_mask(dout_b, param.pad_index, device)
@@ -481,9 +488,8 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
     `evaluate(netG)` (optional) replaces it.  Every 100 iterations the scalar log is flushed to
     <result_path>/gan_loss/log.pkl (:583-586).  Under data parallelism the entry points hand every rank the SAME
     (unsharded) evaluation loader, so every rank computes the full metrics and rank 0 writes the pickle."""
-    if overlap:
-        raise NotImplementedError("overlap=True (MSE on overlapped users) is off in main_2 (gan_training.py:1010)")
     dp = dp or _NoDP()
+    over_it = iter(train_overlap) if overlap else None                            # :373
     g_params = list(netG.parameters())
     opt_final_rec = Adam(g_params, lr=0.001, betas=(0.9, 0.98))                  # :359
     k_val = [5, 10, 20]                                                         # :361
@@ -501,8 +507,16 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
             D_cost, Wasserstein_D = critic_phase(netG, netD, batches, opt_d, param, device, dp)
             ba = a_iter.next(device)
             bb = b_iter.next(device)
+            pair = None
+            if overlap:                                                         # :494-499: ((enc_in, ...)_a, (enc_in, ...)_b)
+                try:
+                    overlap_a, overlap_b = next(over_it)
+                except StopIteration:
+                    over_it = iter(train_overlap)
+                    overlap_a, overlap_b = next(over_it)
+                pair = (overlap_a[0].to(device), overlap_b[0].to(device))
             g_dis, lra, lrb = generator_iteration(netG, netD, ba[:4] + ba[6:], bb[:4] + bb[6:], opt_g, param,
-                                                  device, dp, g_params)
+                                                  device, dp, g_params, overlap_pair=pair)
             plot.plot(param.result_path + "/disc cost_%s" % date, D_cost)
             plot.plot(param.result_path + "/wasserstein distance_%s" % date, Wasserstein_D)
             plot.plot(param.result_path + "/join_recon_a%s" % date, lra)

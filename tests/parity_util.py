@@ -95,6 +95,38 @@ def curve_replay_oracle(z, dtype=torch.float32, collapsed=False):
     return np.array([[float(a), float(b)] for a, b in p1]), np.array(p2), np.array(p3), opt.lr
 
 
+def curve2_loaders(z, device=None):
+    """curves2: the four batch lists of curve_loaders plus the overlapped-user pairs in the reference's layout
+    ((enc_in, ...)_a, (enc_in, ...)_b) -- only element [0] of each side is read (gan_training.py:500-501)."""
+    ld = curve_loaders(z, device)
+    over = []
+    for i in range(z["over.enc_in_a"].shape[0]):
+        a, b = torch.as_tensor(z["over.enc_in_a"][i]), torch.as_tensor(z["over.enc_in_b"][i])
+        if device is not None:
+            a, b = a.to(device), b.to(device)
+        over.append(((a,), (b,)))
+    ld["over"] = over
+    return ld
+
+
+def curve2_replay_oracle(z, dtype=torch.float32, collapsed=False):
+    """curves2 through the oracle: train_gan_all with the overlap term (3 phase-2 + 3 phase-3 iterations), then
+    recommendation_tune.  Returns (phase2 [n,5], phase3 [n,2], tune losses [steps])."""
+    from oracle import recguru_oracle as O
+    m = curve_meta(z)
+    cfg = O.Cfg(m["d"], m["H"], m["N"], m["L"], m["k"], m["V_a"] + 1, m["V_b"] + 1, n_bpr_neg=m["nb"])
+    st = {tag: state_of(z, tag) for tag in ("G", "D")}
+    for dom in "ab":
+        st["G"]["pos_emb_%s.pe" % dom] = O.positional_table(5000, m["d"]).unsqueeze(0)
+    pG, pD = O.leafify(st["G"], dtype), O.leafify(st["D"], dtype)
+    ld = curve2_loaders(z)
+    torch.manual_seed(m["alpha_seed"])
+    p2, p3 = O.train_gan_all(pG, pD, cfg, [ld["ae_a"], ld["ae_b"]], [ld["rec0"], ld["rec1"]], m["iterations"], "a",
+                             collapsed=collapsed, train_overlap=ld["over"])
+    tune = O.recommendation_tune(pG, cfg, [ld["rec0"], ld["rec1"]], int(z["tune_steps"]), "a", collapsed=collapsed)
+    return np.array(p2), np.array(p3), np.array(tune)
+
+
 def curve_bands(z):
     """Per-series absolute tolerance for phases 2 / 3 of the curve fixture: 2 x the stored band + 2e-5.  The band
     (oracle/gen_golden_curves.py add_bands) is the largest deviation from the reference's own float32 values among

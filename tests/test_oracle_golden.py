@@ -253,3 +253,20 @@ def test_loss_curves_through_reference_drivers():
         np.testing.assert_allclose(p2[:, i], z["phase2." + nm], rtol=1e-3, atol=bands["phase2." + nm], err_msg=nm)
     np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
     np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-3, atol=bands["phase3.loss_recon_rec"])
+
+
+def test_overlap_term_and_recommendation_tune_through_reference_drivers():
+    """tests/golden/curves2.npz: the reference's train_gan_all(overlap=True) -- phase 2 with the MSE between the two user
+    embeddings of overlapped users (gan_training.py:28-35,:494-507) -- and recommendation_tune (:895-969), recorded through
+    the reference's own drivers (oracle/gen_golden_curves2.py), replayed by the oracle's restatement within the stored
+    rounding bands (2 x band + 2e-5, as for curves1)."""
+    from parity_util import curve2_replay_oracle, curve_bands
+    z = load_case("curves2")
+    p2, p3, tune = curve2_replay_oracle(z, torch.float32)
+    bands = curve_bands(z)
+    for i, nm in enumerate(("D_cost", "Wasserstein_D", "recon_a", "recon_b", "g_dis")):
+        np.testing.assert_allclose(p2[:, i], z["phase2." + nm], rtol=1e-4, atol=bands["phase2." + nm], err_msg=nm)
+    np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-4, atol=bands["phase3.loss_recommend"])
+    np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-4, atol=bands["phase3.loss_recon_rec"])
+    np.testing.assert_allclose(tune, z["tune.loss"], rtol=1e-4, atol=bands["tune.loss"])
+    assert p2.shape == (3, 5) and p3.shape == (3, 2) and tune.shape == (6,)

@@ -20,7 +20,8 @@ import pytest
 import torch
 
 from golden_util import GOLDEN_DIR, load_case, make_state
-from parity_util import (batches, case_param, curve_bands, curve_loaders, curve_meta, make_args, max_err, state_of)
+from parity_util import (batches, case_param, curve2_loaders, curve_bands, curve_loaders, curve_meta, make_args, max_err,
+                         state_of)
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -268,6 +269,51 @@ def test_loss_curves_replay(tier, capsys):
     # the scalar log carries the reference's series names (tools/plot.py layout)
     assert len(T.plot.values(param.result_path + "/disc cost_%s" % T.date)) == 5
     assert len(T.plot.values(param.result_path + "/tuning_recommendation_loss")) == 5
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16"])
+def test_overlap_term_and_recommendation_tune_replay(tier, capsys):
+    """curves2 (recorded through the reference's own drivers, oracle/gen_golden_curves2.py): the shipped train_gan_all with
+    overlap=True -- the MSE between the user embeddings of overlapped users in every generator update, the overlap loader
+    restarting on the third one -- followed by the shipped recommendation_tune (mask from dec_in, Adam(0.006, (0.9, 0.9))),
+    point by point.  f32: rtol 1e-3 + the fixture's rounding bands; bf16: the bounds of test_loss_curves_replay."""
+    from recguru_amd import ops, training as T
+    from recguru_amd.optim import Adam
+    ops.set_compute_dtype(TIERS[tier])
+    z = load_case("curves2")
+    m, param, G, D = _curve_models(z)
+    ld = curve2_loaders(z)
+    T.plot.reset()
+    opt_gen = Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    opt_dis = Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    torch.manual_seed(m["alpha_seed"])
+    hist = T.train_gan_all(G, D, [ld["ae_a"], ld["ae_b"]], opt_dis, opt_gen, "cuda", param, m["iterations"], ld["over"],
+                           [ld["rec0"], ld["rec1"]], None, domain="a", overlap=True)
+    p2 = np.array([[float(x) for x in row] for row in hist])
+    p3 = np.array([[float(x) for x in row] for row in hist.phase3])
+    param.eval_step = 10 ** 6
+    losses, _ = T.recommendation_tune(G, [ld["rec0"], ld["rec1"]], None, int(z["tune_steps"]), param, "cuda", "a")
+    tune = np.array([float(x) for x in losses])
+    assert p2.shape == (3, 5) and p3.shape == (3, 2) and tune.shape == (6,)
+    bands = curve_bands(z)
+    names2 = ("D_cost", "Wasserstein_D", "recon_a", "recon_b", "g_dis")
+    with capsys.disabled():
+        print("\n[curves2, %s tier] phase-2 max abs err %s | phase-3 %s | recommendation_tune max rel err %.3g" % (
+            tier, {n: "%.2g" % np.abs(p2[:, i] - z["phase2." + n]).max() for i, n in enumerate(names2)},
+            {n: "%.2g" % np.abs(p3[:, i] - z["phase3." + n]).max() for i, n in enumerate(("loss_recommend", "loss_recon_rec"))},
+            float(np.abs(tune / z["tune.loss"] - 1).max())))
+    if tier == "f32":
+        for i, n in enumerate(names2):
+            np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=bands["phase2." + n], err_msg=n)
+        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
+        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=1e-3, atol=bands["phase3.loss_recon_rec"])
+        np.testing.assert_allclose(tune, z["tune.loss"], rtol=1e-3, atol=bands["tune.loss"])
+    else:
+        for i, n in enumerate(names2):
+            np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=0.03, atol=6.5e-3, err_msg=n)
+        np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=0.05, atol=0)
+        np.testing.assert_allclose(p3[:, 1], z["phase3.loss_recon_rec"], rtol=0.03, atol=0)
+        np.testing.assert_allclose(tune, z["tune.loss"], rtol=0.08, atol=0)
 
 
 def test_recommendation_tune_and_log_layout(tmp_path):
