@@ -168,6 +168,8 @@ typedef struct {
    * bqkv [3*H*32] f32 (Q | K | V) stand in, bit for bit what the projection of an all-zero input row gives */
   const float* bqkv; int x_masked;
   const int* first_live;      /* optional [B], as in rg_attn_args */
+  int qkv_hm;                 /* 1: qkv is the head-major triple q | k | v, each [B, H, L, 32] (rg_attn_args.qkv_hm); dqkv stays
+                               * token-major [B, L, 3P].  bf16 tier. */
 } rg_attn_bwd_args;
 int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream);
 

@@ -924,7 +924,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   int b, h;
   if (!rg_head_of_block((int)blockIdx.x, a.B, a.H, b, h)) return;     // XCD-aware head pairing (rg_common.hip.h)
   const int L = a.L, P = a.H * DK, ld = 3 * P;
-  const T* __restrict__ qkv = reinterpret_cast<const T*>(a.qkv) + (size_t)b * L * ld;
+  // q / k / v rows of this head: token-major qkv [B, L, 3P] (row pitch ld) or head-major q | k | v [3][B][H][L][32] (qkv_hm: a
+  // head's rows are contiguous 64-byte runs -- the staging loads of a wave cover whole lines)
+  const size_t hm_tensor = (size_t)a.B * a.H * L * DK;
+  const T* __restrict__ qrow = reinterpret_cast<const T*>(a.qkv) + (a.qkv_hm ? ((size_t)b * a.H + h) * L * DK : (size_t)b * L * ld + h * DK);
+  const T* __restrict__ krow = qrow + (a.qkv_hm ? hm_tensor : (size_t)P);
+  const T* __restrict__ vrow = qrow + (a.qkv_hm ? 2 * hm_tensor : (size_t)(2 * P));
+  const int qld = a.qkv_hm ? DK : ld;
   const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
   const T* __restrict__ O = reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK;
   T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
@@ -976,9 +982,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
       const int rc = max(min(row, L - 1), first);     // clamped address, zeroed / replaced below: no branch between the loads
       rmr[i] = 1.f;
       if (i0 + i < NCH) {
-        load_frag(qr[i], qkv + (size_t)rc * ld + h * DK + c8);
-        load_frag(kr[i], qkv + (size_t)rc * ld + P + h * DK + c8);
-        load_frag(vr[i], qkv + (size_t)rc * ld + 2 * P + h * DK + c8);
+        load_frag(qr[i], qrow + (size_t)rc * qld + c8);
+        load_frag(kr[i], krow + (size_t)rc * qld + c8);
+        load_frag(vr[i], vrow + (size_t)rc * qld + c8);
         load_frag(gr[i], dO + (size_t)rc * P + c8);
         load_frag(orow[i], O + (size_t)rc * P + c8);
         const float x = rmp[a.rowmask ? (size_t)b * L + rc : 0];     // unconditional (see QLive::load)
@@ -1438,6 +1444,7 @@ extern "C" int rg_attn_fwd(const rg_attn_args* a, int dtype, void* stream) {
 extern "C" int rg_attn_bwd(const rg_attn_bwd_args* a, int dtype, void* stream) {
   if (!a || a->B <= 0 || a->L <= 0 || a->H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: empty problem");
   if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: d_k must be 32");
+  if (a->qkv_hm && dtype != RG_BF16) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: qkv_hm is a bf16 form");
   if (dtype == RG_BF16) return launch_bwd<__bf16>(*a, (hipStream_t)stream);
   if (dtype == RG_F32 && a->x_masked == 2)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: bias-row substitution (x_masked == 2) is a bf16-tier form");

@@ -46,7 +46,8 @@ class AttnArgs(ctypes.Structure):
 class AttnBwdArgs(ctypes.Structure):
     _fields_ = [("qkv", c_p), ("dctx", c_p), ("ctx", c_p), ("lse", c_p), ("key_ids", c_p), ("pad_value", c_l),
                 ("causal", c_i), ("dqkv", c_p), ("B", c_i), ("L", c_i), ("H", c_i), ("dk", c_i), ("scale", c_f),
-                ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p), ("bqkv", c_p), ("x_masked", c_i), ("first_live", c_p)]
+                ("drop_p", c_f), ("seed", c_u64), ("rowmask", c_p), ("bqkv", c_p), ("x_masked", c_i), ("first_live", c_p),
+                ("qkv_hm", c_i)]
 
 
 class PostAttnArgs(ctypes.Structure):
@@ -269,14 +270,16 @@ def attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=0.0, seed=0,
 
 
 def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, seed=0, rowmask=None, bqkv=None):
-    """bqkv: the forward ran with unwritten qkv rows at the positions with rowmask == 0 (attn_fwd's bqkv): same here."""
-    B, L, _ = qkv.shape
+    """bqkv: the forward ran with unwritten qkv rows at the positions with rowmask == 0 (attn_fwd's bqkv): same here.
+    qkv: [B,L,3*H*32], or head-major [3,B,H,L,32] (attn_fwd); dqkv is [B,L,3*H*32] either way."""
+    hm = qkv.dim() == 5
+    B, L = (qkv.shape[1], qkv.shape[3]) if hm else qkv.shape[:2]
     assert dctx.is_contiguous() and ctx.is_contiguous() and qkv.is_contiguous()
-    dqkv = torch.empty_like(qkv)
+    dqkv = torch.empty(B, L, 3 * H * 32, device=qkv.device, dtype=qkv.dtype)
     sub = bqkv is not None and rowmask is not None
     a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
                     _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(bqkv) if sub else None, 2 if sub else 0,
-                    _p(first_live(rowmask, B, L)) if sub else None)
+                    _p(first_live(rowmask, B, L)) if sub else None, 1 if hm else 0)
     _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
     return dqkv
 
@@ -1026,7 +1029,10 @@ def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, *a, **k):
 
 
 def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, *a, **k):
-    B, L, P3 = qkv.shape
+    if qkv.dim() == 5:
+        B, L, P3 = qkv.shape[1], qkv.shape[3], 3 * qkv.shape[2] * 32
+    else:
+        B, L, P3 = qkv.shape
     return ("attn_bwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 10.0 * B * H * L * L * 32,
             B * L * (2 * P3 + 2 * P3 // 3) * _esize(qkv))
 

@@ -494,7 +494,9 @@ def _lo_out(sv, shape):
 
 
 QKV_BIAS_ROWS_IN_ATTENTION = True
-QKV_HEAD_MAJOR = True        # inference passes: head-major q | k | v + LDS-DMA staging in the attention forward
+import os as _os0
+QKV_HEAD_MAJOR = not _os0.environ.get("RG_NO_HM")        # head-major q | k | v + LDS-DMA staging in the attention forward
+QKV_HEAD_MAJOR_TRAIN = not _os0.environ.get("RG_NO_HM_TRAIN")   # ... in training passes too (the backward reads head-major qkv)
 EMBED_SCATTER_BINNED = True  # rg_embed_scatter_bwd_binned at >= 65536 positions
 FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
@@ -535,14 +537,14 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     # (allow_unwritten: the caller's consumer of ctx is list-driven too -- the fused block; the rows of ctx in padded
     # tiles are then placeholders computed from unwritten Q rows)
     sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten
-    if (QKV_HEAD_MAJOR and not need_grad and _COMPUTE == torch.bfloat16 and H == 4 and x2.shape[1] == 128
-            and x2.shape[0] >= 4096):
-        # inference passes (nothing saved for a backward): the projection writes q | k | v HEAD-MAJOR ([3, B, H, L, 32]: a head's
-        # K / V tile is one contiguous run) and the attention kernel fills its LDS tiles by LDS-DMA
+    if (QKV_HEAD_MAJOR and _COMPUTE == torch.bfloat16 and H == 4 and x2.shape[1] == 128 and x2.shape[0] >= 4096
+            and (not need_grad or QKV_HEAD_MAJOR_TRAIN)):
+        # the projection writes q | k | v HEAD-MAJOR ([3, B, H, L, 32]: a head's K / V / Q tile is one contiguous run); the
+        # attention forward fills its LDS tiles by LDS-DMA, the backward's staging loads cover whole lines
         qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2, headmajor_L=L)
-        ctx_, _ = hip.attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=False, drop_p=drop_p, seed=seed, rowmask=rowmask,
-                               x_masked=x_masked, bqkv=bqkv if sub else None, pad_rows=pad_rows_cat((bq, bk, bv), H))
-        return None, ctx_, None
+        ctx_, lse = hip.attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed, rowmask=rowmask,
+                                 x_masked=x_masked, bqkv=bqkv if sub else None, pad_rows=pad_rows_cat((bq, bk, bv), H))
+        return qkv, ctx_, lse
     qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2)
     ctx_, lse = hip.attn_fwd(qkv.view(B, L, -1), key_ids, pad_value, causal, H, need_lse=need_grad, drop_p=drop_p, seed=seed,
                              rowmask=rowmask, x_masked=x_masked, bqkv=bqkv if sub else None)
@@ -585,7 +587,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     # the forward's decision (same inputs; x_masked == 2: it was the fused block's forward): were the padded tiles' rows of
     # qkv left unwritten?
     sub = QKV_BIAS_ROWS_IN_ATTENTION and x_masked == 2 and _zero_rows_live(rowmask, x2.shape[0], True, d, 3 * P) is not None
-    dqkv = hip.attn_bwd(qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
+    dqkv = hip.attn_bwd(qkv if qkv.dim() == 5 else qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
                         drop_p=drop_p, seed=seed, rowmask=rowmask, bqkv=bias_cat((bq, bk, bv)) if sub else None)
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))

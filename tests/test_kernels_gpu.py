@@ -1206,11 +1206,19 @@ def test_attention_head_major_equals_token_major(causal, drop_p, L, interior):
         same = (back == tm) | (torch.isnan(back.float()) & torch.isnan(tm.float()))
         assert bool(same.all())
         sub = dict(x_masked=True, bqkv=bias) if fill == 1 else dict(x_masked=True)
-        ref, _ = hip.attn_fwd(tm.view(B, L, 3 * P), ids, pad_value, causal, H, need_lse=False, **sub, **kw)
-        got, _ = hip.attn_fwd(qh, ids, pad_value, causal, H, need_lse=False, pad_rows=pad_rows, **sub, **kw)
+        ref, lse_ref = hip.attn_fwd(tm.view(B, L, 3 * P), ids, pad_value, causal, H, need_lse=True, **sub, **kw)
+        got, lse = hip.attn_fwd(qh, ids, pad_value, causal, H, need_lse=True, pad_rows=pad_rows, **sub, **kw)
         lv = rowmask.view(B, L) != 0
         assert torch.isfinite(ref[lv].float()).all()
         assert torch.equal(got[lv], ref[lv])
+        lm = lv.unsqueeze(1).expand(B, H, L)
+        assert torch.equal(lse[lm], lse_ref[lm])
+        # the backward reads the head-major triple through the same arithmetic: identical dqkv (token-major either way)
+        dctx = (torch.randn(B, L, P, generator=g0).cuda() * rowmask.view(B, L, 1)).to(dt)
+        bk = dict(bqkv=bias) if fill == 1 else {}
+        d0 = hip.attn_bwd(tm.view(B, L, 3 * P), dctx, ref, lse_ref, ids, pad_value, causal, H, **bk, **kw)
+        d1 = hip.attn_bwd(qh, dctx, got, lse, ids, pad_value, causal, H, **bk, **kw)
+        assert torch.isfinite(d0.float()).all() and torch.equal(d1, d0)
 
 
 @pytest.mark.parametrize("dt", DTYPES)
