@@ -7,7 +7,10 @@ error), run here on the CPU.  It restates the ENCODER path (embedding -> N layer
   * the tensors that travel through HBM between kernels stored in `resid` (bf16: today's tier; f32: VERDICT r2 item 2),
   * optionally the intra-kernel intermediates (LayerNorm-1 output as the FFN's residual) kept f32.
 
-  python tests/emulate_tiers.py [B]
+  python tests/emulate_tiers.py [B]                 default initialisation (uniform +-1/sqrt(fan_in), LayerNorm 1 / 0)
+  python tests/emulate_tiers.py --test-weights      the weights and users of tests/test_steps_gpu.py::test_bench_shape_steps_vs_oracle
+                                                    (seeded normal weights, LayerNorm gains 1 + 0.1 n, biases 0.1 n): the numbers
+                                                    to hold against that test's measured errors
 """
 import math
 import os
@@ -60,15 +63,31 @@ def encoder_last(p, cfg, enc_in, domain, mask, resid, y_f32, stores=("emb", "qkv
     return x[:, -1, :]
 
 
+def test_weights(L, d, H, N, V):
+    """The encoder-side parameters of the bench-shape gate (tests/test_steps_gpu.py: seeded_state(G, 4101))."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden_util import make_state
+    from recguru_amd import config, models
+    from parity_util import make_args
+    param = config.get_param(make_args(d, H, 30, L, V, V, N, 16), make_dirs=False)
+    G = models.MyAuto4Rec_c("cpu", param, wf=None, enc_share=True, dec_rec=False)
+    manifest = [(k, tuple(v.shape)) for k, v in G.state_dict().items()]
+    p = {k: torch.as_tensor(v) for k, v in make_state(manifest, 4101).items()}
+    p["pos_emb_a.pe"] = O.positional_table(5000, d).unsqueeze(0)
+    return p
+
+
 def main():
     from recguru_amd import synthetic
-    B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+    tw = "--test-weights" in sys.argv
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    B = int(args[0]) if args else 16
     L, d, H, N, V, k = 200, 128, 4, 3, 100000, 30
     cfg = O.Cfg(d, H, N, L, k, V + 1, V + 1)
     torch.manual_seed(0)
     p = {"src_emb_a.weight": torch.randn(V + 2, d), "pos_emb_a.pe": O.positional_table(5000, d).unsqueeze(0)}
     P = H * 32
-    for i in range(N):
+    for i in range(0 if tw else N):
         pre = "encoder.layers.%d.enc_self_attn." % i
         for nm, (o, c) in (("WQ", (P, d)), ("WK", (P, d)), ("WV", (P, d)), ("linear", (d, P))):
             p[pre + nm + ".weight"] = (torch.rand(o, c) * 2 - 1) / c ** 0.5
@@ -79,7 +98,9 @@ def main():
             p[pre + nm + ".weight"] = (torch.rand(o, c) * 2 - 1) / c ** 0.5
             p[pre + nm + ".bias"] = (torch.rand(o) * 2 - 1) / c ** 0.5
         p[pre + "layer_norm.weight"], p[pre + "layer_norm.bias"] = torch.ones(d), torch.zeros(d)
-    dom = synthetic.make_domain(B, V, L, k, seed=1)
+    if tw:
+        p = test_weights(L, d, H, N, V)
+    dom = synthetic.make_domain(B, V, L, k, seed=41 if tw else 1)
     enc = torch.as_tensor(dom["enc_in"])
     mask = O.nonpad(enc)
     with torch.no_grad():

@@ -594,11 +594,11 @@ def test_post_attn_split_residual(cross, save, drop_p):
         assert e_split < 2.5e-3 and e_split < 0.5 * e_plain, (e_split, e_plain)
     else:
         # same dropout masks as the plain launch: the outputs agree to the rounding of the residual stream
-        assert float((both - plain.float()).abs().max()) < 6e-2
+        assert float((both - plain.float()).abs().max()) <= 2.0 ** -6 * float(plain.float().abs().max())
         assert float(((both != 0) != (plain.float() != 0)).float().mean()) < 1e-3
     if save:
-        for k in ("h1", "y"):
-            assert float((sv[k].float() - svp[k].float()).abs().max()) < 6e-2
+        for k in ("h1", "y"):       # the saves agree to a couple of bf16 ulps of the largest value (the residual input differs by < 1 ulp)
+            assert float((sv[k].float() - svp[k].float()).abs().max()) <= 2.0 ** -6 * float(svp[k].float().abs().max())
 
 
 @pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (128, 512), (384, 128), (512, 128)])

