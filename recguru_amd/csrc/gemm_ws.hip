@@ -32,6 +32,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
   T* __restrict__ C = reinterpret_cast<T*>(a.C);
   const int n0 = wave * 32;
+  // blockIdx.y: first 128-column block of this workgroup (N > 128 with K > 128 -- the d_model = 256 shapes of config-5: a
+  // workgroup keeps the K x 128 slice of W of ITS column block in registers and walks the row tiles; A is re-read per block
+  // from L2 / Infinity Cache)
+  const int cby = (int)blockIdx.y;
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: block cb
   // = tensor cb of [B][4][L][32], head = c8 / 32 -- four consecutive rows of one head are 256 contiguous bytes)
@@ -54,9 +58,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
       for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct)
-          load_frag(w[cb][kc][ks][ct], W + (size_t)(cb * 128 + n0 + ct * 16 + li) * a.ldw + kc * 128 + ks * 32 + 8 * lg);
+          load_frag(w[cb][kc][ks][ct], W + (size_t)((cby + cb) * 128 + n0 + ct * 16 + li) * a.ldw + kc * 128 + ks * 32 + 8 * lg);
   __shared__ __align__(16) float bs[NCB * 128];
-  for (int i = tid; i < NCB * 128; i += 256) bs[i] = a.bias ? a.bias[i] : 0.f;   // visible after the first barrier
+  for (int i = tid; i < NCB * 128; i += 256) bs[i] = a.bias ? a.bias[cby * 128 + i] : 0.f;   // visible after the first barrier
 
   // A work tile is 4 row tiles of 16 rows at rows mb[0..3] (>= M: absent): 64 consecutive rows, or -- with the list
   // of live 16-row tiles a.live16 (rg_live_tiles) -- 4 consecutive list entries; rows of the padded tiles are not read
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
-      load_frag(axn[i], aux + (size_t)m * a.ldaux + cb * 128 + c8);
+      load_frag(axn[i], aux + (size_t)m * a.ldaux + (cby + cb) * 128 + c8);
     }
   };
   int tile = blockIdx.x, kt_ = 0;                         // kt_: index of `tile` among this workgroup's tiles
@@ -163,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8;
             const int m = mb[i] + (tid >> 4);
             if (m < a.M) {
-              const size_t off = c_off(m, cb, c8);
+              const size_t off = c_off(m, cby + cb, c8);
               if constexpr (!AUX) {
                 if (a.epilogue == RG_EPI_NONE) {
                   *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
@@ -231,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
           if (m < a.M) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              *reinterpret_cast<Frag<T>*>(C + c_off(m, cb, (tid & 15) * 8)) = z[cb];
+              *reinterpret_cast<Frag<T>*>(C + c_off(m, cby + cb, (tid & 15) * 8)) = z[cb];
           }
         }
       }
@@ -240,12 +244,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 }
 
 template <int NKC, int NCB>
-static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s) {
+static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
-  int grid = 512;
+  int grid = ny > 1 ? (768 / ny > 96 ? 768 / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
-  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, false>), dim3(grid), dim3(256), 0, s, a);
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, false>), dim3(grid, ny), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
 }
@@ -260,6 +264,9 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;
+  // K and N both beyond 128 (d_model = 256: 256 -> 768 / 512 / 256, 512 -> 256): the <K/128, 1> instantiation once per
+  // 128-column block (gridDim.y); the head-major output form is defined for N = 384 only
+  if (nkc >= 2 && nkc <= 4 && ncb >= 2 && ncb <= 8 && a->c_hm_L <= 0) return 10 * nkc + 1;
   return 0;
 }
 
@@ -274,5 +281,8 @@ int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
   if (nkc == 1 && ncb == 4) return launch_ws<1, 4>(*a, s);
   if (nkc == 3 && ncb == 1) return launch_ws<3, 1>(*a, s);
   if (nkc == 4 && ncb == 1) return launch_ws<4, 1>(*a, s);
+  if (nkc == 2) return launch_ws<2, 1>(*a, s, ncb);
+  if (nkc == 3) return launch_ws<3, 1>(*a, s, ncb);
+  if (nkc == 4) return launch_ws<4, 1>(*a, s, ncb);
   return 1;
 }

@@ -510,7 +510,9 @@ def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
     :594, :539): those rows of the output are the bias, no read, no MFMA (rg_gemm_nt skip_dead_fill = 2)."""
     if not x_masked or rowmask is None or _COMPUTE != torch.bfloat16 or M < max(hip.COMPACT_MIN_ROWS, 4096):
         return None
-    if K != 128 or N not in (128, 256, 384, 512):          # the shapes the list-driven (weight-stationary) GEMM takes
+    # the shapes the list-driven (weight-stationary) GEMM takes: K = 128 with N up to 512, or K = 256 ... 512 with N a multiple
+    # of 128 up to 1024 (one column block per gridDim.y: the d_model = 256 projections of config-5)
+    if not ((K == 128 and N in (128, 256, 384, 512)) or (K in (256, 384, 512) and N % 128 == 0 and 128 <= N <= 1024)):
         return None
     return hip.live_tiles(rowmask, M)
 

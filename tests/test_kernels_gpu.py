@@ -601,7 +601,8 @@ def test_post_attn_split_residual(cross, save, drop_p):
             assert float((sv[k].float() - svp[k].float()).abs().max()) <= 2.0 ** -6 * float(svp[k].float().abs().max())
 
 
-@pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (128, 512), (384, 128), (512, 128)])
+@pytest.mark.parametrize("K,N", [(128, 128), (128, 384), (128, 512), (384, 128), (512, 128),
+                                 (256, 768), (256, 512), (512, 256), (256, 256), (384, 640)])   # K, N > 128: one column block per gridDim.y
 @pytest.mark.parametrize("epi", ["none", "add", "gelu_grad", "posmask", "relu"])
 def test_gemm_ws_matches_generic(K, N, epi):
     """Persistent weight-stationary path (bf16, M >= 4096) against the generic kernel and torch."""
@@ -796,7 +797,8 @@ def _pad_mask(B, L, seed):
     return (torch.arange(L)[None, :] >= (L - lens)[:, None]).float().reshape(-1).cuda().contiguous()
 
 
-@pytest.mark.parametrize("K,N,epi", [(128, 512, "gelu_grad"), (512, 128, "add"), (128, 128, "none"), (384, 128, "add")])
+@pytest.mark.parametrize("K,N,epi", [(128, 512, "gelu_grad"), (512, 128, "add"), (128, 128, "none"), (384, 128, "add"),
+                                     (256, 768, "none"), (256, 512, "gelu_grad"), (512, 256, "add")])
 def test_gemm_ws_live_tile_list(K, N, epi):
     """Weight-stationary GEMM over the list of live 16-row tiles == over every row, when the padded rows carry zeros."""
     from recguru_amd import hip
