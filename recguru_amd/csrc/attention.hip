@@ -507,6 +507,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       const int nfr = CAUSAL ? 0 : min(NTR, (nz - 1) >> 2);     // folded regions (nz == 0: (nz - 1) >> 2 == -1 -> see nrun)
       const int nrun = CAUSAL ? (nkq <= F ? 0 : (nkq - F + TR - 1) / TR) : NTR - max(nfr, 0);     // tail regions that are evaluated
       const int nskip = 16 * TR * max(nfr, 0);            // folded keys: tiles 1 .. TR * nfr
+      // causal: leading regions made of keys before the first live key only (the decoder's masked left padding) give exact
+      // zeros to a query tile whose rows all have a live key (qt * 16 >= klo): rlo = number of such regions, skipped in all
+      // three loops (region rg holds list entries [j0, j1): entirely before klo iff j1 * 16 <= klo)
+      int rlo = 0;
+      if (CAUSAL && qt * 16 >= klo) {
+#pragma unroll
+        for (int rg = 0; rg < NTR; ++rg) {               // (the last region holds the diagonal of some tile: never skipped)
+          const int j1 = rg == 0 ? F : F + rg * TR;
+          if (j1 * 16 <= klo && rg + 1 <= nrun) rlo = rg + 1;
+        }
+      }
       f32x4 s[NKT];
       mx = -INFINITY;
       {
@@ -516,11 +527,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
           load_frag(kfb[buf], Ks + kofs(tile_of(j) * 16 + li, lg));
           load4f(kbb[buf], kbias + tile_of(j) * 16 + 4 * lg);
         };
-        issue(0, 0);
 #pragma unroll
         for (int rg = 0; rg <= NTR; ++rg)
-          if (rg <= nrun) {
+          if (rg <= nrun && rg >= rlo) {
             const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
+            if (rg == rlo) issue(j0, j0 & 1);               // the first evaluated region reads its own first entry
             auto finish = [&](int j, auto MK) {           // entry j's scores are complete: future keys masked (MK), row max
               if constexpr (decltype(MK)::value) {
 #pragma unroll
@@ -718,9 +729,11 @@ template <typename T, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
   constexpr int LPK = NKT * 16;
   constexpr int LDT = LPK + 8;        // transposed images [32][LPK]
+  // two transposed images at a time: phase 1 reads Q^T and dO^T, phase 2 K^T -- which is staged into Q^T's space between the
+  // phases (three images of [32][L + 8] floats are 163 KB at L = 400: with two, the exact-f32 backward reaches L <= 416)
   __shared__ __align__(16) T Qt[DK * LDT];
   __shared__ __align__(16) T dOt[DK * LDT];
-  __shared__ __align__(16) T Kt[DK * LDT];
+  T* const Kt = Qt;
   __shared__ float lse_s[LPK];
   __shared__ float dl_s[LPK];
   __shared__ unsigned char kpad[LPK];
@@ -741,21 +754,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 
   for (int c = tid; c < LPK * 4; c += 256) {
     const int row = c >> 2, c8 = (c & 3) * 8;
-    float qv[8], kv[8], gv[8], ov[8];
+    float qv[8], gv[8], ov[8];
     if (row < L) {
       load8(qv, qkv + (size_t)row * ld + h * DK + c8);
-      load8(kv, qkv + (size_t)row * ld + P + h * DK + c8);
       load8(gv, dO + (size_t)row * P + c8);
       load8(ov, O + (size_t)row * P + c8);
     } else {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { qv[j] = 0.f; kv[j] = 0.f; gv[j] = 0.f; ov[j] = 0.f; }
+      for (int j = 0; j < 8; ++j) { qv[j] = 0.f; gv[j] = 0.f; ov[j] = 0.f; }
     }
     float d = 0.f;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       Qt[(c8 + j) * LDT + row] = (T)qv[j];
-      Kt[(c8 + j) * LDT + row] = (T)kv[j];
       dOt[(c8 + j) * LDT + row] = (T)gv[j];
       d += gv[j] * ov[j];
     }
@@ -833,6 +844,19 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
   }
 
   // ---------------------------------------------------------------- phase 2: dQ
+  __syncthreads();                     // every wave is done with Q^T
+  for (int c = tid; c < LPK * 4; c += 256) {
+    const int row = c >> 2, c8 = (c & 3) * 8;
+    float kv[8];
+    if (row < L) load8(kv, qkv + (size_t)row * ld + P + h * DK + c8);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kv[j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Kt[(c8 + j) * LDT + row] = (T)kv[j];
+  }
+  __syncthreads();
   for (int qt = wave; qt < nt; qt += 4) {
     const int q = qt * 16 + li;        // this lane's query (column of S^T)
     Frag<T> qf, gf;
@@ -1079,6 +1103,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     auto qstep = [&](const int qs) {
       if (!((qmask >> (2 * qs)) & 3u)) return;             // padded query rows only: dO = 0 there, nothing to add to dK / dV
       if (CAUSAL && 2 * qs + 1 < kt && qs * 32 >= klo) return;     // keys entirely in the future of both query tiles: P = dS = 0
+      // a key tile entirely BEFORE the first live key (the decoder's masked left padding): every row at or behind klo has a
+      // live key, so its P and dS are exact zeros on these replaced scores; only rows before klo (fully masked: uniform 1/L over
+      // ALL keys, quirk Q3 -- with the decoder's shifted inputs the first two live rows of a sequence) reach such a tile
+      if (CAUSAL && kt * 16 + 16 <= klo && qs * 32 >= klo) return;
       f32x4 p[2], ds[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
@@ -1417,7 +1445,8 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
     else if (nkt <= 8) RG_BWD(8);
     else if (nkt <= 14) RG_BWD(14);
     else if (nkt <= 16) RG_BWD(16);
-    else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 256 (f32 tier) not supported yet");
+    else if (nkt <= 26) RG_BWD(26);
+    else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 not supported yet");
 #undef RG_BWD
   }
   RG_CHECK_LAUNCH();

@@ -1087,12 +1087,22 @@ def _work_item_loss_train(h, table, pos, neg, mask, k, mode, *a, **kw):
             nl * (k + 2) * d * _esize(table) + n * d * _esize(table) + nl * (k + 1) * 12 + n * 4)
 
 
-_WORK = {"attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
+def _work_item_loss_scatter(h, table_rows, pos, neg, mask, k, coef, gout, dE, *a, **kw):
+    """The binned table gradient (count / scan / fill / accumulate): per live (position, item) pair one gather of h[t]
+    (d elements of the tier dtype), the pair's id and coefficient read twice and its 8-byte entry written and read; the f32
+    table rows the pairs touch are read-modify-written once per bin chunk (not counted: <= 8 B x d x rows)."""
+    n, d = h.shape
+    nl = float(mask.sum())
+    pairs = nl * (k + 1)
+    return "item_loss_scatter_binned_kernel", 2.0 * pairs * d, pairs * (d * _esize(h) + 2 * 12 + 2 * 8)
+
+
+_WORK = {"item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
          "ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
-          "item_loss_scatter_binned", "embed_scatter_bwd_binned", "scale_dev"]
+          "embed_scatter_bwd_binned", "scale_dev"]
 
 
 def start_profile():
