@@ -563,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
-        if (rg <= nrun) {
+        if (rg <= nrun && rg >= rlo) {
           const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
           for (int j = j0; j < j1; ++j)
@@ -604,7 +604,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
       // dropout on the f32 probabilities (f32 tier, generic p): s[j] holds tile t(j)
       auto entry_of = [](int t) { return CAUSAL ? t : (t == 0 ? 0 : NKT - t); };       // inverse of tile_of
-      auto region_on = [&](int j) { return j < F || (j - F) / TR + 1 <= nrun; };        // (uniform) entry j was evaluated
+      auto region_on = [&](int j) { const int rg = j < F ? 0 : (j - F) / TR + 1; return rg <= nrun && rg >= rlo; };   // (uniform) entry j was evaluated
       if constexpr (DM == 1 && !PLUT) {
 #pragma unroll
         for (int j = 0; j < NKT; ++j)
@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
-        if (rg <= nrun) {
+        if (rg <= nrun && rg >= rlo) {
           const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
           for (int ks = j0 / 2; ks < j1 / 2; ++ks) {          // F, TR and NKT are even

@@ -40,12 +40,15 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: block cb
   // = tensor cb of [B][4][L][32], head = c8 / 32 -- four consecutive rows of one head are 256 contiguous bytes)
   const int hmL = a.c_hm_L, hmB = hmL > 0 ? a.M / hmL : 0;
-  auto c_off = [&](int m, int cb, int c8) -> size_t {
+  // m = mt + r with mt the first row of a 16-row tile (workgroup-uniform: its division by L is scalar work) and r < 16
+  auto c_off = [&](int mt, int r, int cb, int c8) -> size_t {
     if (hmL > 0) {
-      const int bb = m / hmL, l = m - bb * hmL;
+      const int bt = __builtin_amdgcn_readfirstlane(mt) / hmL;
+      int bb = bt, l = mt - bt * hmL + r;
+      if (l >= hmL) { l -= hmL; ++bb; }                  // (a 16-row tile spans at most two sequences: L >= 16 is checked by the launcher)
       return ((size_t)((cb * hmB + bb) * 4 + (c8 >> 5)) * hmL + l) * 32 + (c8 & 31);
     }
-    return (size_t)m * a.ldc + cb * 128 + c8;
+    return (size_t)(mt + r) * a.ldc + cb * 128 + c8;
   };
 
   // ---- stationary weights: w[cb][kc][ks][ct]
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8;
             const int m = mb[i] + (tid >> 4);
             if (m < a.M) {
-              const size_t off = c_off(m, cby + cb, c8);
+              const size_t off = c_off(mb[i], tid >> 4, cby + cb, c8);
               if constexpr (!AUX) {
                 if (a.epilogue == RG_EPI_NONE) {
                   *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
@@ -231,11 +234,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (j + i < ndead) {
-          const int m = a.live16[nrt - (j + i)] * 16 + (tid >> 4);
+          const int mt = a.live16[nrt - (j + i)] * 16, m = mt + (tid >> 4);
           if (m < a.M) {
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
-              *reinterpret_cast<Frag<T>*>(C + c_off(m, cby + cb, (tid & 15) * 8)) = z[cb];
+              *reinterpret_cast<Frag<T>*>(C + c_off(mt, tid >> 4, cby + cb, (tid & 15) * 8)) = z[cb];
           }
         }
       }
@@ -260,7 +263,7 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;   // dropout-after-ReLU lives in the generic kernel
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
   if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
-  if (a->c_hm_L > 0 && (a->M % a->c_hm_L) != 0) return 0;
+  if (a->c_hm_L > 0 && ((a->M % a->c_hm_L) != 0 || a->c_hm_L < 16)) return 0;
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;

@@ -8,9 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof_$RD
 rm -rf $O && mkdir -p $O
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 4 --warmup 1 --no_cpu_baseline > $O/bench_under_rocprof.json 2> $O/kt.err
-timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > /dev/null 2> $O/pmcF.err
-timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline > /dev/null 2> $O/pmcW.err
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 4 --warmup 1 --no_cpu_baseline --ae_steps 0 --full_length_steps 0 > $O/bench_under_rocprof.json 2> $O/kt.err
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --ae_steps 0 --full_length_steps 0 > /dev/null 2> $O/pmcF.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 1 --warmup 1 --no_cpu_baseline --no_roofline --ae_steps 0 --full_length_steps 0 > /dev/null 2> $O/pmcW.err
 cd $R
 python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1
 mkdir -p profiles/$RD && cp $O/pmc_traffic.json profiles/$RD/pmc_traffic.json      # bench.py reads roofline.traffic from here
