@@ -507,17 +507,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       const int nfr = CAUSAL ? 0 : min(NTR, (nz - 1) >> 2);     // folded regions (nz == 0: (nz - 1) >> 2 == -1 -> see nrun)
       const int nrun = CAUSAL ? (nkq <= F ? 0 : (nkq - F + TR - 1) / TR) : NTR - max(nfr, 0);     // tail regions that are evaluated
       const int nskip = 16 * TR * max(nfr, 0);            // folded keys: tiles 1 .. TR * nfr
-      // causal: leading regions made of keys before the first live key only (the decoder's masked left padding) give exact
-      // zeros to a query tile whose rows all have a live key (qt * 16 >= klo): rlo = number of such regions, skipped in all
-      // three loops (region rg holds list entries [j0, j1): entirely before klo iff j1 * 16 <= klo)
-      int rlo = 0;
-      if (CAUSAL && qt * 16 >= klo) {
-#pragma unroll
-        for (int rg = 0; rg < NTR; ++rg) {               // (the last region holds the diagonal of some tile: never skipped)
-          const int j1 = rg == 0 ? F : F + rg * TR;
-          if (j1 * 16 <= klo && rg + 1 <= nrun) rlo = rg + 1;
-        }
-      }
+      // (measured and reverted, round 3: skipping the causal forward's LEADING regions made of masked left-padding keys --
+      // exact zeros for query tiles behind the first live key -- needs the first evaluated region to issue its own first LDS
+      // read under a run-time condition; that lost the read-ahead of entry 0 for every tile: 228 -> 276 us per launch)
       f32x4 s[NKT];
       mx = -INFINITY;
       {
@@ -527,11 +519,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
           load_frag(kfb[buf], Ks + kofs(tile_of(j) * 16 + li, lg));
           load4f(kbb[buf], kbias + tile_of(j) * 16 + 4 * lg);
         };
+        issue(0, 0);
 #pragma unroll
         for (int rg = 0; rg <= NTR; ++rg)
-          if (rg <= nrun && rg >= rlo) {
+          if (rg <= nrun) {
             const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
-            if (rg == rlo) issue(j0, j0 & 1);               // the first evaluated region reads its own first entry
             auto finish = [&](int j, auto MK) {           // entry j's scores are complete: future keys masked (MK), row max
               if constexpr (decltype(MK)::value) {
 #pragma unroll
@@ -563,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       f32x2 sum2 = (f32x2){0.f, 0.f};
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
-        if (rg <= nrun && rg >= rlo) {
+        if (rg <= nrun) {
           const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
           for (int j = j0; j < j1; ++j)
@@ -604,7 +596,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       }
       // dropout on the f32 probabilities (f32 tier, generic p): s[j] holds tile t(j)
       auto entry_of = [](int t) { return CAUSAL ? t : (t == 0 ? 0 : NKT - t); };       // inverse of tile_of
-      auto region_on = [&](int j) { const int rg = j < F ? 0 : (j - F) / TR + 1; return rg <= nrun && rg >= rlo; };   // (uniform) entry j was evaluated
+      auto region_on = [&](int j) { return j < F || (j - F) / TR + 1 <= nrun; };        // (uniform) entry j was evaluated
       if constexpr (DM == 1 && !PLUT) {
 #pragma unroll
         for (int j = 0; j < NKT; ++j)
@@ -636,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
-        if (rg <= nrun && rg >= rlo) {
+        if (rg <= nrun) {
           const int j0 = rg == 0 ? 0 : F + (rg - 1) * TR, j1 = min(rg == 0 ? F : j0 + TR, NKT);
 #pragma unroll
           for (int ks = j0 / 2; ks < j1 / 2; ++ks) {          // F, TR and NKT are even

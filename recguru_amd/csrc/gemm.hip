@@ -101,7 +101,9 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
     }
   };
   Frag<T> w0[4][NTW], p0[4];
-  if constexpr (sizeof(T) == 4) {     // f32 parity tier: fragments are twice as wide, one register set only
+  if constexpr (sizeof(T) == 4 || NTW >= 4) {     // f32 parity tier: fragments are twice as wide, one register set only; bf16 with
+                                                  // a 256-column tile (N = 256 LayerNorm epilogues of d_model = 256): two weight sets
+                                                  // of 16 fragments + 64 accumulators spilled 60 VGPRs per lane
     for (int ci = 0; ci < nk; ++ci) {
       load_chunk(w0, p0, ci);
       stage_chunk(p0, ci, As);

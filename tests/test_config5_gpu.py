@@ -93,7 +93,7 @@ def test_config5_vs_oracle(tier, capsys):
         gerr[k] = float(np.abs(g - r).max() / max(np.abs(r).max(), 1e-30))
     with capsys.disabled():
         print("\n[config-5 shape, %s tier] user_embed err rel-to-max %.3g | loss_ae %.5f vs %.5f (rel %.3g) | gradient err / max: %s"
-              % (tier, ue_err, float(la), ref["la"], l_rel, ", ".join("%s %.2g" % (k.split(".")[-3] + "." + k.split(".")[-2], v) for k, v in gerr.items())))
+              % (tier, ue_err, float(la), ref["la"], l_rel, ", ".join("%s %.2g" % (".".join(k.split(".")[-3:-1]) or k, v) for k, v in gerr.items())))
     if tier == "f32":
         np.testing.assert_allclose(ue, ref["ue"], rtol=1e-3, atol=1e-5)
         assert l_rel <= 1e-5

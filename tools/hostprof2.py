@@ -10,7 +10,7 @@ args = bench.parse()
 torch.cuda.set_device(0)
 ops.set_compute_dtype(torch.bfloat16)
 ops.manual_seed(0, 0)
-param, G, D, opt_g, opt_d, loaders = bench.build(args, "cuda:0", 0, 1)
+param, G, D, opt_g, opt_d, opt_rec, loaders = bench.build(args, "cuda:0", 0, 1)
 step = bench.make_step(param, G, D, opt_g, opt_d, loaders, "cuda:0", None, args)
 for _ in range(3):
     step()

@@ -11,7 +11,7 @@ dp = None
 ops.set_compute_dtype(torch.bfloat16)
 ops.set_data_parallel(None)
 ops.manual_seed(0, 0)
-param, G, D, opt_g, opt_d, loaders = bench.build(args, device, 0, 1)
+param, G, D, opt_g, opt_d, opt_rec, loaders = bench.build(args, device, 0, 1)
 step = bench.make_step(param, G, D, opt_g, opt_d, loaders, device, dp, args)
 for _ in range(3):
     step(overlap=False)
