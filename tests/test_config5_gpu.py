@@ -99,8 +99,8 @@ def test_config5_vs_oracle(tier, capsys):
         assert l_rel <= 1e-5
         assert max(gerr.values()) <= 1e-3
     else:
-        assert ue_err <= 0.02 and l_rel <= 8e-4            # measured 0.0096 / 3.6e-4 (round 2)
-        assert max(gerr.values()) <= 0.08
+        assert ue_err <= 0.02 and l_rel <= 3e-4            # measured 0.0101 / 1.3e-4 (round 3)
+        assert max(gerr.values()) <= 0.025                 # measured: 0.011 (encoder layer 0 WQ), 0.0032 ... 0.0066 the others
     g = G.src_emb_a.weight.grad
     assert g is not None and torch.isfinite(g).all()
     touched = torch.zeros(c["V"] + 2, dtype=torch.bool, device="cuda")
