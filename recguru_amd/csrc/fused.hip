@@ -24,7 +24,8 @@
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
-#define FT_M 64      // tokens per tile
+#define FT_M 64      // tokens per tile (the backward kernels; the forward block: 16 * RT)
+#include <stdlib.h>
 #define FD 128       // d_model == P == chunk width
 #define FPAD 8
 #define FLD (FD + FPAD)
@@ -80,34 +81,35 @@ __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, i
 }
 
 // acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
-template <typename T>
-__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][4], const WSet<T>& w, const T* __restrict__ Act, int li, int lg) {
-  // the four token-tile fragments of k-step ks+1 are read while the MFMAs of k-step ks run (one LDS latency per GEMM
-  // step instead of four)
-  Frag<T> af[2][4];
+template <typename T, int RT>
+__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, const T* __restrict__ Act, int li, int lg) {
+  // the RT token-tile fragments of k-step ks+1 are read while the MFMAs of k-step ks run (one LDS latency per GEMM
+  // step instead of RT)
+  Frag<T> af[2][RT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) load_frag(af[0][rt], Act + Tile<T>::off(rt * 16 + li, 8 * lg));
+  for (int rt = 0; rt < RT; ++rt) load_frag(af[0][rt], Act + Tile<T>::off(rt * 16 + li, 8 * lg));
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     if (ks < 3) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) load_frag(af[(ks + 1) & 1][rt], Act + Tile<T>::off(rt * 16 + li, (ks + 1) * 32 + 8 * lg));
+      for (int rt = 0; rt < RT; ++rt) load_frag(af[(ks + 1) & 1][rt], Act + Tile<T>::off(rt * 16 + li, (ks + 1) * 32 + 8 * lg));
     }
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct) mma(w.f[ks][ct], af[ks & 1][rt], acc[ct][rt]);
   }
 }
 
 // accumulators start at the bias of their 4 features (bias add costs nothing afterwards)
-__device__ __forceinline__ void init_acc(f32x4 (&acc)[2][4], const float* __restrict__ bias_lds, int n0, int lg) {
+template <int RT>
+__device__ __forceinline__ void init_acc(f32x4 (&acc)[2][RT], const float* __restrict__ bias_lds, int n0, int lg) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {
     float b[4];
     load4f(b, bias_lds + n0 + ct * 16 + 4 * lg);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b[0], b[1], b[2], b[3]};
+    for (int rt = 0; rt < RT; ++rt) acc[ct][rt] = (f32x4){b[0], b[1], b[2], b[3]};
   }
 }
 
@@ -117,12 +119,13 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][4], const float* __rest
 // combined exactly (Chan et al.: M2 = sum_w M2_w + 32 * sum_w (mean_w - mean)^2) -- as accurate as torch's two-pass
 // LayerNorm with one workgroup barrier instead of two.  On return v holds (v - mean) * rstd * gamma + beta and
 // rstd[rt] the row rstd.
-__device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], const float* __restrict__ gamma_lds,
+template <int RT>
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], const float* __restrict__ gamma_lds,
                                         const float* __restrict__ beta_lds, float* __restrict__ redA, float* __restrict__ redB,
                                         float eps, int n0, int wave, int li, int lg) {
-  float s[4], m2[4];
+  float s[RT], m2[RT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float t = 0.f;
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
@@ -143,12 +146,12 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], cons
   }
   if (lg == 0) {
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) { redA[(rt * 16 + li) * 4 + wave] = s[rt]; redB[(rt * 16 + li) * 4 + wave] = m2[rt]; }
+    for (int rt = 0; rt < RT; ++rt) { redA[(rt * 16 + li) * 4 + wave] = s[rt]; redB[(rt * 16 + li) * 4 + wave] = m2[rt]; }
   }
   lds_barrier();
-  float mean[4];
+  float mean[RT];
 #pragma unroll
-  for (int rt = 0; rt < 4; ++rt) {
+  for (int rt = 0; rt < RT; ++rt) {
     float p[4], q[4];
     load4f(p, redA + (rt * 16 + li) * 4);
     load4f(q, redB + (rt * 16 + li) * 4);
@@ -164,31 +167,31 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][4], float (&rstd)[4], cons
     load4f(g, gamma_lds + n0 + ct * 16 + 4 * lg);
     load4f(b, beta_lds + n0 + ct * 16 + 4 * lg);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt)
+    for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
       for (int r = 0; r < 4; ++r) v[ct][rt][r] = (v[ct][rt][r] - mean[rt]) * rstd[rt] * g[r] + b[r];
   }
 }
 
 // registers -> tile in LDS (4 consecutive features per store)
-template <typename T>
-__device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][4], T* __restrict__ tile, int n0, int li, int lg) {
+template <typename T, int RT>
+__device__ __forceinline__ void regs_to_tile(const f32x4 (&v)[2][RT], T* __restrict__ tile, int n0, int li, int lg) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float t[4] = {v[ct][rt][0], v[ct][rt][1], v[ct][rt][2], v[ct][rt][3]};
       store4(tile + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg), t);
     }
 }
 
 // the part of the registers that rounding to T loses: v - T(v), as a second tile (split residual stream, rg_post_attn_args.x_lo)
-template <typename T>
-__device__ __forceinline__ void regs_to_tile_lo(const f32x4 (&v)[2][4], T* __restrict__ tile, int n0, int li, int lg) {
+template <typename T, int RT>
+__device__ __forceinline__ void regs_to_tile_lo(const f32x4 (&v)[2][RT], T* __restrict__ tile, int n0, int li, int lg) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float t[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) t[r] = v[ct][rt][r] - (float)(T)v[ct][rt][r];
@@ -197,12 +200,12 @@ __device__ __forceinline__ void regs_to_tile_lo(const f32x4 (&v)[2][4], T* __res
 }
 
 // acc += tile (this lane's own 8 x 4 positions)
-template <typename T>
-__device__ __forceinline__ void add_tile(f32x4 (&acc)[2][4], const T* __restrict__ tile, int n0, int li, int lg) {
+template <typename T, int RT>
+__device__ __forceinline__ void add_tile(f32x4 (&acc)[2][RT], const T* __restrict__ tile, int n0, int li, int lg) {
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       float r4[4];
       load4t(r4, tile + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
@@ -214,10 +217,10 @@ __device__ __forceinline__ void add_tile(f32x4 (&acc)[2][4], const T* __restrict
 // rows of a plain tile (mb[rt] = m0 + 16 rt), or the next 4 LIVE row tiles of the workgroup's range when padded row
 // tiles are compacted away.  Thread tid stages chunk i of the tile = row 16 i + (tid >> 4), columns 8 (tid & 15)..
 // cooperative, coalesced copy of a [64 x 128] LDS tile to its rows of a row-major HBM matrix
-template <typename T, bool NT = false>
-__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[4], int M, int tid) {
+template <typename T, bool NT = false, int RT = 4>
+__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[RT], int M, int tid) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
     if (m < M) {
       T* g = gofs(dst, (unsigned int)m * (unsigned int)ld + (unsigned int)(col0 + c8));
@@ -228,12 +231,12 @@ __device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __res
 }
 
 // the tile's rows of a row-major HBM matrix <- 0 (128 columns from col0), coalesced 16-byte stores
-template <typename T>
-__device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col0, const int (&mb)[4], int M, int tid) {
+template <typename T, int RT>
+__device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col0, const int (&mb)[RT], int M, int tid) {
   Frag<T> z;
   frag_zero(z);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RT; ++i) {
     const int c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
     if (m < M) *reinterpret_cast<Frag<T>*>(gofs(dst, (unsigned int)m * (unsigned int)ld + (unsigned int)(col0 + c8))) = z;
   }
@@ -253,24 +256,28 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // passes: most launches of a step) compile all of it away.
 // RES: split residual stream (x = x + x_lo in, out / out_lo out; the LayerNorm outputs y / y2 keep their lo part in a free
 // tile: y_lo parks in the ctx tile during the FFN, x_lo arrives in the y tile, out_lo leaves through the g-chunk tile).
-template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
+// RT: 16-row tiles per work tile -- 4 (64 tokens) or 2 (32 tokens: half the accumulators and activation tiles per workgroup,
+// so that three to four workgroups share a CU instead of two; the per-phase stamps show a wave at 2 per SIMD spending its
+// time on exposed LDS / VALU latencies, not on the matrix pipe or the weight stream)
+template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4>
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
+  constexpr int FTM = 16 * RT;        // tokens per work tile
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0__ = __builtin_amdgcn_s_memtime();
 #endif
   // LDS: ctx tile (later: out staging) | x tile (later: g chunk) | y tile | params | row-stat exchange | [h1 chunk]
-  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
+  constexpr int ACT_BYTES = FTM * Tile<T>::LD * (int)sizeof(T);
   extern __shared__ __align__(16) unsigned char smem[];
   T* Actx = reinterpret_cast<T*>(smem);
   T* Ag = reinterpret_cast<T*>(smem + ACT_BYTES);
   T* Ay = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
   float* prm = reinterpret_cast<float*>(smem + 3 * ACT_BYTES);           // 8*128 + dff floats
   float* redA = prm + 8 * FD + a.dff;                                     // [64][4]
-  float* redB = redA + FT_M * 4;
+  float* redB = redA + FTM * 4;
   // p == 0.5 dropout: nibble of hash bits -> 4 multipliers (0 or 1/(1-p)) from a 16-entry table: 2 address ops, one
   // ds_read_b128 and 4 multiplies per 4 elements instead of a bit extract, an AND and a multiply per element
-  float* klut = redB + FT_M * 4;                                          // [16][4]
+  float* klut = redB + FTM * 4;                                          // [16][4]
   T* Ah = reinterpret_cast<T*>(klut + 64);                                // only when h1_save != NULL
   float *p_bo = prm, *p_g1 = prm + FD, *p_be1 = prm + 2 * FD, *p_b2 = prm + 3 * FD, *p_g2 = prm + 4 * FD,
         *p_be2 = prm + 5 * FD, *p_gc = prm + 6 * FD, *p_bec = prm + 7 * FD, *p_b1 = prm + 8 * FD;
@@ -292,7 +299,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   float* __restrict__ rstd2o = SAVE ? a.rstd2 : nullptr;
   float* __restrict__ rstdco = SAVE ? a.rstd_c : nullptr;
   const int n0 = wave * 32;                 // this wave's 32 output features of every 128-wide block
-  const int ntiles = (a.M + FT_M - 1) / FT_M;
+  const int ntiles = (a.M + FTM - 1) / FTM;
   const int nchunk = a.dff / FD;
   DropCfg drop1 = make_drop(a.drop_p, a.seed_h1), drop2 = make_drop(a.drop_p, a.seed_out);
   if constexpr (DM == 2) { drop1.onebit = 0u; drop2.onebit = 0u; }
@@ -307,42 +314,42 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
   const unsigned int rot0 = (4u * lg + 28u) & 31u, rot1 = (4u * lg + 12u) & 31u;   // hash bit 4 lg + j (16 + 4 lg + j) -> bit 4 + j
 
   WSet<T> wp, wq;                           // wp: Wo / W1 chunks, wq: W2 chunks
-  Frag<T> cpre[4], xpre[4];                 // ctx / x rows of the NEXT tile (staging prefetch)
-  Frag<T> xlpre[RES ? 4 : 1];               // ... and the lo part of x
+  Frag<T> cpre[RT], xpre[RT];               // ctx / x rows of the NEXT tile (staging prefetch)
+  Frag<T> xlpre[RES ? RT : 1];              // ... and the lo part of x
 
   // ---- work-tile enumeration: work tile = blockIdx.x, += gridDim.x.  Plain: rows tile*64..  Compacted (a.live16):
   // 4 consecutive entries of the list of live 16-row tiles (balanced by construction: every
   // work tile is 64 live-ish rows wherever the padding sits).
   LiveWalk lw;                              // list entries by v_readlane (one vector load per 16 tiles), see rg_common.hip.h
   lw.init(a.live16, a.M);
-  const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
+  const int nwork = a.live16 ? (lw.nlive + RT - 1) / RT : ntiles;
   int cur = (int)blockIdx.x, kcur = 0;
-  auto next_group = [&](int (&g)[4]) -> bool {
+  auto next_group = [&](int (&g)[RT]) -> bool {
     if (cur >= nwork) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) g[rt] = a.M;       // absent: prefetch_rows clamps, nothing is stored
+      for (int rt = 0; rt < RT; ++rt) g[rt] = a.M;      // absent: prefetch_rows clamps, nothing is stored
       return false;
     }
     if (!a.live16) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) g[rt] = cur * FT_M + 16 * rt;
+      for (int rt = 0; rt < RT; ++rt) g[rt] = cur * FTM + 16 * rt;
     } else {
-      lw.group(kcur, g, a.M);
+      lw.template group_n<RT>(kcur, g, a.M);
     }
     cur += gridDim.x;
     ++kcur;
     return true;
   };
-  auto prefetch_rows = [&](const int (&g)[4]) {         // rows >= M: clamped address, no branch (never stored)
+  auto prefetch_rows = [&](const int (&g)[RT]) {        // rows >= M: clamped address, no branch (never stored)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int c8 = (tid & 15) * 8, m = min(g[i] + (tid >> 4), a.M - 1);
       load_frag(cpre[i], gofs(ctx, (unsigned int)(m * FD + c8)));
       load_frag(xpre[i], gofs(x, (unsigned int)(m * FD + c8)));
       if constexpr (RES) load_frag(xlpre[i], gofs(xlo, (unsigned int)(m * FD + c8)));
     }
   };
-  int mb[4], mbn[4];
+  int mb[RT], mbn[RT];
   bool have = next_group(mb);
   if (have) {
     load_wset(wp, Wo, FD, n0, 0, li, lg, a.w_packed);
@@ -352,19 +359,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     const bool have_next = next_group(mbn);
     // ---- ctx and x tiles: registers -> LDS (x parks in the g-chunk buffer, free until the FFN)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RT; ++i) {
       const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
       *reinterpret_cast<Frag<T>*>(Actx + Tile<T>::off(r, c8)) = cpre[i];
       *reinterpret_cast<Frag<T>*>(Ag + Tile<T>::off(r, c8)) = xpre[i];
       if constexpr (RES) *reinterpret_cast<Frag<T>*>(Ay + Tile<T>::off(r, c8)) = xlpre[i];     // the y tile is free until LayerNorm 1
     }
-    float rm4[4];
+    float rm4[RT];
+    bool any_live = false;
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) {
+    for (int rt = 0; rt < RT; ++rt) {
       const int m = mb[rt] + li;
       rm4[rt] = (a.rowmask && m < a.M) ? a.rowmask[m] : 1.f;
+      any_live = any_live || rm4[rt] != 0.f;
     }
-    if (a.rowmask && !a.live16 && __ballot(rm4[0] != 0.f || rm4[1] != 0.f || rm4[2] != 0.f || rm4[3] != 0.f) == 0ull) {
+    if (a.rowmask && !a.live16 && __ballot(any_live) == 0ull) {
       // 64 padded positions: the block's output is out * rowmask = 0 whatever the arithmetic gives, and no gradient
       // comes back through these rows -- write the zeros (and finite placeholders for what backward reads) and move on
       zero_to_hbm<T>(out, FD, 0, mb, a.M, tid);
@@ -374,7 +383,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, mb, a.M, tid);
       if (h1save)
         for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, mb, a.M, tid);
-      if (tid < FT_M && mb[0] + tid < a.M) {            // plain tiles only: 64 consecutive rows
+      if (tid < FTM && mb[0] + tid < a.M) {             // plain tiles only: FTM consecutive rows
         if (rstd1o) rstd1o[mb[0] + tid] = 0.f;
         if (rstd2o) rstd2o[mb[0] + tid] = 0.f;
         if (rstdco) rstdco[mb[0] + tid] = 0.f;
@@ -382,14 +391,14 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       lds_barrier();                                    // the staged ctx / x tile of this iteration is dropped
       prefetch_rows(mbn);
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+      for (int rt = 0; rt < RT; ++rt) mb[rt] = mbn[rt];
       have = have_next;
       continue;
     }
     lds_barrier();
     STAMP(0);
     // ---- attention output projection (weights already in wp), bias folded into the accumulators
-    f32x4 acc[2][4];
+    f32x4 acc[2][RT];
     init_acc(acc, p_bo, n0, lg);
     mma_wset<T>(acc, wp, Actx, li, lg);
     load_wset(wp, W1, FD, n0, 0, li, lg, a.w_packed);   // prefetch FFN chunk 0 (hidden behind LN1)
@@ -397,13 +406,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     add_tile<T>(acc, Ag, n0, li, lg);
     if constexpr (RES) add_tile<T>(acc, Ay, n0, li, lg);          // x_lo
     STAMP(1);
-    float rstd[4];
+    float rstd[RT];
     ln_regs(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
     // (past the barrier inside ln_regs every wave is done with the ctx tile, x and x_lo)
     if constexpr (RES) regs_to_tile_lo<T>(acc, Actx, n0, li, lg);   // y_lo parks in the ctx tile (each lane: its own positions)
     if (rstd1o && wave == 0 && lg == 0) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
         if (mb[rt] + li < a.M) rstd1o[mb[rt] + li] = rstd[rt];
     }
     regs_to_tile<T>(acc, Ay, n0, li, lg);
@@ -414,17 +423,17 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       // o rows: the (uniform) dropout / no-dropout switch sits outside the loops and the loads of a row tile are
       // issued together (inside the loops every (rt, ct, head) was a branch + load + wait: ~30 exposed L2 latencies
       // per tile, the decoder launches ran at half the rate of the encoder ones)
-      int mrow[4], brow[4];
+      int mrow[RT], brow[RT];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) { mrow[rt] = min(mb[rt] + li, a.M - 1); brow[rt] = mrow[rt] / a.L; }
+      for (int rt = 0; rt < RT; ++rt) { mrow[rt] = min(mb[rt] + li, a.M - 1); brow[rt] = mrow[rt] / a.L; }
       if (a.cross_s) {          // dropout: o = bo + sum_h s[m,h] * oh[b,h,:]   (H == P / 32 == 4 on this path)
-        float sv[4][4], bo4[2][4];
+        float sv[RT][4], bo4[2][4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) load4f(sv[rt], a.cross_s + (size_t)mrow[rt] * 4);
+        for (int rt = 0; rt < RT; ++rt) load4f(sv[rt], a.cross_s + (size_t)mrow[rt] * 4);
 #pragma unroll
         for (int ct = 0; ct < 2; ++ct) load4f(bo4[ct], a.cross_bo + n0 + ct * 16 + 4 * lg);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           float w4[2][4][4];
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct)
@@ -451,13 +460,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
           }
         }
       } else {
-        float o4[4][2][4];
+        float o4[RT][2][4];
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) load4f(o4[rt][ct], a.o_bcast + (size_t)brow[rt] * FD + n0 + ct * 16 + 4 * lg);
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             float y4[4];
@@ -476,7 +485,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       ln_regs(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
       if (rstdco && wave == 0 && lg == 0) {
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt)
+        for (int rt = 0; rt < RT; ++rt)
           if (mb[rt] + li < a.M) rstdco[mb[rt] + li] = rstd[rt];
       }
       regs_to_tile<T>(acc, Ay, n0, li, lg);
@@ -489,7 +498,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     }
     STAMP(3);
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
-    f32x4 acc2[2][4];
+    f32x4 acc2[2][RT];
     init_acc(acc2, p_b2, n0, lg);
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
@@ -505,7 +514,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       STAMP(5);
       if constexpr (DM != 0) {  // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
           if constexpr (DM == 1) {       // rb & 31 == 4*lg: both feature tiles of this lane sit in one hash word
             const unsigned int w = rg_hash(drop1.seed, rb >> 5);
@@ -526,7 +535,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-        for (int rt = 0; rt < 4; ++rt) {
+        for (int rt = 0; rt < RT; ++rt) {
           if constexpr (Precise<T>::value) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[ct][rt][r] = gelu_t<true>(acc[ct][rt][r]);
@@ -551,7 +560,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     prefetch_rows(mbn);
     if constexpr (DM != 0) {    // dropout on the l2 output, before the residual (transformer.py:186-188)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) {
+      for (int rt = 0; rt < RT; ++rt) {
         const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
         if constexpr (DM == 1) {
           const unsigned int w = rg_hash(drop2.seed, rb >> 5);
@@ -574,13 +583,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     ln_regs(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
     if (rstd2o && wave == 0 && lg == 0) {
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
         if (mb[rt] + li < a.M) rstd2o[mb[rt] + li] = rstd[rt];
     }
 #pragma unroll
     for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt)
+      for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= rm4[rt];
     regs_to_tile<T>(acc2, Actx, n0, li, lg);
@@ -592,7 +601,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     lds_barrier();                                      // before the next tile overwrites Actx / Ag / Ay
     STAMP(10);
 #pragma unroll
-    for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
+    for (int rt = 0; rt < RT; ++rt) mb[rt] = mbn[rt];
     have = have_next;
   }
   if (a.live16) {
@@ -600,10 +609,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
     // everything a backward pass reads --, 4 row tiles per step
     const int nrt = (a.M + 15) >> 4, ndead = nrt - a.live16[0];
     constexpr bool cross = CROSS;
-    for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
-      int md[4];
+    for (int j = RT * (int)blockIdx.x; j < ndead; j += RT * (int)gridDim.x) {
+      int md[RT];
 #pragma unroll
-      for (int rt = 0; rt < 4; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
+      for (int rt = 0; rt < RT; ++rt) md[rt] = j + rt < ndead ? a.live16[nrt - (j + rt)] * 16 : a.M;
       zero_to_hbm<T>(out, FD, 0, md, a.M, tid);
       if constexpr (RES) zero_to_hbm<T>(outlo, FD, 0, md, a.M, tid);
       if (a.skip_dead_saves) continue;      // the backward is list-driven too: it never reads the padded tiles' saves
@@ -611,7 +620,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void post_attn_fwd_k
       if (cross && y2save) zero_to_hbm<T>(y2save, FD, 0, md, a.M, tid);
       if (h1save)
         for (int ch = 0; ch < nchunk; ++ch) zero_to_hbm<T>(h1save, a.dff, ch * FD, md, a.M, tid);
-      if (tid < FT_M) {
+      if (tid < FTM) {
         const int m = md[tid >> 4] + (tid & 15);
         if (m < a.M) {
           if (rstd1o) rstd1o[m] = 0.f;
@@ -638,12 +647,24 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   if ((a->o_bcast || a->cross_s) && a->L <= 0) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross stage needs L");
   if (a->cross_s && (!a->cross_oh || !a->cross_bo || a->H != 4)) return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: cross_s needs cross_oh, cross_bo, H == P / 32 == 4");
   hipStream_t s = (hipStream_t)stream;
-  const int ntiles = (a->M + FT_M - 1) / FT_M;
+  // work tile: 64 tokens.  The 32-token form (kernel template RT = 2: three workgroups per CU instead of two) was built and
+  // measured SLOWER at the bench shape -- 277 -> 292 us (encoder inference), 337 -> 365, 413 -> 467 (decoder training): the
+  // per-tile fixed costs (14 barriers, two LayerNorm exchanges, the weight sets) double per row, which the third wave per
+  // SIMD does not buy back.  It is only instantiated in -DRG_PA_RT2 builds (RG_PA_RT=2 selects it there) for A/B timing.
+#ifdef RG_PA_RT2
+  static const int rt_env = [] { const char* e = getenv("RG_PA_RT"); return e ? atoi(e) : 0; }();
+  const int rt = dtype != RG_BF16 ? 4 : (rt_env == 2 ? 2 : 4);
+#else
+  const int rt = 4;
+#endif
+  const int ftm = 16 * rt;
+  const int ntiles = (a->M + ftm - 1) / ftm;
   const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int act = FT_M * (dtype == RG_BF16 ? FD : FLD) * esz;
-  const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * FT_M * 4 * 4 + 64 * 4 + (a->h1_save ? act : 0);
+  const int act = ftm * (dtype == RG_BF16 ? FD : FLD) * esz;
+  const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * ftm * 4 * 4 + 64 * 4 + (a->h1_save ? act : 0);
   const int per_cu = (160 * 1024) / smem;
-  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 3 ? 3 : per_cu));
+  const int cap_cu = rt == 2 ? 3 : 3;                   // (RT == 2: 3 waves per SIMD by registers)
+  int grid = 256 * (per_cu < 1 ? 1 : (per_cu > cap_cu ? cap_cu : per_cu));
   if (grid > ntiles) grid = ntiles;
   const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
   const bool cross = a->o_bcast || a->cross_s;
@@ -651,11 +672,20 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   const bool res = a->x_lo || a->out_lo;
   if (res && (!a->x_lo || !a->out_lo || dtype != RG_BF16))
     return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: the split residual stream needs x_lo AND out_lo, bf16 tier");
-#define RG_PA3(T, DM, C, S, R)                                                                                            \
+#define RG_PA4(T, DM, C, S, R, RTV)                                                                                       \
   do {                                                                                                                    \
-    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S, R>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
-    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C, S, R>), dim3(grid), dim3(256), smem, s, *a);                       \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S, R, RTV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<T, DM, C, S, R, RTV>), dim3(grid), dim3(256), smem, s, *a);                  \
   } while (0)
+#ifdef RG_PA_RT2
+#define RG_PA3(T, DM, C, S, R)                                                              \
+  do {                                                                                      \
+    if constexpr (sizeof(T) == 2) { if (rt == 2) RG_PA4(T, DM, C, S, R, 2); else RG_PA4(T, DM, C, S, R, 4); } \
+    else RG_PA4(T, DM, C, S, R, 4);                                                         \
+  } while (0)
+#else
+#define RG_PA3(T, DM, C, S, R) RG_PA4(T, DM, C, S, R, 4)
+#endif
 #define RG_PA2(T, DM, C, S)                                                                       \
   do {                                                                                            \
     if constexpr (sizeof(T) == 2) { if (res) RG_PA3(T, DM, C, S, true); else RG_PA3(T, DM, C, S, false); } \
@@ -679,6 +709,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 #undef RG_PA
 #undef RG_PA2
 #undef RG_PA3
+#undef RG_PA4
   RG_CHECK_LAUNCH();
   return 0;
 }

@@ -336,6 +336,23 @@ struct LiveWalk {
       g[rt] = (4 * wt + rt < nlive) ? e * 16 : M;
     }
   }
+  // the same for work tiles of RT row tiles (RT = 1, 2, 4): one vector load serves 64 / RT work tiles
+  template <int RT>
+  __device__ __forceinline__ void group_n(int k, int (&g)[RT], int M) {
+    constexpr int PER = 64 / RT, SH = RT == 4 ? 4 : (RT == 2 ? 5 : 6);
+    const int wt = (int)blockIdx.x + k * (int)gridDim.x;
+    if ((k >> SH) != blk) {             // (uniform) next block of PER work tiles
+      blk = k >> SH;
+      const int lane = threadIdx.x & 63;
+      const long long idx = (long long)RT * ((long long)blockIdx.x + (long long)gridDim.x * (PER * blk + lane / RT)) + (lane % RT);
+      v = list[1 + (int)(idx < (long long)cap ? idx : (long long)cap)];
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+      const int e = __builtin_amdgcn_readlane(v, RT * (k & (PER - 1)) + rt);
+      g[rt] = (RT * wt + rt < nlive) ? e * 16 : M;
+    }
+  }
 };
 
 #define RG_CHECK_LAUNCH()                                   \
