@@ -78,7 +78,11 @@ def _ver(p):
 
 def shadow(p, transpose=False, pack=False):
     """Operand-tier copy of a 2-D f32 parameter: [out,in] or, transposed, [in,out]; pack=True: in the MFMA-fragment-packed
-    layout (hip.CAST_PACK) the fused discriminator kernel reads."""
+    layout (hip.CAST_PACK) the fused discriminator kernel reads.
+    LIFETIME: the returned tensor is valid until the SECOND optimizer step after it was handed out -- refresh_shadows()
+    rewrites two alternating destination buffers in place, so a holder that keeps a shadow across two steps (an autograd graph
+    retained over steps, a table captured once before a training loop) would read newer weights.  Every use in this package
+    takes the shadow at launch time; callers that need a stable copy must clone it."""
     transpose = int(bool(transpose)) | (hip.CAST_PACK if pack else 0)       # cast mode; rides in the key's transpose slot
     if _COMPUTE == torch.float32 and not transpose:
         return p.detach()

@@ -25,6 +25,25 @@ class Adam(object):
                     if p.grad is not None:
                         p.grad.zero_()
 
+    def state_dict(self):
+        """{"state": {parameter index: {"step", "exp_avg", "exp_avg_sq"}}, "param_groups": [...]} -- torch.optim.Adam's layout."""
+        params = [p for g in self.param_groups for p in g["params"]]
+        idx = {id(p): i for i, p in enumerate(params)}
+        return {"state": {idx[id(p)]: {"step": st["step"], "exp_avg": st["exp_avg"].clone(), "exp_avg_sq": st["exp_avg_sq"].clone()}
+                          for p, st in self.state.items()},
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        self.state = {}
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device, torch.float32).clone(),
+                             "exp_avg_sq": st["exp_avg_sq"].to(p.device, torch.float32).clone()}
+        for g, gs in zip(self.param_groups, sd.get("param_groups", [])):
+            g.update({k: v for k, v in gs.items() if k != "params"})
+        self._tables = {}                                 # device tables are rebuilt from the restored state
+
     @torch.no_grad()
     def step(self):
         """One rg_adam_multi_dev launch per parameter group over a DEVICE-RESIDENT segment table listing (chunks of) the
@@ -47,7 +66,10 @@ class Adam(object):
                 live.append((p, st))
             if not live:
                 continue
-            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr()) for p, st in live)
+            # every pointer baked into the table, and the host-side step counts: state restored or edited from outside
+            # (load_state_dict, a replaced exp_avg_sq, an edited step) changes the key and rebuilds the table from the host values
+            key = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"])
+                        for p, st in live)
             cache = self._tables.get(gi)
             if cache is None or cache["key"] != key:
                 rows = []
@@ -64,4 +86,6 @@ class Adam(object):
             for p, st in live:
                 st["step"] += 1                           # host mirror of the device counters (used when the table is rebuilt)
                 ops.bump(p)
+            cache["key"] = tuple((p.data_ptr(), p.grad.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), st["step"])
+                                 for p, st in live)      # the key the NEXT step expects (the device counters advanced with the host's)
             ops.refresh_shadows([p for p, _ in live])

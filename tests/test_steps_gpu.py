@@ -568,3 +568,43 @@ def test_single_domain_bench_shape_vs_oracle(capsys):
         with capsys.disabled():
             print("\n[single-domain, bench shape, %s] loss_ae %.6f vs %.6f | bpr_sas %.6f vs %.6f" % (tier, la, la_ref, lb, lb_ref))
         np.testing.assert_allclose([la, lb], [la_ref, lb_ref], rtol=tol, atol=1e-5)
+
+
+def test_adam_state_dict_roundtrip_and_external_edits():
+    """the device-resident Adam table is rebuilt when the optimizer state is restored or edited from outside
+    (load_state_dict; a replaced exp_avg_sq; an edited step count) -- against torch.optim.Adam on the same gradients."""
+    from recguru_amd.optim import Adam
+    torch.manual_seed(3)
+    mk = lambda: [torch.nn.Parameter(torch.randn(37, 16, device="cuda")), torch.nn.Parameter(torch.randn(129, device="cuda"))]
+    ps, ref = mk(), None
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt, topt = Adam(ps, lr=1e-2, betas=(0.5, 0.9)), torch.optim.Adam(ref, lr=1e-2, betas=(0.5, 0.9))
+    grads = [[torch.randn_like(p) for p in ps] for _ in range(5)]
+
+    def step(o, params, gs):
+        for p, g in zip(params, gs):
+            p.grad = g.clone()
+        o.step()
+    for i in range(2):
+        step(opt, ps, grads[i]); step(topt, ref, grads[i])
+    sd = opt.state_dict()
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = Adam(ps2, lr=1e-2, betas=(0.5, 0.9))
+    step(opt2, ps2, grads[0])                     # a table exists before the restore
+    for p2, p in zip(ps2, ps):
+        p2.data.copy_(p.data)
+    opt2.load_state_dict(sd)
+    step(opt, ps, grads[2]); step(opt2, ps2, grads[2]); step(topt, ref, grads[2])
+    for a, b, c in zip(ps, ps2, ref):
+        torch.testing.assert_close(b, a, rtol=0, atol=0)
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)
+    # external edits with unchanged pointers of p / grad / exp_avg: step count and a replaced second-moment buffer
+    st, tst = opt.state[ps[0]], topt.state[ref[0]]
+    st["step"] = 10
+    tst["step"] = torch.tensor(10.0) if torch.is_tensor(tst["step"]) else 10
+    st["exp_avg_sq"] = st["exp_avg_sq"] * 4.0
+    tst["exp_avg_sq"].mul_(4.0)
+    step(opt, ps, grads[3]); step(topt, ref, grads[3])
+    step(opt, ps, grads[4]); step(topt, ref, grads[4])
+    for a, c in zip(ps, ref):
+        torch.testing.assert_close(a, c, rtol=1e-5, atol=1e-6)

@@ -4,6 +4,7 @@
 # then on the box:      RG_HIP_LIB=recguru_amd/build/variants/name1.so python tools/kb_attn.py
 set -e
 cd "$(dirname "$0")/.."
+trap 'rm -f recguru_amd/csrc/_variant_*.hip' EXIT      # a failed hipcc must not leave a variant where build.py's *.hip glob finds it
 src=$1; shift
 python -m recguru_amd.build > /dev/null
 mkdir -p recguru_amd/build/variants
