@@ -33,5 +33,17 @@ timeout 300 python3 tools/kb_embed_scatter.py > $O/kb_embed_scatter.txt 2>&1
 bash tools/pmc_pa.sh train > $O/sq_post_attn.txt 2>&1
 bash tools/pmc_attn.sh 0.5 > $O/sq_attention.txt 2>&1
 find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+# config-5 (2 M items, L = 400, d = 256, k = 1024) at B = 4096: bench line + kernel trace
+C5="--items 2000000 --seq_len 400 --d_model 256 --n_head 8 --n_negs 1024 --batch 4096 --batches_per_domain 1 --ae_steps 0 --full_length_steps 0 --no_cpu_baseline"
+mkdir -p $O/c5
+timeout 900 python3 bench.py $C5 --steps 3 --warmup 1 2> $O/c5/bench.err | tail -1 > $O/c5/bench.json
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5/kt -- python3 $R/bench.py $C5 --steps 2 --warmup 1 --no_roofline > $O/c5/bench_under_rocprof.json 2> $O/c5/kt.err)
+find $O/c5/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/c5/kernel_stats.csv
+rm -rf $O/c5/kt
+timeout 600 python3 bench.py --mode ae --no_cpu_baseline 2>> $O/bench.err | tail -1 > $O/bench_ae_step.json
+timeout 600 python3 bench.py --residual split --no_cpu_baseline --ae_steps 0 --full_length_steps 0 2>> $O/bench.err | tail -1 > $O/bench_split_residual.json
+timeout 900 python3 bench.py --dtype f32 --steps 3 --warmup 1 --no_cpu_baseline --ae_steps 0 --full_length_steps 0 2>> $O/bench.err | tail -1 > $O/bench_f32_tier.json
+timeout 300 python3 tools/kb_attn_hm.py > $O/kb_attention_head_major.txt 2>&1
+timeout 300 python3 tools/kb_post_attn.py > $O/kb_post_attn.txt 2>&1
 rm -rf $O/kt $O/pmcF $O/pmcW $R/gpurun_out/pmc_pa $R/gpurun_out/pmc_attn
 ls -la $O
