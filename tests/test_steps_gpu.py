@@ -209,7 +209,7 @@ def _curve_models(z, device="cuda"):
     return m, param, G.to(device), D.to(device)
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16"])
+@pytest.mark.parametrize("tier", ["f32", "bf16", "bf16_split_resid"])
 def test_loss_curves_replay(tier, capsys):
     """20 train_recon_x steps + train_gan_all(iterations=9) = 5 phase-2 + 5 phase-3 iterations, as the reference's
     drivers ran them (oracle/gen_golden_curves.py).  f32: rtol 1e-3 per point in phase 1; in phases 2 / 3 the
@@ -218,6 +218,7 @@ def test_loss_curves_replay(tier, capsys):
     from recguru_amd import blocks, ops, training as T
     from recguru_amd.optim import Adam
     ops.set_compute_dtype(TIERS[tier])
+    ops.set_residual_dtype(torch.float32 if tier == "bf16_split_resid" else torch.bfloat16)
     z = load_case("curves1")
     m, param, G, D = _curve_models(z)
     ld = curve_loaders(z)                        # CPU tensors: get_next_batch moves them, like the reference's loaders
