@@ -539,6 +539,83 @@ def test_large_batch_bf16_composition_vs_oracle(capsys):
     assert all(v <= 0.015 for v in worst.values()), worst       # measured <= 0.0073 of each gradient's largest element
 
 
+_ORACLE_CURVE = {}
+
+
+def _bench_shape_curve_oracle(steps, its):
+    """`steps` train_recon_x steps (Noam schedule, warm-up 7) and `its` phase-2 iterations of the ORACLE's drivers at the bench
+    shape (L=200, d=128, N=3, V=100k, k=30, B=16; 3 batches per domain, dropout 0), on the CPU; cached across the tiers."""
+    if _ORACLE_CURVE:
+        return _ORACLE_CURVE
+    from oracle import recguru_oracle as O
+    from recguru_amd import synthetic
+    c = BENCH
+    param, G, D, sG, sD, _ = _bench_setup("cpu")
+    cfg = O.Cfg(c["d"], c["H"], c["N"], c["L"], c["k"], c["V"] + 1, c["V"] + 1)
+    for dom in "ab":
+        sG["pos_emb_%s.pe" % dom] = O.positional_table(5000, c["d"]).unsqueeze(0)
+    pG, pD = O.leafify(sG), O.leafify(sD)
+    loaders = []
+    for seed, k in ((71, c["k"]), (72, c["k"]), (73, 5)):            # ae_a, ae_b, and the recommendation batches (n_bpr_neg = 5) of domain a
+        dm = synthetic.make_domain(3 * c["B"], c["V"], c["L"], k, seed=seed)
+        t = {n: torch.as_tensor(dm[n]) for n in ("enc_in", "dec_in", "dec_out", "n_items")}
+        z = torch.zeros(c["B"], dtype=torch.long)
+        loaders.append([((t["enc_in"][i:i + c["B"]], t["dec_in"][i:i + c["B"]], t["dec_out"][i:i + c["B"]]),
+                         t["n_items"][i:i + c["B"]], z, z) for i in range(0, 3 * c["B"], c["B"])])
+    p1, _ = O.train_recon_x(pG, cfg, steps, loaders[:2], 7)
+    torch.manual_seed(99)
+    p2, p3 = O.train_gan_all(pG, pD, cfg, loaders[:2], [loaders[2], loaders[2]], its / 0.6 + 1e-9, "a", collapsed=True)
+    _ORACLE_CURVE.update(p1=np.array([[float(a), float(b)] for a, b in p1]), p2=np.array(p2), p3=np.array(p3), loaders=loaders)
+    return _ORACLE_CURVE
+
+
+@pytest.mark.parametrize("tier", ["f32", "bf16", "bf16_split_resid"])
+def test_bench_shape_loss_curve_vs_oracle(tier, capsys):
+    """North-star: "loss curves matching the CPU reference within tolerance" AT the metric's shape (seq_len 200, hidden 128,
+    100k-item domains): 6 steps of the shipped train_recon_x (Noam learning rates up to 0.03) followed by the shipped
+    train_gan_all with 2 phase-2 iterations (10 critic + 2 generator updates) and 2 phase-3 iterations (reconstruction + BPR
+    tune), dropout 0, against the oracle's drivers on the CPU.
+    f32 tier: rtol 1e-3 on every reconstruction loss, 3e-4 absolute on the W-GAN scalars (their own rounding band, DESIGN.md
+    2); bf16 tiers: <= 2 x the drift measured on an MI355X."""
+    from recguru_amd import blocks, ops, training as T
+    from recguru_amd.optim import Adam
+    steps, its = 6, 2
+    ref = _bench_shape_curve_oracle(steps, its)
+    ops.set_compute_dtype(TIERS[tier])
+    ops.set_residual_dtype(torch.float32 if tier == "bf16_split_resid" else torch.bfloat16)
+    param, G, D, sG, sD, _ = _bench_setup("cuda")
+    res = "/tmp/rg_curve_%d" % os.getpid()
+    os.makedirs(res, exist_ok=True)
+    param.result_path = res
+    ld = ref["loaders"]
+    T.plot.reset()
+    opt_rec = blocks.ScheduledOptim(Adam(G.parameters(), betas=(0.9, 0.98), eps=1e-09), 1.0, BENCH["d"], 7)
+    losses = T.train_recon_x(G, opt_rec, steps, ld[:2], param, "cuda", neg_sample=True, loss_type="s_soft", opt_type="schedule",
+                             log_every=0)
+    p1 = np.array([[float(a), float(b)] for a, b in losses])
+    opt_gen = Adam(G.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    opt_dis = Adam(D.parameters(), lr=0.0001, betas=(0.5, 0.9))
+    torch.manual_seed(99)
+    hist = T.train_gan_all(G, D, ld[:2], opt_dis, opt_gen, "cuda", param, its / 0.6 + 1e-9, None, [ld[2], ld[2]], None, domain="a",
+                           overlap=False)
+    p2 = np.array([[float(x) for x in row] for row in hist])
+    p3 = np.array([[float(x) for x in row] for row in hist.phase3])
+    assert p2.shape == ref["p2"].shape == (its, 5) and p3.shape == ref["p3"].shape
+    e1 = float(np.abs(p1 / ref["p1"] - 1).max())
+    e2r = float(np.abs(p2[:, 2:4] / ref["p2"][:, 2:4] - 1).max())
+    e2a = float(np.abs(p2[:, [0, 1, 4]] - ref["p2"][:, [0, 1, 4]]).max())
+    e3 = float(np.abs(p3 / ref["p3"] - 1).max())
+    with capsys.disabled():
+        print("\n[bench-shape loss curve, %s tier] phase 1 (6 steps, loss %.2f -> %.2f) max rel err %.3g | phase 2 recon max rel "
+              "err %.3g, D_cost / W_D / g_dis max abs err %.3g | phase 3 (BPR, recon) max rel err %.3g"
+              % (tier, ref["p1"][0, 0], ref["p1"][-1, 0], e1, e2r, e2a, e3))
+    if tier == "f32":
+        assert e1 <= 1e-3 and e2r <= 1e-3 and e2a <= 3e-4 and e3 <= 2e-3
+    else:
+        assert e1 <= 0.05 and e2r <= 0.05 and e2a <= 0.02 and e3 <= 0.08
+    assert np.isfinite(p1).all() and np.isfinite(p2).all() and np.isfinite(p3).all()
+
+
 def test_single_domain_bench_shape_vs_oracle(capsys):
     """BASELINE configs[1] (single-domain AutoRec, 100k items, L=200, d=128) at a batch the oracle finishes in seconds:
     MyRec reconstruction loss (train_auto.py:29-54, mask = dec_in != 0) and the recommender's BPR-sas loss, both tiers."""
