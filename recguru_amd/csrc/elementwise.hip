@@ -342,6 +342,47 @@ __global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_kernel(const T* __restr
   }
 }
 
+// the same for N == 64 * NPL exactly: a lane owns NPL CONTIGUOUS features (one 8 / 16-byte load per operand instead of NPL
+// 2 / 4-byte ones; gamma and beta live in registers across the row loop)
+template <typename T, int NPL>
+__global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_vec_kernel(const T* __restrict__ x, const float* __restrict__ o,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   T* __restrict__ y, float* __restrict__ rstd_out, long long M,
+                                                                   int L, float eps) {
+  constexpr int N = 64 * NPL;
+  struct alignas(sizeof(T) * NPL) VT { T e[NPL]; };
+  struct alignas(sizeof(float) * NPL) VF { float e[NPL]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invn = 1.f / (float)N;
+  const VF g = *reinterpret_cast<const VF*>(gamma + lane * NPL), be = *reinterpret_cast<const VF*>(beta + lane * NPL);
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  for (long long m = gw; m < M; m += nw) {
+    const long long b = m / L;
+    const VT xv = *reinterpret_cast<const VT*>(x + (size_t)m * N + lane * NPL);
+    const VF ov = *reinterpret_cast<const VF*>(o + (size_t)b * N + lane * NPL);
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      v[j] = (float)xv.e[j] + ov.e[j];
+      s += v[j];
+    }
+    const float mean = wave_sum(s) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float dd = v[j] - mean;
+      q += dd * dd;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+    VT yv;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) yv.e[j] = (T)((v[j] - mean) * rstd * g.e[j] + be.e[j]);
+    *reinterpret_cast<VT*>(y + (size_t)m * N + lane * NPL) = yv;
+    if (lane == 0) rstd_out[m] = rstd;
+  }
+}
+
 // out[b,:] = sum_t x[b,t,:]   (f32 accumulation, tier-dtype result: it feeds the next GEMM)
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void seq_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int N) {
@@ -980,6 +1021,13 @@ template <typename T>
 static int launch_bcast_ln(const void* x, const float* o, const float* gamma, const float* beta, void* y, float* rstd,
                            long long M, int L, int N, float eps, hipStream_t s) {
   const int grid = ew_grid(M, 16);
+#define RG_BV(NPL) hipLaunchKernelGGL((bcast_add_ln_vec_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)x, o, gamma, beta, (T*)y, rstd, M, L, eps)
+  if (N == 128 || N == 256) {                              // whole-wave rows of contiguous per-lane vectors
+    if (N == 128) RG_BV(2); else RG_BV(4);
+    RG_CHECK_LAUNCH();
+    return 0;
+  }
+#undef RG_BV
 #define RG_BL(NPL) hipLaunchKernelGGL((bcast_add_ln_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)x, o, gamma, beta, (T*)y, rstd, M, L, N, eps)
   if (N <= 64) RG_BL(1);
   else if (N <= 128) RG_BL(2);

@@ -480,10 +480,27 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   return 0;
 }
 
-// 1 if an instantiation takes this problem
+static bool tn_native(int N1, int N2) {
+  return (N2 == 128 && (N1 == 512 || N1 == 384 || N1 == 256 || N1 == 128)) || (N1 == 128 && N2 == 512);
+}
+
+// Wider problems (d_model = 256: 512 x 256, 256 x 512, 768 x 256, 256 x 256) run as a grid of native blocks, one launch per
+// block on the same stream and scratch: block (i, j) reads columns [i*b1, +b1) of Y and [j*b2, +b2) of X, so Y is read
+// N2 / b2 times and X N1 / b1 times -- the generic 64 x 64 kernel re-reads them N2 / 64 and N1 / 64 times.
+static bool tn_blocks(int N1, int N2, int* b1, int* b2) {
+  if (tn_native(N1, N2)) { *b1 = N1; *b2 = N2; return true; }
+  if ((N1 & 127) || (N2 & 127) || N1 > 1024 || N2 > 512) return false;
+  if (N2 == 512 && N1 <= 512) { *b1 = 128; *b2 = 512; return true; }       // X (the wide operand) read N1 / 128 times
+  *b2 = 128;
+  *b1 = (N1 % 512 == 0) ? 512 : (N1 % 384 == 0) ? 384 : (N1 % 256 == 0) ? 256 : 128;
+  return true;
+}
+
+// 1 if an instantiation (or a grid of them) takes this problem
 int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
   if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7) || a->colsum_T > 0) return 0;
-  return (a->N2 == 128 && (a->N1 == 512 || a->N1 == 384 || a->N1 == 256 || a->N1 == 128)) || (a->N1 == 128 && a->N2 == 512);
+  int b1, b2;
+  return tn_blocks(a->N1, a->N2, &b1, &b2) ? 1 : 0;
 }
 
 // kernel family that runs the big shapes (profiler names: rg_gemm_tn_plan)
@@ -495,12 +512,35 @@ const char* rg_gemm_tn_big_name(const rg_gemm_tn_args* a) {
 // bytes of partial-sum scratch the big kernel can use for this problem (0 if it does not take it)
 size_t rg_gemm_tn_big_workspace(const rg_gemm_tn_args* a, int dtype) {
   if (!rg_gemm_tn_big_select(a, dtype)) return 0;
-  return (size_t)256 * a->N1 * a->N2 * sizeof(float);
+  int b1, b2;
+  tn_blocks(a->N1, a->N2, &b1, &b2);
+  return (size_t)256 * b1 * b2 * sizeof(float);
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
+static int tn_big_native(const rg_gemm_tn_args* a, hipStream_t s);
+
 int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
   if (!rg_gemm_tn_big_select(a, dtype)) return 1;
+  int b1, b2;
+  tn_blocks(a->N1, a->N2, &b1, &b2);
+  if (b1 == a->N1 && b2 == a->N2) return tn_big_native(a, s);
+  for (int i = 0; i < a->N1 / b1; ++i)
+    for (int j = 0; j < a->N2 / b2; ++j) {
+      rg_gemm_tn_args t = *a;
+      t.Y = (const __bf16*)a->Y + (size_t)i * b1;
+      t.X = (const __bf16*)a->X + (size_t)j * b2;
+      t.dW = a->dW + (size_t)i * b1 * a->lddw + (size_t)j * b2;
+      t.colsum = (a->colsum && j == 0) ? a->colsum + (size_t)i * b1 : nullptr;      // the bias gradient once per Y block
+      t.N1 = b1;
+      t.N2 = b2;
+      const int rc = tn_big_native(&t, s);
+      if (rc) return rc < 0 ? rc : rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: block launch refused");
+    }
+  return 0;
+}
+
+static int tn_big_native(const rg_gemm_tn_args* a, hipStream_t s) {
   if (a->N1 == 512 && a->N2 == 128) return launch_big<512, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 512) return launch_big<128, 512>(*a, s);
   if (a->N1 == 384 && a->N2 == 128) return launch_big<384, 128>(*a, s);

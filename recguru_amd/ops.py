@@ -244,6 +244,17 @@ def _live(rowmask, M, shapes_ok=True):
     return hip.live_tiles(rowmask, M)
 
 
+def _live_tn(rowmask, M, n1, n2):
+    """A list for the weight-gradient product ALONE (d_model = 256: the other token-level kernels of the backward are the
+    generic ones, which write every row): the padded tiles' rows of its Y operand are zeros, so skipping them is exact."""
+    if not TN_LIST_WIDE or n1 % 128 or n2 % 128 or n1 > 1024 or n2 > 1024:
+        return None
+    return _live(rowmask, M, True)
+
+
+TN_LIST_WIDE = True
+
+
 # ------------------------------------------------------------------------------------------------
 # Parameter gradients are accumulated IN PLACE: the weight-gradient kernels (gemm_tn, colsum, ln_bwd, the
 # scatter-adds) all compute dW += ..., so a backward writes straight into p.grad and hands autograd None
@@ -473,6 +484,19 @@ def masked_by(x, rowmask):
 # ------------------------------------------------------------------------------------------------
 # attention / FFN building blocks (plain functions over explicit tensors; used by the layer Functions)
 # ------------------------------------------------------------------------------------------------
+WS_PROJ_PLUS_LN = True
+_ZERO_ROWS = {}
+
+
+def _zero_row(n, dev):
+    """[1, n] f32 zeros: the broadcast addend of a plain LayerNorm through rg_bcast_add_ln (L = M: every row reads row 0)."""
+    key = (n, str(dev))
+    z = _ZERO_ROWS.get(key)
+    if z is None:
+        z = _ZERO_ROWS[key] = torch.zeros(1, n, device=dev, dtype=torch.float32)
+    return z
+
+
 def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
 
@@ -562,6 +586,16 @@ def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv,
     """MultiHeadAttention.forward (transformer.py:151-161), unfused (any width): returns y and what backward needs."""
     qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need_grad, drop_p, seed,
                                    rowmask, x_masked)
+    M, d = x2.shape
+    P = Wo.shape[1]
+    if (WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d % 128 == 0 and P % 128 == 0 and d > 128
+            and P // 128 <= 4 and d // 128 <= 8):
+        # d_model = 256 (config-5): the whole-row LayerNorm epilogue only exists in the generic 64 x 256 tile kernel, which runs
+        # this product at 7 % of the HBM rate; the weight-stationary kernel (+ bias + residual, one column block per gridDim.y)
+        # followed by a LayerNorm pass over its bf16 output is 3x faster (the sum is rounded to bf16 once before the LayerNorm)
+        z = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_ADD, aux=x2)
+        y, rstd = hip.bcast_add_ln(z, _zero_row(d, z.device), g.detach(), be.detach(), M, LN_EPS)
+        return y, (qkv, ctx_, lse, rstd)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
     y = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x2,
                     gamma=g.detach(), beta=be.detach(), rstd_out=rstd, eps=LN_EPS)
@@ -588,7 +622,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
         hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
     else:
         dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
-        hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
+        hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live if live is not None else _live_tn(rowmask, dz.shape[0], P, d))
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
     # the forward's decision (same inputs; x_masked == 2: it was the fused block's forward): were the padded tiles' rows of
     # qkv left unwritten?
@@ -650,7 +684,8 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
         dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out, live=live)
     else:
         dz = dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
-    hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
+    live_tn = live if live is not None else _live_tn(rowmask, dout.shape[0], d, dff)
+    hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live_tn)
     if FUSE_FFN_BWD and hip.ffn_bwd_data_supported(d, dff):
         # one launch for both data-path products: dh1 is written once (for dW1) and never read back
         dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),
@@ -659,7 +694,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
         return dy, (rW1, rb1, rW2, rb2, rg, rbe)
     dh1 = hip.gemm_nt(dl2, shadow(W2, transpose=True), epilogue=hip.EPI_GELU_GRAD, aux=h1,
                       epi_nonzero_scale=_inv_keep(drop_p), live=live, skip_dead_fill=True)   # both consumers list-driven
-    hip.gemm_tn(dh1, y, dW1, db1, live=live)
+    hip.gemm_tn(dh1, y, dW1, db1, live=live_tn)
     dy = hip.gemm_nt(dh1, shadow(W1, transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dy, (rW1, rb1, rW2, rb2, rg, rbe)
 

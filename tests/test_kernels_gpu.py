@@ -240,10 +240,11 @@ def test_ln_bwd(dt, N):
     torch.testing.assert_close(db, b.grad, **t2)
 
 
+@pytest.mark.parametrize("N", [96, 128, 256])     # strided lanes / a lane's 2 / 4 contiguous features
 @pytest.mark.parametrize("dt", DTYPES)
-def test_bcast_add_ln_seq_sum(dt):
+def test_bcast_add_ln_seq_sum(dt, N):
     from recguru_amd import hip
-    B, L, N = 3, 11, 128
+    B, L = 3, 11
     x = rnd(B * L, N, dt=dt, seed=1)
     o = rnd(B, N, dt=torch.float32, seed=2)
     g = 1 + 0.1 * rnd(N, dt=torch.float32, seed=3)
@@ -635,7 +636,9 @@ def test_gemm_ws_matches_generic(K, N, epi):
     torch.testing.assert_close(out_ws.float(), out_gen.float(), rtol=2e-2, atol=2e-2)
 
 
-@pytest.mark.parametrize("N1,N2,gelu", [(512, 128, False), (128, 512, True), (384, 128, False), (128, 128, False)])
+@pytest.mark.parametrize("N1,N2,gelu", [(512, 128, False), (128, 512, True), (384, 128, False), (128, 128, False),
+                                        # grids of native blocks (d_model = 256): dW1, dW2, fused QKV, out-projection
+                                        (512, 256, False), (256, 512, True), (768, 256, False), (256, 256, False)])
 def test_gemm_tn_big_matches_generic(N1, N2, gelu):
     """Whole-dW-per-workgroup wgrad path (bf16, T >= 8192) vs the generic 64x64-tile kernel and torch."""
     from recguru_amd import hip
@@ -818,7 +821,7 @@ def test_gemm_ws_live_tile_list(K, N, epi):
     assert float(full[mask == 0].abs().max()) == 0.0          # zero inputs give zero outputs: nothing was lost
 
 
-@pytest.mark.parametrize("N1,N2,gelu", [(128, 512, True), (512, 128, False), (128, 128, False)])
+@pytest.mark.parametrize("N1,N2,gelu", [(128, 512, True), (512, 128, False), (128, 128, False), (256, 512, True), (768, 256, False)])
 def test_gemm_tn_big_live_tile_list(N1, N2, gelu):
     from recguru_amd import hip
     dt = torch.bfloat16
