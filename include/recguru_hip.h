@@ -392,6 +392,14 @@ int rg_scale_dev(void* x, long long n, const float* s /* device */, int dtype, v
  * rg_cross_rows: out [M,N] f32 = bo + sum_h s[m,h] * oh[m/L,h,:] -- the collapsed cross-attention output per row
  *   under attention-map dropout (s from rg_cross_drop_scale). */
 int rg_dropout(void* x, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* The wide FFN block (d_model = 256) around the weight-stationary GEMM, which has neither a prologue nor a LayerNorm epilogue
+ * (PositionWiseFeedForwardNet.forward, transformer.py:179-188: l1 -> dropout -> GELU -> l2 -> dropout -> + residual -> LayerNorm):
+ * rg_dropout_gelu: rg_dropout on x [M,N] in place (drop_p == 0: x untouched) and g [M,N] = gelu(x as stored).  N % 8 == 0.
+ * rg_add_drop_ln: y = LayerNorm(x + dropout(z)) * rowmask (rowmask [M] f32 or NULL), rstd [M] for rg_ln_bwd; the mask of z is
+ *   the one rg_dropout(z, seed) would apply, z is not rewritten.  x, z, y [M,N] of dtype, N in {128, 256}. */
+int rg_dropout_gelu(void* x, void* g, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream);
+int rg_add_drop_ln(const void* x, const void* z, const float* gamma, const float* beta, const float* rowmask, void* y, float* rstd,
+                   long long M, int N, float drop_p, unsigned long long seed, float eps, int dtype, void* stream);
 int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N,
                   void* stream);
 

@@ -806,6 +806,72 @@ __global__ __launch_bounds__(EW_BLOCK) void dropout_kernel(T* __restrict__ x, lo
   }
 }
 
+// In-place dropout as above AND g = gelu(the value as stored): the activated operand of the second FFN product, for the
+// weight-stationary GEMM (which has no prologue).  The weight-gradient product recomputes gelu() from the same stored x.
+template <typename T, bool PRECISE>
+__global__ __launch_bounds__(EW_BLOCK) void dropout_gelu_kernel(T* __restrict__ x, T* __restrict__ g, long long M, int N, DropCfg drop) {
+  const int n8 = N >> 3;
+  const long long total = M * n8;
+  for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += (long long)gridDim.x * EW_BLOCK) {
+    const long long m = i / n8;
+    const int c8 = (int)(i - m * n8) * 8;
+    float v[8];
+    load8(v, x + (size_t)m * N + c8);
+    if (drop.thresh) {
+      float k8[8];
+      rg_keep8(drop, (unsigned int)m * (unsigned int)N + (unsigned int)c8, k8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= k8[j];
+      store8(x + (size_t)m * N + c8, v);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = gelu_t<PRECISE>((float)(T)v[j]);
+    store8(g + (size_t)m * N + c8, v);
+  }
+}
+
+// y[m,:] = LayerNorm(x[m,:] + dropout(z)[m,:]) * rowmask[m]  (N == 64 * NPL: a lane owns NPL contiguous features).  The mask of
+// z is the one rg_dropout(z, seed) would apply (index m*N + c), so rg_ln_bwd's dz_drop regenerates it; z itself is not rewritten.
+template <typename T, int NPL>
+__global__ __launch_bounds__(EW_BLOCK) void add_drop_ln_kernel(const T* __restrict__ x, const T* __restrict__ z,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ rowmask, T* __restrict__ y,
+                                                              float* __restrict__ rstd_out, long long M, DropCfg drop, float eps) {
+  constexpr int N = 64 * NPL;
+  struct alignas(sizeof(T) * NPL) VT { T e[NPL]; };
+  struct alignas(sizeof(float) * NPL) VF { float e[NPL]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invn = 1.f / (float)N;
+  const VF g = *reinterpret_cast<const VF*>(gamma + lane * NPL), be = *reinterpret_cast<const VF*>(beta + lane * NPL);
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  for (long long m = gw; m < M; m += nw) {
+    const VT xv = *reinterpret_cast<const VT*>(x + (size_t)m * N + lane * NPL);
+    const VT zv = *reinterpret_cast<const VT*>(z + (size_t)m * N + lane * NPL);
+    const float rm = rowmask ? rowmask[m] : 1.f;
+    float v[NPL];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float k = drop.thresh ? rg_keep(drop, (unsigned int)m * (unsigned int)N + (unsigned int)(lane * NPL + j)) : 1.f;
+      v[j] = (float)xv.e[j] + (float)(T)((float)zv.e[j] * k);      // the dropped addend rounded as rg_dropout stores it
+      s += v[j];
+    }
+    const float mean = wave_sum(s) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float dd = v[j] - mean;
+      q += dd * dd;
+    }
+    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+    VT yv;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) yv.e[j] = (T)(((v[j] - mean) * rstd * g.e[j] + be.e[j]) * rm);
+    *reinterpret_cast<VT*>(y + (size_t)m * N + lane * NPL) = yv;
+    if (lane == 0) rstd_out[m] = rstd;
+  }
+}
+
 // o[m, :] = bo + sum_h s[m, h] * oh[m / L, h, :]  : the collapsed decoder cross-attention output per ROW under
 // attention-map dropout (what the fused kernel forms in registers), for the unfused block path.
 __global__ __launch_bounds__(EW_BLOCK) void cross_rows_kernel(const float* __restrict__ s, const float* __restrict__ oh,
@@ -936,6 +1002,40 @@ extern "C" int rg_dropout(void* x, long long M, int N, float drop_p, unsigned lo
              hipLaunchKernelGGL(dropout_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (__bf16*)x, M, N, drop),
              hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (float*)x, M, N, drop),
              "dropout")
+}
+
+extern "C" int rg_dropout_gelu(void* x, void* g, long long M, int N, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  if (M <= 0 || N <= 0) return 0;
+  if (N & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "dropout_gelu: N % 8 != 0");
+  const DropCfg drop = make_drop(drop_p, seed);
+  hipStream_t s = (hipStream_t)stream;
+  const int grid = ew_grid(M * (N >> 3), EW_BLOCK);
+  DISPATCH_T(dtype,
+             hipLaunchKernelGGL((dropout_gelu_kernel<__bf16, false>), dim3(grid), dim3(EW_BLOCK), 0, s, (__bf16*)x, (__bf16*)g, M, N, drop),
+             hipLaunchKernelGGL((dropout_gelu_kernel<float, true>), dim3(grid), dim3(EW_BLOCK), 0, s, (float*)x, (float*)g, M, N, drop),
+             "dropout_gelu")
+}
+
+template <typename T>
+static int launch_add_drop_ln(const void* x, const void* z, const float* gamma, const float* beta, const float* rowmask, void* y,
+                              float* rstd, long long M, int N, const DropCfg& drop, float eps, hipStream_t s) {
+  const int grid = ew_grid(M, 16);
+#define RG_ADL(NPL) hipLaunchKernelGGL((add_drop_ln_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)x, (const T*)z, gamma, beta, rowmask, (T*)y, rstd, M, drop, eps)
+  if (N == 128) RG_ADL(2);
+  else if (N == 256) RG_ADL(4);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "add_drop_ln: N must be 128 or 256");
+#undef RG_ADL
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rg_add_drop_ln(const void* x, const void* z, const float* gamma, const float* beta, const float* rowmask, void* y,
+                              float* rstd, long long M, int N, float drop_p, unsigned long long seed, float eps, int dtype,
+                              void* stream) {
+  if (M <= 0) return 0;
+  const DropCfg drop = make_drop(drop_p, seed);
+  if (dtype == RG_BF16) return launch_add_drop_ln<__bf16>(x, z, gamma, beta, rowmask, y, rstd, M, N, drop, eps, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_add_drop_ln<float>(x, z, gamma, beta, rowmask, y, rstd, M, N, drop, eps, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "add_drop_ln: bad dtype");
 }
 
 extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N, void* stream) {

@@ -90,7 +90,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
-           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse"]
+           "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse",
+           "rg_dropout_gelu", "rg_add_drop_ln"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -382,6 +383,27 @@ def dropout_(x, drop_p, seed):
     assert x.is_contiguous() and x.dim() == 2
     _check(lib().rg_dropout(_vp(x), c_ll(x.shape[0]), x.shape[1], c_f(drop_p), c_u64(seed), dt_of(x), _stream()), "rg_dropout")
     return x
+
+
+def dropout_gelu(x, drop_p, seed):
+    """rg_dropout on x in place (drop_p == 0: untouched); returns gelu(x as stored) in x's dtype."""
+    assert x.is_contiguous() and x.dim() == 2
+    g = torch.empty_like(x)
+    _check(lib().rg_dropout_gelu(_vp(x), _vp(g), c_ll(x.shape[0]), x.shape[1], c_f(drop_p), c_u64(seed), dt_of(x), _stream()),
+           "rg_dropout_gelu")
+    return g
+
+
+def add_drop_ln(x, z, gamma, beta, rowmask=None, drop_p=0.0, seed=0, eps=1e-8):
+    """y = LayerNorm(x + dropout(z)) * rowmask, rstd; x, z [M, N] of the tier dtype, N in {128, 256}."""
+    M, N = x.shape
+    assert x.is_contiguous() and z.is_contiguous() and z.shape == x.shape and z.dtype == x.dtype
+    assert rowmask is None or (rowmask.dtype == torch.float32 and rowmask.numel() == M and rowmask.is_contiguous())
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _check(lib().rg_add_drop_ln(_vp(x), _vp(z), _vp(gamma), _vp(beta), _vp(rowmask), _vp(y), _vp(rstd), c_ll(M), N, c_f(drop_p),
+                                c_u64(seed), c_f(eps), dt_of(x), _stream()), "rg_add_drop_ln")
+    return y, rstd
 
 
 def cross_rows(s, oh, bo, L):
@@ -1102,7 +1124,7 @@ _WORK = {"item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd"
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
-          "embed_scatter_bwd_binned", "scale_dev"]
+          "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse"]
 
 
 def start_profile():

@@ -643,6 +643,16 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
     width).  With dropout: l1 -> dropout -> GELU -> l2 -> dropout -> + y -> LayerNorm, the two dropouts as in-place
     passes over the GEMM outputs (h1 keeps the DROPPED pre-activation, as the fused kernel saves it)."""
     h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
+    M, d = y.shape
+    dff = W1.shape[0]
+    if (WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4):
+        # d_model = 256 (config-5): GELU prologue and LayerNorm epilogue only exist in the generic tile kernel (1.2 TB/s on this
+        # product); here the activation is one elementwise pass (with the h1 dropout), the product the weight-stationary kernel
+        # and dropout + residual + LayerNorm + pad mask one row pass.  l2 is rounded to bf16 before the LayerNorm.
+        gact = hip.dropout_gelu(h1, drop_p, seed_h1)
+        l2 = hip.gemm_nt(gact, shadow(W2), b2.detach())
+        out, rstd = hip.add_drop_ln(y, l2, g.detach(), be.detach(), rowmask, drop_p, seed_out, LN_EPS)
+        return out, (h1, rstd)
     if drop_p > 0:
         hip.dropout_(h1, drop_p, seed_h1)
         l2 = hip.gemm_nt(h1, shadow(W2), b2.detach(), prologue=hip.PRO_GELU, out_f32=True)

@@ -258,6 +258,37 @@ def test_bcast_add_ln_seq_sum(dt, N):
                                **(dict(rtol=1e-5, atol=1e-4) if dt == torch.float32 else tol(dt)))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.3])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_dropout_gelu_and_add_drop_ln(dt, p):
+    """The wide-FFN passes == the separate dropout passes they replace (same stateless masks), then torch."""
+    from recguru_amd import hip
+    M, N, F = 333, 256, 512
+    h = rnd(M, F, dt=dt, seed=1)
+    h_ref = h.clone()
+    if p > 0:
+        hip.dropout_(h_ref, p, 77)
+    gact = hip.dropout_gelu(h, p, 77)
+    assert torch.equal(h, h_ref)                                   # same mask, same rounding, in place
+    gr = gelu_tanh(h_ref.float())
+    torch.testing.assert_close(gact.float(), gr, **(dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)))
+    for N in (128, 256):
+        x = rnd(M, N, dt=dt, seed=2)
+        z = rnd(M, N, dt=dt, seed=3)
+        g = 1 + 0.1 * rnd(N, dt=torch.float32, seed=4)
+        b = 0.1 * rnd(N, dt=torch.float32, seed=5)
+        mask = (torch.arange(M, device="cuda") % 5 != 0).float()
+        y, rstd = hip.add_drop_ln(x, z, g, b, mask, p, 99)
+        zd = z.clone()
+        if p > 0:
+            hip.dropout_(zd, p, 99)
+        y2, rstd2 = hip.bcast_add_ln(x, zd.float(), g, b, 1)
+        torch.testing.assert_close(rstd, rstd2, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(y.float(), y2.float() * mask[:, None], **(dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)))
+        ref = torch.nn.functional.layer_norm(x.float() + zd.float(), (N,), g, b, 1e-8) * mask[:, None]
+        torch.testing.assert_close(y.float(), ref, **tol(dt))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gp_helpers(dt):
     from recguru_amd import hip
