@@ -70,11 +70,10 @@ typedef struct {
                                  (epilogue NONE) -- exact when the caller guarantees that those rows of A are all zero: the
                                  padded positions of a layer input (transformer.py:594 / :539 multiply every layer output by
                                  the pad mask, and the embedding by it, :105), whose Q / K / V rows are the biases */
-  /* c_hm_L > 0 (weight-stationary path only: bf16, N % 128 == 0, M = B * c_hm_L): C is written HEAD-MAJOR, as N / 128 tensors
-   * [B][4][c_hm_L][32] one after the other -- the 128-column block cb of row m = b * L + l goes to
-   * ((cb * B + b) * 4 + head) * L * 32 + l * 32, head = column / 32.  For the fused Q / K / V projection (N = 384) this is
-   * q | k | v [B, H = 4, L, 32]: a head's K (V, Q) tile is ONE contiguous run of L * 64 bytes, which the attention kernels
-   * stage by LDS-DMA (rg_attn_args.qkv_hm).  ldc is ignored. */
+  /* c_hm_L > 0 (weight-stationary path only: bf16, N = 3 * H * 32 with H % 4 == 0, M = B * c_hm_L): C is written HEAD-MAJOR, as
+   * the three tensors q | k | v [B][H][c_hm_L][32] one after the other -- column c of row m = b * L + l goes to
+   * (((c / (32 H)) * B + b) * H + (c / 32) % H) * L * 32 + l * 32 + c % 32.  A head's K (V, Q) tile is ONE contiguous run of
+   * L * 64 bytes, which the attention kernels stage by LDS-DMA (rg_attn_args.qkv_hm).  ldc is ignored. */
   int c_hm_L;
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);

@@ -37,16 +37,18 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // from L2 / Infinity Cache)
   const int cby = (int)blockIdx.y;
   const int ntiles = (a.M + WS_M - 1) / WS_M;
-  // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: block cb
-  // = tensor cb of [B][4][L][32], head = c8 / 32 -- four consecutive rows of one head are 256 contiguous bytes)
-  const int hmL = a.c_hm_L, hmB = hmL > 0 ? a.M / hmL : 0;
+  // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: N = 3 * H * 32
+  // columns q | k | v -> three tensors [B][H][L][32]; a 128-column block is four heads of one tensor -- block cb = tensor
+  // cb / (H/4), heads 4 * (cb % (H/4)) + c8 / 32 -- and four consecutive rows of one head are 256 contiguous bytes)
+  const int hmL = a.c_hm_L, hmB = hmL > 0 ? a.M / hmL : 0, hmBpt = a.N / 384;      // 128-column blocks per tensor = H / 4
   // m = mt + r with mt the first row of a 16-row tile (workgroup-uniform: its division by L is scalar work) and r < 16
   auto c_off = [&](int mt, int r, int cb, int c8) -> size_t {
     if (hmL > 0) {
       const int bt = __builtin_amdgcn_readfirstlane(mt) / hmL;
       int bb = bt, l = mt - bt * hmL + r;
       if (l >= hmL) { l -= hmL; ++bb; }                  // (a 16-row tile spans at most two sequences: L >= 16 is checked by the launcher)
-      return ((size_t)((cb * hmB + bb) * 4 + (c8 >> 5)) * hmL + l) * 32 + (c8 & 31);
+      const int w = cb / hmBpt, hb = cb - w * hmBpt;     // (cb is workgroup-uniform: scalar)
+      return ((size_t)(((w * hmB + bb) * hmBpt + hb) * 4 + (c8 >> 5)) * hmL + l) * 32 + (c8 & 31);
     }
     return (size_t)(mt + r) * a.ldc + cb * 128 + c8;
   };
@@ -263,13 +265,13 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;   // dropout-after-ReLU lives in the generic kernel
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
   if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
-  if (a->c_hm_L > 0 && ((a->M % a->c_hm_L) != 0 || a->c_hm_L < 16)) return 0;
+  if (a->c_hm_L > 0 && ((a->M % a->c_hm_L) != 0 || a->c_hm_L < 16 || (a->N % 384) != 0)) return 0;
   if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;
   // K and N both beyond 128 (d_model = 256: 256 -> 768 / 512 / 256, 512 -> 256): the <K/128, 1> instantiation once per
-  // 128-column block (gridDim.y); the head-major output form is defined for N = 384 only
-  if (nkc >= 2 && nkc <= 4 && ncb >= 2 && ncb <= 8 && a->c_hm_L <= 0) return 10 * nkc + 1;
+  // 128-column block (gridDim.y)
+  if (nkc >= 2 && nkc <= 4 && ncb >= 2 && ncb <= 8) return 10 * nkc + 1;
   return 0;
 }
 

@@ -163,8 +163,8 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill=True
     (only for outputs whose consumers are all list- or rowmask-driven), or come out as the bias row with
     skip_dead_fill=2 (exact when those rows of A are zero).
-    headmajor_L = L > 0 (weight-stationary shapes only): C comes out head-major, as N / 128 tensors [M / L, 4, L, 32]
-    (rg_gemm_nt_args.c_hm_L) -- returned as a [N / 128, M / L, 4, L, 32] tensor."""
+    headmajor_L = L > 0 (weight-stationary shapes only, N = 3 * H * 32 with H % 4 == 0): C comes out head-major, as the three
+    tensors q | k | v [M / L, H, L, 32] (rg_gemm_nt_args.c_hm_L) -- returned as a [3, M / L, H, L, 32] tensor."""
     M, K = A.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.dtype == A.dtype
@@ -175,7 +175,7 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     if M == 0:
         return out
     if headmajor_L:
-        assert N % 128 == 0 and M % headmajor_L == 0 and out.is_contiguous() and not out_f32
+        assert N % 384 == 0 and M % headmajor_L == 0 and out.is_contiguous() and not out_f32
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
@@ -185,7 +185,7 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
     if headmajor_L:
-        return out.view(N // 128, M // headmajor_L, 4, headmajor_L, 32)
+        return out.view(3, M // headmajor_L, N // 96, headmajor_L, 32)
     return out
 
 

@@ -567,8 +567,8 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     # (allow_unwritten: the caller's consumer of ctx is list-driven too -- the fused block; the rows of ctx in padded
     # tiles are then placeholders computed from unwritten Q rows)
     sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten
-    if (QKV_HEAD_MAJOR and _COMPUTE == torch.bfloat16 and H == 4 and x2.shape[1] == 128 and x2.shape[0] >= 4096
-            and (not need_grad or QKV_HEAD_MAJOR_TRAIN)):
+    if (QKV_HEAD_MAJOR and _COMPUTE == torch.bfloat16 and (H, x2.shape[1]) in ((4, 128), (8, 256)) and x2.shape[0] >= 4096
+            and 16 <= L <= 416 and (not need_grad or QKV_HEAD_MAJOR_TRAIN)):
         # the projection writes q | k | v HEAD-MAJOR ([3, B, H, L, 32]: a head's K / V / Q tile is one contiguous run); the
         # attention forward fills its LDS tiles by LDS-DMA, the backward's staging loads cover whole lines
         qkv = hip.gemm_nt(x2, wqkv, bqkv, live=live, skip_dead_fill=1 if sub else 2, headmajor_L=L)

@@ -1203,15 +1203,16 @@ def test_attention_substitutes_bias_rows_for_unwritten_qkv(causal, drop_p):
 
 @pytest.mark.parametrize("causal", [False, True])
 @pytest.mark.parametrize("drop_p", [0.0, 0.5, 0.3])
-@pytest.mark.parametrize("L,interior", [(200, False), (200, True), (50, False), (120, True), (400, False)])
-def test_attention_head_major_equals_token_major(causal, drop_p, L, interior):
+@pytest.mark.parametrize("L,interior,H", [(200, False, 4), (200, True, 4), (50, False, 4), (120, True, 4), (400, False, 4),
+                                          (400, True, 8), (96, False, 8)])
+def test_attention_head_major_equals_token_major(causal, drop_p, L, interior, H):
     """Head-major q | k | v ([3, B, H, L, 32], written by the weight-stationary projection with c_hm_L) + LDS-DMA staging in the
     attention forward: the same arithmetic on the same values as the token-major form -- bit-identical context rows.  With a
     live-tile list the padded tiles stay UNWRITTEN (NaN here): rows before first_live come from pad_rows; `interior` puts
     rowmask == 0 rows behind first_live too (the fix-up pass)."""
     from recguru_amd import hip, ops
     dt = torch.bfloat16
-    H, d = 4, 128
+    d = 32 * H                          # (H = 8: d_model 256, the projection as column blocks of the K = 256 kernel)
     B = max(6, (16384 + L - 1) // L + 1)
     P = H * 32
     g0 = torch.Generator().manual_seed(L + int(causal))
