@@ -159,7 +159,11 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], co
     float M2 = (q[0] + q[1]) + (q[2] + q[3]);
 #pragma unroll
     for (int w = 0; w < 4; ++w) { const float dm = p[w] * (1.f / 32.f) - mean[rt]; M2 += 32.f * dm * dm; }
-    rstd[rt] = rsqrtf(M2 * (1.f / FD) + eps);
+    // the bare v_rsq_f32 (the argument is >= eps: no denormal range to rescale).  rsqrtf()'s expansion -- compare, scale,
+    // v_rsq, rescale, select per row -- was compiled next to the LDS reads of gamma / beta into the same registers, and with
+    // two workgroups per CU (two waves per SIMD) lanes 48-63 of those registers came out with the earlier VALU values in
+    // ~4 % of the rows of EVERY launch (never with one wave per SIMD; tools/race_post_attn.py, tests/test_determinism_gpu.py)
+    rstd[rt] = __builtin_amdgcn_rsqf(M2 * (1.f / FD) + eps);
   }
 #pragma unroll
   for (int ct = 0; ct < 2; ++ct) {

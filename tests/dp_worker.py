@@ -20,7 +20,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-BENCH_SHAPE = dict(B=16, L=200, d=128, H=4, N=3, V=100000, k=30)
+BENCH_SHAPE = dict(B=int(os.environ.get("RG_BENCH_B", "16")), L=200, d=128, H=4, N=3, V=100000, k=30)   # RG_BENCH_B: tools/race_trace.py at scale
 
 
 def _tier():
@@ -34,14 +34,15 @@ def bench_case(device):
     from recguru_amd.config import get_param
     from recguru_amd.models import Discriminator, MyAuto4Rec_c
     s = BENCH_SHAPE
-    param = get_param(make_args(s["d"], s["H"], s["k"], s["L"], s["V"], s["V"], s["N"], s["B"]), make_dirs=False)
+    param = get_param(make_args(s["d"], s["H"], s["k"], s["L"], s["V"], s["V"], s["N"], s["B"],
+                                dropout=float(os.environ.get("RG_BENCH_DROPOUT", "0"))), make_dirs=False)
     torch.manual_seed(0)
     G = MyAuto4Rec_c(device, param, wf=None, enc_share=True, dec_rec=False).to(torch.float32).to(device)
     D = Discriminator(param.d_model, 1, param.dis_dim).to(torch.float32).to(device)
     D.eval()
     bt = {}
     for dom, seed in (("a", 1), ("b", 2)):
-        dm = synthetic.make_domain(s["B"], s["V"], s["L"], s["k"], seed=seed)
+        dm = synthetic.make_domain(s["B"], s["V"], s["L"], s["k"], seed=seed, min_len=int(os.environ.get("RG_BENCH_MINLEN", "5")))
         bt[dom] = tuple(torch.as_tensor(dm[n]).to(device) for n in ("enc_in", "dec_in", "dec_out", "n_items"))
     torch.manual_seed(77)
     alpha = torch.rand(s["B"], 1)
@@ -170,6 +171,8 @@ def main():
         torch.cuda.set_device(local)
         device = "cuda:%d" % local
     dp = rdist.init_from_env(backend)
+    if os.environ.get("RG_DP_NO_BEGIN_SYNC"):                 # diagnosis: every exchange inside sync_grads
+        dp.begin_sync = lambda params: None
     if mode == "grads":
         from golden_util import load_case
         z = what if what == "bench" else load_case(what)
