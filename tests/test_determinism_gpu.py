@@ -121,3 +121,35 @@ def test_step_bitwise_reproducible_at_scale(monkeypatch, d):
     assert len(runs[0]) == len(runs[1]) > 300
     bad = [(i, n) for i, ((n, c), (_, c0)) in enumerate(zip(runs[1], runs[0])) if c != c0 and not any(n.startswith(a) for a in ATOMIC)]
     assert not bad, "launches whose returned tensors differ between two identical runs: %s" % bad[:8]
+
+
+@pytest.mark.parametrize("gp", [True, False])
+def test_fused_discriminator_operand_stacks_bitwise_reproducible(gp):
+    """rg_disc_rows at B = 4096 (the bench batch): the stacks it hands to the three weight-gradient products have the same bits
+    in every launch (its scalar sums and bias gradients are atomic accumulators and are not compared)."""
+    from recguru_amd import hip, ops
+    from recguru_amd.models import Discriminator
+    B, d = 4096, 128
+    ops.set_compute_dtype(torch.bfloat16)
+    torch.manual_seed(0)
+    D = Discriminator(d, 1, 5 * d).cuda().train()
+    real = torch.randn(B, d, device="cuda").bfloat16()
+    fake = torch.randn(B, d, device="cuda").bfloat16()
+    alpha = torch.rand(B, device="cuda")
+    W, Wt, biases, w4, b4 = ops._disc_operands(D)
+    ws = ops._disc_ws(real.device, B, d, 5 * d, 10 * d, 5 * d, 3)
+    xy = (ws["Y1"], ws["X1"], ws["Y2"], ws["X2"], ws["Y3"], ws["X3"])
+
+    def once():
+        sc = torch.zeros(3, device="cuda")
+        bg = tuple(torch.zeros(k, device="cuda") for k in (5 * d, 10 * d, 5 * d, 5 * d, 1))
+        for t in xy:
+            t.zero_()
+        hip.disc_rows(real, fake, alpha if gp else None, W, Wt, biases, w4, b4, 0.2, (1, 2, 3), (4, 5, 6), -1.0 / B, 1.0 / B, 0.1,
+                      sc, xy, bias_grads=bg)
+        return [t.clone() for t in xy]
+
+    ref = once()
+    for i in range(10):
+        for j, (a, b) in enumerate(zip(once(), ref)):
+            assert torch.equal(_bits(a), _bits(b)), "launch %d: stack %d differs from the first launch" % (i, j)

@@ -63,6 +63,7 @@ for r in range(runs):
     del log[:]
     from recguru_amd import ops as _ops
     _ops.manual_seed(0, 0)                     # same dropout masks in every run (RG_BENCH_DROPOUT > 0)
+    _ops.set_residual_dtype(torch.float32 if os.environ.get("RG_RESID") == "split" else torch.bfloat16)
     run_steps("bench", rank, world, None)
     torch.cuda.synchronize()
     cur = [(n, int(c)) for n, c in log]
