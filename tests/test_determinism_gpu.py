@@ -153,3 +153,60 @@ def test_fused_discriminator_operand_stacks_bitwise_reproducible(gp):
     for i in range(10):
         for j, (a, b) in enumerate(zip(once(), ref)):
             assert torch.equal(_bits(a), _bits(b)), "launch %d: stack %d differs from the first launch" % (i, j)
+
+
+def test_row_wise_kernels_equal_their_chunked_launches():
+    """Row- / sequence-independent kernels: one launch over the whole batch (grids that fill every CU twice or more) must equal,
+    bit for bit, the concatenation of launches over 1/16 of the rows (at most one workgroup per CU) -- an occupancy-dependent
+    error that is the same in every launch would pass the repeat tests above, not this one.  Dropout off (the masks are indexed
+    by absolute row)."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    d, H, L, B = 128, 4, 256, 256
+    M, NC = B * L, 16
+    g0 = torch.Generator().manual_seed(11)
+    r = lambda *s: (torch.randn(*s, generator=g0) * 0.5).cuda().to(dt)
+    z = lambda k: torch.zeros(k, device="cuda")
+    gam, bet = 1 + 0.1 * torch.randn(d, generator=g0).cuda(), 0.1 * torch.randn(d, generator=g0).cuda()
+    pk = lambda w, t=0: hip.cast(w.float().contiguous(), dt, transpose=t | hip.CAST_PACK)
+    Wo, W1, W2 = r(d, d), r(512, d), r(d, 512)
+    x, ctx = r(M, d), r(M, d)
+    ids = torch.randint(1, 50, (B, L), generator=g0).cuda()
+    rows = lambda t, c: t[c * (M // NC):(c + 1) * (M // NC)]
+    seqs = lambda t, c: t[c * (B // NC):(c + 1) * (B // NC)]
+
+    def same(name, whole, parts):
+        for j, w in enumerate(whole):
+            cat = torch.cat([p[j] for p in parts], 0)
+            neq = _bits(w.contiguous()) != _bits(cat.contiguous())
+            assert not bool(neq.any()), "%s, output %d: %d elements of the whole-batch launch differ from the chunked ones" % (name, j, int(neq.sum()))
+
+    # fused block, training form (out + every saved tensor)
+    def pa(c_, x_):
+        out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True)
+        return [out] + [sv[k] for k in sorted(sv)]
+    same("post_attn_fwd", pa(ctx, x), [pa(rows(ctx, c).contiguous(), rows(x, c).contiguous()) for c in range(NC)])
+    # weight-stationary GEMM (fused Q / K / V projection) and the generic kernel's small-M form of the same product
+    w384, b384 = r(384, d), torch.randn(384, generator=g0).cuda()
+    same("gemm_nt", [hip.gemm_nt(x, w384, b384)], [[hip.gemm_nt(rows(x, c).contiguous(), w384, b384)] for c in range(NC)])
+    # attention forward / backward per sequence
+    qkv = r(B, L, 3 * d)
+    fw = lambda q_, i_: list(hip.attn_fwd(q_, i_, 51, False, H, need_lse=True))
+    whole = fw(qkv, ids)
+    same("attn_fwd", whole, [fw(seqs(qkv, c).contiguous(), seqs(ids, c).contiguous()) for c in range(NC)])
+    dctx = r(B, L, d)
+    bw = lambda q_, g_, c_, l_, i_: [hip.attn_bwd(q_, g_, c_, l_, i_, 51, False, H)]
+    same("attn_bwd", bw(qkv, dctx, whole[0], whole[1], ids),
+         [bw(seqs(qkv, c).contiguous(), seqs(dctx, c).contiguous(), seqs(whole[0], c).contiguous(), seqs(whole[1], c).contiguous(),
+             seqs(ids, c).contiguous()) for c in range(NC)])
+    # FFN backward data path and the attention-tail backward (their gamma / beta gradient accumulators are not compared)
+    h1, dl2, dz = r(M, 512), r(M, d), r(M, d)
+    W2tp, W1tp, Wotp = pk(W2, hip.CAST_TRANSPOSE), pk(W1, hip.CAST_TRANSPOSE), pk(Wo, hip.CAST_TRANSPOSE)
+    fb = lambda a_, b_, c_: list(hip.ffn_bwd_data(a_, b_, c_, W2tp, W1tp, w_packed=True))[:2]
+    same("ffn_bwd_data", fb(dl2, dz, h1), [fb(rows(dl2, c).contiguous(), rows(dz, c).contiguous(), rows(h1, c).contiguous()) for c in range(NC)])
+    y, dy = r(M, d), r(M, d)
+    rstd = torch.rand(M, generator=g0).cuda() + 0.5
+    ones = torch.ones(M, device="cuda")
+    ao = lambda a_, b_, c_, m_: list(hip.attn_out_bwd(a_, b_, c_, gam, bet, m_, z(d), z(d), Wotp, w_packed=True))
+    same("attn_out_bwd", ao(dy, y, rstd, ones), [ao(rows(dy, c).contiguous(), rows(y, c).contiguous(), rows(rstd, c).contiguous(),
+                                                     rows(ones, c).contiguous()) for c in range(NC)])
