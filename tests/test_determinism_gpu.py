@@ -210,3 +210,54 @@ def test_row_wise_kernels_equal_their_chunked_launches():
     ao = lambda a_, b_, c_, m_: list(hip.attn_out_bwd(a_, b_, c_, gam, bet, m_, z(d), z(d), Wotp, w_packed=True))
     same("attn_out_bwd", ao(dy, y, rstd, ones), [ao(rows(dy, c).contiguous(), rows(y, c).contiguous(), rows(rstd, c).contiguous(),
                                                      rows(ones, c).contiguous()) for c in range(NC)])
+
+
+def test_row_wise_kernels_equal_their_chunked_launches_d256():
+    """The same at d_model = 256 (config-5's unfused block path): the weight-stationary GEMM's column-block forms, the generic
+    kernel where K = 768, the LayerNorm / activation row passes, attention at H = 8, L = 400 (token-major and head-major)."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    d, H, L, B = 256, 8, 400, 128
+    M, NC = B * L, 8
+    g0 = torch.Generator().manual_seed(13)
+    r = lambda *s: (torch.randn(*s, generator=g0) * 0.5).cuda().to(dt)
+    gam, bet = 1 + 0.1 * torch.randn(d, generator=g0).cuda(), 0.1 * torch.randn(d, generator=g0).cuda()
+    rows = lambda t, c: t[c * (M // NC):(c + 1) * (M // NC)].contiguous()
+    seqs = lambda t, c: t[c * (B // NC):(c + 1) * (B // NC)].contiguous()
+
+    def same(name, whole, parts, dim=0):
+        for j, w in enumerate(whole):
+            cat = torch.cat([p[j] for p in parts], dim)
+            neq = _bits(w.contiguous()) != _bits(cat.contiguous())
+            assert not bool(neq.any()), "%s, output %d: %d elements differ" % (name, j, int(neq.sum()))
+
+    x, x5, x7 = r(M, d), r(M, 512), r(M, 768)
+    for name, a_, w_, kw in (("256 -> 768", x, r(768, d), {}), ("256 -> 512", x, r(512, d), {}), ("512 -> 256", x5, r(d, 512), {}),
+                             ("256 -> 256 + residual", x, r(d, d), dict(epilogue=hip.EPI_ADD, aux=r(M, d))),
+                             ("768 -> 256 + residual (generic)", x7, r(d, 768), dict(epilogue=hip.EPI_ADD, aux=r(M, d)))):
+        bias = torch.randn(w_.shape[0], generator=g0).cuda()
+        ck = lambda c: dict(kw, aux=rows(kw["aux"], c)) if "aux" in kw else kw
+        same("gemm_nt " + name, [hip.gemm_nt(a_, w_, bias, **kw)], [[hip.gemm_nt(rows(a_, c), w_, bias, **ck(c))] for c in range(NC)])
+    z_ = r(M, d)
+    same("add_drop_ln", list(hip.add_drop_ln(x, z_, gam, bet)), [list(hip.add_drop_ln(rows(x, c), rows(z_, c), gam, bet)) for c in range(NC)])
+    same("bcast_add_ln", list(hip.bcast_add_ln(x, torch.zeros(1, d, device="cuda"), gam, bet, M)),
+         [list(hip.bcast_add_ln(rows(x, c), torch.zeros(1, d, device="cuda"), gam, bet, M // NC)) for c in range(NC)])
+    h = r(M, 512)
+    same("dropout_gelu", [hip.dropout_gelu(h.clone(), 0.0, 0)], [[hip.dropout_gelu(rows(h, c), 0.0, 0)] for c in range(NC)])
+    ids = torch.randint(1, 50, (B, L), generator=g0).cuda()
+    qkv = r(B, L, 3 * d)
+    fw = lambda q_, i_: list(hip.attn_fwd(q_, i_, 51, False, H, need_lse=True))
+    whole = fw(qkv, ids)
+    same("attn_fwd", whole, [fw(seqs(qkv, c), seqs(ids, c)) for c in range(NC)])
+    dctx = r(B, L, d)
+    bw = lambda q_, g_, c_, l_, i_: [hip.attn_bwd(q_, g_, c_, l_, i_, 51, False, H)]
+    same("attn_bwd", bw(qkv, dctx, whole[0], whole[1], ids),
+         [bw(seqs(qkv, c), seqs(dctx, c), seqs(whole[0], c), seqs(whole[1], c), seqs(ids, c)) for c in range(NC)])
+    # head-major projection + LDS-DMA attention forward over the whole batch == the token-major pair
+    w768, b768 = r(768, d), torch.randn(768, generator=g0).cuda()
+    pad_rows = torch.cat([b768.view(3 * H, 32), torch.zeros(1, 32, device="cuda")], 0).to(dt).contiguous()
+    qh = hip.gemm_nt(x, w768, b768, headmajor_L=L)
+    tm = hip.gemm_nt(x, w768, b768).view(B, L, 3 * d)
+    got = hip.attn_fwd(qh, ids, 51, False, H, need_lse=True, pad_rows=pad_rows)
+    ref = hip.attn_fwd(tm, ids, 51, False, H, need_lse=True)
+    assert torch.equal(_bits(got[0]), _bits(ref[0])) and torch.equal(_bits(got[1]), _bits(ref[1]))
