@@ -261,3 +261,43 @@ def test_row_wise_kernels_equal_their_chunked_launches_d256():
     got = hip.attn_fwd(qh, ids, 51, False, H, need_lse=True, pad_rows=pad_rows)
     ref = hip.attn_fwd(tm, ids, 51, False, H, need_lse=True)
     assert torch.equal(_bits(got[0]), _bits(ref[0])) and torch.equal(_bits(got[1]), _bits(ref[1]))
+
+
+@pytest.mark.parametrize("k,d", [(30, 128), (1024, 256)])
+def test_item_loss_rows_and_embedding_equal_their_chunked_launches(k, d):
+    """The item loss's row pass (coefficients and dh of every position: register form at k = 30, online form at k = 1024) and
+    the embedding + positional gather over the whole batch == the same over chunks of the positions."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    V = 50000
+    ntok, NC = (131072, 8) if k == 30 else (8192, 4)
+    g0 = torch.Generator().manual_seed(17)
+    tab = (torch.randn(V + 2, d, generator=g0) * 0.3).cuda().to(dt)
+    h = (torch.randn(ntok, d, generator=g0) * 0.5).cuda().to(dt)
+    pos = torch.randint(1, V + 1, (ntok,), generator=g0).cuda()
+    neg = torch.randint(1, V + 1, (ntok * k,), generator=g0).cuda()
+    mask = (torch.rand(ntok, generator=g0) > 0.2).float().cuda()
+    form = hip.item_loss_train_supported(k, d)
+    assert form in (1, 2)
+    cnt = float(mask.sum())
+
+    def rows_pass(h_, p_, n_, m_):
+        sums = torch.tensor([0.0, cnt], device="cuda")
+        lse = torch.empty(h_.shape[0], device="cuda") if form == 2 else None
+        coef, dh = hip.item_loss_train(h_, tab, p_, n_, m_, k, hip.LOSS_SAMPLED_CE, sums, lse=lse)
+        live = m_ != 0                                  # slots of masked positions are never written
+        coef = coef.view(-1, k + 1)[live]
+        return [coef, dh[live]] + ([lse[live]] if form == 2 else [])
+
+    whole = rows_pass(h, pos, neg, mask)
+    c = ntok // NC
+    parts = [rows_pass(h[i * c:(i + 1) * c].contiguous(), pos[i * c:(i + 1) * c].contiguous(), neg[i * c * k:(i + 1) * c * k].contiguous(),
+                       mask[i * c:(i + 1) * c].contiguous()) for i in range(NC)]
+    for j, w in enumerate(whole):
+        assert torch.equal(_bits(w.contiguous()), _bits(torch.cat([p[j] for p in parts], 0).contiguous())), "item loss rows, output %d" % j
+    L = 256
+    pe = torch.randn(L, d, generator=g0).cuda()
+    ids = pos.clone()
+    e_whole = hip.embed_pe_fwd(tab, pe, ids, mask, L)
+    e_parts = torch.cat([hip.embed_pe_fwd(tab, pe, ids[i * c:(i + 1) * c].contiguous(), mask[i * c:(i + 1) * c].contiguous(), L) for i in range(NC)], 0)
+    assert torch.equal(_bits(e_whole), _bits(e_parts))
