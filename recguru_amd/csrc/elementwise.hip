@@ -332,7 +332,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_kernel(const T* __restr
       const float dd = n < N ? v[j] - mean : 0.f;
       q += dd * dd;
     }
-    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invn + eps);      // (argument >= eps: the bare v_rsq_f32, see fused.hip ln_regs)
 #pragma unroll
     for (int j = 0; j < NPL; ++j) {
       const int n = lane + 64 * j;
@@ -374,7 +374,7 @@ __global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_vec_kernel(const T* __r
       const float dd = v[j] - mean;
       q += dd * dd;
     }
-    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invn + eps);      // (argument >= eps: the bare v_rsq_f32, see fused.hip ln_regs)
     VT yv;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) yv.e[j] = (T)((v[j] - mean) * rstd * g.e[j] + be.e[j]);
@@ -863,7 +863,7 @@ __global__ __launch_bounds__(EW_BLOCK) void add_drop_ln_kernel(const T* __restri
       const float dd = v[j] - mean;
       q += dd * dd;
     }
-    const float rstd = rsqrtf(wave_sum(q) * invn + eps);
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invn + eps);      // (argument >= eps: the bare v_rsq_f32, see fused.hip ln_regs)
     VT yv;
 #pragma unroll
     for (int j = 0; j < NPL; ++j) yv.e[j] = (T)(((v[j] - mean) * rstd * g.e[j] + be.e[j]) * rm);

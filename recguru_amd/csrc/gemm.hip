@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(rg_gemm_nt_args a) {
       const float d = (n < a.N) ? x[j] - mean : 0.f;
       q += d * d;
     }
-    const float rstd = rsqrtf(wave_sum(q) * invn + a.ln_eps);
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invn + a.ln_eps);   // (argument >= eps: the bare v_rsq_f32, see fused.hip ln_regs)
     const float rm = a.rowmask ? a.rowmask[m] : 1.f;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
