@@ -455,7 +455,11 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   const bool dma = tn_use_dma() != 0 && (long long)TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + ((a.T + 31) / 32 / 256 + 2) * 8 <= 160 * 1024;
   const int ct = dma ? TnDma<N1, N2>::CT : TB_T;
   const int nchunks = (a.T + ct - 1) / ct;
-  int grid = nchunks < 256 ? nchunks : 256;
+  // 192 workgroups, not one per CU: every workgroup leaves a partial dW tile (written, then read by the reduce launch), and
+  // three quarters of the CUs already keep the memory system full (512x128 / 384x128 / 128x128 on the live rows of the bench
+  // shape: 150.7 / 125.7 / 65.3 us at 256, 145.2 / 118.8 / 64.8 at 192, 145.7 / 117.1 / 67.8 at 160).  RG_TN_GRID overrides.
+  static const int grid_cap = [] { const char* e = getenv("RG_TN_GRID"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 256 ? v : 192; }();
+  int grid = nchunks < grid_cap ? nchunks : grid_cap;
   const int per = (nchunks + grid - 1) / grid;
   const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + (TnDma<N1, N2>::CT / 16) * per * 4 : TB_T * (N1 + 8 + N2 + 8) * 2;
 #define RG_TNB(KERN)                                                                                                     \
