@@ -100,9 +100,9 @@ template <> struct VStage<float> {
 // qlive[t] = 1 iff the 16-query tile t of sequence b holds a row with rowmask != 0 (all 1 without a rowmask).  One
 // coalesced load per row and a ballot per wave, in two halves so that the caller can put its own global loads
 // between the mask load and its first use; visible after the caller's next LDS barrier.
-template <int NT16>
+template <int NT16, int NTH = 256>        // NTH: threads of the workgroup
 struct QLive {
-  static constexpr int NR = (NT16 * 16 + 255) / 256;
+  static constexpr int NR = (NT16 * 16 + NTH - 1) / NTH;
   float v[NR];
   bool has_mask;
   int len;
@@ -110,7 +110,7 @@ struct QLive {
   __device__ __forceinline__ void load(const float* __restrict__ rowmask, const float* __restrict__ dummy, int b, int L, int tid) {
 #pragma unroll
     for (int i = 0; i < NR; ++i) {      // unconditional loads from clamped addresses, selected afterwards (no branch, no wait)
-      const int r = i * 256 + tid;
+      const int r = i * NTH + tid;
       v[i] = dummy[rowmask ? (size_t)b * L + min(r, L - 1) : 0];      // raw value; interpreted in publish()
     }
     has_mask = rowmask != nullptr;
@@ -120,9 +120,9 @@ struct QLive {
     const int lane = tid & 63;
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
-      const unsigned long long m = __ballot(has_mask ? (i * 256 + tid < len && v[i] != 0.f) : true);
+      const unsigned long long m = __ballot(has_mask ? (i * NTH + tid < len && v[i] != 0.f) : true);
       if (lane < 4) {
-        const int t = (i * 256 + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
+        const int t = (i * NTH + (tid & ~63)) / 16 + lane;          // this wave's 4 tiles
         if (t < NT16) qlive[t] = ((m >> (16 * lane)) & 0xFFFFull) != 0ull;
       }
     }
@@ -132,11 +132,11 @@ struct QLive {
 // One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
 // rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
 // computed once per head instead of once per lane and element.  Layout [word][query].
-template <int NW, int LPK>
+template <int NW, int LPK, int NTH = 256>
 __device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, const DropCfg& drop, int b, int h, int H, int L, int tid) {
   const unsigned int nw = rg_lpad(L) >> 5;
   const unsigned int wbase = ((unsigned int)b * H + h) * L * nw;
-  for (int i = tid; i < NW * LPK; i += 256) {
+  for (int i = tid; i < NW * LPK; i += NTH) {
     const int w = i / LPK, row = i - w * LPK;
     dmask[i] = (row < L && (unsigned int)w < nw) ? rg_hash(drop.seed, wbase + (unsigned int)row * nw + w) : 0u;
   }
@@ -915,9 +915,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // into the (otherwise unused) pad columns of the wave's own rows of the Q / K tiles and read back with the
 // transposing LDS read as the [key][query] operand of a 16x16x16 MFMA against K^T; the four partial dQ^T are summed
 // through the (by then dead) Q/K/V/dO tiles at the end.
-template <int NKT, bool CAUSAL, int DM, bool ONEPASS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
+// NTH: 256 threads, two workgroups per CU -- or 512 (two-phase form only) where the four staged tiles leave room for ONE
+// workgroup per CU (L = 400: 133 KB + the dropout bit table): eight waves keep two per SIMD for the issue-bound softmax work
+template <int NKT, bool CAUSAL, int DM, bool ONEPASS, int NTH = 256>
+__global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
   static_assert(!ONEPASS || NKT >= 8, "the dS scratch tiles need 4 x 32 rows of pad columns");
+  static_assert(!ONEPASS || NTH == 256, "the one-pass dQ reduction is written for four waves");
+  constexpr int NWV = NTH / 64;
   typedef __bf16 T;
   constexpr int LPK = NKT * 16;
   constexpr int LDR = DK + 8;
@@ -956,14 +960,14 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   if constexpr (DM == 2) drop.onebit = 0u;      // compile the bit-mode branches of the helpers away
   const unsigned int dbase = ((unsigned int)b * a.H + h) * L;
   const unsigned int lp4 = rg_lpad(L);
-  QLive<NKT> ql;
+  QLive<NKT, NTH> ql;
   const float* __restrict__ rmp = a.rowmask ? a.rowmask : a.lse;
   ql.load(a.rowmask, rmp, b, L, tid); // consumed after the staging loads below are in flight
-  float lse_r[QLive<NKT>::NR];        // same for the per-row softmax statistics and key ids
-  bool padk_r[QLive<NKT>::NR];
+  float lse_r[QLive<NKT, NTH>::NR];        // same for the per-row softmax statistics and key ids
+  bool padk_r[QLive<NKT, NTH>::NR];
 #pragma unroll
-  for (int i = 0; i < QLive<NKT>::NR; ++i) {
-    const int r = i * 256 + tid;
+  for (int i = 0; i < QLive<NKT, NTH>::NR; ++i) {
+    const int r = i * NTH + tid;
     const float lv = a.lse[((size_t)b * a.H + h) * L + min(r, L - 1)];
     const int64_t kid = a.key_ids[(size_t)b * L + min(r, L - 1)];
     lse_r[i] = (r < L) ? lv : 0.f;
@@ -973,7 +977,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   __syncthreads();
 
   // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
-  constexpr int NCH = (LPK * 4 + 255) / 256;
+  constexpr int NCH = (LPK * 4 + NTH - 1) / NTH;
   const bool sub = a.x_masked == 2 && a.rowmask != nullptr && a.bqkv != nullptr;
   const int first = (sub && a.first_live) ? min(a.first_live[b], L - 1) : 0;      // see the forward
   Frag<T> qbf, kbf, vbf;              // bias rows of this head, this thread's chunk (tid & 3)
@@ -994,7 +998,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     float rmr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+      const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
       const int rc = max(min(row, L - 1), first);     // clamped address, zeroed / replaced below: no branch between the loads
       rmr[i] = 1.f;
       if (i0 + i < NCH) {
@@ -1008,13 +1012,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
       }
     }
     // the head's dropout words are hashed under the latency of the staging loads just issued
-    if constexpr (DM == 1) { if (i0 == 0) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid); }
+    if constexpr (DM == 1) { if (i0 == 0) fill_dmask<NW, LPK, NTH>(dmask, drop, b, h, a.H, L, tid); }
     // dctx rows with rowmask == 0 are zero by contract (rg_attn_bwd_args.rowmask) and are TAKEN as zero whatever the
     // buffer holds: its producer may leave the rows of padded 16-row tiles unwritten (rg_gemm_nt_args.skip_dead_fill).
     // The qkv / ctx rows of such positions are real data (a padded position is still a key unless its id is pad_value).
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int row = (tid + 256 * (i0 + i)) >> 2;
+      const int row = (tid + NTH * (i0 + i)) >> 2;
       if (i0 + i >= NCH || row >= L) { frag_zero(qr[i]); frag_zero(kr[i]); frag_zero(vr[i]); frag_zero(gr[i]); frag_zero(orow[i]); }
       else if (rmr[i] == 0.f || row < first) {
         frag_zero(gr[i]);
@@ -1025,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int c = tid + 256 * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+      const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
       if (i0 + i < NCH && c < LPK * 4) {
         *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr[i];
         *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr[i];
@@ -1046,8 +1050,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   }
   ql.publish(qlive, tid);
 #pragma unroll
-  for (int i = 0; i < QLive<NKT>::NR; ++i) {
-    const int r = i * 256 + tid;
+  for (int i = 0; i < QLive<NKT, NTH>::NR; ++i) {
+    const int r = i * NTH + tid;
     if (r >= LPK) break;
     const float lse = lse_r[i];
     const bool full = lse < -5e8f;                  // -1e9 + log L rounds to -1e9: row was uniform 1/L (Q3)
@@ -1078,7 +1082,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
   // ---------------------------------------------------------------- phase 1: dK^T, dV^T
   const int nkeyt = (L + 15) >> 4;                  // key tiles that hold a key (nt rounds up to a pair: at L = 200 the 14th
                                                     // tile is keys 208 .. 223 -- nothing to differentiate)
-  for (int kt = wave; kt < nkeyt; kt += 4) {
+  for (int kt = wave; kt < nkeyt; kt += NWV) {
     const int key = kt * 16 + li;                   // this lane's key (column of S)
     Frag<T> kf, vf;
     load_frag(kf, Ks + key * LDR + 8 * lg);
@@ -1209,7 +1213,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args 
 
   if constexpr (!ONEPASS) {
   // ---------------------------------------------------------------- phase 2: dQ^T
-  for (int qt = wave; qt < nt; qt += 4) {
+  for (int qt = wave; qt < nt; qt += NWV) {
     const int q = qt * 16 + li;                     // this lane's query (column of S^T)
     Frag<T> qf, gf;
     load_frag(qf, Qs + q * LDR + 8 * lg);
@@ -1426,8 +1430,23 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
     else if (nkt <= 8) RG_BWD16(8);
     else if (nkt <= 14) RG_BWD16(14);
     else if (nkt <= 16) RG_BWD16(16);
-    else if (nkt <= 26) RG_BWD16(26);
-    else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 not supported yet");
+    else if (nkt <= 26) {
+      // 26 key tiles: 161 KB of LDS = one workgroup per CU -- with eight waves (RG_ATTN_BWD_256=1: the four-wave form, for A/B)
+      static const bool four = getenv("RG_ATTN_BWD_256") != nullptr;
+      if (four) RG_BWD16(26);
+      else {
+        const dim3 block8(512);
+#define RG_BWD26(C)                                                                                          \
+  do {                                                                                                       \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<26, C, 0, false, 512>), grid, block8, 0, s, a);      \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<26, C, 1, false, 512>), grid, block8, 0, s, a); \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<26, C, 2, false, 512>), grid, block8, 0, s, a);              \
+  } while (0)
+        if (a.causal) RG_BWD26(true);
+        else RG_BWD26(false);
+#undef RG_BWD26
+      }
+    } else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: L > 416 not supported yet");
 #undef RG_BWD16
 #undef RG_BWD16_2
   } else {
