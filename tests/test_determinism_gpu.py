@@ -335,3 +335,45 @@ def test_adam_step_bitwise_reproducible():
         topt.step()
     for a, b in zip(ref[:len(ps)], ps):
         torch.testing.assert_close(a, b.detach(), rtol=2e-6, atol=2e-7)
+
+
+def test_critic_phase_user_embeddings_same_bits_on_one_and_two_streams(monkeypatch):
+    """The critic phase computes the user embeddings of update i + 1 on a second stream beside the discriminator kernels of
+    update i (training.critic_phase).  With dropout off the embeddings are the same function of the same inputs in both modes:
+    every (ae, be) pair handed to critic_update has the same bits with the overlap on and off (B = 512 full-length users per
+    domain: the encoder's kernels fill every CU twice while the discriminator's run next to them)."""
+    monkeypatch.setenv("RG_BENCH_B", "512")
+    monkeypatch.setenv("RG_BENCH_MINLEN", "199")
+    monkeypatch.setenv("RG_DP_TIER", "bf16")
+    import importlib
+    import dp_worker
+    importlib.reload(dp_worker)
+    from recguru_amd import ops, training as T
+    from recguru_amd.optim import Adam
+    try:
+        ops.set_compute_dtype(torch.bfloat16)
+        ops.set_data_parallel(None)
+        param, G, D, bt, _ = dp_worker.bench_case("cuda")
+        B = bt["a"][0].shape[0]
+        batches = [(bt["a"][0].roll(i, 0).contiguous(), bt["b"][0].roll(2 * i, 0).contiguous()) for i in range(4)]
+        opt_d = Adam(D.parameters(), lr=1e-4, betas=(0.5, 0.9))
+        seen = []
+        real = T.critic_update
+
+        def spy(netD, ae, be, *a, **k):
+            seen.append((_checksum(ae), _checksum(be)))
+            return real(netD, ae, be, *a, **k)
+
+        monkeypatch.setattr(T, "critic_update", spy)
+        runs = []
+        for overlap in (True, False, True):
+            del seen[:]
+            ops.manual_seed(0, 0)
+            T.critic_phase(G, D, batches, opt_d, param, "cuda", T._NoDP(), overlap=overlap)
+            torch.cuda.synchronize()
+            runs.append([(int(a), int(b)) for a, b in seen])
+        assert len(runs[0]) == 4 and runs[0] == runs[1] == runs[2], runs
+    finally:
+        ops.set_data_parallel(None)
+        monkeypatch.undo()
+        importlib.reload(dp_worker)
