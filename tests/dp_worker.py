@@ -20,8 +20,10 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 sys.path.insert(0, HERE)
 
-BENCH_SHAPE = dict(B=int(os.environ.get("RG_BENCH_B", "16")), L=200, d=int(os.environ.get("RG_BENCH_D", "128")),
-                   H=int(os.environ.get("RG_BENCH_D", "128")) // 32, N=3, V=100000, k=30)   # RG_BENCH_*: tools/race_trace.py, test_determinism_gpu.py
+BENCH_SHAPE = dict(B=int(os.environ.get("RG_BENCH_B", "16")), L=int(os.environ.get("RG_BENCH_L", "200")),
+                   d=int(os.environ.get("RG_BENCH_D", "128")), H=int(os.environ.get("RG_BENCH_D", "128")) // 32, N=3,
+                   V=int(os.environ.get("RG_BENCH_V", "100000")), k=int(os.environ.get("RG_BENCH_K", "30")))
+# (RG_BENCH_*: tools/race_trace.py, tools/repeat_steps.py, tests/test_determinism_gpu.py)
 
 
 def _tier():
