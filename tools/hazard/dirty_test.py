@@ -1,0 +1,34 @@
+"""Does the fused block read a register or LDS word it has not written?  At M = 4096 (one workgroup per CU: the size at which the
+round-3 defect never showed) the block is launched after tools/hazard/dirty.hip has left a pattern in every VGPR / AGPR and all of
+the LDS; a result that depends on the pattern is an uninitialised read.
+  hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/hazard/dirty.hip -o /tmp/libdirty.so
+  [RG_HIP_LIB=<old build>] python tools/hazard/dirty_test.py"""
+import ctypes, os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from recguru_amd import hip
+lib = ctypes.CDLL("/tmp/libdirty.so")
+dt = torch.bfloat16
+d, M = 128, int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+g0 = torch.Generator().manual_seed(3)
+r = lambda *s: (torch.randn(*s, generator=g0) * 0.5).cuda().to(dt)
+pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK)
+wo, w1, w2 = pk(r(d, d)), pk(r(512, d)), pk(r(d, 512))
+z = lambda k: torch.zeros(k, device="cuda")
+gam = 1 + 0.1 * torch.randn(d, generator=g0).cuda(); bet = 0.1 * torch.randn(d, generator=g0).cuda()
+x, ctx = r(M, d), r(M, d)
+
+
+def run(pattern):
+    if pattern is not None:
+        lib.dirty(ctypes.c_uint(pattern), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    out, sv = hip.post_attn_fwd(ctx, x, wo, z(d), gam, bet, w1, z(512), w2, z(d), gam, bet, None, save=True, w_packed=True, compact=False)
+    return [out.clone()] + [sv[k].clone() for k in sorted(sv)]
+
+
+ref = run(None)
+for pattern in (0x00000000, 0x7FC00000, 0x3F800000, 0xFFFFFFFF, 0x477FE000, 0x12345678):
+    bad = []
+    for rep in range(5):
+        cur = run(pattern)
+        bad.append([int((a.float() != b.float()).sum()) for a, b in zip(cur, ref)])
+    print("registers + LDS pre-filled with 0x%08X: differing elements per tensor (out, h1, rstd1, rstd2, y) over 5 launches: %s" % (pattern, bad), flush=True)
