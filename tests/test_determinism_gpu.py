@@ -377,3 +377,35 @@ def test_critic_phase_user_embeddings_same_bits_on_one_and_two_streams(monkeypat
         ops.set_data_parallel(None)
         monkeypatch.undo()
         importlib.reload(dp_worker)
+
+
+def test_lastq_and_ln_bwd_equal_their_chunked_launches():
+    """Single-query attention (per sequence) and the LayerNorm backward's dz (per row) over the whole batch == over chunks."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    d, H, L, B, NC = 128, 4, 200, 4096, 8
+    g0 = torch.Generator().manual_seed(23)
+    r = lambda *s: (torch.randn(*s, generator=g0) * 0.5).cuda().to(dt)
+    ids = torch.randint(1, 50, (B, L), generator=g0).cuda()
+    kv = r(B, L, 2 * d)
+    q_last, dctx = r(B, d), r(B, d)
+    c = B // NC
+    whole = hip.attn_lastq_fwd(q_last, kv, ids, 51, H, 0.0, 0)
+    parts = torch.cat([hip.attn_lastq_fwd(q_last[i * c:(i + 1) * c].contiguous(), kv[i * c:(i + 1) * c].contiguous(),
+                                          ids[i * c:(i + 1) * c].contiguous(), 51, H, 0.0, 0) for i in range(NC)], 0)
+    assert torch.equal(_bits(whole), _bits(parts))
+    wq, wkv = hip.attn_lastq_bwd(q_last, kv, dctx, ids, 51, H, 0.0, 0)
+    pq, pkv = zip(*[hip.attn_lastq_bwd(q_last[i * c:(i + 1) * c].contiguous(), kv[i * c:(i + 1) * c].contiguous(),
+                                       dctx[i * c:(i + 1) * c].contiguous(), ids[i * c:(i + 1) * c].contiguous(), 51, H, 0.0, 0) for i in range(NC)])
+    assert torch.equal(_bits(wq), _bits(torch.cat(pq, 0))) and torch.equal(_bits(wkv), _bits(torch.cat(pkv, 0)))
+    M = 65536
+    cm = M // NC
+    y, dy = r(M, d), r(M, d)
+    rstd = torch.rand(M, generator=g0).cuda() + 0.5
+    gam, bet = 1 + 0.1 * torch.randn(d, generator=g0).cuda(), 0.1 * torch.randn(d, generator=g0).cuda()
+    ones = torch.ones(M, device="cuda")
+    z = lambda: torch.zeros(d, device="cuda")
+    dz = hip.ln_bwd(dy, y, rstd, gam, bet, ones, z(), z())
+    dzp = torch.cat([hip.ln_bwd(dy[i * cm:(i + 1) * cm].contiguous(), y[i * cm:(i + 1) * cm].contiguous(), rstd[i * cm:(i + 1) * cm].contiguous(),
+                                gam, bet, ones[i * cm:(i + 1) * cm].contiguous(), z(), z()) for i in range(NC)], 0)
+    assert torch.equal(_bits(dz), _bits(dzp))
