@@ -401,6 +401,11 @@ int rg_add_drop_ln(const void* x, const void* z, const float* gamma, const float
                    long long M, int N, float drop_p, unsigned long long seed, float eps, int dtype, void* stream);
 int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N,
                   void* stream);
+/* rg_cross_rows + the LayerNorm that follows it (DecoderLayer's dec_enc_attn under attention-map dropout, transformer.py:160-161,
+ * :259) in one row pass: y = LayerNorm(x + bo + sum_h s[m,h] * oh[m/L,h,:]), rstd [M] for rg_ln_bwd; the f32 [M,N] matrix of
+ * rg_cross_rows is never formed.  x, y [M,N] of dtype, N in {128, 256}. */
+int rg_cross_add_ln(const void* x, const float* s, const float* oh, const float* bo, const float* gamma, const float* beta, void* y,
+                    float* rstd, long long M, int L, int H, int N, float eps, int dtype, void* stream);
 
 /* ---- input side: batch assembly and negative sampling on the device ------------------
  * Users are CSR rows: items[offsets[u] .. offsets[u+1]) is user u's chronological item sequence, and

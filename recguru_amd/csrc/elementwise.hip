@@ -383,6 +383,57 @@ __global__ __launch_bounds__(EW_BLOCK) void bcast_add_ln_vec_kernel(const T* __r
   }
 }
 
+// y[m,:] = LayerNorm(x[m,:] + bo + sum_h s[m,h] * oh[m / L, h, :]): rg_cross_rows and the LayerNorm row pass in one (the f32
+// [M, N] matrix of per-row cross-attention outputs never reaches HBM); same accumulation order as the two launches
+template <typename T, int NPL>
+__global__ __launch_bounds__(EW_BLOCK) void cross_add_ln_kernel(const T* __restrict__ x, const float* __restrict__ s,
+                                                               const float* __restrict__ oh, const float* __restrict__ bo,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               T* __restrict__ y, float* __restrict__ rstd_out, long long M, int L,
+                                                               int H, float eps) {
+  constexpr int N = 64 * NPL;
+  struct alignas(sizeof(T) * NPL) VT { T e[NPL]; };
+  struct alignas(sizeof(float) * NPL) VF { float e[NPL]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invn = 1.f / (float)N;
+  const VF g = *reinterpret_cast<const VF*>(gamma + lane * NPL), be = *reinterpret_cast<const VF*>(beta + lane * NPL);
+  const VF b0 = *reinterpret_cast<const VF*>(bo + lane * NPL);
+  const long long gw = (long long)blockIdx.x * 4 + wave, nw = (long long)gridDim.x * 4;
+  for (long long m = gw; m < M; m += nw) {
+    const long long b = m / L;
+    const VT xv = *reinterpret_cast<const VT*>(x + (size_t)m * N + lane * NPL);
+    float acc[NPL];
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) acc[j] = b0.e[j];
+    for (int h = 0; h < H; ++h) {
+      const float sh = s[m * H + h];
+      const VF ov = *reinterpret_cast<const VF*>(oh + ((size_t)b * H + h) * N + lane * NPL);
+#pragma unroll
+      for (int j = 0; j < NPL; ++j) acc[j] += sh * ov.e[j];
+    }
+    float v[NPL];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      v[j] = (float)xv.e[j] + acc[j];
+      sum += v[j];
+    }
+    const float mean = wave_sum(sum) * invn;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) {
+      const float dd = v[j] - mean;
+      q += dd * dd;
+    }
+    const float rstd = __builtin_amdgcn_rsqf(wave_sum(q) * invn + eps);
+    VT yv;
+#pragma unroll
+    for (int j = 0; j < NPL; ++j) yv.e[j] = (T)((v[j] - mean) * rstd * g.e[j] + be.e[j]);
+    *reinterpret_cast<VT*>(y + (size_t)m * N + lane * NPL) = yv;
+    if (lane == 0) rstd_out[m] = rstd;
+  }
+}
+
 // out[b,:] = sum_t x[b,t,:]   (f32 accumulation, tier-dtype result: it feeds the next GEMM)
 template <typename T>
 __global__ __launch_bounds__(EW_BLOCK) void seq_sum_kernel(const T* __restrict__ x, T* __restrict__ out, int L, int N) {
@@ -1036,6 +1087,27 @@ extern "C" int rg_add_drop_ln(const void* x, const void* z, const float* gamma, 
   if (dtype == RG_BF16) return launch_add_drop_ln<__bf16>(x, z, gamma, beta, rowmask, y, rstd, M, N, drop, eps, (hipStream_t)stream);
   if (dtype == RG_F32) return launch_add_drop_ln<float>(x, z, gamma, beta, rowmask, y, rstd, M, N, drop, eps, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "add_drop_ln: bad dtype");
+}
+
+template <typename T>
+static int launch_cross_add_ln(const void* x, const float* s_, const float* oh, const float* bo, const float* gamma, const float* beta,
+                               void* y, float* rstd, long long M, int L, int H, int N, float eps, hipStream_t st) {
+  const int grid = ew_grid(M, 16);
+#define RG_CAL(NPL) hipLaunchKernelGGL((cross_add_ln_kernel<T, NPL>), dim3(grid), dim3(EW_BLOCK), 0, st, (const T*)x, s_, oh, bo, gamma, beta, (T*)y, rstd, M, L, H, eps)
+  if (N == 128) RG_CAL(2);
+  else if (N == 256) RG_CAL(4);
+  else return rg_set_error_msg(RG_ERR_UNSUPPORTED, "cross_add_ln: N must be 128 or 256");
+#undef RG_CAL
+  RG_CHECK_LAUNCH();
+  return 0;
+}
+extern "C" int rg_cross_add_ln(const void* x, const float* s, const float* oh, const float* bo, const float* gamma, const float* beta,
+                               void* y, float* rstd, long long M, int L, int H, int N, float eps, int dtype, void* stream) {
+  if (M <= 0) return 0;
+  if (L <= 0 || H <= 0) return rg_set_error_msg(RG_ERR_INVALID, "cross_add_ln: L and H must be positive");
+  if (dtype == RG_BF16) return launch_cross_add_ln<__bf16>(x, s, oh, bo, gamma, beta, y, rstd, M, L, H, N, eps, (hipStream_t)stream);
+  if (dtype == RG_F32) return launch_cross_add_ln<float>(x, s, oh, bo, gamma, beta, y, rstd, M, L, H, N, eps, (hipStream_t)stream);
+  return rg_set_error_msg(RG_ERR_INVALID, "cross_add_ln: bad dtype");
 }
 
 extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, float* out, long long M, int L, int H, int N, void* stream) {

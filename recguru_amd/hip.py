@@ -91,7 +91,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
            "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse",
-           "rg_dropout_gelu", "rg_add_drop_ln"]
+           "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -403,6 +403,19 @@ def add_drop_ln(x, z, gamma, beta, rowmask=None, drop_p=0.0, seed=0, eps=1e-8):
     rstd = torch.empty(M, device=x.device, dtype=torch.float32)
     _check(lib().rg_add_drop_ln(_vp(x), _vp(z), _vp(gamma), _vp(beta), _vp(rowmask), _vp(y), _vp(rstd), c_ll(M), N, c_f(drop_p),
                                 c_u64(seed), c_f(eps), dt_of(x), _stream()), "rg_add_drop_ln")
+    return y, rstd
+
+
+def cross_add_ln(x, s, oh, bo, gamma, beta, L, eps=1e-8):
+    """y = LayerNorm(x + bo + sum_h s[m,h] * oh[m//L,h,:]), rstd: cross_rows + bcast_add_ln(L=1) in one pass."""
+    M, N = x.shape
+    H = s.shape[1]
+    assert x.is_contiguous() and s.dtype == torch.float32 and s.is_contiguous() and s.shape[0] == M
+    assert oh.dtype == torch.float32 and oh.is_contiguous() and oh.shape[1:] == (H, N)
+    y = torch.empty_like(x)
+    rstd = torch.empty(M, device=x.device, dtype=torch.float32)
+    _check(lib().rg_cross_add_ln(_vp(x), _vp(s), _vp(oh), _vp(bo), _vp(gamma), _vp(beta), _vp(y), _vp(rstd), c_ll(M), L, H, N, c_f(eps),
+                                 dt_of(x), _stream()), "rg_cross_add_ln")
     return y, rstd
 
 
@@ -1124,7 +1137,7 @@ _WORK = {"item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd"
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
 _PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
-          "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse"]
+          "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse", "cross_add_ln"]
 
 
 def start_profile():

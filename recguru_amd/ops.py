@@ -902,8 +902,11 @@ class DecoderLayerFn(_Fn):
             y1, sa = _attn_block_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
                                      drop_p, seeds[0], rowmask, _X_MASKED)
             if drop_p > 0:          # per-row cross-attention output under attention-map dropout
-                o_rows = hip.cross_rows(s_cross, oh, cbo.detach(), L)
-                y2, rstd_c = hip.bcast_add_ln(y1, o_rows, cg.detach(), cbe.detach(), 1, LN_EPS)
+                if d in (128, 256):
+                    y2, rstd_c = hip.cross_add_ln(y1, s_cross, oh, cbo.detach(), cg.detach(), cbe.detach(), L, LN_EPS)
+                else:
+                    o_rows = hip.cross_rows(s_cross, oh, cbo.detach(), L)
+                    y2, rstd_c = hip.bcast_add_ln(y1, o_rows, cg.detach(), cbe.detach(), 1, LN_EPS)
             else:
                 y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
             out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])

@@ -289,6 +289,28 @@ def test_dropout_gelu_and_add_drop_ln(dt, p):
         torch.testing.assert_close(y.float(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("N,H", [(128, 4), (256, 8)])
+@pytest.mark.parametrize("dt", DTYPES)
+def test_cross_add_ln_equals_cross_rows_plus_ln(dt, N, H):
+    """rg_cross_add_ln == rg_cross_rows followed by the LayerNorm row pass (same f32 accumulation order: same bits)."""
+    from recguru_amd import hip
+    B, L = 7, 33
+    M = B * L
+    x = rnd(M, N, dt=dt, seed=1)
+    s = torch.rand(M, H, device="cuda")
+    oh = rnd(B, H, N, dt=torch.float32, seed=2)
+    bo = 0.1 * rnd(N, dt=torch.float32, seed=3)
+    g = 1 + 0.1 * rnd(N, dt=torch.float32, seed=4)
+    b = 0.1 * rnd(N, dt=torch.float32, seed=5)
+    y, rstd = hip.cross_add_ln(x, s, oh, bo, g, b, L)
+    o = hip.cross_rows(s, oh, bo, L)
+    y2, rstd2 = hip.bcast_add_ln(x, o, g, b, 1)
+    torch.testing.assert_close(rstd, rstd2, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(y.float(), y2.float(), **(dict(rtol=1e-6, atol=1e-6) if dt == torch.float32 else dict(rtol=0, atol=0)))
+    ref = torch.nn.functional.layer_norm(x.float() + bo + torch.einsum("mh,mhn->mn", s, oh.repeat_interleave(L, 0)), (N,), g, b, 1e-8)
+    torch.testing.assert_close(y.float(), ref, **tol(dt))
+
+
 @pytest.mark.parametrize("dt", DTYPES)
 def test_gp_helpers(dt):
     from recguru_amd import hip
