@@ -44,6 +44,8 @@ int rg_version(void);
 #define RG_EPI_ADD 4         /* C = acc + bias + aux                         (residual grads) */
 #define RG_EPI_RESID_LN 5    /* C = LayerNorm(acc + bias + aux; gamma, beta, eps) * rowmask;
                                 rstd_out[m] saved.  transformer.py:161,188 and :594,:539      */
+#define RG_EPI_DROP_GELU 6   /* weight-stationary path only: C = dropout(acc + bias; drop_p, drop_seed) AND C2 = gelu(C as stored) --
+                                the FFN's first product with both of its consumers' operands in one epilogue (transformer.py:181-184) */
 
 typedef struct {
   const void* A; int lda;     /* [M,K] dtype */
@@ -75,6 +77,7 @@ typedef struct {
    * (((c / (32 H)) * B + b) * H + (c / 32) % H) * L * 32 + l * 32 + c % 32.  A head's K (V, Q) tile is ONE contiguous run of
    * L * 64 bytes, which the attention kernels stage by LDS-DMA (rg_attn_args.qkv_hm).  ldc is ignored. */
   int c_hm_L;
+  void* C2;                   /* RG_EPI_DROP_GELU: second output [M,N] of the tier dtype, row pitch ldc */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 

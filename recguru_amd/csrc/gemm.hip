@@ -321,6 +321,9 @@ extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
   }
   // the generic tile kernel reads EVERY row: a live-tile list means the padded tiles' rows of A / aux may never have
   // been written by their producers (rg_ln_bwd, skip_dead_fill), so falling through silently would compute on garbage
+  if (a->epilogue == RG_EPI_DROP_GELU)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: RG_EPI_DROP_GELU is a form of the weight-stationary kernel (bf16, K and N "
+                            "multiples of 128, M >= 4096, C2 given, no aux / list / head-major output)");
   if (a->c_hm_L > 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: c_hm_L (head-major output) is a form of the weight-stationary kernel "
                             "(bf16, K and N multiples of 128 up to 512, M >= 4096, M % c_hm_L == 0)");

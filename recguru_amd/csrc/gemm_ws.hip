@@ -32,6 +32,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
   T* __restrict__ C = reinterpret_cast<T*>(a.C);
   const int n0 = wave * 32;
+  const DropCfg drop = make_drop(a.epilogue == RG_EPI_DROP_GELU ? a.drop_p : 0.f, a.drop_seed);
   // blockIdx.y: first 128-column block of this workgroup (N > 128 with K > 128 -- the d_model = 256 shapes of config-5: a
   // workgroup keeps the K x 128 slice of W of ITS column block in registers and walks the row tiles; A is re-read per block
   // from L2 / Infinity Cache)
@@ -176,6 +177,21 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
               if constexpr (!AUX) {
                 if (a.epilogue == RG_EPI_NONE) {
                   *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
+                } else if (a.epilogue == RG_EPI_DROP_GELU) {
+                  // h1 = dropout(l1) as the backward reads it back, and the activated operand of the second product, from
+                  // the value AS STORED (rounded to T): what rg_dropout_gelu does in a pass of its own
+                  float v[8];
+                  load8(v, Cs + r * WS_LD + c8);
+                  if (drop.thresh) {
+                    float k8[8];
+                    rg_keep8(drop, (unsigned int)m * (unsigned int)a.N + (unsigned int)((cby + cb) * 128 + c8), k8);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= k8[j];
+                  }
+                  store8(C + off, v);
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) v[j] = gelu_t<false>((float)(T)v[j]);
+                  store8(reinterpret_cast<T*>(a.C2) + off, v);
                 } else {              // RG_EPI_RELU
                   float v[8];
                   load8(v, Cs + r * WS_LD + c8);
@@ -253,7 +269,7 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   int grid = ny > 1 ? (768 / ny > 96 ? 768 / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
-  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, false>), dim3(grid, ny), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
@@ -266,7 +282,8 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
   if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
   if (a->c_hm_L > 0 && ((a->M % a->c_hm_L) != 0 || a->c_hm_L < 16 || (a->N % 384) != 0)) return 0;
-  if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
+  if (a->epilogue == RG_EPI_DROP_GELU) { if (!a->C2 || a->aux || a->c_hm_L > 0 || a->live16) return 0; }
+  else if (a->epilogue != RG_EPI_NONE && !a->aux) return 0;
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;
   // K and N both beyond 128 (d_model = 256: 256 -> 768 / 512 / 256, 512 -> 256): the <K/128, 1> instantiation once per

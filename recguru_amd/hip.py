@@ -15,7 +15,7 @@ _lib = None
 
 F32, BF16 = 0, 1
 PRO_NONE, PRO_GELU = 0, 1
-EPI_NONE, EPI_RELU, EPI_MUL_POSMASK, EPI_GELU_GRAD, EPI_ADD, EPI_RESID_LN = 0, 1, 2, 3, 4, 5
+EPI_NONE, EPI_RELU, EPI_MUL_POSMASK, EPI_GELU_GRAD, EPI_ADD, EPI_RESID_LN, EPI_DROP_GELU = 0, 1, 2, 3, 4, 5, 6
 
 c_p, c_i, c_f, c_l = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64
 c_u64 = ctypes.c_uint64
@@ -27,7 +27,7 @@ class GemmNtArgs(ctypes.Structure):
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
                 ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p),
-                ("skip_dead_fill", c_i), ("c_hm_L", c_i)]
+                ("skip_dead_fill", c_i), ("c_hm_L", c_i), ("C2", c_p)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -158,11 +158,12 @@ POISON_UNWRITTEN = False
 
 def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogue=EPI_NONE, aux=None,
             gamma=None, beta=None, rowmask=None, rstd_out=None, eps=1e-8, debug_ablate=0, epi_scale=0.0,
-            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False, headmajor_L=0):
+            epi_nonzero_scale=0.0, drop_p=0.0, drop_seed=0, live=None, skip_dead_fill=False, headmajor_L=0, out2=None):
     """C = epi(pro(A) @ W.T + bias).  A [M,K], W [N,K] same dtype; returns C [M,N].  live: list of live 16-row tiles
     (live_tiles) -- the other tiles' rows are not read and come out as zeros, or stay UNWRITTEN with skip_dead_fill=True
     (only for outputs whose consumers are all list- or rowmask-driven), or come out as the bias row with
     skip_dead_fill=2 (exact when those rows of A are zero).
+    epilogue=EPI_DROP_GELU with out2 [M,N] (weight-stationary shapes only): C = dropout(acc + bias) and out2 = gelu(C as stored).
     headmajor_L = L > 0 (weight-stationary shapes only, N = 3 * H * 32 with H % 4 == 0): C comes out head-major, as the three
     tensors q | k | v [M / L, H, L, 32] (rg_gemm_nt_args.c_hm_L) -- returned as a [3, M / L, H, L, 32] tensor."""
     M, K = A.shape
@@ -180,7 +181,7 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L))
+                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L), _p(out2))
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")

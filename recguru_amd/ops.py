@@ -485,6 +485,7 @@ def masked_by(x, rowmask):
 # attention / FFN building blocks (plain functions over explicit tensors; used by the layer Functions)
 # ------------------------------------------------------------------------------------------------
 WS_PROJ_PLUS_LN = True
+WS_DROP_GELU_EPILOGUE = True     # d_model 256: dropout + GELU of the FFN's first product in its epilogue (False: rg_dropout_gelu pass)
 _ZERO_ROWS = {}
 
 
@@ -642,10 +643,18 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
     """PositionWiseFeedForwardNet.forward (transformer.py:179-188) + the `* pad_mask` of :594/:539, unfused (any
     width).  With dropout: l1 -> dropout -> GELU -> l2 -> dropout -> + y -> LayerNorm, the two dropouts as in-place
     passes over the GEMM outputs (h1 keeps the DROPPED pre-activation, as the fused kernel saves it)."""
-    h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
     M, d = y.shape
     dff = W1.shape[0]
-    if (WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4):
+    wide = WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4
+    if wide and WS_DROP_GELU_EPILOGUE:
+        # ... with the activation pass folded into the first product's epilogue (both of its outputs leave the same LDS tile)
+        gact = torch.empty(M, dff, device=y.device, dtype=y.dtype)
+        h1 = hip.gemm_nt(y, shadow(W1), b1.detach(), epilogue=hip.EPI_DROP_GELU, drop_p=drop_p, drop_seed=seed_h1, out2=gact)
+        l2 = hip.gemm_nt(gact, shadow(W2), b2.detach())
+        out, rstd = hip.add_drop_ln(y, l2, g.detach(), be.detach(), rowmask, drop_p, seed_out, LN_EPS)
+        return out, (h1, rstd)
+    h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
+    if wide:
         # d_model = 256 (config-5): GELU prologue and LayerNorm epilogue only exist in the generic tile kernel (1.2 TB/s on this
         # product); here the activation is one elementwise pass (with the h1 dropout), the product the weight-stationary kernel
         # and dropout + residual + LayerNorm + pad mask one row pass.  l2 is rounded to bf16 before the LayerNorm.

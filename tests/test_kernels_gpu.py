@@ -289,6 +289,25 @@ def test_dropout_gelu_and_add_drop_ln(dt, p):
         torch.testing.assert_close(y.float(), ref, **tol(dt))
 
 
+@pytest.mark.parametrize("p", [0.0, 0.5, 0.3])
+@pytest.mark.parametrize("K,N", [(256, 512), (128, 512), (256, 256)])
+def test_gemm_ws_drop_gelu_epilogue_equals_the_separate_pass(p, K, N):
+    """RG_EPI_DROP_GELU (weight-stationary kernel): both outputs have the bits of rg_gemm_nt followed by rg_dropout_gelu."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    M = 4096 + 64 * 3 + 7
+    A = rnd(M, K, dt=dt, seed=1)
+    W = rnd(N, K, dt=dt, scale=K ** -0.5, seed=2)
+    bias = 0.1 * rnd(N, dt=torch.float32, seed=3)
+    g2 = torch.empty(M, N, device="cuda", dtype=dt)
+    h = hip.gemm_nt(A, W, bias, epilogue=hip.EPI_DROP_GELU, drop_p=p, drop_seed=11, out2=g2)
+    h_ref = hip.gemm_nt(A, W, bias)
+    g_ref = hip.dropout_gelu(h_ref, p, 11)
+    assert torch.equal(h, h_ref) and torch.equal(g2, g_ref)
+    with pytest.raises(RuntimeError):                      # the generic kernel does not have this epilogue
+        hip.gemm_nt(A[:100].contiguous(), W, bias, epilogue=hip.EPI_DROP_GELU, drop_p=p, drop_seed=11, out2=g2[:100].contiguous())
+
+
 @pytest.mark.parametrize("N,H", [(128, 4), (256, 8)])
 @pytest.mark.parametrize("dt", DTYPES)
 def test_cross_add_ln_equals_cross_rows_plus_ln(dt, N, H):
