@@ -484,6 +484,7 @@ def masked_by(x, rowmask):
 # ------------------------------------------------------------------------------------------------
 # attention / FFN building blocks (plain functions over explicit tensors; used by the layer Functions)
 # ------------------------------------------------------------------------------------------------
+WS_SPLIT_K_DX = True             # d_model 256: dx = dqkv Wqkv + residual as two K = 384 weight-stationary products
 WS_PROJ_PLUS_LN = True
 WS_DROP_GELU_EPILOGUE = True     # d_model 256: dropout + GELU of the FFN's first product in its epilogue (False: rg_dropout_gelu pass)
 _ZERO_ROWS = {}
@@ -635,7 +636,16 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)                 # every row: a padded position that is a live key has dK, dV != 0
     # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
     # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
-    dx = hip.gemm_nt(dqkv2, shadow_cat((Wq, Wk, Wv), transpose=True), epilogue=hip.EPI_ADD, aux=dz, live=live)
+    Wt = shadow_cat((Wq, Wk, Wv), transpose=True)          # [d, 3P]
+    if (WS_SPLIT_K_DX and _COMPUTE == torch.bfloat16 and live is None and dqkv2.shape[0] >= 4096 and 3 * P == 768 and d % 128 == 0
+            and 128 < d <= 1024):
+        # K = 768 is beyond the weight-stationary kernel's four 128-deep K blocks (the generic tile kernel ran this product at
+        # 2.1 TB/s): two K halves instead, the second accumulating onto the first's output in place (the partial sum is rounded
+        # to bf16 once in between)
+        dx = hip.gemm_nt(dqkv2[:, :384], Wt[:, :384], epilogue=hip.EPI_ADD, aux=dz)
+        dx = hip.gemm_nt(dqkv2[:, 384:], Wt[:, 384:], epilogue=hip.EPI_ADD, aux=dx, out=dx)
+    else:
+        dx = hip.gemm_nt(dqkv2, Wt, epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dx, (rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg, rbe)
 
 
