@@ -71,8 +71,8 @@ def _checksum(t):
     return (v * w[torch.arange(v.numel(), device=v.device) % 7]).sum()
 
 
-@pytest.mark.parametrize("d", [128, 256])
-def test_step_bitwise_reproducible_at_scale(monkeypatch, d):
+@pytest.mark.parametrize("d,resid", [(128, "bf16"), (256, "bf16"), (128, "split")])
+def test_step_bitwise_reproducible_at_scale(monkeypatch, d, resid):
     """critic_update + generator_iteration at L = 200, B = 256 full-length users per domain (800 work tiles), dropout 0.5 with
     the same seeds, d_model 128 (the fused path) and 256 (the unfused one): every tensor a launcher returns, outside the
     atomically accumulated ones, has the same bits in both runs."""
@@ -108,6 +108,7 @@ def test_step_bitwise_reproducible_at_scale(monkeypatch, d):
         for _ in range(2):
             del log[:]
             ops.manual_seed(0, 0)
+            ops.set_residual_dtype(torch.float32 if resid == "split" else torch.bfloat16)     # (the split residual stream)
             dp_worker.run_steps("bench", 0, 1, None)
             torch.cuda.synchronize()
             runs.append([(n, int(c)) for n, c in log])
@@ -116,6 +117,7 @@ def test_step_bitwise_reproducible_at_scale(monkeypatch, d):
             setattr(hip, n, orig[n])
         ops.set_data_parallel(None)
         ops.set_compute_dtype(torch.bfloat16)
+        ops.set_residual_dtype(torch.bfloat16)
         monkeypatch.undo()
         importlib.reload(dp_worker)
     assert len(runs[0]) == len(runs[1]) > 300
