@@ -188,6 +188,21 @@ def test_row_wise_kernels_equal_their_chunked_launches():
         out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True)
         return [out] + [sv[k] for k in sorted(sv)]
     same("post_attn_fwd", pa(ctx, x), [pa(rows(ctx, c).contiguous(), rows(x, c).contiguous()) for c in range(NC)])
+    # ... the split-residual form (x = hi + lo in, out / out_lo out) and the decoder form (collapsed cross-attention stage)
+    x_lo = (r(M, d).float() * 0.01).to(dt)
+
+    def pa_res(c_, x_, l_):
+        out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True, x_lo=l_)
+        return [out] + [sv[k] for k in sorted(sv)]
+    same("post_attn_fwd (split residual)", pa_res(ctx, x, x_lo),
+         [pa_res(rows(ctx, c).contiguous(), rows(x, c).contiguous(), rows(x_lo, c).contiguous()) for c in range(NC)])
+    o = torch.randn(B, d, generator=g0).cuda()
+
+    def pa_dec(c_, x_, o_):
+        out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True,
+                                    L=L, cross=(o_, gam, bet))
+        return [out] + [sv[k] for k in sorted(sv)]
+    same("post_attn_fwd (decoder)", pa_dec(ctx, x, o), [pa_dec(rows(ctx, c).contiguous(), rows(x, c).contiguous(), seqs(o, c).contiguous()) for c in range(NC)])
     # weight-stationary GEMM (fused Q / K / V projection) and the generic kernel's small-M form of the same product
     w384, b384 = r(384, d), torch.randn(384, generator=g0).cuda()
     same("gemm_nt", [hip.gemm_nt(x, w384, b384)], [[hip.gemm_nt(rows(x, c).contiguous(), w384, b384)] for c in range(NC)])
