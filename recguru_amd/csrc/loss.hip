@@ -554,7 +554,10 @@ static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
 #define RG_CHUNK 2048        // entries per accumulate work item (item loss)
 #define RG_CHUNK_EMB 512     // ... embedding scatter: a hot item's thousands of positions spread over many workgroups
 #define RG_MAXBINS 8192
-#define RG_PPW 8192          // (position, item) pairs per workgroup in count / fill
+#define RG_PPW 8192          // (position, item) pairs per workgroup in count / fill ...
+#define RG_PPW_WIDE 65536    // ... and with thousands of bins (256-row bins of a 2 M-row table: 7 813): a workgroup spends one GLOBAL
+                             // atomic per non-empty bin in each of the two kernels -- at 8 192 pairs nearly one per pair (575 M per
+                             // launch at config-5); at 65 536 pairs a bin gets ~8 entries per workgroup
 
 struct BinWs {
   float* c; int* hist; int* start; int* cursor; int* chunk_start;
@@ -562,6 +565,7 @@ struct BinWs {
   int chunk;         // entries per accumulate work item
   uint2* ent;        // sorted entries: x = (position << RG_RPB_LOG) | row-in-bin, y = c as bits  (one 8-byte store / load)
   int nbins;
+  int ppw;           // pairs per workgroup of bin_count / bin_fill
   int bin_log;       // log2 of the table rows per bin: RG_RPB_LOG (64 rows), or RG_WIDE_LOG (256 rows) for catalogues beyond RG_MAXBINS * 64 rows
   const float* cscale;  // non-null: the c values are for gout = 1 and bin_fill multiplies them by cscale[0]
   const float* lse;     // non-null (rg_item_loss_train's online form): c holds RAW logits; bin_fill forms
@@ -577,8 +581,8 @@ __device__ __forceinline__ void pair_items4(const rg_item_loss_args& a, long lon
 #pragma unroll
   for (int u = 0; u < RG_PB; ++u) {
     const long long pc = min(p + 256 * u, p1 - 1);
-    const long long t = pc / n;
-    const int idx = (int)(pc - t * n);
+    const long long t = (long long)((unsigned int)pc / (unsigned int)n);     // (pairs < 2^31 by the workspace contract: a 32-bit
+    const int idx = (int)(pc - t * n);                                        //  division instead of the 64-bit expansion)
     mk[u] = a.mask[t];
     const int64_t* __restrict__ src = idx == 0 ? a.pos + t : a.neg + t * a.k + (idx - 1);
     it[u] = *src;
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(256) void bin_count_kernel(rg_item_loss_args a, Bin
   const long long npairs = a.ntok * n;
   for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
   __syncthreads();
-  const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
+  const long long p0 = (long long)blockIdx.x * w.ppw, p1 = min(p0 + w.ppw, npairs);
   for (long long p = p0 + threadIdx.x; p < p1; p += 256 * RG_PB) {
     long long it[RG_PB];
     pair_items4(a, p, p1, n, it);
@@ -644,7 +648,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
   const float gsc = w.cscale ? w.cscale[0] : 1.f;
   for (int i = threadIdx.x; i < w.nbins; i += 256) lh[i] = 0;
   __syncthreads();
-  const long long p0 = (long long)blockIdx.x * RG_PPW, p1 = min(p0 + RG_PPW, npairs);
+  const long long p0 = (long long)blockIdx.x * w.ppw, p1 = min(p0 + w.ppw, npairs);
   for (long long p = p0 + threadIdx.x; p < p1; p += 256 * RG_PB) {
     long long it[RG_PB];
     pair_items4(a, p, p1, n, it);
@@ -670,7 +674,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
 #pragma unroll
       for (int u = 0; u < RG_PB; ++u) {
         const long long pc = min(p + 256 * u, p1 - 1);
-        const long long t = pc / n;
+        const long long t = (long long)((unsigned int)pc / (unsigned int)n);
         cv[u] = (__expf(cv[u] - w.lse[t]) - (pc - t * n == 0 ? 1.f : 0.f)) * a.mask[t] * ic;
       }
     }
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(256) void bin_fill_kernel(rg_item_loss_args a, BinW
       const long long pu = p + 256 * u;
       const int b = (int)(it[u] >> w.bin_log);
       const int e = base[b] + atomicAdd(&lh[b], 1);
-      w.ent[e] = make_uint2(((unsigned int)(pu / n) << w.bin_log) | (unsigned int)(it[u] & ((1 << w.bin_log) - 1)), __float_as_uint(cv[u]));
+      w.ent[e] = make_uint2((((unsigned int)pu / (unsigned int)n) << w.bin_log) | (unsigned int)(it[u] & ((1 << w.bin_log) - 1)), __float_as_uint(cv[u]));
     }
   }
 }
@@ -1049,7 +1053,8 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   else if (a.d == 128) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 16, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   else hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 32, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   // K2..K4
-  const int gp = (int)((npairs + RG_PPW - 1) / RG_PPW);
+  w.ppw = w.nbins > 4096 ? RG_PPW_WIDE : RG_PPW;
+  const int gp = (int)((npairs + w.ppw - 1) / w.ppw);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 4, s, a, w);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, w);
   hipFuncSetAttribute(reinterpret_cast<const void*>(bin_fill_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, w.nbins * 8);
