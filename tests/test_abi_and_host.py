@@ -143,3 +143,16 @@ def test_dropout_flag_reaches_the_modules():
     G.eval()
     D.eval()
     assert G.encoder.layers[0].drop_p() == 0.0 and G.pos_emb_a.drop_p() == 0.0 and D.drop_p() == 0.0
+
+
+def test_tools_and_entry_points_compile():
+    """Every measurement aid under tools/ and the repo-root entry points are at least syntactically valid Python."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "tools", "hazard", "*.py")) + \
+        [os.path.join(root, f) for f in ("bench.py", "__graft_entry__.py", "train_gan.py", "train_auto.py")]
+    assert len(files) > 30
+    for f in files:
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
