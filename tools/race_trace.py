@@ -57,7 +57,8 @@ for n in NAMES:
 
 # outputs written with float atomics (summation order differs from run to run): compared only for information
 ATOMIC = ("gemm_tn", "colsum", "embed_scatter", "item_loss_fwd[0]", "item_loss_scatter", "sum_into", "adam", "mse", "disc_rows",
-          "live_tiles")                      # (the list buffer's tail behind the entries is never written)
+          "live_tiles",                      # (the list buffer's tail behind the entries is never written)
+          "item_loss_train[0]")             # (coefficient slots of masked positions are never written)
 first = None
 for r in range(runs):
     del log[:]
