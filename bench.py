@@ -34,7 +34,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # MI355X_MICROARCH.md, dense
+# MI355X_MICROARCH.md, dense.  bf16x3: a product is three bf16 MFMAs, so its ALGORITHMIC flops are priced at a third of the bf16 peak
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 MFMA_KERNELS = ("gemm", "attn", "post_attn")           # kernels priced against the MFMA peak; the rest against HBM
 # counter passes of the newest round first (profiles/rNN/pmc_traffic.json, written by tools/profile_round.sh rNN);
@@ -84,7 +85,9 @@ def parse():
     ap.add_argument("--n_blocks", type=int, default=3)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--n_negs", type=int, default=30)
-    ap.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    ap.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16",
+                    help="bf16: bf16 operands and activations (the headline tier); f32: exact-f32 MFMA; bf16x3: f32 activations, every "
+                         "MFMA operand split into a bf16 pair, three MFMAs per product (inside rtol 1e-3 / atol 1e-5 like f32)")
     ap.add_argument("--residual", choices=["bf16", "split"], default="bf16",
                     help="bf16 tier: residual stream between kernels as one bf16 tensor, or split into a bf16 pair hi + lo "
                          "(ops.set_residual_dtype(torch.float32): ~16 significant bits, DESIGN.md 2)")
@@ -352,7 +355,7 @@ def main():
     local = 0 if os.environ.get("RG_BENCH_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_compute_dtype(args.dtype)
     ops.set_residual_dtype(torch.float32 if args.residual == "split" else torch.bfloat16)
     ops.set_data_parallel(dp)
     ops.manual_seed(0, rank)                  # independent dropout streams per rank

@@ -23,6 +23,11 @@ extern "C" {
 
 #define RG_F32 0
 #define RG_BF16 1
+#define RG_X3 2 /* "bf16x3": buffers are f32 exactly as for RG_F32 (the two tiers can be mixed call by call); every MFMA operand
+                   is split into a bf16 pair hi + lo and a product is three bf16 MFMAs (lo.hi + hi.lo + hi.hi, f32 accumulate):
+                   ~16 significant bits per operand at 3/16 of the exact-f32 matrix-pipe time.  Taken by the GEMM-class entry
+                   points (rg_gemm_nt, rg_gemm_tn, rg_attn_fwd / bwd, rg_post_attn_fwd, rg_ffn_bwd_data, rg_attn_out_bwd,
+                   rg_disc_rows); everything else has no matrix product and is called with RG_F32. */
 
 #define RG_ERR_INVALID (-1)
 #define RG_ERR_UNSUPPORTED (-2)

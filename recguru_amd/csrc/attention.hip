@@ -91,6 +91,18 @@ template <> struct VStage<float> {
   }
 };
 
+template <> struct VStage<x3> {             // f32 in LDS, transposed like the f32 tier's
+  static constexpr bool TRANSPOSED = true;
+  static __device__ __forceinline__ void frag(Frag<x3>& f, const x3* Vt, int ldv, int k0, int dv0, int li, int lg) {
+    const x3* vp = Vt + (dv0 + li) * ldv + k0 + 4 * lg;
+    load_frag_2x4(f, vp, vp + 16);
+  }
+  static __device__ __forceinline__ void frag2(Frag<x3>& f, const x3* Vt, int ldv, int kA, int kB, int dv0, int li, int lg) {
+    const x3* vp = Vt + (dv0 + li) * ldv + 4 * lg;
+    load_frag_2x4(f, vp + kA, vp + kB);
+  }
+};
+
 // Masking is branch-free: kbias[key] in LDS is 0 for a live key, -1e30 for a replaced (pad) key and
 // -inf beyond L.  s + (-1e30) == -1e30 exactly in f32, so every replaced score is the same value --
 // the "replace-fill" semantics of masked_fill_(-1e9): a fully masked row is uniform over all L keys
@@ -1479,6 +1491,7 @@ extern "C" int rg_attn_fwd(const rg_attn_args* a, int dtype, void* stream) {
   }
   if (dtype == RG_BF16) return launch_fwd<__bf16>(*a, (hipStream_t)stream);
   if (dtype == RG_F32) return launch_fwd<float>(*a, (hipStream_t)stream);
+  if (dtype == RG_X3) return launch_fwd<x3>(*a, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "attn_fwd: bad dtype");
 }
 extern "C" int rg_attn_bwd(const rg_attn_bwd_args* a, int dtype, void* stream) {
@@ -1486,8 +1499,9 @@ extern "C" int rg_attn_bwd(const rg_attn_bwd_args* a, int dtype, void* stream) {
   if (a->dk != DK) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: d_k must be 32");
   if (a->qkv_hm && dtype != RG_BF16) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: qkv_hm is a bf16 form");
   if (dtype == RG_BF16) return launch_bwd<__bf16>(*a, (hipStream_t)stream);
-  if (dtype == RG_F32 && a->x_masked == 2)
+  if (dtype != RG_BF16 && a->x_masked == 2)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_bwd: bias-row substitution (x_masked == 2) is a bf16-tier form");
   if (dtype == RG_F32) return launch_bwd<float>(*a, (hipStream_t)stream);
+  if (dtype == RG_X3) return launch_bwd<x3>(*a, (hipStream_t)stream);
   return rg_set_error_msg(RG_ERR_INVALID, "attn_bwd: bad dtype");
 }

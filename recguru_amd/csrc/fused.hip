@@ -708,6 +708,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   } while (0)
   if (dtype == RG_BF16) RG_PA_T(__bf16);
   else if (dtype == RG_F32) RG_PA_T(float);
+  else if (dtype == RG_X3) RG_PA_T(x3);
   else return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: bad dtype");
 #undef RG_PA_T
 #undef RG_PA
@@ -1015,6 +1016,7 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
   } while (0)
   if (dtype == RG_BF16) { if (lnf) RG_FB(__bf16, true); else RG_FB(__bf16, false); }
   else if (dtype == RG_F32) { if (lnf) RG_FB(float, true); else RG_FB(float, false); }
+  else if (dtype == RG_X3) { if (lnf) RG_FB(x3, true); else RG_FB(x3, false); }
   else return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: bad dtype");
 #undef RG_FB
   if (lnf && (a->ln_dgamma || a->ln_dbeta))
@@ -1183,6 +1185,9 @@ extern "C" int rg_attn_out_bwd(const rg_attn_out_bwd_args* a, int dtype, void* s
   } else if (dtype == RG_F32) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     hipLaunchKernelGGL((attn_out_bwd_kernel<float>), dim3(grid), dim3(256), smem, s, *a);
+  } else if (dtype == RG_X3) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_bwd_kernel<x3>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL((attn_out_bwd_kernel<x3>), dim3(grid), dim3(256), smem, s, *a);
   } else return rg_set_error_msg(RG_ERR_INVALID, "attn_out_bwd: bad dtype");
   if (a->dgamma || a->dbeta)
     hipLaunchKernelGGL(ffn_bwd_ln_reduce_kernel, dim3(grid < 32 ? grid : 32), dim3(256), 0, s, a->ln_partials, grid, a->dgamma, a->dbeta);

@@ -306,7 +306,7 @@ extern "C" int rg_gemm_nt_plan(const rg_gemm_nt_args* a, int dtype, char* name, 
   if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt_plan: null argument");
   const int ws = (a->debug_ablate & 16) ? 0 : rg_gemm_ws_select(a, dtype);
   if (ws) snprintf(name, cap, "gemm_ws_kernel<%d,%d>", ws / 10, ws % 10);
-  else snprintf(name, cap, "gemm_nt_kernel<%s,%d>", dtype == RG_BF16 ? "bf16" : "f32", nt_ntw(*a));
+  else snprintf(name, cap, "gemm_nt_kernel<%s,%d>", dtype == RG_BF16 ? "bf16" : (dtype == RG_X3 ? "x3" : "f32"), nt_ntw(*a));
   return 0;
 }
 
@@ -332,6 +332,7 @@ extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
                             "problem (bf16, K and N multiples of 128 up to 512, M >= 4096 required)");
   if (dtype == RG_BF16) return launch_nt<__bf16>(*a, s);
   if (dtype == RG_F32) return launch_nt<float>(*a, s);
+  if (dtype == RG_X3) return launch_nt<x3>(*a, s);
   return rg_set_error_msg(RG_ERR_INVALID, "gemm_nt: bad dtype");
 }
 
@@ -347,6 +348,11 @@ extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
 
 // fragment whose 8 slots (g, j) are rows t0 + 8g + j of column c of a row-major LDS tile
 __device__ __forceinline__ void load_frag_tr(Frag<float>& f, const float* tile, int ld, int t0, int c0,
+                                             int li, int lg, int use_tr) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = tile[(t0 + 8 * lg + j) * ld + c0 + li];
+}
+__device__ __forceinline__ void load_frag_tr(Frag<x3>& f, const x3* tile, int ld, int t0, int c0,
                                              int li, int lg, int use_tr) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = tile[(t0 + 8 * lg + j) * ld + c0 + li];
@@ -480,7 +486,7 @@ extern "C" size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* a, int dtype) {
 extern "C" int rg_gemm_tn_plan(const rg_gemm_tn_args* a, int dtype, char* name, int cap) {
   if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_plan: null argument");
   if (a->splits == 0 && rg_gemm_tn_big_select(a, dtype)) snprintf(name, cap, "%s<%d,%d>", rg_gemm_tn_big_name(a), a->N1, a->N2);
-  else snprintf(name, cap, "gemm_tn_kernel<%s>", dtype == RG_BF16 ? "bf16" : "f32");
+  else snprintf(name, cap, "gemm_tn_kernel<%s>", dtype == RG_BF16 ? "bf16" : (dtype == RG_X3 ? "x3" : "f32"));
   return 0;
 }
 
@@ -506,6 +512,7 @@ extern "C" int rg_gemm_tn(const rg_gemm_tn_args* a, int dtype, void* stream) {
   dim3 grid(g1, g2, splits);
   if (dtype == RG_BF16) hipLaunchKernelGGL((gemm_tn_kernel<__bf16>), grid, dim3(256), 0, s, *a);
   else if (dtype == RG_F32) hipLaunchKernelGGL((gemm_tn_kernel<float>), grid, dim3(256), 0, s, *a);
+  else if (dtype == RG_X3) hipLaunchKernelGGL((gemm_tn_kernel<x3>), grid, dim3(256), 0, s, *a);
   else return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: bad dtype");
   RG_CHECK_LAUNCH();
   return 0;

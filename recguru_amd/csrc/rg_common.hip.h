@@ -1,8 +1,12 @@
 // Common device helpers for the RecGURU gfx950 kernels.
 //
-// One tile vocabulary for both precision tiers:
+// One tile vocabulary for the three precision tiers:
 //   * T = __bf16 : v_mfma_f32_16x16x32_bf16 (perf tier; operands bf16, accumulation f32)
 //   * T = float  : 8 x v_mfma_f32_16x16x4_f32 (parity tier; bit-exact f32 fma chain)
+//   * T = x3     : f32 in memory and in every elementwise step, but each MFMA operand is split into a bf16 pair
+//                  hi + lo (~16 significant bits) and a product is THREE bf16 MFMAs, lo.hi + hi.lo + hi.hi, accumulated
+//                  in f32 (the dropped lo.lo term is 2^-16 of the product): 48 matrix-pipe cycles per k-step against 256
+//                  for the exact-f32 form, error ~1e-5 of the operand instead of bf16's 4e-3 (tests/emulate_tiers.py).
 // A "k-step" is always 32 contraction elements.  Within a k-step lane l = 16*g + i owns the 8
 // slots (g, j), j = 0..7 of row/column i.  Which physical k a slot means is up to the caller as
 // long as the A and the B fragment agree:
@@ -21,11 +25,45 @@ typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4_t;
 
 #define RG_F32 0
 #define RG_BF16 1
+#define RG_X3 2
 #define RG_WAVE 64
+
+// x3: a float in memory (same size, same layout: any f32 buffer is an x3 buffer) -- a distinct type only so that the kernel
+// templates get a third instantiation whose mma() is the split-operand product.
+struct x3 {
+  float f;
+  x3() = default;
+  __host__ __device__ __forceinline__ x3(float v) : f(v) {}
+  __host__ __device__ __forceinline__ operator float() const { return f; }
+};
+static_assert(sizeof(x3) == 4 && alignof(x3) == 4, "x3 is layout-identical to float");
+__device__ __forceinline__ const float* fptr(const x3* p) { return reinterpret_cast<const float*>(p); }
+__device__ __forceinline__ float* fptr(x3* p) { return reinterpret_cast<float*>(p); }
 
 template <typename T> struct Frag;
 template <> struct Frag<float> { float v[8]; };
 template <> struct Frag<__bf16> { bf16x8_t v; };
+template <> struct Frag<x3> { float v[8]; };
+
+// hi = bf16(x) and lo = bf16(x - hi), both round-to-nearest, two elements per step: v_cvt_pk_bf16_f32, shift / and back to
+// f32, v_pk_add_f32 (exact: x - hi has at most 16 significant bits), v_cvt_pk_bf16_f32 -- 2.5 VALU operations per element.
+// The compiler shares the split of a fragment between all the mma() calls that use it (common subexpressions of one
+// scope), so a kernel pays it once per fragment it loads.
+typedef __attribute__((ext_vector_type(2))) float rg_f2;
+typedef __attribute__((ext_vector_type(2))) __bf16 rg_bf2;
+__device__ __forceinline__ void split_x3(const float (&v)[8], bf16x8_t& hi, bf16x8_t& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; j += 2) {
+    const rg_f2 x = (rg_f2){v[j], v[j + 1]};
+    const rg_bf2 h = __builtin_convertvector(x, rg_bf2);
+    union { rg_bf2 b; unsigned int u; } hu;
+    hu.b = h;
+    const rg_f2 hf = (rg_f2){__uint_as_float(hu.u << 16), __uint_as_float(hu.u & 0xFFFF0000u)};
+    const rg_bf2 l = __builtin_convertvector(x - hf, rg_bf2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+}
 
 __device__ __forceinline__ void mma(const Frag<__bf16>& a, const Frag<__bf16>& b, f32x4& c) {
   c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.v, b.v, c, 0, 0, 0);
@@ -35,7 +73,20 @@ __device__ __forceinline__ void mma(const Frag<float>& a, const Frag<float>& b, 
   for (int j = 0; j < 8; ++j) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a.v[j], b.v[j], c, 0, 0, 0);
 }
 
+__device__ __forceinline__ void mma(const Frag<x3>& a, const Frag<x3>& b, f32x4& c) {
+  bf16x8_t ah, al, bh, bl;
+  split_x3(a.v, ah, al);
+  split_x3(b.v, bh, bl);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, c, 0, 0, 0);      // small terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, c, 0, 0, 0);
+}
+
 template <typename T> __device__ __forceinline__ void frag_zero(Frag<T>& f);
+template <> __device__ __forceinline__ void frag_zero<x3>(Frag<x3>& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
+}
 template <> __device__ __forceinline__ void frag_zero<float>(Frag<float>& f) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) f.v[j] = 0.f;
@@ -59,6 +110,12 @@ __device__ __forceinline__ void load_frag(Frag<float>& f, const float* p) {
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
   f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
 }
+__device__ __forceinline__ void load_frag(Frag<x3>& f, const x3* p) {
+  const float4 a = *reinterpret_cast<const float4*>(p);
+  const float4 b = *reinterpret_cast<const float4*>(fptr(p) + 4);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
 // two runs of 4 contiguous elements: slots j<4 from p0, j>=4 from p1 (stacked-accumulator mapping)
 __device__ __forceinline__ void load_frag_2x4(Frag<__bf16>& f, const __bf16* p0, const __bf16* p1) {
   const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p0);
@@ -67,6 +124,12 @@ __device__ __forceinline__ void load_frag_2x4(Frag<__bf16>& f, const __bf16* p0,
   f.v[4] = b[0]; f.v[5] = b[1]; f.v[6] = b[2]; f.v[7] = b[3];
 }
 __device__ __forceinline__ void load_frag_2x4(Frag<float>& f, const float* p0, const float* p1) {
+  const float4 a = *reinterpret_cast<const float4*>(p0);
+  const float4 b = *reinterpret_cast<const float4*>(p1);
+  f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
+  f.v[4] = b.x; f.v[5] = b.y; f.v[6] = b.z; f.v[7] = b.w;
+}
+__device__ __forceinline__ void load_frag_2x4(Frag<x3>& f, const x3* p0, const x3* p1) {
   const float4 a = *reinterpret_cast<const float4*>(p0);
   const float4 b = *reinterpret_cast<const float4*>(p1);
   f.v[0] = a.x; f.v[1] = a.y; f.v[2] = a.z; f.v[3] = a.w;
@@ -90,6 +153,7 @@ __device__ __forceinline__ void load8(float* o, const __bf16* p) {
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = (float)a[j];
 }
+__device__ __forceinline__ void load8(float* o, const x3* p) { load8(o, fptr(p)); }
 __device__ __forceinline__ void store8(float* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
   *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -100,11 +164,18 @@ __device__ __forceinline__ void store8(__bf16* p, const float* v) {
   for (int j = 0; j < 8; ++j) a[j] = (__bf16)v[j];
   *reinterpret_cast<bf16x8_t*>(p) = a;
 }
+__device__ __forceinline__ void store8(x3* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<float4*>(fptr(p) + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
 __device__ __forceinline__ void load4f(float* o, const float* p) {
   const float4 a = *reinterpret_cast<const float4*>(p);
   o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
 }
 __device__ __forceinline__ void store4(float* p, const float* v) {
+  *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store4(x3* p, const float* v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
 }
 __device__ __forceinline__ void store4(__bf16* p, const float* v) {
@@ -121,6 +192,10 @@ typedef __attribute__((ext_vector_type(4))) float rg_f4;
 __device__ __forceinline__ void frag_store_nt(float* p, const Frag<float>& f) {
   __builtin_nontemporal_store((rg_f4){f.v[0], f.v[1], f.v[2], f.v[3]}, reinterpret_cast<rg_f4*>(p));
   __builtin_nontemporal_store((rg_f4){f.v[4], f.v[5], f.v[6], f.v[7]}, reinterpret_cast<rg_f4*>(p + 4));
+}
+__device__ __forceinline__ void frag_store_nt(x3* p, const Frag<x3>& f) {
+  __builtin_nontemporal_store((rg_f4){f.v[0], f.v[1], f.v[2], f.v[3]}, reinterpret_cast<rg_f4*>(p));
+  __builtin_nontemporal_store((rg_f4){f.v[4], f.v[5], f.v[6], f.v[7]}, reinterpret_cast<rg_f4*>(fptr(p) + 4));
 }
 __device__ __forceinline__ void frag_store_nt(__bf16* p, const Frag<__bf16>& f) {
   union { bf16x8_t b; rg_f4 x; } u;
@@ -191,6 +266,7 @@ __device__ __forceinline__ float gelu_f(float x) { return gelu_t<true>(x); }
 __device__ __forceinline__ float gelu_grad_f(float x) { return gelu_grad_t<true>(x); }
 // 4 consecutive elements -> float[4]
 __device__ __forceinline__ void load4t(float* o, const float* p) { load4f(o, p); }
+__device__ __forceinline__ void load4t(float* o, const x3* p) { load4f(o, fptr(p)); }
 __device__ __forceinline__ void load4t(float* o, const __bf16* p) {
   const bf16x4_t a = *reinterpret_cast<const bf16x4_t*>(p);
 #pragma unroll
@@ -199,6 +275,8 @@ __device__ __forceinline__ void load4t(float* o, const __bf16* p) {
 
 template <typename T> struct Precise { static constexpr bool value = true; };
 template <> struct Precise<__bf16> { static constexpr bool value = false; };
+// x3: the 7-instruction exp2 / rcp GELU (v_exp_f32 and v_rcp_f32 are good to ~1 ulp: 1e-7, two orders below the operand split)
+template <> struct Precise<x3> { static constexpr bool value = false; };
 
 // Dropout masks are stateless: keep(seed, idx) is a hash of a per-call seed and the element index,
 // so the backward kernels regenerate exactly the forward's mask (nn.Dropout semantics: element kept

@@ -13,7 +13,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RG_HIP_LIB") or os.path.join(_HERE, "librecguru_hip.so")   # RG_HIP_LIB: another build of the SAME library (A/B kernel experiments, tools/ab_variants.sh)
 _lib = None
 
-F32, BF16 = 0, 1
+F32, BF16, X3 = 0, 1, 2
+# bf16x3 tier (ops.set_compute_dtype("bf16x3")): tensors are f32; the GEMM-class entry points are called with RG_X3 (split bf16
+# operands, three MFMAs per product), every other kernel with RG_F32
+SPLIT_OPERANDS = False
 PRO_NONE, PRO_GELU = 0, 1
 EPI_NONE, EPI_RELU, EPI_MUL_POSMASK, EPI_GELU_GRAD, EPI_ADD, EPI_RESID_LN, EPI_DROP_GELU = 0, 1, 2, 3, 4, 5, 6
 
@@ -134,6 +137,12 @@ def dt_of(t):
     raise TypeError("recguru_amd: activations must be float32 or bfloat16, got %s" % t.dtype)
 
 
+def mt_of(t):
+    """dtype code for the entry points that contain matrix products (include/recguru_hip.h: RG_X3)."""
+    d = dt_of(t)
+    return X3 if (d == F32 and SPLIT_OPERANDS) else d
+
+
 def _p(t):
     if t is None:
         return None
@@ -183,8 +192,8 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
                    drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L), _p(out2))
     if _PROF is not None:
-        _note_plan(lib().rg_gemm_nt_plan, a, dt_of(A))
-    _check(lib().rg_gemm_nt(ctypes.byref(a), dt_of(A), _stream()), "rg_gemm_nt")
+        _note_plan(lib().rg_gemm_nt_plan, a, mt_of(A))
+    _check(lib().rg_gemm_nt(ctypes.byref(a), mt_of(A), _stream()), "rg_gemm_nt")
     if headmajor_L:
         return out.view(3, M // headmajor_L, N // 96, headmajor_L, 32)
     return out
@@ -219,12 +228,12 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
     if partials:
         fn = lib().rg_gemm_tn_workspace
         fn.restype = ctypes.c_size_t
-        need = int(fn(ctypes.byref(a), dt_of(Y)))
+        need = int(fn(ctypes.byref(a), mt_of(Y)))
         if need:
             a.partials = _p(_tn_workspace(Y.device, need))
     if _PROF is not None:
-        _note_plan(lib().rg_gemm_tn_plan, a, dt_of(Y))
-    _check(lib().rg_gemm_tn(ctypes.byref(a), dt_of(Y), _stream()), "rg_gemm_tn")
+        _note_plan(lib().rg_gemm_tn_plan, a, mt_of(Y))
+    _check(lib().rg_gemm_tn(ctypes.byref(a), mt_of(Y), _stream()), "rg_gemm_tn")
     return dW
 
 
@@ -250,7 +259,7 @@ def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed
                  (2 if bqkv is not None else 1) if (x_masked and rowmask is not None) else 0,
                  _p(first_live(rowmask, B, L)) if (x_masked and rowmask is not None and bqkv is not None) else None,
                  1 if hm else 0, _p(pad_rows) if hm else None)
-    _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_fwd")
+    _check(lib().rg_attn_fwd(ctypes.byref(a), mt_of(qkv), _stream()), "rg_attn_fwd")
     return ctx, lse
 
 
@@ -267,7 +276,7 @@ def attn_fwd_x(x, wqkv, bqkv, key_ids, pad_value, causal, H, drop_p=0.0, seed=0,
     ctx = torch.empty(B, L, H * 32, device=x.device, dtype=x.dtype)
     a = AttnArgs(None, _p(key_ids), int(pad_value), int(bool(causal)), _p(ctx), None, B, L, H, 32,
                  1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(x), _p(wqkv), _p(bqkv), d, int(bool(x_masked)), None, 0, None)
-    _check(lib().rg_attn_fwd(ctypes.byref(a), dt_of(x), _stream()), "rg_attn_fwd")
+    _check(lib().rg_attn_fwd(ctypes.byref(a), mt_of(x), _stream()), "rg_attn_fwd")
     return ctx
 
 
@@ -282,7 +291,7 @@ def attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, drop_p=0.0, see
     a = AttnBwdArgs(_p(qkv), _p(dctx), _p(ctx), _p(lse), _p(key_ids), int(pad_value), int(bool(causal)),
                     _p(dqkv), B, L, H, 32, 1.0 / (32 ** 0.5), drop_p, seed, _p(rowmask), _p(bqkv) if sub else None, 2 if sub else 0,
                     _p(first_live(rowmask, B, L)) if sub else None, 1 if hm else 0)
-    _check(lib().rg_attn_bwd(ctypes.byref(a), dt_of(qkv), _stream()), "rg_attn_bwd")
+    _check(lib().rg_attn_bwd(ctypes.byref(a), mt_of(qkv), _stream()), "rg_attn_bwd")
     return dqkv
 
 
@@ -918,7 +927,7 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
                      _p(sv.get("rstd2")), M, d, P, dff, eps, drop_p, seed_h1, seed_out, _p(cs), _p(coh), _p(cbo), cH,
                      _p(live16), 1 if (live16 is not None and skip_dead_saves) else 0, 1 if w_packed else 0,
                      _p(x_lo), _p(out_lo))
-    _check(lib().rg_post_attn_fwd(ctypes.byref(a), dt_of(ctx), _stream()), "rg_post_attn_fwd")
+    _check(lib().rg_post_attn_fwd(ctypes.byref(a), mt_of(ctx), _stream()), "rg_post_attn_fwd")
     return out, sv
 
 
@@ -939,7 +948,7 @@ def attn_out_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, Wot, live=Non
     ws = _tn_workspace(dy.device, int(fn(M)), "attn_out_ln")
     a = AttnOutBwdArgs(_p(dy), _p(y), _p(rstd), _p(gamma), _p(beta), _p(rowmask), _p(Wot), _p(dz), _p(dctx),
                        _p(dgamma), _p(dbeta), _p(ws), M, d, P, 1 if w_packed else 0, _p(live))
-    _check(lib().rg_attn_out_bwd(ctypes.byref(a), dt_of(dy), _stream()), "rg_attn_out_bwd")
+    _check(lib().rg_attn_out_bwd(ctypes.byref(a), mt_of(dy), _stream()), "rg_attn_out_bwd")
     return dz, dctx
 
 
@@ -977,7 +986,7 @@ def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False,
         a.ln_dout, a.ln_out, a.ln_rstd, a.ln_gamma, a.ln_beta, a.ln_rowmask = _p(dout), _p(out), _p(rstd), _p(gamma), _p(beta), _p(rowmask)
         a.dl2_out, a.ln_dgamma, a.ln_dbeta, a.ln_partials = _p(dl2o), _p(dgamma), _p(dbeta), _p(ws)
         a.ln_drop_p, a.ln_drop_seed = float(drop_p), int(drop_seed)
-    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), dt_of(src), _stream()), "rg_ffn_bwd_data")
+    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), mt_of(src), _stream()), "rg_ffn_bwd_data")
     return (dh1, dy, dl2o) if ln is not None else (dh1, dy)
 
 

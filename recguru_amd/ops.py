@@ -19,15 +19,31 @@ GP_LAMBDA = 0.1     # gan_training.py:21
 
 
 def set_compute_dtype(dt):
+    """torch.bfloat16 (bf16 tier), torch.float32 (exact-f32 tier) or "bf16x3": the f32 tier's tensors and elementwise arithmetic
+    with every matrix product on split bf16 operands (hip.SPLIT_OPERANDS; include/recguru_hip.h RG_X3) -- inside the north-star
+    tolerance like the f32 tier at a third of its matrix-pipe time."""
     global _COMPUTE
+    x3 = dt == "bf16x3"
+    if x3:
+        dt = torch.float32
+    elif dt == "bf16":
+        dt = torch.bfloat16
+    elif dt == "f32":
+        dt = torch.float32
     assert dt in (torch.float32, torch.bfloat16)
     _COMPUTE = dt
+    hip.SPLIT_OPERANDS = x3
     _SHADOWS.clear()
     _REFRESH_CACHE.clear()
 
 
 def compute_dtype():
+    """The STORAGE dtype of activations (torch.float32 for both the f32 and the bf16x3 tier); compute_tier() names the tier."""
     return _COMPUTE
+
+
+def compute_tier():
+    return "bf16" if _COMPUTE == torch.bfloat16 else ("bf16x3" if hip.SPLIT_OPERANDS else "f32")
 
 
 # Residual stream of the bf16 tier: torch.bfloat16 = one bf16 tensor per layer input / output (8 significant bits);

@@ -27,7 +27,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEAD = ("dec_enc_attn.WQ", "dec_enc_attn.WK")
 NOISE = DEAD + ("WK.bias",)
-TIERS = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16_split_resid": torch.bfloat16}
+TIERS = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16_split_resid": torch.bfloat16, "bf16x3": "bf16x3"}
+EXACT = ("f32", "bf16x3")            # the tiers held to the north-star tolerance rtol 1e-3 / atol 1e-5
 
 
 @pytest.fixture(autouse=True)
@@ -115,7 +116,7 @@ def _moved_frac_bad(new, ref, old, lr, tol):
     return float((np.abs((new - old) - (ref - old)) > tol * lr).mean())
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
 def test_bench_shape_steps_vs_oracle(tier, capsys):
     from recguru_amd import ops, training as T
     from recguru_amd.optim import Adam
@@ -153,7 +154,7 @@ def test_bench_shape_steps_vs_oracle(tier, capsys):
     with capsys.disabled():
         print("\n[bench shape, %s tier] user_embed err rel-to-max %.3g | loss_ae rel %.3g | D_cost/W_D/g_dis abs %.3g | "
               "GP rel %.3g | Adam-step mismatch fraction D %.3g G %.3g" % (tier, ue_err, l_rel, dc_abs, gp_rel, bad_d, bad_g))
-    if tier == "f32":
+    if tier in EXACT:
         np.testing.assert_allclose(ue_a, ref["ue_a"], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(ue_b, ref["ue_b"], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose([float(la), float(lb)], [ref["la"], ref["lb"]], rtol=1e-3, atol=1e-5)
@@ -161,6 +162,8 @@ def test_bench_shape_steps_vs_oracle(tier, capsys):
                                    rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(gp, ref["gp"], rtol=1e-3, atol=1e-5)
         assert bad_d <= 0.005 and bad_g <= 0.01
+        if tier == "bf16x3":
+            assert ue_err <= 1e-4         # (<= 1e-3 of max; the CPU emulation of the split predicts 7e-6)
     else:
         b = BF16_BOUNDS if tier == "bf16" else SPLIT_BOUNDS
         assert ue_err <= b["ue_rel_to_max"] and l_rel <= b["loss_rel"] and dc_abs <= b["dcost_abs"]
@@ -209,7 +212,7 @@ def _curve_models(z, device="cuda"):
     return m, param, G.to(device), D.to(device)
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
 def test_loss_curves_replay(tier, capsys):
     """20 train_recon_x steps + train_gan_all(iterations=9) = 5 phase-2 + 5 phase-3 iterations, as the reference's
     drivers ran them (oracle/gen_golden_curves.py).  f32: rtol 1e-3 per point in phase 1; in phases 2 / 3 the
@@ -245,7 +248,7 @@ def test_loss_curves_replay(tier, capsys):
                            for i, n in enumerate(names2)},
             {n: "%.2g (band %.2g)" % (np.abs(p3[:, i] - z["phase3." + n]).max(), bands["phase3." + n])
              for i, n in enumerate(("loss_recommend", "loss_recon_rec"))}))
-    if tier == "f32":
+    if tier in EXACT:
         np.testing.assert_allclose(p1, z["phase1.loss"], rtol=1e-3, atol=1e-5)
         for i, n in enumerate(names2):
             np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=bands["phase2." + n], err_msg=n)
@@ -272,7 +275,7 @@ def test_loss_curves_replay(tier, capsys):
     assert len(T.plot.values(param.result_path + "/tuning_recommendation_loss")) == 5
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16"])
 def test_overlap_term_and_recommendation_tune_replay(tier, capsys):
     """curves2 (recorded through the reference's own drivers, oracle/gen_golden_curves2.py): the shipped train_gan_all with
     overlap=True -- the MSE between the user embeddings of overlapped users in every generator update, the overlap loader
@@ -303,7 +306,7 @@ def test_overlap_term_and_recommendation_tune_replay(tier, capsys):
             tier, {n: "%.2g" % np.abs(p2[:, i] - z["phase2." + n]).max() for i, n in enumerate(names2)},
             {n: "%.2g" % np.abs(p3[:, i] - z["phase3." + n]).max() for i, n in enumerate(("loss_recommend", "loss_recon_rec"))},
             float(np.abs(tune / z["tune.loss"] - 1).max())))
-    if tier == "f32":
+    if tier in EXACT:
         for i, n in enumerate(names2):
             np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=bands["phase2." + n], err_msg=n)
         np.testing.assert_allclose(p3[:, 0], z["phase3.loss_recommend"], rtol=1e-3, atol=bands["phase3.loss_recommend"])
@@ -569,7 +572,7 @@ def _bench_shape_curve_oracle(steps, its):
     return _ORACLE_CURVE
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
 def test_bench_shape_loss_curve_vs_oracle(tier, capsys):
     """North-star: "loss curves matching the CPU reference within tolerance" AT the metric's shape (seq_len 200, hidden 128,
     100k-item domains): 6 steps of the shipped train_recon_x (Noam learning rates up to 0.03) followed by the shipped
@@ -612,7 +615,7 @@ def test_bench_shape_loss_curve_vs_oracle(tier, capsys):
     # measured on an MI355X (round 3): f32 3.7e-6 / 7.9e-6 / 9.5e-4 / 1.2e-3; bf16 1.2e-3 / 1.2e-3 / 6.5e-3 / 1.5e-3; split residual
     # stream 9.5e-4 / 7.8e-4 / 6.8e-3 / 2.7e-3.  The W-GAN scalars and the phase-3 BPR loss are the rounding-sensitive series
     # (ReLU masks inside the gradient penalty, Adam's +-lr steps: DESIGN.md 2): their f32 bounds are 2 x measured, not 1e-3
-    if tier == "f32":
+    if tier in EXACT:
         assert e1 <= 1e-3 and e2r <= 1e-3 and e2a <= 2e-3 and e3 <= 2.5e-3
     else:
         assert e1 <= 2.5e-3 and e2r <= 2.5e-3 and e2a <= 0.014 and e3 <= 6e-3
@@ -641,7 +644,7 @@ def test_single_domain_bench_shape_vs_oracle(capsys):
         lb_ref = float(O.bpr_loss_sas(pl, nl, O.nonpad(bt[1]).view(-1)))
     cb = tuple(t.cuda() for t in bt)
     m_in = (cb[1] != 0).view(-1).float()
-    for tier, tol in (("f32", 1e-3), ("bf16", 7e-4)):           # measured: f32 5e-7, bf16 3e-4
+    for tier, tol in (("f32", 1e-3), ("bf16x3", 1e-3), ("bf16", 7e-4)):           # measured: f32 5e-7, bf16 3e-4
         ops.set_compute_dtype(TIERS[tier])
         with torch.no_grad():
             la = float(at.loss_ae(R, *cb, True, B, L, param, m_in))

@@ -41,7 +41,7 @@ def parse():
     p.add_argument("--n_blocks", type=int, default=None)
     p.add_argument("--dropout", type=float, default=None)
     p.add_argument("--data_path", type=str, default=None)
-    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16")
     p.add_argument("--synthetic", type=int, default=0)
     p.add_argument("--epochs", type=int, default=500, help="epochs per stage (train_auto.py:101 hard-codes 500)")
     p.add_argument("--steps", type=int, default=200, help="pre-training steps")
@@ -66,7 +66,7 @@ def main():
     os.makedirs(args.result_path, exist_ok=True)
     param = config.get_param(args)
     device = "cuda:0"
-    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_compute_dtype(args.dtype)
     L, V = param.enc_maxlen, param.vocab_size - 1
     item_fre = None
     if args.synthetic:

@@ -4,7 +4,7 @@
 three optimizers -> main_2 (phase 1 recon, phase 2 W-GAN, phase 3 BPR tune).
 
 Extra flags (next to the preserved ones): --seq_len --vocab_size_a/b --n_blocks --dropout --data_path
---steps_tune --phase1_steps --dtype {bf16,f32} --synthetic N_USERS.  --n_gpu is real here: launch with
+--steps_tune --phase1_steps --dtype {bf16,f32,bf16x3} --synthetic N_USERS.  --n_gpu is real here: launch with
 `python -m torch.distributed.run --nproc-per-node N train_gan.py ...` (one process per GPU, RCCL).
 """
 import argparse
@@ -51,7 +51,7 @@ def parse():
     p.add_argument("--data_path", type=str, default=None)
     p.add_argument("--steps_tune", type=int, default=None)
     p.add_argument("--phase1_steps", type=int, default=200)
-    p.add_argument("--dtype", choices=["bf16", "f32"], default="bf16")
+    p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16")
     p.add_argument("--synthetic", type=int, default=0, help="users per domain of generated data (0 = read data_path)")
     return p.parse_args()
 
@@ -76,7 +76,7 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    ops.set_compute_dtype(args.dtype)
     ops.set_data_parallel(dp)
 
     L, k = param.enc_maxlen, param.n_negs
