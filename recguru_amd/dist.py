@@ -39,6 +39,28 @@ class DataParallel(object):
         self.bucket_elems = bucket_bytes // 4
         self.big_elems = 1 << 20                    # gradients of >= 4 MB are all-reduced in place, on their own
         self._pending = []                          # (data_ptr, numel, work) of exchanges started by begin_sync()
+        self._stats = None                          # start_stats(): [bytes, collectives, [(event, event), ...]]
+
+    # -- measurement (bench.py at N > 1): what the gradient exchange moved and what it cost the compute stream -----------
+    def start_stats(self):
+        self._stats = [0, 0, []]
+
+    def stop_stats(self):
+        """{"bytes": payload bytes handed to all-reduce, "collectives": their number, "exposed_ms": time the CURRENT stream
+        spent inside sync_grads() -- HIP events on that stream around the call: the collectives run on the backend's stream and
+        the compute stream waits for them, so this is the part of the exchange that was not hidden under other work}."""
+        st, self._stats = self._stats, None
+        if st is None:
+            return None
+        if st[2]:
+            torch.cuda.synchronize()
+        return {"bytes": st[0], "collectives": st[1], "exposed_ms": sum(a.elapsed_time(b) for a, b in st[2]),
+                "backend": dist.get_backend(self.group), "world": dist.get_world_size(self.group)}
+
+    def _count(self, t):
+        if self._stats is not None:
+            self._stats[0] += t.numel() * t.element_size()
+            self._stats[1] += 1
 
     def scale_mean(self, loss):
         return loss / self.world
@@ -62,6 +84,7 @@ class DataParallel(object):
             g = p.grad
             if g is None or g.numel() < self.big_elems or not g.is_contiguous() or getattr(p, "_rg_gbase", None) is not None:
                 continue
+            self._count(g)
             work = dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
             self._pending.append((g.data_ptr(), g.numel(), work))
 
@@ -71,6 +94,10 @@ class DataParallel(object):
         buckets (few large collectives: xGMI links are point-to-point, so per-collective latency matters more than on a
         switch) and come back with one multi-tensor copy.  Gradients that are row slices of one shared buffer (the fused
         Q/K/V gradient base of ops._gt_cat) are reduced once, as that buffer."""
+        ev = None
+        if self._stats is not None and torch.cuda.is_available():
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         pending, self._pending = self._pending, []
         seen, big, small = set((ptr, n) for ptr, n, _ in pending), [], []
         for p in params:
@@ -87,6 +114,7 @@ class DataParallel(object):
             (big if (g.numel() >= self.big_elems and g.is_contiguous()) else small).append(g)
         try:
             for g in big:
+                self._count(g)
                 dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.group)
             bucket, size = [], 0
             for g in small:
@@ -100,6 +128,9 @@ class DataParallel(object):
         finally:
             for _, _, work in pending:                      # exchanges started by begin_sync(): always waited for
                 work.wait()
+            if ev is not None:
+                ev[1].record()
+                self._stats[2].append(ev)
 
     def discard_pending(self):
         """Wait for and forget exchanges started by begin_sync() whose sync_grads() never came (an exception between the
@@ -110,9 +141,11 @@ class DataParallel(object):
 
     def _reduce(self, bucket):
         if len(bucket) == 1 and bucket[0].is_contiguous():
+            self._count(bucket[0])
             dist.all_reduce(bucket[0], op=dist.ReduceOp.SUM, group=self.group)
             return
         flat = torch.cat([g.reshape(-1) for g in bucket])
+        self._count(flat)
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         outs, off = [], 0
         for g in bucket:

@@ -1048,6 +1048,11 @@ def _esize(t):
     return t.element_size()
 
 
+def _tn(t):
+    """Tier name of a launch on tensor t, as it appears in the kernel's template arguments."""
+    return "bf16" if t.dtype == torch.bfloat16 else ("x3" if SPLIT_OPERANDS else "f32")
+
+
 def _work_gemm_nt(A, W, *a, **k):
     M, K = A.shape
     N = W.shape[0]
@@ -1060,7 +1065,7 @@ def _work_gemm_nt(A, W, *a, **k):
 def _work_gemm_tn(Y, X, *a, **k):
     T, N1 = Y.shape
     N2 = X.shape[1]
-    return ("gemm_tn_kernel<%s>" % ("bf16" if Y.dtype == torch.bfloat16 else "f32"), 2.0 * T * N1 * N2,
+    return ("gemm_tn_kernel<%s>" % _tn(Y), 2.0 * T * N1 * N2,
             T * (N1 + N2) * _esize(Y) + N1 * N2 * 4)
 
 
@@ -1069,7 +1074,7 @@ def _work_attn_fwd(qkv, key_ids, pad_value, causal, H, *a, **k):
         B, L, P3 = qkv.shape[1], qkv.shape[3], 3 * qkv.shape[2] * 32
     else:
         B, L, P3 = qkv.shape
-    return ("attn_fwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 4.0 * B * H * L * L * 32,
+    return ("attn_fwd_kernel<%s>" % _tn(qkv), 4.0 * B * H * L * L * 32,
             B * L * (P3 + P3 // 3) * _esize(qkv))
 
 
@@ -1078,7 +1083,7 @@ def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, *a, **k):
         B, L, P3 = qkv.shape[1], qkv.shape[3], 3 * qkv.shape[2] * 32
     else:
         B, L, P3 = qkv.shape
-    return ("attn_bwd_kernel<%s>" % ("bf16" if qkv.dtype == torch.bfloat16 else "f32"), 10.0 * B * H * L * L * 32,
+    return ("attn_bwd_kernel<%s>" % _tn(qkv), 10.0 * B * H * L * L * 32,
             B * L * (2 * P3 + 2 * P3 // 3) * _esize(qkv))
 
 
@@ -1096,7 +1101,7 @@ def _work_post_attn(ctx, x, Wo, bo, g1, be1, W1, *a, **k):
     M, P = ctx.shape
     d, dff = x.shape[1], W1.shape[0]
     by = M * (P + 2 * d) * _esize(ctx) + (M * (d + dff) * _esize(ctx) if k.get("save") else 0)
-    return ("post_attn_fwd_kernel<%s>" % ("bf16" if ctx.dtype == torch.bfloat16 else "f32"),
+    return ("post_attn_fwd_kernel<%s>" % _tn(ctx),
             2.0 * M * (d * P + 2 * d * dff), by)
 
 
@@ -1111,7 +1116,7 @@ def _work_ffn_bwd(dl2, dz, h1, *a, **k):
     src = k["ln"][0] if k.get("ln") is not None else dl2
     M, d = src.shape
     dff = h1.shape[1]
-    return ("ffn_bwd_data_kernel<%s>" % ("bf16" if src.dtype == torch.bfloat16 else "f32"), 4.0 * M * d * dff,
+    return ("ffn_bwd_data_kernel<%s>" % _tn(src), 4.0 * M * d * dff,
             M * ((4 if k.get("ln") is not None else 3) * d + 2 * dff) * _esize(src))
 
 

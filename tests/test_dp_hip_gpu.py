@@ -213,6 +213,16 @@ def test_bench_self_launch_two_ranks():
     assert line["config"]["sequences_per_step"] == 12 * 64 * 2
     assert line["ae_step"]["sequences_per_step"] == 2 * 64 * 2 and line["value_full_length"] > 0
     assert all(np.isfinite(v) for v in line["config"]["last_step"].values())
+    # what the collective layer itself saw: backend, world size, devices, and the exchange of one step --
+    # 5 critic updates (one flat bucket of D gradients each) + 1 generator update (the G gradients)
+    ex = line["exchange"]
+    assert ex["backend"] == ("nccl" if _two_gpus() else "gloo") and ex["collective_world"] == 2
+    assert ex["visible_devices"] >= (2 if _two_gpus() else 1)
+    d, dis = 128, 5 * 128
+    n_d = (d * dis + dis) + (dis * 2 * dis + 2 * dis) + (2 * dis * dis + dis) + (dis + 1)
+    assert ex["collectives_per_step"] >= 6 and ex["allreduce_bytes_per_step_per_rank"] >= 5 * 4 * n_d
+    assert ex["allreduce_exposed_ms_per_step"] > 0
+    assert line["tiers"]["bf16x3"]["value"] > 0 and line["tiers"]["f32"]["value"] > 0
 
 
 def test_bench_line_contract_single_gpu():
@@ -223,6 +233,8 @@ def test_bench_line_contract_single_gpu():
     r = line["roofline"]
     assert r["bound"] in ("hbm", "mfma") and 0 < r["frac"] <= r["frac_nominal"] + 1e-9
     assert line["ae_step"]["value"] > 0 and line["value_full_length"] > 0
+    assert "exchange" not in line and line["config5"] is None          # (config-5 rides only in the default-shape line)
+    assert line["value_bf16x3_tier"] == line["tiers"]["bf16x3"]["value"] > 0 and line["value_f32_tier"] > 0
     ae = _bench(["--gpus", "1", "--mode", "ae"] + SMALL)
     assert ae["metric"] == "user-sequences/sec (AE step)" and ae["config"]["sequences_per_step"] == 2 * 64
     assert "ae_step" not in ae and ae["value"] > 0

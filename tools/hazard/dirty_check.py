@@ -2,7 +2,7 @@
 round-3 defect never showed) the block is launched after tools/hazard/dirty.hip has left a pattern in every VGPR / AGPR and all of
 the LDS; a result that depends on the pattern is an uninitialised read.
   hipcc --offload-arch=gfx950 -O2 -shared -fPIC tools/hazard/dirty.hip -o /tmp/libdirty.so
-  [RG_HIP_LIB=<old build>] python tools/hazard/dirty_test.py"""
+  [RG_HIP_LIB=<old build>] python tools/hazard/dirty_check.py"""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from recguru_amd import hip
