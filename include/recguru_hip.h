@@ -326,6 +326,9 @@ int rg_adam_multi_dev(rg_adam_seg_dev* segs /* device, updated in place */, int 
  * row_off / col_off = n / k offsets (multiples of 16 / 32). */
 #define RG_CAST_TRANSPOSE 1
 #define RG_CAST_PACK 2
+#define RG_CAST_SPLIT 4 /* with RG_CAST_PACK and an f32 destination: the RG_X3 tier's PRESPLIT operand -- the 2 KB slot of a fragment
+                           holds the 64 lanes' hi parts bf16(v) (1 KB: 16 bytes per lane), then their lo parts bf16(v - hi) (1 KB).
+                           What rg_post_attn_fwd / rg_ffn_bwd_data / rg_attn_out_bwd take as w_packed weights under RG_X3. */
 int rg_cast(const float* src, void* dst, int R, int C, int transpose, int dtype, void* stream);
 /* Multi-tensor cast: ONE launch refreshes every operand-tier weight copy after an optimizer step (136 per-tensor casts
  * per training iteration otherwise).  Segment s: dst[(r + row_off) * ld + c + col_off] = src[r, c], or with transpose
@@ -476,7 +479,8 @@ typedef struct {
   const int* live16;
   int skip_dead_saves;   /* with live16: 1 = leave the padded tiles' rows of the *_save / rstd* buffers untouched (every
                             consumer is list-driven as well), 0 = write zeros / finite placeholders there */
-  int w_packed;          /* 1: Wo, W1, W2 are fragment-packed copies (rg_cast RG_CAST_PACK: contiguous 1 KB operand fragments) */
+  int w_packed;          /* 1: Wo, W1, W2 are fragment-packed copies (rg_cast RG_CAST_PACK: contiguous 1 KB operand fragments;
+                            under RG_X3: RG_CAST_PACK | RG_CAST_SPLIT, the presplit form) */
   /* Split residual stream (bf16 tier only; both or neither): the layer input and output travel through HBM as a bf16
    * PAIR  value = hi + lo  (hi = bf16(value): the tensor every MFMA-operand consumer reads; lo = bf16(value - hi): read
    * only here, as part of the residual addend) -- ~16 significant bits for the residual stream at 2 x 2 bytes, where one

@@ -1,5 +1,13 @@
-"""Build librecguru_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+"""Build librecguru_hip.so for gfx950 with hipcc (cross-compiles without a GPU).
+
+Every source is compiled with -save-temps so that its device ISA stays beside the object (recguru_amd/build/isa/<name>.s), and
+every build ends with the ISA screen of recguru_amd/isa_screen.py: hipcc (ROCm 7.2) can place register spills in front of the
+exec restore of a join block -- silent wrong values in the lanes that skipped the branch -- and a kernel that
+shows the pattern FAILS the build (RG_BUILD_NO_SCREEN=1 to look at such a build anyway).  build/BUILD_INFO.json records the
+compiler version, the flags and the hash of the library the screen passed on."""
 import glob
+import hashlib
+import json
 import os
 import subprocess
 import sys
@@ -28,20 +36,64 @@ def build(force=False, verbose=False, jobs=4):
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
-        if force or _stale(o, [s] + hdrs):
-            cmd = ["hipcc"] + FLAGS + ["-c", s, "-o", o]
+        if force or _stale(o, [s] + hdrs) or not os.path.exists(_isa_of(o)):
+            cmd = ["hipcc"] + FLAGS + ["-save-temps=obj", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
             if len(procs) >= jobs:
                 _drain(procs)
     _drain(procs)
+    for o in objs:                              # keep the device ISA, drop the other intermediates of -save-temps
+        stem = o[:-2]
+        tmp = stem + "-hip-amdgcn-amd-amdhsa-gfx950.s"
+        if os.path.exists(tmp):
+            os.replace(tmp, _isa_of(o))
+        for junk in glob.glob(stem + "-hip-amdgcn-*") + glob.glob(stem + "-host-*") + glob.glob(stem + ".hip-hip-*"):
+            os.remove(junk)
     if force or _stale(LIB, objs):
         cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    _screen_and_record([_isa_of(o) for o in objs], verbose)
     return LIB
+
+
+def _isa_of(obj):
+    d = os.path.join(os.path.dirname(obj), "isa")          # (a directory of its own: .gpurunignore keeps the ~30 MB of text off the GPU box)
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, os.path.basename(obj)[:-2] + ".s")
+
+
+def _screen_and_record(isa_files, verbose):
+    from . import isa_screen
+    info_path = os.path.join(HERE, "build", "BUILD_INFO.json")
+    sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
+    try:
+        with open(info_path) as f:
+            if json.load(f).get("library_sha256") == sha:
+                return                           # this very library has been screened
+    except (OSError, ValueError):
+        pass
+    flagged, warnings = [], 0
+    for fn in isa_files:
+        bad, warn = isa_screen.screen(fn)
+        warnings += len(warn)
+        flagged += [(os.path.basename(fn), kernel, no, block, len(ins)) for kernel, no, block, ins in bad]
+    ver = subprocess.run(["hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode().strip().splitlines()
+    info = {"hipcc": ver[:3], "flags": FLAGS, "library_sha256": sha, "isa_files": len(isa_files), "screen": "recguru_amd/isa_screen.py",
+            "flagged_join_blocks": [list(x) for x in flagged], "spill_in_front_of_exec_restore_warnings": warnings}
+    if flagged and not os.environ.get("RG_BUILD_NO_SCREEN"):
+        msg = "\n".join("  %s: %s: %d vector instruction(s) in front of the exec restore at line %d (join block %s)" % (f, k, n, no, b)
+                        for f, k, no, b, n in flagged)
+        raise RuntimeError("hipcc placed spill code under a narrowed exec mask (recguru_amd/isa_screen.py, DESIGN.md 2a) -- these kernels "
+                           "return wrong values in the lanes that skipped the branch; change the source until the pattern is gone "
+                           "(RG_BUILD_NO_SCREEN=1 builds anyway):\n" + msg)
+    with open(info_path, "w") as f:
+        json.dump(info, f, indent=1)
+    if verbose:
+        print("ISA screen: %d files, %d flagged join blocks, %d warnings" % (len(isa_files), len(flagged), warnings))
 
 
 def _drain(procs):

@@ -929,15 +929,52 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // through the (by then dead) Q/K/V/dO tiles at the end.
 // NTH: 256 threads, two workgroups per CU -- or 512 (two-phase form only) where the four staged tiles leave room for ONE
 // workgroup per CU (L = 400: 133 KB + the dropout bit table): eight waves keep two per SIMD for the issue-bound softmax work
-template <int NKT, bool CAUSAL, int DM, bool ONEPASS, int NTH = 256>
+// operand helpers of the backward kernel below, for both of its tiers: one bf16 image per staged tile, or (bf16x3) a hi and a lo
+// image PL elements apart
+template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<__bf16>& raw) { *reinterpret_cast<Frag<__bf16>*>(dst) = raw; }
+template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<x3>& raw) {
+  bf16x8_t hi, lo;
+  split_x3(raw.v, hi, lo);
+  *reinterpret_cast<bf16x8_t*>(dst) = hi;
+  *reinterpret_cast<bf16x8_t*>(dst + PL) = lo;
+}
+template <int PL> __device__ __forceinline__ void load_op(Frag<__bf16>& f, const __bf16* p) { load_frag(f, p); }
+template <int PL> __device__ __forceinline__ void load_op(FragX3& f, const __bf16* p) {
+  f.hi = *reinterpret_cast<const bf16x8_t*>(p);
+  f.lo = *reinterpret_cast<const bf16x8_t*>(p + PL);
+}
+template <int PL> __device__ __forceinline__ void vstage_op(Frag<__bf16>& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
+  VStage<__bf16>::frag(f, V, ldv, k0, dv0, li, lg);
+}
+template <int PL> __device__ __forceinline__ void vstage_op(FragX3& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
+  Frag<__bf16> h, l;
+  VStage<__bf16>::frag(h, V, ldv, k0, dv0, li, lg);
+  VStage<__bf16>::frag(l, V + PL, ldv, k0, dv0, li, lg);
+  f.hi = h.v;
+  f.lo = l.v;
+}
+__device__ __forceinline__ void acc_to_op(Frag<__bf16>& f, const f32x4& lo, const f32x4& hi) { acc_to_frag(f, lo, hi); }
+__device__ __forceinline__ void acc_to_op(FragX3& f, const f32x4& lo, const f32x4& hi) {
+  const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  split_x3(v, f.hi, f.lo);
+}
+
+// G: the type of qkv / dctx / ctx / dqkv in memory -- __bf16, or x3 (the bf16x3 tier: f32 in memory; the four staged tiles are
+// split into hi and lo bf16 images while they are staged, PL elements apart, P and dS are split when they leave the
+// accumulators, every product is three MFMAs; two-phase form, eight waves, L <= 224: 153 KB of LDS at L = 200).
+template <int NKT, bool CAUSAL, int DM, bool ONEPASS, int NTH = 256, typename G = __bf16>
 __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
   static_assert(!ONEPASS || NKT >= 8, "the dS scratch tiles need 4 x 32 rows of pad columns");
   static_assert(!ONEPASS || NTH == 256, "the one-pass dQ reduction is written for four waves");
+  constexpr bool X3 = std::is_same<G, x3>::value;
+  static_assert(!X3 || !ONEPASS, "bf16x3: two-phase form");
   constexpr int NWV = NTH / 64;
-  typedef __bf16 T;
+  typedef __bf16 T;                                           // element of the LDS tiles
+  typedef typename OpT<G>::type OP;                           // operand fragment
   constexpr int LPK = NKT * 16;
   constexpr int LDR = DK + 8;
-  __shared__ __align__(16) T QKVG[4 * LPK * LDR];            // one block: reused as f32 scratch by the ONEPASS reduction
+  constexpr int PL = X3 ? 4 * LPK * LDR : 0;                  // bf16x3: the lo images sit PL elements behind the hi images
+  __shared__ __align__(16) T QKVG[4 * LPK * LDR * (X3 ? 2 : 1)];   // one block: reused as f32 scratch by the ONEPASS reduction
   T* const Qs = QKVG;
   T* const Ks = QKVG + LPK * LDR;
   T* const Vs = QKVG + 2 * LPK * LDR;
@@ -959,13 +996,13 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
   // q / k / v rows of this head: token-major qkv [B, L, 3P] (row pitch ld) or head-major q | k | v [3][B][H][L][32] (qkv_hm: a
   // head's rows are contiguous 64-byte runs -- the staging loads of a wave cover whole lines)
   const size_t hm_tensor = (size_t)a.B * a.H * L * DK;
-  const T* __restrict__ qrow = reinterpret_cast<const T*>(a.qkv) + (a.qkv_hm ? ((size_t)b * a.H + h) * L * DK : (size_t)b * L * ld + h * DK);
-  const T* __restrict__ krow = qrow + (a.qkv_hm ? hm_tensor : (size_t)P);
-  const T* __restrict__ vrow = qrow + (a.qkv_hm ? 2 * hm_tensor : (size_t)(2 * P));
+  const G* __restrict__ qrow = reinterpret_cast<const G*>(a.qkv) + (a.qkv_hm ? ((size_t)b * a.H + h) * L * DK : (size_t)b * L * ld + h * DK);
+  const G* __restrict__ krow = qrow + (a.qkv_hm ? hm_tensor : (size_t)P);
+  const G* __restrict__ vrow = qrow + (a.qkv_hm ? 2 * hm_tensor : (size_t)(2 * P));
   const int qld = a.qkv_hm ? DK : ld;
-  const T* __restrict__ dO = reinterpret_cast<const T*>(a.dctx) + (size_t)b * L * P + h * DK;
-  const T* __restrict__ O = reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK;
-  T* __restrict__ dqkv = reinterpret_cast<T*>(a.dqkv) + (size_t)b * L * ld;
+  const G* __restrict__ dO = reinterpret_cast<const G*>(a.dctx) + (size_t)b * L * P + h * DK;
+  const G* __restrict__ O = reinterpret_cast<const G*>(a.ctx) + (size_t)b * L * P + h * DK;
+  G* __restrict__ dqkv = reinterpret_cast<G*>(a.dqkv) + (size_t)b * L * ld;
   const int nt = (L + 31) / 32 * 2;   // live 16-row tiles (keys and queries), wave-uniform
   const float c2 = a.scale * 1.4426950408889634f;
   DropCfg drop = make_drop(a.drop_p, a.seed);
@@ -992,21 +1029,21 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
   constexpr int NCH = (LPK * 4 + NTH - 1) / NTH;
   const bool sub = a.x_masked == 2 && a.rowmask != nullptr && a.bqkv != nullptr;
   const int first = (sub && a.first_live) ? min(a.first_live[b], L - 1) : 0;      // see the forward
-  Frag<T> qbf, kbf, vbf;              // bias rows of this head, this thread's chunk (tid & 3)
+  Frag<G> qbf, kbf, vbf;              // bias rows of this head, this thread's chunk (tid & 3)
   frag_zero(qbf);
   frag_zero(kbf);
   frag_zero(vbf);
   if (sub) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      qbf.v[j] = (T)a.bqkv[h * DK + (tid & 3) * 8 + j];
-      kbf.v[j] = (T)a.bqkv[P + h * DK + (tid & 3) * 8 + j];
-      vbf.v[j] = (T)a.bqkv[2 * P + h * DK + (tid & 3) * 8 + j];
+      qbf.v[j] = (G)a.bqkv[h * DK + (tid & 3) * 8 + j];
+      kbf.v[j] = (G)a.bqkv[P + h * DK + (tid & 3) * 8 + j];
+      vbf.v[j] = (G)a.bqkv[2 * P + h * DK + (tid & 3) * 8 + j];
     }
   }
 #pragma unroll
   for (int i0 = 0; i0 < NCH; i0 += 4) {
-    Frag<T> qr[4], kr[4], vr[4], gr[4], orow[4];
+    Frag<G> qr[4], kr[4], vr[4], gr[4], orow[4];
     float rmr[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1043,9 +1080,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
     for (int i = 0; i < 4; ++i) {
       const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
       if (i0 + i < NCH && c < LPK * 4) {
-        *reinterpret_cast<Frag<T>*>(Qs + row * LDR + c8) = qr[i];
-        *reinterpret_cast<Frag<T>*>(Ks + row * LDR + c8) = kr[i];
-        *reinterpret_cast<Frag<T>*>(Vs + row * LDR + c8) = vr[i];
+        stage_op<PL>(Qs + row * LDR + c8, qr[i]);
+        stage_op<PL>(Ks + row * LDR + c8, kr[i]);
+        stage_op<PL>(Vs + row * LDR + c8, vr[i]);
         float d = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += (float)gr[i].v[j] * (float)orow[i].v[j];
@@ -1054,9 +1091,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
         if ((c & 3) == 0) dl_s[row] = d;
         if constexpr (DM == 1) {      // p == 0.5 mode: the 1/(1-p) = 2 rides (exactly) on the staged dO, masks are ANDs
 #pragma unroll
-          for (int j = 0; j < 8; ++j) gr[i].v[j] = (T)((float)gr[i].v[j] * drop.inv_keep);
+          for (int j = 0; j < 8; ++j) gr[i].v[j] = (G)((float)gr[i].v[j] * drop.inv_keep);
         }
-        *reinterpret_cast<Frag<T>*>(Gs + row * LDR + c8) = gr[i];
+        stage_op<PL>(Gs + row * LDR + c8, gr[i]);
       }
     }
   }
@@ -1096,9 +1133,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
                                                     // tile is keys 208 .. 223 -- nothing to differentiate)
   for (int kt = wave; kt < nkeyt; kt += NWV) {
     const int key = kt * 16 + li;                   // this lane's key (column of S)
-    Frag<T> kf, vf;
-    load_frag(kf, Ks + key * LDR + 8 * lg);
-    load_frag(vf, Vs + key * LDR + 8 * lg);
+    OP kf, vf;
+    load_op<PL>(kf, Ks + key * LDR + 8 * lg);
+    load_op<PL>(vf, Vs + key * LDR + 8 * lg);
     const float kb = kbias[key];
     f32x4 dkt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1120,9 +1157,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
       for (int u = 0; u < 2; ++u) {
         const int q0 = qs * 32 + u * 16;
         const bool diag = kt * 16 + 15 > q0;        // (uniform) this key tile reaches past the first query of the tile
-        Frag<T> qf, gf;
-        load_frag(qf, Qs + (q0 + li) * LDR + 8 * lg);
-        load_frag(gf, Gs + (q0 + li) * LDR + 8 * lg);
+        OP qf, gf;
+        load_op<PL>(qf, Qs + (q0 + li) * LDR + 8 * lg);
+        load_op<PL>(gf, Gs + (q0 + li) * LDR + 8 * lg);
         f32x4 sv = (f32x4){kb, kb, kb, kb}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};     // key bias rides in the accumulator
         mma(qf, kf, sv);
         mma(gf, vf, dp);
@@ -1169,14 +1206,14 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
           p[u][r] = pp.x; p[u][r + 1] = pp.y;
         }
       }
-      Frag<T> pf, dsf;
-      acc_to_frag(pf, p[0], p[1]);
-      acc_to_frag(dsf, ds[0], ds[1]);
+      OP pf, dsf;
+      acc_to_op(pf, p[0], p[1]);
+      acc_to_op(dsf, ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        Frag<T> gtf, qtf;
-        VStage<T>::frag(gtf, Gs, LDR, qs * 32, dt * 16, li, lg);
-        VStage<T>::frag(qtf, Qs, LDR, qs * 32, dt * 16, li, lg);
+        OP gtf, qtf;
+        vstage_op<PL>(gtf, Gs, LDR, qs * 32, dt * 16, li, lg);
+        vstage_op<PL>(qtf, Qs, LDR, qs * 32, dt * 16, li, lg);
         mma(gtf, pf, dvt[dt]);     // dV^T[dv][key] += sum_q dO[q][dv] P[q][key]
         mma(qtf, dsf, dkt[dt]);    // dK^T[dk][key] += sum_q Q[q][dk] dS[q][key]
       }
@@ -1227,9 +1264,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
   // ---------------------------------------------------------------- phase 2: dQ^T
   for (int qt = wave; qt < nt; qt += NWV) {
     const int q = qt * 16 + li;                     // this lane's query (column of S^T)
-    Frag<T> qf, gf;
-    load_frag(qf, Qs + q * LDR + 8 * lg);
-    load_frag(gf, Gs + q * LDR + 8 * lg);
+    OP qf, gf;
+    load_op<PL>(qf, Qs + q * LDR + 8 * lg);
+    load_op<PL>(gf, Gs + q * LDR + 8 * lg);
     const float lse_q = lse2_s[q], dl_q = dl_s[q];
     const int qrel = q - 4 * lg;
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1248,9 +1285,9 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int k0 = ks * 32 + u * 16;
-        Frag<T> kf, vf;
-        load_frag(kf, Ks + (k0 + li) * LDR + 8 * lg);
-        load_frag(vf, Vs + (k0 + li) * LDR + 8 * lg);
+        OP kf, vf;
+        load_op<PL>(kf, Ks + (k0 + li) * LDR + 8 * lg);
+        load_op<PL>(vf, Vs + (k0 + li) * LDR + 8 * lg);
         float kb4[4];
         load4f(kb4, kbias + k0 + 4 * lg);
         f32x4 sv = (f32x4){kb4[0], kb4[1], kb4[2], kb4[3]}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -1266,12 +1303,12 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
           else ds[u][r] = pe * (dp[r] - dl_q);
         }
       }
-      Frag<T> dsf;
-      acc_to_frag(dsf, ds[0], ds[1]);
+      OP dsf;
+      acc_to_op(dsf, ds[0], ds[1]);
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        Frag<T> ktf;
-        VStage<T>::frag(ktf, Ks, LDR, ks * 32, dt * 16, li, lg);
+        OP ktf;
+        vstage_op<PL>(ktf, Ks, LDR, ks * 32, dt * 16, li, lg);
         mma(ktf, dsf, dqt[dt]);    // dQ^T[dk][q] += sum_key K[key][dk] dS^T[key][q]
       }
     }
@@ -1462,6 +1499,32 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
 #undef RG_BWD16
 #undef RG_BWD16_2
   } else {
+    if constexpr (std::is_same<T, x3>::value) {
+      // bf16x3, L <= 224: the bf16 tier's two-phase kernel on split operand tiles (eight waves, one workgroup per CU)
+      if (nkt <= 14 && !a.qkv_hm) {            // (16 key tiles: 168 KB of split tiles -- beyond a CU's LDS; the generic form below)
+        const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+        const dim3 block8(512);
+#define RG_BWDX2(N, C)                                                                                            \
+  do {                                                                                                            \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, false, 512, x3>), grid, block8, 0, s, a);        \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1, false, 512, x3>), grid, block8, 0, s, a);   \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2, false, 512, x3>), grid, block8, 0, s, a);                \
+  } while (0)
+#define RG_BWDX(N)                        \
+  do {                                    \
+    if (a.causal) RG_BWDX2(N, true);      \
+    else RG_BWDX2(N, false);              \
+  } while (0)
+        if (nkt <= 2) RG_BWDX(2);
+        else if (nkt <= 4) RG_BWDX(4);
+        else if (nkt <= 8) RG_BWDX(8);
+        else RG_BWDX(14);
+#undef RG_BWDX
+#undef RG_BWDX2
+        RG_CHECK_LAUNCH();
+        return 0;
+      }
+    }
 #define RG_BWD(N) hipLaunchKernelGGL((attn_bwd_kernel<T, N>), grid, block, 0, s, a)
     if (nkt <= 2) RG_BWD(2);
     else if (nkt <= 4) RG_BWD(4);

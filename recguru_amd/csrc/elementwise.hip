@@ -618,15 +618,28 @@ __global__ __launch_bounds__(EW_BLOCK) void adam_multi_dev_kernel(rg_adam_seg_de
 // stored as consecutive MFMA A/B fragments -- block (n / 16, k / 32) is 64 lanes x 8 elements, lane 16 g + i holding
 // M[16 nb + i][32 kb + 8 g .. + 8] -- so that a wave's fragment load is ONE contiguous 1 KB (bf16) read instead of 16
 // rows x 64 B.  Writes the 32 x 32 source tile at (r0, c0) held in `tile` (two whole blocks).  nks = logical K / 32.
+// split (mode bit 2, RG_CAST_SPLIT; f32 destination only): the bf16x3 tier's presplit operand -- the 2 KB slot of a fragment
+// holds the 64 lanes' hi parts bf16(v) (1 KB), then their lo parts bf16(v - hi) (1 KB), so a kernel's fragment load is two
+// contiguous 16-byte reads per lane with no conversion work behind them (fused.hip load_wset).
 template <typename T>
 __device__ __forceinline__ void cast_pack_tile(const float (&tile)[32][33], T* __restrict__ dst, int r0, int c0, int transpose,
-                                               int n_off, int k_off, int nks) {
+                                               int n_off, int k_off, int nks, int split = 0) {
   const int n0 = (transpose ? c0 : r0) + n_off, k0 = (transpose ? r0 : c0) + k_off;
   for (int o = threadIdx.x; o < 1024; o += EW_BLOCK) {
     const int b2 = o >> 9, within = o & 511, lane = within >> 3, j = within & 7, lg = lane >> 4, li = lane & 15;
     const int nl = b2 * 16 + li, kl = lg * 8 + j;
     const float v = transpose ? tile[kl][nl] : tile[nl][kl];
-    dst[((size_t)(n0 / 16 + b2) * nks + k0 / 32) * 512 + within] = (T)v;
+    const size_t frag = (size_t)(n0 / 16 + b2) * nks + k0 / 32;
+    if constexpr (sizeof(T) == 4) {
+      if (split) {
+        __bf16* d2 = reinterpret_cast<__bf16*>(dst) + frag * 1024;
+        const __bf16 h = (__bf16)v;
+        d2[within] = h;
+        d2[512 + within] = (__bf16)(v - (float)h);
+        continue;
+      }
+    }
+    dst[frag * 512 + within] = (T)v;
   }
 }
 
@@ -640,7 +653,7 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_kernel(const float* __restrict_
       const int r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
       for (int k = ty; k < 32; k += 8) tile[k][tx] = src[(size_t)(r0 + k) * C + c0 + tx];
       __syncthreads();
-      cast_pack_tile<T>(tile, dst, r0, c0, transpose & 1, 0, 0, ((transpose & 1) ? R : C) / 32);
+      cast_pack_tile<T>(tile, dst, r0, c0, transpose & 1, 0, 0, ((transpose & 1) ? R : C) / 32, transpose & 4);
       __syncthreads();
     }
     return;
@@ -677,7 +690,7 @@ __global__ __launch_bounds__(EW_BLOCK) void cast_multi_kernel(const rg_cast_seg*
   for (int k = ty; k < 32; k += 8) tile[k][tx] = (r0 + k < sg.R && c0 + tx < sg.C) ? sg.src[(size_t)(r0 + k) * sg.C + c0 + tx] : 0.f;
   __syncthreads();
   if (sg.transpose & 2) {              // fragment-packed copy: R, C, row_off, col_off multiples of 32 / 16 (checked by the host)
-    cast_pack_tile<T>(tile, dst, r0, c0, sg.transpose & 1, sg.row_off, sg.col_off, sg.ld / 32);
+    cast_pack_tile<T>(tile, dst, r0, c0, sg.transpose & 1, sg.row_off, sg.col_off, sg.ld / 32, sg.transpose & 4);
   } else if (sg.transpose) {
     for (int k = ty; k < 32; k += 8)
       if (c0 + k < sg.C && r0 + tx < sg.R) dst[(size_t)(c0 + k + sg.row_off) * sg.ld + r0 + tx + sg.col_off] = (T)tile[tx][k];
@@ -1393,6 +1406,8 @@ extern "C" int rg_cast(const float* src, void* dst, int R, int C, int transpose,
   if (R <= 0 || C <= 0) return 0;
   if ((transpose & 2) && ((R & 31) || (C & 31)))
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "cast: the fragment-packed layout needs R and C multiples of 32");
+  if ((transpose & 4) && (!(transpose & 2) || dtype != RG_F32))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "cast: RG_CAST_SPLIT is a form of the fragment-packed f32 copy (RG_CAST_PACK, RG_F32)");
   hipStream_t s = (hipStream_t)stream;
   const int grid = transpose ? min(((C + 31) / 32) * ((R + 31) / 32), 4096) : ew_grid((long long)R * C, EW_BLOCK);
   DISPATCH_T(dtype,

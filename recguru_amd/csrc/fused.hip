@@ -21,6 +21,8 @@
 // LDS (bf16): ctx tile + g chunk + y tile (+ the h1 staging tile when saving) = 3-4 x 16 KB, XOR-swizzled rows,
 // + 8 KB of parameters and row statistics: 56-72 KB per workgroup, 2 workgroups per CU (256 VGPRs per wave allow
 // two waves per SIMD in any case).
+#define RG_X3_PLANE (64 * 128 * 2)   // bf16x3 tier: a [64 x 128] activation tile is a bf16 hi tile + a bf16 lo tile (rg_common.hip.h)
+#include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -36,6 +38,7 @@
 // conflict-free under the hardware's 16-lane service groups ({0-3, 12-15, 20-27}, ...: lanes of two lg values land in
 // complementary chunk sets); a padded row (272 B) put two lanes of every group on one bank -- 43 % of the kernel's
 // LDS cycles were bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  f32 (parity tier): padded rows.
+// bf16x3 tier: T = x3p, two bf16 tiles (hi, lo) of exactly the bf16 tier's layout, RG_X3_PLANE bytes apart.
 template <typename T> struct Tile {
   static constexpr int LD = sizeof(T) == 2 ? FD : FLD;          // row pitch in elements
   static __device__ __forceinline__ int off(int row, int col) {  // col: any element whose 16-byte chunk holds it
@@ -43,11 +46,17 @@ template <typename T> struct Tile {
     else return row * FLD + col;
   }
 };
+// raw f32 tile of the bf16x3 tier (rg_common.hip.h x3r): unpadded 512-byte rows -- the size of the split pair it may replace --,
+// the sixteen 32-byte chunks of a row XOR-swizzled by the row index
+template <> struct Tile<x3r> {
+  static constexpr int LD = FD;
+  static __device__ __forceinline__ int off(int row, int col) { return row * FD + ((((col >> 3) ^ row) & 15) << 3) + (col & 7); }
+};
 
 // One GEMM step = a set of 8 weight fragments (4 k-steps x 2 feature tiles of this wave), loaded
 // straight from L2 one GEMM ahead of its use (software pipelining: the load of set s+1 is issued
 // before the MFMAs of set s), against a [64 x 128] activation tile in LDS.
-template <typename T> struct WSet { Frag<T> f[4][2]; };
+template <typename T> struct WSet { typename OpT<T>::type f[4][2]; };
 
 // Global addresses are formed as (uniform base pointer) + (32-bit element offset): hipcc then keeps the base in scalar
 // registers and one 32-bit offset per lane (the saddr form of global_load / global_store) instead of a 64-bit pointer
@@ -72,8 +81,24 @@ __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, i
   const unsigned int nks = (unsigned int)ldw >> 5;
   const T* base = W + (packed ? ((unsigned int)(row0 >> 4) * nks + (unsigned int)(k0 >> 5)) * 512u
                               : (unsigned int)row0 * (unsigned int)ldw + (unsigned int)k0);
-  const unsigned int lofs = packed ? (unsigned int)(lg * 16 + li) * 8u : (unsigned int)li * (unsigned int)ldw + 8u * lg;
   const unsigned int sct = packed ? nks * 512u : 16u * (unsigned int)ldw, sks = packed ? 512u : 32u;
+  if constexpr (std::is_same<T, x3>::value) {
+    if (packed) {
+      // presplit fragment-packed copy (rg_cast, RG_X3 + RG_CAST_PACK): a fragment is 2 KB = 64 lanes x 16 B of hi parts, then
+      // the same of lo parts -- 512 four-byte slots, so the fragment addressing is the packed f32 layout's
+      const unsigned int lofs = (unsigned int)(lg * 16 + li) * 4u;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int ct = 0; ct < 2; ++ct) {
+          const x3* fp = gofs(base + (ct * sct + ks * sks), lofs);
+          w.f[ks][ct].hi = *reinterpret_cast<const bf16x8_t*>(fp);
+          w.f[ks][ct].lo = *reinterpret_cast<const bf16x8_t*>(fp + 256);
+        }
+      return;
+    }
+  }
+  const unsigned int lofs = packed ? (unsigned int)(lg * 16 + li) * 8u : (unsigned int)li * (unsigned int)ldw + 8u * lg;
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -82,17 +107,18 @@ __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, i
 
 // acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
 template <typename T, int RT>
-__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, const T* __restrict__ Act, int li, int lg) {
+__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, const typename LdsT<T>::type* __restrict__ Act, int li, int lg) {
+  typedef typename LdsT<T>::type LT;
   // the RT token-tile fragments of k-step ks+1 are read while the MFMAs of k-step ks run (one LDS latency per GEMM
   // step instead of RT)
-  Frag<T> af[2][RT];
+  typename OpT<T>::type af[2][RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; ++rt) load_frag(af[0][rt], Act + Tile<T>::off(rt * 16 + li, 8 * lg));
+  for (int rt = 0; rt < RT; ++rt) load_frag(af[0][rt], Act + Tile<LT>::off(rt * 16 + li, 8 * lg));
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     if (ks < 3) {
 #pragma unroll
-      for (int rt = 0; rt < RT; ++rt) load_frag(af[(ks + 1) & 1][rt], Act + Tile<T>::off(rt * 16 + li, (ks + 1) * 32 + 8 * lg));
+      for (int rt = 0; rt < RT; ++rt) load_frag(af[(ks + 1) & 1][rt], Act + Tile<LT>::off(rt * 16 + li, (ks + 1) * 32 + 8 * lg));
     }
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt)
@@ -119,7 +145,11 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][RT], const float* __res
 // combined exactly (Chan et al.: M2 = sum_w M2_w + 32 * sum_w (mean_w - mean)^2) -- as accurate as torch's two-pass
 // LayerNorm with one workgroup barrier instead of two.  On return v holds (v - mean) * rstd * gamma + beta and
 // rstd[rt] the row rstd.
-template <int RT>
+// ALLST: every lane group stores the (identical) partial statistics instead of `if (lg == 0)` -- four times the (tiny) LDS
+// write traffic for NO lane-divergent branch in the LayerNorm: in post_attn_fwd_kernel<x3, 2, true, false> hipcc parked eleven
+// live VGPRs in AGPRs at the top of that branch's join block IN FRONT of its exec restore, i.e. for lanes 0-15 only
+// (recguru_amd/isa_screen.py).  The bf16x3 instantiations (512 registers: the ones that spill to AGPRs) use it.
+template <int RT, bool ALLST = false>
 __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], const float* __restrict__ gamma_lds,
                                         const float* __restrict__ beta_lds, float* __restrict__ redA, float* __restrict__ redB,
                                         float eps, int n0, int wave, int li, int lg) {
@@ -144,7 +174,7 @@ __device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], co
     q += __shfl_xor(q, 32);
     m2[rt] = q;
   }
-  if (lg == 0) {
+  if (ALLST || lg == 0) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) { redA[(rt * 16 + li) * 4 + wave] = s[rt]; redB[(rt * 16 + li) * 4 + wave] = m2[rt]; }
   }
@@ -221,15 +251,17 @@ __device__ __forceinline__ void add_tile(f32x4 (&acc)[2][RT], const T* __restric
 // rows of a plain tile (mb[rt] = m0 + 16 rt), or the next 4 LIVE row tiles of the workgroup's range when padded row
 // tiles are compacted away.  Thread tid stages chunk i of the tile = row 16 i + (tid >> 4), columns 8 (tid & 15)..
 // cooperative, coalesced copy of a [64 x 128] LDS tile to its rows of a row-major HBM matrix
-template <typename T, bool NT = false, int RT = 4>
-__device__ __forceinline__ void tile_to_hbm(const T* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[RT], int M, int tid) {
+template <typename T, bool NT = false, int RT = 4, typename LT>
+__device__ __forceinline__ void tile_to_hbm(const LT* __restrict__ tile, T* __restrict__ dst, int ld, int col0, const int (&mb)[RT], int M, int tid) {
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
     const int r = 16 * i + (tid >> 4), c8 = (tid & 15) * 8, m = mb[i] + (tid >> 4);
     if (m < M) {
       T* g = gofs(dst, (unsigned int)m * (unsigned int)ld + (unsigned int)(col0 + c8));
-      if constexpr (NT) frag_store_nt(g, *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8)));
-      else *reinterpret_cast<Frag<T>*>(g) = *reinterpret_cast<const Frag<T>*>(tile + Tile<T>::off(r, c8));
+      Frag<T> raw;
+      unstage8(raw, tile + Tile<LT>::off(r, c8));
+      if constexpr (NT) frag_store_nt(g, raw);
+      else *reinterpret_cast<Frag<T>*>(g) = raw;
     }
   }
 }
@@ -265,24 +297,32 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // time on exposed LDS / VALU latencies, not on the matrix pipe or the weight stream)
 template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
+  typedef typename LdsT<T>::type LT;  // element type of the LDS tiles (T, or x3p: a hi and a lo bf16 tile)
+  static_assert(!std::is_same<T, x3>::value || RT == 4, "the split tiles are [64 x 128] (RG_X3_PLANE)");
   constexpr int FTM = 16 * RT;        // tokens per work tile
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0__ = __builtin_amdgcn_s_memtime();
 #endif
   // LDS: ctx tile (later: out staging) | x tile (later: g chunk) | y tile | params | row-stat exchange | [h1 chunk]
-  constexpr int ACT_BYTES = FTM * Tile<T>::LD * (int)sizeof(T);
+  constexpr int ACT_BYTES = FTM * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
-  T* Actx = reinterpret_cast<T*>(smem);
-  T* Ag = reinterpret_cast<T*>(smem + ACT_BYTES);
-  T* Ay = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
+  LT* Actx = reinterpret_cast<LT*>(smem);
+  LT* Ag = reinterpret_cast<LT*>(smem + ACT_BYTES);
+  LT* Ay = reinterpret_cast<LT*>(smem + 2 * ACT_BYTES);
+  // tiles that are not matrix operands -- the residual x (parked in the g-chunk buffer) and the output on its way to HBM (in
+  // the ctx tile): raw f32 in the bf16x3 tier (exact residual stream, no split work), the ordinary tile otherwise
+  typedef typename ResT<T>::type XT;
+  XT* Ax = reinterpret_cast<XT*>(Ag);
+  XT* Aout = reinterpret_cast<XT*>(Actx);
+  constexpr bool KEEPY = std::is_same<T, x3>::value;     // the LayerNorm-1 output stays in registers as the FFN's residual (exact)
   float* prm = reinterpret_cast<float*>(smem + 3 * ACT_BYTES);           // 8*128 + dff floats
   float* redA = prm + 8 * FD + a.dff;                                     // [64][4]
   float* redB = redA + FTM * 4;
   // p == 0.5 dropout: nibble of hash bits -> 4 multipliers (0 or 1/(1-p)) from a 16-entry table: 2 address ops, one
   // ds_read_b128 and 4 multiplies per 4 elements instead of a bit extract, an AND and a multiply per element
   float* klut = redB + FTM * 4;                                          // [16][4]
-  T* Ah = reinterpret_cast<T*>(klut + 64);                                // only when h1_save != NULL
+  LT* Ah = reinterpret_cast<LT*>(klut + 64);                                // only when h1_save != NULL
   float *p_bo = prm, *p_g1 = prm + FD, *p_be1 = prm + 2 * FD, *p_b2 = prm + 3 * FD, *p_g2 = prm + 4 * FD,
         *p_be2 = prm + 5 * FD, *p_gc = prm + 6 * FD, *p_bec = prm + 7 * FD, *p_b1 = prm + 8 * FD;
 
@@ -365,9 +405,9 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
 #pragma unroll
     for (int i = 0; i < RT; ++i) {
       const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      *reinterpret_cast<Frag<T>*>(Actx + Tile<T>::off(r, c8)) = cpre[i];
-      *reinterpret_cast<Frag<T>*>(Ag + Tile<T>::off(r, c8)) = xpre[i];
-      if constexpr (RES) *reinterpret_cast<Frag<T>*>(Ay + Tile<T>::off(r, c8)) = xlpre[i];     // the y tile is free until LayerNorm 1
+      stage8(Actx + Tile<LT>::off(r, c8), cpre[i]);
+      stage8(Ax + Tile<XT>::off(r, c8), xpre[i]);
+      if constexpr (RES) stage8(Ay + Tile<LT>::off(r, c8), xlpre[i]);     // the y tile is free until LayerNorm 1
     }
     float rm4[RT];
     bool any_live = false;
@@ -407,19 +447,19 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
     mma_wset<T>(acc, wp, Actx, li, lg);
     load_wset(wp, W1, FD, n0, 0, li, lg, a.w_packed);   // prefetch FFN chunk 0 (hidden behind LN1)
     // + residual x (from LDS), LayerNorm 1 on the registers
-    add_tile<T>(acc, Ag, n0, li, lg);
-    if constexpr (RES) add_tile<T>(acc, Ay, n0, li, lg);          // x_lo
+    add_tile<XT>(acc, Ax, n0, li, lg);
+    if constexpr (RES) add_tile<LT>(acc, Ay, n0, li, lg);          // x_lo
     STAMP(1);
     float rstd[RT];
-    ln_regs(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
+    ln_regs<RT, KEEPY>(acc, rstd, p_g1, p_be1, redA, redB, a.eps, n0, wave, li, lg);
     // (past the barrier inside ln_regs every wave is done with the ctx tile, x and x_lo)
-    if constexpr (RES) regs_to_tile_lo<T>(acc, Actx, n0, li, lg);   // y_lo parks in the ctx tile (each lane: its own positions)
+    if constexpr (RES) regs_to_tile_lo<LT>(acc, Actx, n0, li, lg);   // y_lo parks in the ctx tile (each lane: its own positions)
     if (rstd1o && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
         if (mb[rt] + li < a.M) rstd1o[mb[rt] + li] = rstd[rt];
     }
-    regs_to_tile<T>(acc, Ay, n0, li, lg);
+    regs_to_tile<LT>(acc, Ay, n0, li, lg);
     STAMP(2);
     if constexpr (CROSS) {
       // collapsed decoder cross-attention: y2 = LayerNorm(y1 + o[b]); y1 is saved from its tile first
@@ -447,10 +487,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             float y4[4];
-            load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
+            if constexpr (KEEPY) { y4[0] = acc[ct][rt][0]; y4[1] = acc[ct][rt][1]; y4[2] = acc[ct][rt][2]; y4[3] = acc[ct][rt][3]; }
+            else load4t(y4, Ay + Tile<LT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));     // the ROUNDED y1, as the unfused path sees it
             if constexpr (RES) {
               float yl[4];
-              load4t(yl, Actx + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+              load4t(yl, Actx + Tile<LT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
               for (int r = 0; r < 4; ++r) y4[r] += yl[r];
             }
@@ -474,10 +515,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
 #pragma unroll
           for (int ct = 0; ct < 2; ++ct) {
             float y4[4];
-            load4t(y4, Ay + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+            if constexpr (KEEPY) { y4[0] = acc[ct][rt][0]; y4[1] = acc[ct][rt][1]; y4[2] = acc[ct][rt][2]; y4[3] = acc[ct][rt][3]; }
+            else load4t(y4, Ay + Tile<LT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
             if constexpr (RES) {
               float yl[4];
-              load4t(yl, Actx + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+              load4t(yl, Actx + Tile<LT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
               for (int r = 0; r < 4; ++r) y4[r] += yl[r];
             }
@@ -486,14 +528,21 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
           }
       }
       lds_barrier();                                    // ysave copy done before the tile is overwritten
-      ln_regs(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
+      ln_regs<RT, KEEPY>(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
       if (rstdco && wave == 0 && lg == 0) {
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
           if (mb[rt] + li < a.M) rstdco[mb[rt] + li] = rstd[rt];
       }
-      regs_to_tile<T>(acc, Ay, n0, li, lg);
-      if constexpr (RES) regs_to_tile_lo<T>(acc, Actx, n0, li, lg);
+      regs_to_tile<LT>(acc, Ay, n0, li, lg);
+      if constexpr (RES) regs_to_tile_lo<LT>(acc, Actx, n0, li, lg);
+    }
+    f32x4 yres[KEEPY ? 2 : 1][KEEPY ? RT : 1];
+    if constexpr (KEEPY) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) yres[ct][rt] = acc[ct][rt];
     }
     lds_barrier();                                      // y tile complete (and x no longer needed in Ag)
     {
@@ -535,7 +584,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
           }
         }
       }
-      if (h1save) regs_to_tile<T>(acc, Ah, n0, li, lg);
+      if (h1save) regs_to_tile<LT>(acc, Ah, n0, li, lg);
 #pragma unroll
       for (int ct = 0; ct < 2; ++ct)
 #pragma unroll
@@ -552,7 +601,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
             }
           }
         }
-      regs_to_tile<T>(acc, Ag, n0, li, lg);
+      regs_to_tile<LT>(acc, Ag, n0, li, lg);
       STAMP(6);
       lds_barrier();
       STAMP(7);
@@ -582,9 +631,16 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
       }
     }
     // ---- + residual y (LDS), LayerNorm 2 on the registers, * rowmask, out via the (free) ctx tile
-    add_tile<T>(acc2, Ay, n0, li, lg);
-    if constexpr (RES) add_tile<T>(acc2, Actx, n0, li, lg);       // y_lo
-    ln_regs(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
+    if constexpr (KEEPY) {
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct)
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) acc2[ct][rt] += yres[ct][rt];
+    } else {
+      add_tile<LT>(acc2, Ay, n0, li, lg);
+    }
+    if constexpr (RES) add_tile<LT>(acc2, Actx, n0, li, lg);       // y_lo
+    ln_regs<RT, KEEPY>(acc2, rstd, p_g2, p_be2, redA, redB, a.eps, n0, wave, li, lg);
     if (rstd2o && wave == 0 && lg == 0) {
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt)
@@ -596,11 +652,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
       for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] *= rm4[rt];
-    regs_to_tile<T>(acc2, Actx, n0, li, lg);
-    if constexpr (RES) regs_to_tile_lo<T>(acc2, Ag, n0, li, lg);  // (the barrier inside ln_regs: the last g chunk has been consumed)
+    regs_to_tile<XT>(acc2, Aout, n0, li, lg);
+    if constexpr (RES) regs_to_tile_lo<LT>(acc2, Ag, n0, li, lg);  // (the barrier inside ln_regs: the last g chunk has been consumed)
     STAMP(9);
     lds_barrier();
-    tile_to_hbm<T>(Actx, out, FD, 0, mb, a.M, tid);
+    tile_to_hbm<T>(Aout, out, FD, 0, mb, a.M, tid);
     if constexpr (RES) tile_to_hbm<T>(Ag, outlo, FD, 0, mb, a.M, tid);
     lds_barrier();                                      // before the next tile overwrites Actx / Ag / Ay
     STAMP(10);
@@ -642,6 +698,11 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void
 #endif
 }
 
+// bytes of one [rows x 128] activation tile in LDS: bf16 swizzled rows; f32 padded rows; bf16x3 a hi and a lo bf16 tile
+static int act_tile_bytes(int dtype, int rows) {
+  return dtype == RG_BF16 ? rows * FD * 2 : (dtype == RG_X3 ? rows * FD * 2 * 2 : rows * FLD * 4);
+}
+
 extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
@@ -663,8 +724,7 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 #endif
   const int ftm = 16 * rt;
   const int ntiles = (a->M + ftm - 1) / ftm;
-  const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int act = ftm * (dtype == RG_BF16 ? FD : FLD) * esz;
+  const int act = act_tile_bytes(dtype, ftm);
   const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * ftm * 4 * 4 + 64 * 4 + (a->h1_save ? act : 0);
   const int per_cu = (160 * 1024) / smem;
   const int cap_cu = rt == 2 ? 3 : 3;                   // (RT == 2: 3 waves per SIMD by registers)
@@ -730,12 +790,17 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 // arrive -- the staging layout (16 lanes x 8 features per row) is rg_ln_bwd's; dz never leaves the chip.
 template <typename T, bool LNF>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_kernel(rg_ffn_bwd_args a) {
-  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
+  typedef typename LdsT<T>::type LT;
+  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
-  T* Adl = reinterpret_cast<T*>(smem);
-  T* Adz = reinterpret_cast<T*>(smem + ACT_BYTES);
-  T* Adh = reinterpret_cast<T*>(smem + 2 * ACT_BYTES);
-  T* Ah = reinterpret_cast<T*>(smem + 3 * ACT_BYTES);
+  LT* Adl = reinterpret_cast<LT*>(smem);
+  // dz (the residual gradient), the h1 chunk (read element-wise only) and dy on its way out are not matrix operands: raw f32
+  // tiles in the bf16x3 tier (rg_common.hip.h x3r), the ordinary tile otherwise
+  typedef typename ResT<T>::type XT;
+  XT* Adz = reinterpret_cast<XT*>(smem + ACT_BYTES);
+  LT* Adh = reinterpret_cast<LT*>(smem + 2 * ACT_BYTES);
+  XT* Ah = reinterpret_cast<XT*>(smem + 3 * ACT_BYTES);
+  XT* Ady = reinterpret_cast<XT*>(smem);                 // (the dl2 tile's space, after its last read)
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: scalar address math
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ dl2 = reinterpret_cast<const T*>(LNF ? a.ln_dout : a.dl2);      // LNF: dout and the saved LN output
@@ -809,7 +874,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-      *reinterpret_cast<Frag<T>*>(Ah + Tile<T>::off(r, c8)) = hpre[i];
+      stage8(Ah + Tile<XT>::off(r, c8), hpre[i]);
     }
   };
   int mb[4], mbn[4];
@@ -859,22 +924,22 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
         float o8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
-        store8(Adz + Tile<T>::off(r, c8), o8);
+        store8(Adz + Tile<XT>::off(r, c8), o8);
         if (ldrop.thresh != 0u || ldrop.onebit) {
           float k8[8];
           rg_keep8(ldrop, (unsigned int)m * (unsigned int)FD + (unsigned int)c8, k8);
 #pragma unroll
           for (int j = 0; j < 8; ++j) o8[j] *= k8[j];
         }
-        store8(Adl + Tile<T>::off(r, c8), o8);
+        store8(Adl + Tile<LT>::off(r, c8), o8);
         if (live) store8(gofs(dl2o, (unsigned int)(m * FD + c8)), o8);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-        *reinterpret_cast<Frag<T>*>(Adl + Tile<T>::off(r, c8)) = cpre[i];
-        *reinterpret_cast<Frag<T>*>(Adz + Tile<T>::off(r, c8)) = xpre[i];
+        stage8(Adl + Tile<LT>::off(r, c8), cpre[i]);
+        stage8(Adz + Tile<XT>::off(r, c8), xpre[i]);
       }
     }
     h_to_lds();
@@ -907,7 +972,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) {
           float x4[4];
-          load4t(x4, Ah + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+          load4t(x4, Ah + Tile<XT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             float v = acc[ct][rt][r] * gelu_grad_t<Precise<T>::value>(x4[r]);
@@ -915,7 +980,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
             acc[ct][rt][r] = v;
           }
         }
-      regs_to_tile<T>(acc, Adh, n0, li, lg);
+      regs_to_tile<LT>(acc, Adh, n0, li, lg);
       lds_barrier();                                     // dh1 chunk complete, h1 chunk no longer read
       if (ch + 1 < nchunk) h_to_lds();
       tile_to_hbm<T>(Adh, dh1, a.dff, ch * FD, mb, a.M, tid);
@@ -927,13 +992,13 @@ __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_ke
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) {
         float r4[4];
-        load4t(r4, Adz + Tile<T>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
+        load4t(r4, Adz + Tile<XT>::off(rt * 16 + li, n0 + ct * 16 + 4 * lg));
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc2[ct][rt][r] += r4[r];
       }
-    regs_to_tile<T>(acc2, Adl, n0, li, lg);              // every wave is past its last read of the dl2 tile
+    regs_to_tile<XT>(acc2, Ady, n0, li, lg);              // every wave is past its last read of the dl2 tile
     lds_barrier();
-    tile_to_hbm<T>(Adl, dy, FD, 0, mb, a.M, tid);
+    tile_to_hbm<T>(Ady, dy, FD, 0, mb, a.M, tid);
     lds_barrier();
 #pragma unroll
     for (int rt = 0; rt < 4; ++rt) mb[rt] = mbn[rt];
@@ -986,7 +1051,7 @@ extern "C" int rg_ffn_bwd_data_supported(int d, int dff) { return d == FD && dff
 
 static int ffn_bwd_grid(int M, int dtype) {               // persistent workgroups: two per CU (bf16), one (f32)
   const int ntiles = (M + FT_M - 1) / FT_M;
-  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * (dtype == RG_BF16 ? 2 : 4);
+  const int smem = 4 * act_tile_bytes(dtype, FT_M);
   const int per_cu = (160 * 1024) / smem;
   const int grid = 256 * (per_cu < 1 ? 1 : (per_cu > 2 ? 2 : per_cu));
   return grid > ntiles ? ntiles : grid;
@@ -1006,8 +1071,7 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
     return rg_set_error_msg(RG_ERR_INVALID, "ffn_bwd_data: the fused LayerNorm backward needs ln_out, ln_rstd, ln_gamma, ln_beta, dl2_out, ln_partials");
   hipStream_t s = (hipStream_t)stream;
   const int ntiles = (a->M + FT_M - 1) / FT_M;
-  const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int smem = 4 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz + (lnf ? 3 * FD * 4 : 0);
+  const int smem = 4 * act_tile_bytes(dtype, FT_M) + (lnf ? 3 * FD * 4 : 0);
   const int grid = ffn_bwd_grid(a->M, dtype);
 #define RG_FB(T, L)                                                                                                       \
   do {                                                                                                                    \
@@ -1031,10 +1095,12 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
 // in registers (one weight set, loaded once per workgroup).  HBM-bound: 2 tiles of LDS, ~100 VGPRs, 4 workgroups per CU.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_out_bwd_kernel(rg_attn_out_bwd_args a) {
-  constexpr int ACT_BYTES = FT_M * Tile<T>::LD * (int)sizeof(T);
+  typedef typename LdsT<T>::type LT;
+  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
-  T* Adz = reinterpret_cast<T*>(smem);
-  T* Aout = reinterpret_cast<T*>(smem + ACT_BYTES);
+  LT* Adz = reinterpret_cast<LT*>(smem);
+  typedef typename ResT<T>::type XT;                     // dctx on its way out: not a matrix operand (raw f32 in the bf16x3 tier)
+  XT* Aout = reinterpret_cast<XT*>(smem + ACT_BYTES);
   float* lnp = reinterpret_cast<float*>(smem + 2 * ACT_BYTES);      // gamma | beta | 1 / gamma
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
@@ -1126,7 +1192,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_bwd_kernel(rg_attn_out_bwd_ar
         float o8[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) o8[j] = rstd * (g[j] - s1 - xh[j] * s2);
-        store8(Adz + Tile<T>::off(r, c8), o8);
+        store8(Adz + Tile<LT>::off(r, c8), o8);
         if (live) store8(gofs(dz, (unsigned int)(m * FD + c8)), o8);
       }
     }
@@ -1138,7 +1204,7 @@ __global__ __launch_bounds__(256, 2) void attn_out_bwd_kernel(rg_attn_out_bwd_ar
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     mma_wset<T>(acc, w, Adz, li, lg);                   // dctx = dz . Wot^T
-    regs_to_tile<T>(acc, Aout, n0, li, lg);
+    regs_to_tile<XT>(acc, Aout, n0, li, lg);
     lds_barrier();
     tile_to_hbm<T>(Aout, dctx, FD, 0, mb, a.M, tid);
 #pragma unroll
@@ -1176,8 +1242,7 @@ extern "C" int rg_attn_out_bwd(const rg_attn_out_bwd_args* a, int dtype, void* s
     return rg_set_error_msg(RG_ERR_INVALID, "attn_out_bwd: NULL operand");
   if ((long long)a->M * FD * 4 >= (1ll << 32)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_out_bwd: M too large for 32-bit offsets");
   hipStream_t s = (hipStream_t)stream;
-  const int esz = dtype == RG_BF16 ? 2 : 4;
-  const int smem = 2 * FT_M * (dtype == RG_BF16 ? FD : FLD) * esz + 3 * FD * 4;
+  const int smem = 2 * act_tile_bytes(dtype, FT_M) + 3 * FD * 4;
   const int grid = attn_out_bwd_grid(a->M);
   if (dtype == RG_BF16) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(attn_out_bwd_kernel<__bf16>), hipFuncAttributeMaxDynamicSharedMemorySize, smem);

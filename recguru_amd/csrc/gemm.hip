@@ -485,7 +485,8 @@ extern "C" size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* a, int dtype) {
 
 extern "C" int rg_gemm_tn_plan(const rg_gemm_tn_args* a, int dtype, char* name, int cap) {
   if (!a || !name || cap <= 0) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_plan: null argument");
-  if (a->splits == 0 && rg_gemm_tn_big_select(a, dtype)) snprintf(name, cap, "%s<%d,%d>", rg_gemm_tn_big_name(a), a->N1, a->N2);
+  if (a->splits == 0 && rg_gemm_tn_big_select(a, dtype))
+    snprintf(name, cap, "%s<%s%d,%d>", dtype == RG_X3 ? "gemm_tn_big_kernel" : rg_gemm_tn_big_name(a), dtype == RG_X3 ? "x3," : "", a->N1, a->N2);
   else snprintf(name, cap, "gemm_tn_kernel<%s>", dtype == RG_BF16 ? "bf16" : (dtype == RG_X3 ? "x3" : "f32"));
   return 0;
 }

@@ -11,10 +11,12 @@
 // instruction = 256 contiguous bytes) and tn_big_reduce_kernel sums the slices into dW; without it, f32 atomics
 // (a 16x16 accumulator register is 4 x 64-byte segments per instruction: 256 x |dW| of those cost more than the GEMM).
 #include <cstdlib>
+#include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
-#define TB_T 64      // tokens per chunk: two MFMA k-steps per barrier pair and >= 80 KB of loads in flight per CU
+#define TB_T_BF16 64 // tokens per chunk (bf16): two MFMA k-steps per barrier pair and >= 80 KB of loads in flight per CU
+#define TB_T_X3 32   // bf16x3: f32 rows, the same bytes per chunk
 
 // fragment whose 8 slots (g, j) are rows 8g + j of column c0 + (lane & 15) of a row-major LDS tile
 __device__ __forceinline__ void frag_tr16(Frag<__bf16>& f, const __bf16* tile, int ld, int c0, int li, int lg) {
@@ -30,18 +32,42 @@ __device__ __forceinline__ void frag_tr16(Frag<__bf16>& f, const __bf16* tile, i
   for (int j = 0; j < 4; ++j) { f.v[j] = u0.b[j]; f.v[4 + j] = u1.b[j]; }
 }
 
-template <int N1, int N2, bool GELU_X>
+// operand fragment of one column tile, token-major, from the staged image(s): bf16 -- one image; bf16x3 -- the hi image and,
+// `lo_ofs` elements behind it, the lo image (the rows were split while they were staged)
+__device__ __forceinline__ void frag_tr_op(Frag<__bf16>& f, const __bf16* tile, int ld, int c0, int li, int lg, int lo_ofs) {
+  frag_tr16(f, tile, ld, c0, li, lg);
+}
+__device__ __forceinline__ void frag_tr_op(FragX3& f, const __bf16* tile, int ld, int c0, int li, int lg, int lo_ofs) {
+  Frag<__bf16> h, l;
+  frag_tr16(h, tile, ld, c0, li, lg);
+  frag_tr16(l, tile + lo_ofs, ld, c0, li, lg);
+  f.hi = h.v;
+  f.lo = l.v;
+}
+__device__ __forceinline__ void mma_ones(const Frag<__bf16>& a, const Frag<__bf16>& ones, f32x4& c) { mma(a, ones, c); }
+__device__ __forceinline__ void mma_ones(const FragX3& a, const Frag<__bf16>& ones, f32x4& c) {      // column sums: (hi + lo) . 1
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, ones.v, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, ones.v, c, 0, 0, 0);
+}
+
+// T = __bf16, or x3 (the bf16x3 tier: Y and X are f32 in memory; a chunk's rows are split into a hi and a lo bf16 image while
+// they are staged -- 2.5 VALU operations per element, once -- and every product is three MFMAs; chunks of 32 tokens, the bytes
+// of the bf16 tier's 64)
+template <typename T, int N1, int N2, bool GELU_X>
 __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
-  typedef __bf16 T;
+  constexpr bool X3 = std::is_same<T, x3>::value;
+  constexpr int TB_T = X3 ? TB_T_X3 : TB_T_BF16;
+  typedef typename OpT<T>::type OP;
   constexpr bool SPLIT1 = N1 >= N2;
   constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;      // n1 tiles per wave
   constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;      // n2 tiles per wave
   constexpr int LDY = N1 + 8, LDX = N2 + 8;
-  constexpr int CY = TB_T * N1 / 8, CX = TB_T * N2 / 8;          // 16-byte chunks per staged tile
+  constexpr int CY = TB_T * N1 / 8, CX = TB_T * N2 / 8;          // 8-element pieces per staged tile
   constexpr int PY = (CY + 511) / 512, PX = (CX + 511) / 512;    // per-thread prefetch registers
+  constexpr int YLO = X3 ? TB_T * LDY : 0, XLO = X3 ? TB_T * LDX : 0;   // element offset of the lo image behind the hi image
   extern __shared__ __align__(16) unsigned char smem_tb[];
-  T* Ys = reinterpret_cast<T*>(smem_tb);                // [TB_T][LDY]
-  T* Xs = Ys + TB_T * LDY;                              // [TB_T][LDX]
+  __bf16* Ys = reinterpret_cast<__bf16*>(smem_tb);      // [TB_T][LDY] (x3: hi | lo)
+  __bf16* Xs = Ys + TB_T * LDY + YLO;                   // [TB_T][LDX] (x3: hi | lo)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ Y = reinterpret_cast<const T*>(a.Y);
@@ -50,7 +76,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   const int m2 = SPLIT1 ? 0 : wave * NT * 16;
   // a.live16 (optional): the list of live 16-row tiles (rg_live_tiles) -- a chunk is then 4 consecutive LIST entries
   // instead of 64 consecutive tokens; rows of padded tiles carry zero upstream gradient and are never read
-  const int nchunks = a.live16 ? (a.live16[0] + 3) >> 2 : (a.T + TB_T - 1) / TB_T;
+  const int nchunks = a.live16 ? (a.live16[0] + TB_T / 16 - 1) / (TB_T / 16) : (a.T + TB_T - 1) / TB_T;
   const int per = (nchunks + gridDim.x - 1) / gridDim.x;
   const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
@@ -63,9 +89,20 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
 #pragma unroll
     for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  Frag<T> ones;
+  Frag<__bf16> ones;
   frag_fill(ones, 1.f);
   Frag<T> py[PY], px[PX];
+  // raw rows -> the staged image(s)
+  auto put = [&](__bf16* dst, int lo_ofs, const Frag<T>& raw) {
+    if constexpr (X3) {
+      bf16x8_t hi, lo;
+      split_x3(raw.v, hi, lo);
+      *reinterpret_cast<bf16x8_t*>(dst) = hi;
+      *reinterpret_cast<bf16x8_t*>(dst + lo_ofs) = lo;
+    } else {
+      *reinterpret_cast<Frag<T>*>(dst) = raw;
+    }
+  };
   // First rows of a chunk's 16-row sub-tiles.  With a live list they are read ONE CHUNK AHEAD of the prefetch that
   // needs them (list entry -> row address -> data is two dependent memory latencies otherwise, once per chunk), by a
   // per-lane VECTOR load (lane q & 3 holds entry q) queued behind the chunk's data loads: it has landed by the time
@@ -114,7 +151,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
       const int c = tid + 512 * i;
       if (c < CY) {
         const int r = c / (N1 / 8), c8 = (c % (N1 / 8)) * 8;
-        *reinterpret_cast<Frag<T>*>(Ys + r * LDY + c8) = py[i];
+        put(Ys + r * LDY + c8, YLO, py[i]);
       }
     }
 #pragma unroll
@@ -123,12 +160,12 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
       if (c < CX) {
         const int r = c / (N2 / 8), c8 = (c % (N2 / 8)) * 8;
         if (GELU_X) {
-          float v[8];
+          Frag<T> g;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = gelu_t<false>((float)px[i].v[j]);
-          store8(Xs + r * LDX + c8, v);
+          for (int j = 0; j < 8; ++j) g.v[j] = (T)gelu_t<false>((float)px[i].v[j]);
+          put(Xs + r * LDX + c8, XLO, g);
         } else {
-          *reinterpret_cast<Frag<T>*>(Xs + r * LDX + c8) = px[i];
+          put(Xs + r * LDX + c8, XLO, px[i]);
         }
       }
     }
@@ -137,28 +174,28 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
 #pragma unroll
     for (int k = 0; k < TB_T / 32; ++k) {               // MFMA k-steps of 32 tokens
       if constexpr (MT <= NT) {                         // hold the shorter side's fragments, stream the longer
-        Frag<T> af[MT];
+        OP af[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          frag_tr16(af[i], Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg);
-          if (do_cs) mma(af[i], ones, cs[i]);
+          frag_tr_op(af[i], Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg, YLO);
+          if (do_cs) mma_ones(af[i], ones, cs[i]);
         }
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
-          Frag<T> bf;
-          frag_tr16(bf, Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg);
+          OP bf;
+          frag_tr_op(bf, Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg, XLO);
 #pragma unroll
           for (int i = 0; i < MT; ++i) mma(af[i], bf, acc[i][j]);
         }
       } else {
-        Frag<T> bf[NT];
+        OP bf[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j) frag_tr16(bf[j], Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg);
+        for (int j = 0; j < NT; ++j) frag_tr_op(bf[j], Xs + k * 32 * LDX, LDX, m2 + j * 16, li, lg, XLO);
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
-          Frag<T> af;
-          frag_tr16(af, Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg);
-          if (do_cs) mma(af, ones, cs[i]);
+          OP af;
+          frag_tr_op(af, Ys + k * 32 * LDY, LDY, m1 + i * 16, li, lg, YLO);
+          if (do_cs) mma_ones(af, ones, cs[i]);
 #pragma unroll
           for (int j = 0; j < NT; ++j) mma(af, bf[j], acc[i][j]);
         }
@@ -449,11 +486,12 @@ static int tn_use_dma() {            // RG_TN_REGSTAGE=1: the register-staged ke
   return v;
 }
 
-template <int N1, int N2>
+template <int N1, int N2, typename T = __bf16>
 static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
+  constexpr bool X3 = std::is_same<T, x3>::value;           // bf16x3: the register-staged kernel (its rows are split on the way to LDS)
   // the DMA kernel keeps its slice of the live-tile list in LDS behind the ring: T up to ~4 M rows (64 K chunks per workgroup)
-  const bool dma = tn_use_dma() != 0 && (long long)TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + ((a.T + 31) / 32 / 256 + 2) * 8 <= 160 * 1024;
-  const int ct = dma ? TnDma<N1, N2>::CT : TB_T;
+  const bool dma = !X3 && tn_use_dma() != 0 && (long long)TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + ((a.T + 31) / 32 / 256 + 2) * 8 <= 160 * 1024;
+  const int ct = dma ? TnDma<N1, N2>::CT : (X3 ? TB_T_X3 : TB_T_BF16);
   const int nchunks = (a.T + ct - 1) / ct;
   // 192 workgroups, not one per CU: every workgroup leaves a partial dW tile (written, then read by the reduce launch), and
   // three quarters of the CUs already keep the memory system full (512x128 / 384x128 / 128x128 on the live rows of the bench
@@ -461,18 +499,22 @@ static int launch_big(const rg_gemm_tn_args& a, hipStream_t s) {
   static const int grid_cap = [] { const char* e = getenv("RG_TN_GRID"); const int v = e ? atoi(e) : 0; return v > 0 && v <= 256 ? v : 192; }();
   int grid = nchunks < grid_cap ? nchunks : grid_cap;
   const int per = (nchunks + grid - 1) / grid;
-  const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + (TnDma<N1, N2>::CT / 16) * per * 4 : TB_T * (N1 + 8 + N2 + 8) * 2;
+  const int smem = dma ? TnDma<N1, N2>::NST * TnDma<N1, N2>::STG + (TnDma<N1, N2>::CT / 16) * per * 4
+                       : (X3 ? TB_T_X3 * (N1 + 8 + N2 + 8) * 2 * 2 : TB_T_BF16 * (N1 + 8 + N2 + 8) * 2);
 #define RG_TNB(KERN)                                                                                                     \
   do {                                                                                                                    \
     hipFuncSetAttribute(reinterpret_cast<const void*>(KERN), hipFuncAttributeMaxDynamicSharedMemorySize, smem);           \
     hipLaunchKernelGGL((KERN), dim3(grid), dim3(512), smem, s, a);                                                        \
   } while (0)
-  if (a.prologue_x == RG_PRO_GELU) {
+  if constexpr (X3) {
+    if (a.prologue_x == RG_PRO_GELU) RG_TNB((gemm_tn_big_kernel<T, N1, N2, true>));
+    else RG_TNB((gemm_tn_big_kernel<T, N1, N2, false>));
+  } else if (a.prologue_x == RG_PRO_GELU) {
     if (dma) RG_TNB((gemm_tn_dma_kernel<N1, N2, true>));
-    else RG_TNB((gemm_tn_big_kernel<N1, N2, true>));
+    else RG_TNB((gemm_tn_big_kernel<T, N1, N2, true>));
   } else {
     if (dma) RG_TNB((gemm_tn_dma_kernel<N1, N2, false>));
-    else RG_TNB((gemm_tn_big_kernel<N1, N2, false>));
+    else RG_TNB((gemm_tn_big_kernel<T, N1, N2, false>));
   }
 #undef RG_TNB
   if (a.partials) {
@@ -502,7 +544,7 @@ static bool tn_blocks(int N1, int N2, int* b1, int* b2) {
 
 // 1 if an instantiation (or a grid of them) takes this problem
 int rg_gemm_tn_big_select(const rg_gemm_tn_args* a, int dtype) {
-  if (dtype != RG_BF16 || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7) || a->colsum_T > 0) return 0;
+  if ((dtype != RG_BF16 && dtype != RG_X3) || !a->use_tr || a->T < 8192 || (a->ldy & 7) || (a->ldx & 7) || a->colsum_T > 0) return 0;
   int b1, b2;
   return tn_blocks(a->N1, a->N2, &b1, &b2) ? 1 : 0;
 }
@@ -522,29 +564,38 @@ size_t rg_gemm_tn_big_workspace(const rg_gemm_tn_args* a, int dtype) {
 }
 
 // returns 1 if the shape is not handled here (caller falls back to the generic kernel)
-static int tn_big_native(const rg_gemm_tn_args* a, hipStream_t s);
+static int tn_big_native(const rg_gemm_tn_args* a, int dtype, hipStream_t s);
 
 int rg_gemm_tn_big_try(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
   if (!rg_gemm_tn_big_select(a, dtype)) return 1;
   int b1, b2;
   tn_blocks(a->N1, a->N2, &b1, &b2);
-  if (b1 == a->N1 && b2 == a->N2) return tn_big_native(a, s);
+  if (b1 == a->N1 && b2 == a->N2) return tn_big_native(a, dtype, s);
+  const size_t esz = dtype == RG_BF16 ? 2 : 4;
   for (int i = 0; i < a->N1 / b1; ++i)
     for (int j = 0; j < a->N2 / b2; ++j) {
       rg_gemm_tn_args t = *a;
-      t.Y = (const __bf16*)a->Y + (size_t)i * b1;
-      t.X = (const __bf16*)a->X + (size_t)j * b2;
+      t.Y = (const char*)a->Y + (size_t)i * b1 * esz;
+      t.X = (const char*)a->X + (size_t)j * b2 * esz;
       t.dW = a->dW + (size_t)i * b1 * a->lddw + (size_t)j * b2;
       t.colsum = (a->colsum && j == 0) ? a->colsum + (size_t)i * b1 : nullptr;      // the bias gradient once per Y block
       t.N1 = b1;
       t.N2 = b2;
-      const int rc = tn_big_native(&t, s);
+      const int rc = tn_big_native(&t, dtype, s);
       if (rc) return rc < 0 ? rc : rg_set_error_msg(RG_ERR_INVALID, "gemm_tn: block launch refused");
     }
   return 0;
 }
 
-static int tn_big_native(const rg_gemm_tn_args* a, hipStream_t s) {
+static int tn_big_native(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
+  if (dtype == RG_X3) {
+    if (a->N1 == 512 && a->N2 == 128) return launch_big<512, 128, x3>(*a, s);
+    if (a->N1 == 128 && a->N2 == 512) return launch_big<128, 512, x3>(*a, s);
+    if (a->N1 == 384 && a->N2 == 128) return launch_big<384, 128, x3>(*a, s);
+    if (a->N1 == 256 && a->N2 == 128) return launch_big<256, 128, x3>(*a, s);
+    if (a->N1 == 128 && a->N2 == 128) return launch_big<128, 128, x3>(*a, s);
+    return 1;
+  }
   if (a->N1 == 512 && a->N2 == 128) return launch_big<512, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 512) return launch_big<128, 512>(*a, s);
   if (a->N1 == 384 && a->N2 == 128) return launch_big<384, 128>(*a, s);

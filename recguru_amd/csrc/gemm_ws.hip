@@ -11,20 +11,31 @@
 // barriers order LDS only (lds_barrier), and -- weight fragment as the A operand -- each
 // accumulator register holds 4 consecutive features of one token, so results leave through a
 // packed LDS tile and 16-byte coalesced stores (aux operands are read the same way).
+//
+// bf16x3 tier (T = x3): A and C are f32 in memory; the A tile is split ONCE while it is staged (a hi and a lo bf16 tile in
+// LDS, rg_common.hip.h), the weight slice is split once per workgroup (K = 128: stationary) or per tile and chunk (K > 128:
+// the slice of the current 128-wide chunk, re-read from L2 -- a stationary K = 384 slice would be 192 VGPRs), the C tile is raw
+// f32.  One 128-column block per workgroup (gridDim.y): HBM-bound at twice the bf16 tier's bytes.
+#define WS_M 64
+#define WS_LD (128 + 8)
+#define RG_X3_PLANE (WS_M * WS_LD * 2)
+#include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
-#define WS_M 64
-#define WS_LD (128 + 8)
-
 // AUX: the epilogue reads an aux operand (compile-time: a load under a runtime condition gets a vmcnt(0) at the join,
 // which also drained the next tile's A prefetch -- one exposed HBM latency per tile even for the aux-free GEMMs)
-template <int NKC, int NCB, bool AUX>
+template <typename T, int NKC, int NCB, bool AUX>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   static_assert(NKC == 1 || NCB == 1, "either K or N spans a single 128-wide block");
-  typedef __bf16 T;
-  __shared__ __align__(16) T As[WS_M * WS_LD];
-  __shared__ __align__(16) T Cs[WS_M * WS_LD];
+  constexpr bool X3 = std::is_same<T, x3>::value;
+  static_assert(!X3 || NCB == 1, "bf16x3: one column block per workgroup");
+  constexpr bool STREAM = X3 && NKC > 1;          // the weight slice of ONE chunk in registers, reloaded per tile and chunk
+  typedef typename LdsT<T>::type LT;              // A tile: T, or a hi and a lo bf16 tile
+  typedef typename ResT<T>::type XT;              // C tile: T, or raw f32
+  typedef typename OpT<T>::type OP;
+  __shared__ __align__(16) LT As[WS_M * WS_LD * LdsT<T>::PLANES];
+  __shared__ __align__(16) XT Cs[WS_M * WS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
@@ -54,17 +65,21 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
     return (size_t)(mt + r) * a.ldc + cb * 128 + c8;
   };
 
-  // ---- stationary weights: w[cb][kc][ks][ct]
-  Frag<T> w[NCB][NKC][4][2];
+  // ---- stationary weights: w[cb][kc][ks][ct]   (STREAM: [cb][0][ks][ct] = the current chunk's slice)
+  OP w[NCB][STREAM ? 1 : NKC][4][2];
+  auto load_w = [&](int cb, int kc, int slot) {
 #pragma unroll
-  for (int cb = 0; cb < NCB; ++cb)
+    for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-    for (int kc = 0; kc < NKC; ++kc)
+      for (int ct = 0; ct < 2; ++ct)
+        load_frag(w[cb][slot][ks][ct], W + (size_t)((cby + cb) * 128 + n0 + ct * 16 + li) * a.ldw + kc * 128 + ks * 32 + 8 * lg);
+  };
+  if constexpr (!STREAM) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int ct = 0; ct < 2; ++ct)
-          load_frag(w[cb][kc][ks][ct], W + (size_t)((cby + cb) * 128 + n0 + ct * 16 + li) * a.ldw + kc * 128 + ks * 32 + 8 * lg);
+      for (int kc = 0; kc < NKC; ++kc) load_w(cb, kc, kc);
+  }
   __shared__ __align__(16) float bs[NCB * 128];
   for (int i = tid; i < NCB * 128; i += 256) bs[i] = a.bias ? a.bias[cby * 128 + i] : 0.f;   // visible after the first barrier
 
@@ -119,8 +134,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int c = tid + 256 * i, r = c >> 4, c8 = (c & 15) * 8;
-        *reinterpret_cast<Frag<T>*>(As + r * WS_LD + c8) = pre[i];
+        stage8(As + r * WS_LD + c8, pre[i]);
       }
+      if constexpr (STREAM) load_w(0, kc, 0);             // (L2 hits; split in registers under the barrier below)
       // unconditional (rows of an absent next tile are clamped inside prefetch): loads under a runtime branch get a
       // vmcnt(0) at the join, which exposed one HBM latency per tile
       if (kc + 1 < NKC) prefetch(mb, kc + 1);
@@ -144,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b4[0], b4[1], b4[2], b4[3]};
           }
         }
-        Frag<T> af[2][4];                                 // k-step ks+1's fragments are read under the MFMAs of k-step ks
+        OP af[2][4];                                      // k-step ks+1's fragments are read under the MFMAs of k-step ks
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) load_frag(af[0][rt], As + (rt * 16 + li) * WS_LD + 8 * lg);
 #pragma unroll
@@ -156,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 #pragma unroll
           for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
-            for (int ct = 0; ct < 2; ++ct) mma(w[cb][kc][ks][ct], af[ks & 1][rt], acc[ct][rt]);
+            for (int ct = 0; ct < 2; ++ct) mma(w[cb][STREAM ? 0 : kc][ks][ct], af[ks & 1][rt], acc[ct][rt]);
         }
         if (kc == NKC - 1) {
           // ---- epilogue of this 128-feature block: packed tile -> coalesced 16-byte stores
@@ -176,7 +192,9 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
               const size_t off = c_off(mb[i], tid >> 4, cby + cb, c8);
               if constexpr (!AUX) {
                 if (a.epilogue == RG_EPI_NONE) {
-                  *reinterpret_cast<Frag<T>*>(C + off) = *reinterpret_cast<const Frag<T>*>(Cs + r * WS_LD + c8);
+                  Frag<T> raw;
+                  unstage8(raw, Cs + r * WS_LD + c8);
+                  *reinterpret_cast<Frag<T>*>(C + off) = raw;
                 } else if (a.epilogue == RG_EPI_DROP_GELU) {
                   // h1 = dropout(l1) as the backward reads it back, and the activated operand of the second product, from
                   // the value AS STORED (rounded to T): what rg_dropout_gelu does in a pass of its own
@@ -264,19 +282,27 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   }
 }
 
-template <int NKC, int NCB>
+template <int NKC, int NCB, typename T = __bf16>
 static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   int grid = ny > 1 ? (768 / ny > 96 ? 768 / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
-  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_ws_kernel<NKC, NCB, false>), dim3(grid, ny), dim3(256), 0, s, a);
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(grid, ny), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
 }
 
 // 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
 int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
+  if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no list, no head-major form
+    if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->epilogue == RG_EPI_DROP_GELU || a->c_hm_L > 0 || a->live16) return 0;
+    if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;
+    if ((a->K & 127) || (a->N & 127) || a->M < 4096 || a->K > 512 || a->N > 1024) return 0;
+    if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
+    if (a->epilogue != RG_EPI_NONE && a->epilogue != RG_EPI_RELU && !a->aux) return 0;
+    return 10 * (a->K / 128) + 1;
+  }
   if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 0;
   if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;   // dropout-after-ReLU lives in the generic kernel
   if ((a->K & 127) || (a->N & 127) || a->M < 4096) return 0;
@@ -296,6 +322,12 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
 int rg_gemm_ws_try(const rg_gemm_nt_args* a, int dtype, hipStream_t s) {
   if (!rg_gemm_ws_select(a, dtype)) return 1;
   const int nkc = a->K / 128, ncb = a->N / 128;
+  if (dtype == RG_X3) {
+    if (nkc == 1) return launch_ws<1, 1, x3>(*a, s, ncb);
+    if (nkc == 2) return launch_ws<2, 1, x3>(*a, s, ncb);
+    if (nkc == 3) return launch_ws<3, 1, x3>(*a, s, ncb);
+    return launch_ws<4, 1, x3>(*a, s, ncb);
+  }
   if (nkc == 1 && ncb == 1) return launch_ws<1, 1>(*a, s);
   if (nkc == 1 && ncb == 2) return launch_ws<1, 2>(*a, s);
   if (nkc == 2 && ncb == 1) return launch_ws<2, 1>(*a, s);

@@ -278,6 +278,102 @@ template <> struct Precise<__bf16> { static constexpr bool value = false; };
 // x3: the 7-instruction exp2 / rcp GELU (v_exp_f32 and v_rcp_f32 are good to ~1 ulp: 1e-7, two orders below the operand split)
 template <> struct Precise<x3> { static constexpr bool value = false; };
 
+// ---- bf16x3 with operands split ONCE (the kernels that stage their operands through LDS) --------------------------------
+// An LDS tile of the x3 tier is a PAIR of bf16 tiles, hi and lo, laid out exactly like the bf16 tier's tile (same offsets, same
+// swizzles, same bank behaviour); the lo tile sits RG_X3_PLANE bytes behind the hi tile (a per-file constant, defined before
+// this header is included).  An element is split when it is WRITTEN to the tile (staging from HBM, an accumulator leaving
+// the registers) -- once -- and every wave's operand-fragment read is two plain 16-byte LDS reads with no VALU work behind
+// them; weights come from the fragment-packed presplit copy rg_cast writes (hi fragment, then lo fragment, 1 KB each).
+struct x3p { unsigned short u; };                      // one bf16 slot of a split tile (the address type of such a tile)
+struct FragX3 { bf16x8_t hi, lo; };                    // operand fragment, already split
+template <typename T> struct LdsT { typedef T type; static constexpr int PLANES = 1; };
+template <> struct LdsT<x3> { typedef x3p type; static constexpr int PLANES = 2; };
+template <typename T> struct OpT { typedef Frag<T> type; };
+template <> struct OpT<x3> { typedef FragX3 type; };
+__device__ __forceinline__ void mma(const FragX3& a, const FragX3& b, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, b.hi, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, b.hi, c, 0, 0, 0);
+}
+// operand fragment straight from f32 memory (split on the way: for operands a workgroup loads once)
+__device__ __forceinline__ void load_frag(FragX3& f, const x3* p) {
+  float v[8];
+  load8(v, reinterpret_cast<const float*>(p));
+  split_x3(v, f.hi, f.lo);
+}
+#ifdef RG_X3_PLANE
+__device__ __forceinline__ const x3p* lo_of(const x3p* p) { return reinterpret_cast<const x3p*>(reinterpret_cast<const char*>(p) + RG_X3_PLANE); }
+__device__ __forceinline__ x3p* lo_of(x3p* p) { return reinterpret_cast<x3p*>(reinterpret_cast<char*>(p) + RG_X3_PLANE); }
+__device__ __forceinline__ void load_frag(FragX3& f, const x3p* p) {
+  f.hi = *reinterpret_cast<const bf16x8_t*>(p);
+  f.lo = *reinterpret_cast<const bf16x8_t*>(lo_of(p));
+}
+// 8 raw elements (as loaded from HBM) -> the tile
+__device__ __forceinline__ void stage8(x3p* dst, const Frag<x3>& raw) {
+  bf16x8_t hi, lo;
+  split_x3(raw.v, hi, lo);
+  *reinterpret_cast<bf16x8_t*>(dst) = hi;
+  *reinterpret_cast<bf16x8_t*>(lo_of(dst)) = lo;
+}
+// ... and back: hi + lo (exact in f32: the two parts do not overlap)
+__device__ __forceinline__ void unstage8(Frag<x3>& raw, const x3p* src) {
+  const bf16x8_t hi = *reinterpret_cast<const bf16x8_t*>(src), lo = *reinterpret_cast<const bf16x8_t*>(lo_of(src));
+#pragma unroll
+  for (int j = 0; j < 8; ++j) raw.v[j] = (float)hi[j] + (float)lo[j];
+}
+__device__ __forceinline__ void store8(x3p* p, const float* v) {
+  Frag<x3> r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r.v[j] = v[j];
+  stage8(p, r);
+}
+__device__ __forceinline__ void load8(float* o, const x3p* p) {
+  Frag<x3> r;
+  unstage8(r, p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = r.v[j];
+}
+__device__ __forceinline__ void store4(x3p* p, const float* v) {
+  bf16x4_t hi, lo;
+#pragma unroll
+  for (int j = 0; j < 4; j += 2) {
+    const rg_f2 x = (rg_f2){v[j], v[j + 1]};
+    const rg_bf2 h = __builtin_convertvector(x, rg_bf2);
+    union { rg_bf2 b; unsigned int u; } hu;
+    hu.b = h;
+    const rg_f2 hf = (rg_f2){__uint_as_float(hu.u << 16), __uint_as_float(hu.u & 0xFFFF0000u)};
+    const rg_bf2 l = __builtin_convertvector(x - hf, rg_bf2);
+    hi[j] = h[0]; hi[j + 1] = h[1];
+    lo[j] = l[0]; lo[j + 1] = l[1];
+  }
+  *reinterpret_cast<bf16x4_t*>(p) = hi;
+  *reinterpret_cast<bf16x4_t*>(lo_of(p)) = lo;
+}
+__device__ __forceinline__ void load4t(float* o, const x3p* p) {
+  const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p), lo = *reinterpret_cast<const bf16x4_t*>(lo_of(p));
+#pragma unroll
+  for (int j = 0; j < 4; ++j) o[j] = (float)hi[j] + (float)lo[j];
+}
+#endif
+// x3r: a raw f32 slot of the x3 tier -- for tiles that are NOT matrix operands (residuals, outputs on their way to HBM):
+// splitting those would cost VALU work and round a residual to 16 bits for nothing.  A [64 x 128] tile of them is exactly as
+// large as the split pair, so it can take the place of one.
+struct x3r { float f; };
+template <typename T> struct ResT { typedef typename LdsT<T>::type type; };
+template <> struct ResT<x3> { typedef x3r type; };
+__device__ __forceinline__ void stage8(x3r* dst, const Frag<x3>& raw) {
+  *reinterpret_cast<float4*>(dst) = make_float4(raw.v[0], raw.v[1], raw.v[2], raw.v[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(raw.v[4], raw.v[5], raw.v[6], raw.v[7]);
+}
+__device__ __forceinline__ void unstage8(Frag<x3>& raw, const x3r* src) { load8(raw.v, reinterpret_cast<const float*>(src)); }
+__device__ __forceinline__ void store8(x3r* p, const float* v) { store8(reinterpret_cast<float*>(p), v); }
+__device__ __forceinline__ void load8(float* o, const x3r* p) { load8(o, reinterpret_cast<const float*>(p)); }
+__device__ __forceinline__ void store4(x3r* p, const float* v) { store4(reinterpret_cast<float*>(p), v); }
+__device__ __forceinline__ void load4t(float* o, const x3r* p) { load4f(o, reinterpret_cast<const float*>(p)); }
+// the same two for the tiers whose tile holds the raw element
+template <typename T> __device__ __forceinline__ void stage8(T* dst, const Frag<T>& raw) { *reinterpret_cast<Frag<T>*>(dst) = raw; }
+template <typename T> __device__ __forceinline__ void unstage8(Frag<T>& raw, const T* src) { raw = *reinterpret_cast<const Frag<T>*>(src); }
+
 // Dropout masks are stateless: keep(seed, idx) is a hash of a per-call seed and the element index,
 // so the backward kernels regenerate exactly the forward's mask (nn.Dropout semantics: element kept
 // with probability 1-p and scaled by 1/(1-p); only the random stream differs from torch's Philox).

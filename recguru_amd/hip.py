@@ -560,7 +560,7 @@ def cast_multi(seg_table_dev, tiles_dev, ntiles, dtype):
     _check(lib().rg_cast_multi(_vp(seg_table_dev), _vp(tiles_dev), int(ntiles), code, _stream()), "rg_cast_multi")
 
 
-CAST_TRANSPOSE, CAST_PACK = 1, 2
+CAST_TRANSPOSE, CAST_PACK, CAST_SPLIT = 1, 2, 4
 
 
 def cast(src, dtype, transpose=False):

@@ -92,14 +92,17 @@ def _ver(p):
     return (p.data_ptr(), p._version, getattr(p, "_rg_gen", 0))
 
 
-def shadow(p, transpose=False, pack=False):
+def shadow(p, transpose=False, pack=False, split=False):
     """Operand-tier copy of a 2-D f32 parameter: [out,in] or, transposed, [in,out]; pack=True: in the MFMA-fragment-packed
-    layout (hip.CAST_PACK) the fused discriminator kernel reads.
+    layout (hip.CAST_PACK) the fused kernels read; split=True (honoured in the bf16x3 tier only, with pack): the presplit form
+    of that layout (hip.CAST_SPLIT: hi and lo bf16 parts of every fragment) the fused BLOCK kernels read under RG_X3.
     LIFETIME: the returned tensor is valid until the SECOND optimizer step after it was handed out -- refresh_shadows()
     rewrites two alternating destination buffers in place, so a holder that keeps a shadow across two steps (an autograd graph
     retained over steps, a table captured once before a training loop) would read newer weights.  Every use in this package
     takes the shadow at launch time; callers that need a stable copy must clone it."""
     transpose = int(bool(transpose)) | (hip.CAST_PACK if pack else 0)       # cast mode; rides in the key's transpose slot
+    if split and pack and hip.SPLIT_OPERANDS:
+        transpose |= hip.CAST_SPLIT
     if _COMPUTE == torch.float32 and not transpose:
         return p.detach()
     key = (id(p), transpose, _COMPUTE)
@@ -636,7 +639,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     if FUSE_ATTN_OUT_BWD and d == 128 and P == 128:
         # LayerNorm backward + dctx = dz Wo in ONE launch (dz is read back only by the weight-gradient product)
         dz, dctx = hip.attn_out_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe,
-                                    shadow(Wo, transpose=True, pack=True), live=live, w_packed=True)
+                                    shadow(Wo, transpose=True, pack=True, split=True), live=live, w_packed=True)
         hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
     else:
         dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
@@ -719,7 +722,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)
     if FUSE_FFN_BWD and FUSE_FFN_BWD_LN and hip.ffn_bwd_data_supported(d, dff):
         # LayerNorm backward + both data-path products in ONE launch: dz never reaches HBM, dl2 is written once
-        dh1, dy, dl2 = hip.ffn_bwd_data(None, None, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),
+        dh1, dy, dl2 = hip.ffn_bwd_data(None, None, h1, shadow(W2, transpose=True, pack=True, split=True), shadow(W1, transpose=True, pack=True, split=True),
                                         nz_scale=_inv_keep(drop_p), live=live, w_packed=True,
                                         ln=(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out))
         hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
@@ -733,7 +736,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live_tn)
     if FUSE_FFN_BWD and hip.ffn_bwd_data_supported(d, dff):
         # one launch for both data-path products: dh1 is written once (for dW1) and never read back
-        dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, shadow(W2, transpose=True, pack=True), shadow(W1, transpose=True, pack=True),
+        dh1, dy = hip.ffn_bwd_data(dl2, dz, h1, shadow(W2, transpose=True, pack=True, split=True), shadow(W1, transpose=True, pack=True, split=True),
                                    nz_scale=_inv_keep(drop_p), live=live, w_packed=True)
         hip.gemm_tn(dh1, y, dW1, db1, live=live)
         return dy, (rW1, rb1, rW2, rb2, rg, rbe)
@@ -761,8 +764,8 @@ class EncoderLayerFn(_Fn):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
                                            drop_p, seeds[0], rowmask, xm, allow_unwritten=True)
             xm = 2 if xm else 0
-            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True, split=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True, split=True), b1.detach(), shadow(W2, pack=True, split=True), b2.detach(), g2.detach(),
                                         be2.detach(),
                                         rowmask, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
                                         skip_dead_saves=_lists_everywhere(W1, B * L), x_lo=_lo_in(x2))
@@ -830,8 +833,8 @@ class EncoderLastLayerFn(_Fn):
                                         rowmask=rmf if fold else None, bkv=bkv if fold else None)
         out_lo = None
         if _fusable(x_last, Wo, W1):
-            out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+            out, sv = hip.post_attn_fwd(c_last, x_last, shadow(Wo, pack=True, split=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True, split=True), b1.detach(), shadow(W2, pack=True, split=True), b2.detach(), g2.detach(),
                                         be2.detach(),
                                         rm_last, w_packed=True, save=need, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1], seed_out=seeds[2],
                                         x_lo=_lo_in(x_last, rows=lambda t: t.reshape(B, L, d)[:, -1, :]))
@@ -923,8 +926,8 @@ class DecoderLayerFn(_Fn):
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
                                            rowmask, _X_MASKED, allow_unwritten=True)
             xm_d = 2 if _X_MASKED else 0
-            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True), bo.detach(), g1.detach(), be1.detach(),
-                                        shadow(W1, pack=True), b1.detach(), shadow(W2, pack=True), b2.detach(), g2.detach(),
+            out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True, split=True), bo.detach(), g1.detach(), be1.detach(),
+                                        shadow(W1, pack=True, split=True), b1.detach(), shadow(W2, pack=True, split=True), b2.detach(), g2.detach(),
                                         be2.detach(),
                                         rowmask, w_packed=True, save=need, L=L, eps=LN_EPS, drop_p=drop_p, seed_h1=seeds[1],
                                         seed_out=seeds[2], skip_dead_saves=_lists_everywhere(W1, B * L), x_lo=_lo_in(x2), **cross_kw)

@@ -156,3 +156,56 @@ def test_tools_and_entry_points_compile():
     for f in files:
         with open(f) as fh:
             compile(fh.read(), f, "exec")
+
+
+def test_isa_screen_flags_a_spill_in_front_of_the_exec_restore(tmp_path):
+    """recguru_amd/isa_screen.py (run by every build): hipcc can park live VGPRs in AGPRs at the top of a join block IN FRONT of its
+    `s_or_b64 exec` -- the copies then run for the lanes that took the branch only.  The screen must flag exactly that
+    and must not flag the same copies behind the restore, nor a branch body's own AGPR writes."""
+    from recguru_amd import isa_screen
+    bad = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[18:19], s[4:5]
+	s_cbranch_execz .LBB0_2
+	ds_write_b32 v1, v2
+.LBB0_2:
+	v_accvgpr_write_b32 a144, v119
+	s_mov_b64 s[80:81], s[24:25]
+	s_or_b64 exec, exec, s[18:19]
+	s_endpgm
+"""
+    good = bad.replace("\tv_accvgpr_write_b32 a144, v119\n\ts_mov_b64 s[80:81], s[24:25]\n\ts_or_b64 exec, exec, s[18:19]\n",
+                       "\ts_mov_b64 s[80:81], s[24:25]\n\ts_or_b64 exec, exec, s[18:19]\n\tv_accvgpr_write_b32 a144, v119\n")
+    body = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[18:19], s[4:5]
+	v_accvgpr_write_b32 a9, v35
+	s_or_b64 exec, exec, s[18:19]
+	s_endpgm
+"""
+    for name, text, n_bad in (("bad.s", bad, 1), ("good.s", good, 0), ("body.s", body, 0)):
+        p = tmp_path / name
+        p.write_text(text)
+        flagged, _ = isa_screen.screen(str(p))
+        assert len(flagged) == n_bad, (name, flagged)
+        if n_bad:
+            assert flagged[0][0] == "_Z6kernelv" and flagged[0][2] == ".LBB0_2" and "a144" in flagged[0][3][0]
+
+
+def test_built_library_passes_the_isa_screen():
+    """The device ISA the build kept (recguru_amd/build/isa/*.s) has no join block that runs vector instructions under a narrowed exec,
+    and BUILD_INFO.json records the compiler and the hash of the library that was screened."""
+    import glob
+    import hashlib
+    import json
+    from recguru_amd import hip, isa_screen
+    isa = sorted(glob.glob(os.path.join(ROOT, "recguru_amd", "build", "isa", "*.s")))
+    if not isa:
+        pytest.skip("no device ISA beside the objects (library built elsewhere)")
+    assert len(isa) >= 10
+    for fn in isa:
+        flagged, _ = isa_screen.screen(fn)
+        assert not flagged, (fn, flagged[:2])
+    info = json.load(open(os.path.join(ROOT, "recguru_amd", "build", "BUILD_INFO.json")))
+    assert info["flagged_join_blocks"] == [] and "clang" in " ".join(info["hipcc"])
+    assert info["library_sha256"] == hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()
