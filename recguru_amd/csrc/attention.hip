@@ -154,6 +154,74 @@ __device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, con
   }
 }
 
+// operand helpers of the kernels below whose LDS tiles are bf16: one image per staged tile, or (bf16x3) a hi and a lo image PL
+// elements apart; the f32 tier (raw f32 tiles) goes through the Frag<float> overloads
+template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<__bf16>& raw) { *reinterpret_cast<Frag<__bf16>*>(dst) = raw; }
+template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<x3>& raw) {
+  bf16x8_t hi, lo;
+  split_x3(raw.v, hi, lo);
+  *reinterpret_cast<bf16x8_t*>(dst) = hi;
+  *reinterpret_cast<bf16x8_t*>(dst + PL) = lo;
+}
+template <int PL> __device__ __forceinline__ void load_op(Frag<__bf16>& f, const __bf16* p) { load_frag(f, p); }
+template <int PL> __device__ __forceinline__ void load_op(FragX3& f, const __bf16* p) {
+  f.hi = *reinterpret_cast<const bf16x8_t*>(p);
+  f.lo = *reinterpret_cast<const bf16x8_t*>(p + PL);
+}
+template <int PL> __device__ __forceinline__ void vstage_op(Frag<__bf16>& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
+  VStage<__bf16>::frag(f, V, ldv, k0, dv0, li, lg);
+}
+template <int PL> __device__ __forceinline__ void vstage_op(FragX3& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
+  Frag<__bf16> h, l;
+  VStage<__bf16>::frag(h, V, ldv, k0, dv0, li, lg);
+  VStage<__bf16>::frag(l, V + PL, ldv, k0, dv0, li, lg);
+  f.hi = h.v;
+  f.lo = l.v;
+}
+__device__ __forceinline__ void acc_to_op(Frag<__bf16>& f, const f32x4& lo, const f32x4& hi) { acc_to_frag(f, lo, hi); }
+__device__ __forceinline__ void acc_to_op(FragX3& f, const f32x4& lo, const f32x4& hi) {
+  const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  split_x3(v, f.hi, f.lo);
+}
+
+template <int PL> __device__ __forceinline__ void stage_op(float* dst, const Frag<float>& raw) { *reinterpret_cast<Frag<float>*>(dst) = raw; }
+template <int PL> __device__ __forceinline__ void load_op(Frag<float>& f, const float* p) { load_frag(f, p); }
+__device__ __forceinline__ void acc_to_op(Frag<float>& f, const f32x4& lo, const f32x4& hi) { acc_to_frag(f, lo, hi); }
+// the two 16-key halves of a V k-step at independent key offsets (forward kernel)
+template <int PL> __device__ __forceinline__ void vstage2_op(Frag<__bf16>& f, const __bf16* V, int ldv, int kA, int kB, int dv0, int li, int lg) {
+  VStage<__bf16>::frag2(f, V, ldv, kA, kB, dv0, li, lg);
+}
+template <int PL> __device__ __forceinline__ void vstage2_op(Frag<float>& f, const float* V, int ldv, int kA, int kB, int dv0, int li, int lg) {
+  VStage<float>::frag2(f, V, ldv, kA, kB, dv0, li, lg);
+}
+template <int PL> __device__ __forceinline__ void vstage2_op(FragX3& f, const __bf16* V, int ldv, int kA, int kB, int dv0, int li, int lg) {
+  Frag<__bf16> h, l;
+  VStage<__bf16>::frag2(h, V, ldv, kA, kB, dv0, li, lg);
+  VStage<__bf16>::frag2(l, V + PL, ldv, kA, kB, dv0, li, lg);
+  f.hi = h.v;
+  f.lo = l.v;
+}
+template <typename T> __device__ __forceinline__ void op_zero(Frag<T>& f) { frag_zero(f); }
+__device__ __forceinline__ void op_zero(FragX3& f) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { f.hi[j] = (__bf16)0.f; f.lo[j] = (__bf16)0.f; }
+}
+// row sums of P: ones . P (bf16x3: ones . (hi + lo), two MFMAs)
+template <typename T> __device__ __forceinline__ void ones_mma(const Frag<T>& ones, const Frag<T>& p, f32x4& c) { mma(ones, p, c); }
+__device__ __forceinline__ void ones_mma(const Frag<__bf16>& ones, const FragX3& p, f32x4& c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, p.lo, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones.v, p.hi, c, 0, 0, 0);
+}
+// p == 0.5 dropout on the PACKED P fragment: 16-bit AND masks per element (m0: elements 0..3, m1: 4..7)
+__device__ __forceinline__ void and_frag(bf16x8_t& v, const uint2& m0, const uint2& m1) {
+  uint4 pu = __builtin_bit_cast(uint4, v);
+  pu.x &= m0.x; pu.y &= m0.y; pu.z &= m1.x; pu.w &= m1.y;
+  v = __builtin_bit_cast(bf16x8_t, pu);
+}
+__device__ __forceinline__ void and_op(Frag<__bf16>& f, const uint2& m0, const uint2& m1) { and_frag(f.v, m0, m1); }
+__device__ __forceinline__ void and_op(FragX3& f, const uint2& m0, const uint2& m1) { and_frag(f.hi, m0, m1); and_frag(f.lo, m0, m1); }
+__device__ __forceinline__ void and_op(Frag<float>& f, const uint2& m0, const uint2& m1) {}      // (never instantiated: PLUT needs bf16 tiles)
+
 // DM: dropout mode -- 0 none, 1 p == 0.5 (bit table in LDS, AND masks), 2 generic p (16-bit hash fields)
 // (256, 2): a register budget of 256 makes hipcc select the VGPR form of the MFMAs; with the default budget
 // of 512 it parks every score accumulator in AGPRs and copies it out and back (~6 v_accvgpr moves per score).
@@ -174,21 +242,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   // -(row >> 2) & 3: the ds_read_b128 fragment reads (lane (li, lg): chunk lg of row li) are conflict-free under the
   // hardware's lane groups, and without the pad the head's tiles fit FOUR workgroups per CU instead of three under
   // dropout (39.4 KB with the bit table; the kernel is VALU-bound and the fourth wave per SIMD is worth 12-19 %).
-  constexpr int LDK = sizeof(T) == 2 ? DK : DK + 8;
-  auto kofs = [](int row, int chunk) { return sizeof(T) == 2 ? row * DK + ((chunk ^ ((-(row >> 2)) & 3)) << 3) : row * (DK + 8) + chunk * 8; };
-  constexpr bool VT = VStage<T>::TRANSPOSED;
+  // bf16x3 tier (T = x3, f32 in memory): the K and V tiles are bf16 tiles in the bf16 tier's layouts, twice -- a hi and a lo image,
+  // PLK / PLV elements apart, split while they are staged -- and Q is split when it is loaded, P when it leaves the accumulators.
+  constexpr bool X3 = std::is_same<T, x3>::value;
+  typedef typename std::conditional<X3, __bf16, T>::type E;        // element of the LDS tiles
+  typedef typename OpT<T>::type OP;                                 // operand fragment
+  constexpr int LDK = sizeof(E) == 2 ? DK : DK + 8;
+  auto kofs = [](int row, int chunk) { return sizeof(E) == 2 ? row * DK + ((chunk ^ ((-(row >> 2)) & 3)) << 3) : row * (DK + 8) + chunk * 8; };
+  constexpr bool VT = VStage<E>::TRANSPOSED;
   static_assert(!HM || (sizeof(T) == 2 && !XIN), "head-major staging: bf16 qkv form");
+  static_assert(!X3 || (!XIN && !HM), "bf16x3: token-major qkv");
   constexpr int LDV = VT ? LPK + 8 : (HM ? DK : DK + 8);
   constexpr int VELEMS = VT ? DK * LDV : LPK * LDV;
-  __shared__ __align__(16) T Ks[LPK * LDK];
-  __shared__ __align__(16) T Vs[VELEMS];
+  constexpr int PLK = X3 ? LPK * LDK : 0, PLV = X3 ? VELEMS : 0;
+  __shared__ __align__(16) E Ks[LPK * LDK * (X3 ? 2 : 1)];
+  __shared__ __align__(16) E Vs[VELEMS * (X3 ? 2 : 1)];
   __shared__ __align__(16) float kbias[LPK];
   constexpr int NW = (NKT + 1) / 2;   // 32-key hash words per attention row
   __shared__ __align__(16) unsigned int dmask[DM == 1 ? NW * LPK : 4];   // [word][query]: the head's dropout bits (p == 0.5 mode)
   // p == 0.5, bf16: the dropout mask is applied to the PACKED P fragment -- nibble of hash bits -> 4 x 16-bit masks from a
   // 16-entry table (2 VALU + 1 ds_read_b64 + 2 ANDs per 4 elements instead of a bit extract + AND per element), and the
   // f32 probabilities stay undropped, so the row sums come out of the ones-MFMA exactly as without dropout
-  constexpr bool PLUT = DM == 1 && sizeof(T) == 2;
+  constexpr bool PLUT = DM == 1 && sizeof(E) == 2;
   constexpr bool MSUM = DM == 0 || PLUT;
   __shared__ __align__(8) unsigned int dlut[PLUT ? 32 : 2];
   __shared__ int klo_s;               // first key that is not replaced by the pad mask (L if none)
@@ -338,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
             store4(Ks + kofs(key, 2 * nb + (lg >> 1)) + 4 * (lg & 1), o4);
           } else if (VT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) Vs[(nb * 16 + 4 * lg + r) * LDV + key] = (T)o4[r];
+            for (int r = 0; r < 4; ++r) Vs[(nb * 16 + 4 * lg + r) * LDV + key] = (E)o4[r];
           } else {
             store4(Vs + key * LDV + nb * 16 + 4 * lg, o4);
           }
@@ -428,12 +503,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     for (int i = 0; i < 4; ++i) {
       const int c = tid + 256 * (i0 + i), key = c >> 2, c8 = (c & 3) * 8;
       if (i0 + i < NCH && c < LPK * 4) {
-        *reinterpret_cast<Frag<T>*>(Ks + kofs(key, c8 >> 3)) = kr[i];
-        if (VT) {
+        stage_op<PLK>(Ks + kofs(key, c8 >> 3), kr[i]);
+        if constexpr (VT) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) Vs[(c8 + j) * LDV + key] = vr[i].v[j];
         } else {
-          *reinterpret_cast<Frag<T>*>(Vs + key * LDV + c8) = vr[i];
+          stage_op<PLV>(Vs + key * LDV + c8, vr[i]);
         }
       }
     }
@@ -454,8 +529,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   const T* __restrict__ qsrc = XIN ? reinterpret_cast<const T*>(a.ctx) + (size_t)b * L * P + h * DK
                                    : (HM ? qkv + hm_head : qkv + h * DK);
   const int qld = XIN ? P : (HM ? DK : ld);
-  Frag<T> qnext;
-  frag_zero(qnext);
+  OP qnext;
+  op_zero(qnext);
   if (wl) {
     const int q = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
     if (q < L) load_frag(qnext, qsrc + (size_t)q * qld + 8 * lg);
@@ -471,8 +546,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       for (int c = tid; c < L * 4; c += 256) {
         const int row = c >> 2, ch = c & 3;
         if (row >= first_hm && a.rowmask[(size_t)b * L + row] == 0.f) {
-          *reinterpret_cast<Frag<T>*>(Ks + kofs(row, ch)) = *reinterpret_cast<const Frag<T>*>(padr + (a.H + h) * DK + 8 * ch);
-          *reinterpret_cast<Frag<T>*>(Vs + VStageHM::off(row, 8 * ch)) = *reinterpret_cast<const Frag<T>*>(padr + (2 * a.H + h) * DK + 8 * ch);
+          *reinterpret_cast<Frag<E>*>(Ks + kofs(row, ch)) = *reinterpret_cast<const Frag<E>*>(padr + (a.H + h) * DK + 8 * ch);
+          *reinterpret_cast<Frag<E>*>(Vs + VStageHM::off(row, 8 * ch)) = *reinterpret_cast<const Frag<E>*>(padr + (2 * a.H + h) * DK + 8 * ch);
         }
       }
       lds_barrier();
@@ -490,11 +565,11 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     wl &= wl - 1u;                         // next live tile, if any: its Q fragment is prefetched under this tile's work
     const int q = qt * 16 + li;            // this lane's query (column of S^T)
     const int qrel = q - 4 * lg;           // key (= kt*16 + 4*lg + r) > q  <=>  kt*16 + r > qrel
-    const Frag<T> qf = qnext;
+    const OP qf = qnext;
     if (wl) {
       const int q2 = (wave + 4 * __builtin_ctz(wl)) * 16 + li;
       if (q2 < L) load_frag(qnext, qsrc + (size_t)q2 * qld + 8 * lg);
-      else frag_zero(qnext);
+      else op_zero(qnext);
     }
     f32x4 o[2];
     float sum, mx;
@@ -525,10 +600,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       f32x4 s[NKT];
       mx = -INFINITY;
       {
-        Frag<T> kfb[2];
+        OP kfb[2];
         float kbb[2][4];
         auto issue = [&](int j, int buf) {
-          load_frag(kfb[buf], Ks + kofs(tile_of(j) * 16 + li, lg));
+          load_op<PLK>(kfb[buf], Ks + kofs(tile_of(j) * 16 + li, lg));
           load4f(kbb[buf], kbias + tile_of(j) * 16 + 4 * lg);
         };
         issue(0, 0);
@@ -635,9 +710,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
       ASTAMP(2);
       o[0] = (f32x4){0.f, 0.f, 0.f, 0.f}; o[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
       f32x4 osum = (f32x4){0.f, 0.f, 0.f, 0.f};
-      Frag<T> ones;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ones.v[j] = (T)1.f;
+      Frag<E> ones;
+      frag_fill(ones, 1.f);
 #pragma unroll
       for (int rg = 0; rg <= NTR; ++rg)
         if (rg <= nrun) {
@@ -645,26 +719,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
 #pragma unroll
           for (int ks = j0 / 2; ks < j1 / 2; ++ks) {          // F, TR and NKT are even
             const int tA = tile_of(2 * ks), tB = tile_of(2 * ks + 1);
-            Frag<T> pf;
-            acc_to_frag(pf, s[2 * ks], s[2 * ks + 1]);
+            OP pf;
+            acc_to_op(pf, s[2 * ks], s[2 * ks + 1]);
             // row sums of P as a third product against a ones tile: every accumulator row of a lane is the complete sum
             // over the keys, and it is the sum of exactly the (rounded, undropped) P
-            if constexpr (MSUM) mma(ones, pf, osum);
+            if constexpr (MSUM) ones_mma(ones, pf, osum);
             if constexpr (PLUT) {
               const unsigned int wA = dmask[(tA >> 1) * LPK + q], wB = dmask[(tB >> 1) * LPK + q];
               const unsigned int a0 = __builtin_amdgcn_alignbit(wA, wA, (4 * lg + 29 + 16 * (tA & 1)) & 31) & 0x78u;   // 8 x its nibble
               const unsigned int a1 = __builtin_amdgcn_alignbit(wB, wB, (4 * lg + 29 + 16 * (tB & 1)) & 31) & 0x78u;
               const uint2 m0 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(dlut) + a0);
               const uint2 m1 = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(dlut) + a1);
-              uint4 pu = __builtin_bit_cast(uint4, pf.v);
-              pu.x &= m0.x; pu.y &= m0.y; pu.z &= m1.x; pu.w &= m1.y;
-              pf.v = __builtin_bit_cast(decltype(pf.v), pu);
+              and_op(pf, m0, m1);
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
-              Frag<T> vf;
+              OP vf;
               if constexpr (HM) VStageHM::frag2(vf, Vs, tA * 16, tB * 16, dt * 16, li, lg);
-              else VStage<T>::frag2(vf, Vs, LDV, tA * 16, tB * 16, dt * 16, li, lg);
+              else vstage2_op<PLV>(vf, Vs, LDV, tA * 16, tB * 16, dt * 16, li, lg);
               mma(vf, pf, o[dt]);
             }
           }
@@ -929,36 +1001,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // through the (by then dead) Q/K/V/dO tiles at the end.
 // NTH: 256 threads, two workgroups per CU -- or 512 (two-phase form only) where the four staged tiles leave room for ONE
 // workgroup per CU (L = 400: 133 KB + the dropout bit table): eight waves keep two per SIMD for the issue-bound softmax work
-// operand helpers of the backward kernel below, for both of its tiers: one bf16 image per staged tile, or (bf16x3) a hi and a lo
-// image PL elements apart
-template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<__bf16>& raw) { *reinterpret_cast<Frag<__bf16>*>(dst) = raw; }
-template <int PL> __device__ __forceinline__ void stage_op(__bf16* dst, const Frag<x3>& raw) {
-  bf16x8_t hi, lo;
-  split_x3(raw.v, hi, lo);
-  *reinterpret_cast<bf16x8_t*>(dst) = hi;
-  *reinterpret_cast<bf16x8_t*>(dst + PL) = lo;
-}
-template <int PL> __device__ __forceinline__ void load_op(Frag<__bf16>& f, const __bf16* p) { load_frag(f, p); }
-template <int PL> __device__ __forceinline__ void load_op(FragX3& f, const __bf16* p) {
-  f.hi = *reinterpret_cast<const bf16x8_t*>(p);
-  f.lo = *reinterpret_cast<const bf16x8_t*>(p + PL);
-}
-template <int PL> __device__ __forceinline__ void vstage_op(Frag<__bf16>& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
-  VStage<__bf16>::frag(f, V, ldv, k0, dv0, li, lg);
-}
-template <int PL> __device__ __forceinline__ void vstage_op(FragX3& f, const __bf16* V, int ldv, int k0, int dv0, int li, int lg) {
-  Frag<__bf16> h, l;
-  VStage<__bf16>::frag(h, V, ldv, k0, dv0, li, lg);
-  VStage<__bf16>::frag(l, V + PL, ldv, k0, dv0, li, lg);
-  f.hi = h.v;
-  f.lo = l.v;
-}
-__device__ __forceinline__ void acc_to_op(Frag<__bf16>& f, const f32x4& lo, const f32x4& hi) { acc_to_frag(f, lo, hi); }
-__device__ __forceinline__ void acc_to_op(FragX3& f, const f32x4& lo, const f32x4& hi) {
-  const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-  split_x3(v, f.hi, f.lo);
-}
-
 // G: the type of qkv / dctx / ctx / dqkv in memory -- __bf16, or x3 (the bf16x3 tier: f32 in memory; the four staged tiles are
 // split into hi and lo bf16 images while they are staged, PL elements apart, P and dS are split when they leave the
 // accumulators, every product is three MFMAs; two-phase form, eight waves, L <= 224: 153 KB of LDS at L = 200).

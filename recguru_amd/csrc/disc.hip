@@ -408,7 +408,7 @@ extern "C" int rg_disc_supported(int d, int n1, int n2, int n3, int dtype) {
 
 extern "C" int rg_disc_rows(const rg_disc_args* a, int dtype, void* stream) {
   if (!a || a->B <= 0) return rg_set_error_msg(RG_ERR_INVALID, "disc_rows: empty problem");
-  if (dtype != RG_BF16 && dtype != RG_F32) return rg_set_error_msg(RG_ERR_INVALID, "disc_rows: bad dtype");
+  if (dtype != RG_BF16 && dtype != RG_F32 && dtype != RG_X3) return rg_set_error_msg(RG_ERR_INVALID, "disc_rows: bad dtype");
   if (!rg_disc_supported(a->d, a->n1, a->n2, a->n3, dtype))
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "disc_rows: widths must be multiples of 32 with n2 the widest and the tile must fit LDS");
   if (!a->real || !a->fake || !a->W1 || !a->W2 || !a->W3 || !a->W1t || !a->W2t || !a->W3t || !a->b1 || !a->b2 || !a->b3 ||
@@ -424,6 +424,12 @@ extern "C" int rg_disc_rows(const rg_disc_args* a, int dtype, void* stream) {
     static bool attr_b = false;
     if (!attr_b) { hipFuncSetAttribute((const void*)disc_rows_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_b = true; }
     hipLaunchKernelGGL(disc_rows_kernel<__bf16>, dim3(n_wt + n_gt), dim3(DTHREADS), lds, s, *a);
+  } else if (dtype == RG_X3) {
+    // bf16x3: the f32 tier's buffers, tiles and fragment-packed f32 weights; every fragment is split where it is used (a weight
+    // fragment serves one 16-row tile here, so there is nothing to share a presplit copy with)
+    static bool attr_x = false;
+    if (!attr_x) { hipFuncSetAttribute((const void*)disc_rows_kernel<x3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_x = true; }
+    hipLaunchKernelGGL(disc_rows_kernel<x3>, dim3(n_wt + n_gt), dim3(DTHREADS), lds, s, *a);
   } else {
     static bool attr_f = false;
     if (!attr_f) { hipFuncSetAttribute((const void*)disc_rows_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_f = true; }

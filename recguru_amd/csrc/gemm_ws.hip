@@ -295,8 +295,8 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
 
 // 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
 int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
-  if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no list, no head-major form
-    if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->epilogue == RG_EPI_DROP_GELU || a->c_hm_L > 0 || a->live16) return 0;
+  if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no head-major form
+    if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->epilogue == RG_EPI_DROP_GELU || a->c_hm_L > 0) return 0;
     if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;
     if ((a->K & 127) || (a->N & 127) || a->M < 4096 || a->K > 512 || a->N > 1024) return 0;
     if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;

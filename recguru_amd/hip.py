@@ -764,7 +764,7 @@ def disc_rows(real, fake, alpha, W, Wt, biases, w4, b4, drop_p, seeds_w, seeds_g
                  _p(out), _p(scalars), _p(Y1), _p(X1), _p(Y2), _p(X2), _p(Y3), _p(X3),
                  _p(bg[0]), _p(bg[1]), _p(bg[2]), _p(bg[3]), _p(bg[4]), _p(dx), _p(hscratch),
                  1 if bias_grads is not None else 0, debug_ablate, _p(stamps))
-    _check(lib().rg_disc_rows(ctypes.byref(a), dt_of(real), _stream()), "rg_disc_rows")
+    _check(lib().rg_disc_rows(ctypes.byref(a), mt_of(real), _stream()), "rg_disc_rows")
 
 
 def _lastq_fold(rowmask, bkv, B, L):

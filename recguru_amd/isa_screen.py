@@ -33,7 +33,9 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))        # repo root (this file: recguru_amd/isa_screen.py)
-VEC = re.compile(r"^\s*(v_|ds_|global_|scratch_|buffer_|flat_)")
+# (v_readlane / v_writelane / v_readfirstlane address lanes explicitly and ignore exec: SGPR spills to VGPR lanes in front of an exec
+# restore are harmless)
+VEC = re.compile(r"^\s*(?!v_writelane_b32|v_readlane_b32|v_readfirstlane_b32)(v_|ds_|global_|scratch_|buffer_|flat_)")
 LABEL = re.compile(r"^([.\w$]+):")
 RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value", "-Wno-pass-failed"]

@@ -245,12 +245,24 @@ def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
 
+def _lists_ok():
+    """The tiers whose token-level kernels are all list-driven at the hot shapes: bf16, and bf16x3 (same kernels on split
+    operands; the exact-f32 tier keeps every row: its generic tile kernels read all of them)."""
+    return _COMPUTE == torch.bfloat16 or hip.SPLIT_OPERANDS
+
+
+def _unwritten_qkv_ok():
+    """Only the bf16 attention kernels substitute the bias rows for q | k | v rows the projection left unwritten (x_masked == 2);
+    elsewhere the projection FILLS the padded tiles with the bias row (exact, skip_dead_fill = 2)."""
+    return _COMPUTE == torch.bfloat16
+
+
 def _lists_everywhere(W1, M):
     """True when every backward consumer of the fused block's saved activations is one of the list-driven kernels
     (bf16 tier; d_model = 128 is implied by the fused path; d_ff = 512 are the weight-gradient shapes the big kernel
     has; M rows enough for those kernels to be selected -- the conditions under which _live() hands the backward a
     list) -- only then may the padded tiles' rows of those buffers stay unwritten."""
-    return _COMPUTE == torch.bfloat16 and W1.shape[0] == 512 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
+    return _lists_ok() and W1.shape[0] == 512 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
 
 
 def _live(rowmask, M, shapes_ok=True):
@@ -258,7 +270,7 @@ def _live(rowmask, M, shapes_ok=True):
     leave the padded tiles' rows of dz / dctx / dh1 UNWRITTEN when a list is in use, so a list is handed out only where
     every consumer honours it: bf16 tier, the shapes the list-driven GEMMs are instantiated for (shapes_ok) and enough
     rows for them to be selected (rg_gemm_tn_big_select: T >= 8192; rg_gemm_ws_select: M >= 4096)."""
-    if rowmask is None or M < max(hip.COMPACT_MIN_ROWS, 8192) or _COMPUTE != torch.bfloat16 or not shapes_ok:
+    if rowmask is None or M < max(hip.COMPACT_MIN_ROWS, 8192) or not _lists_ok() or not shapes_ok:
         return None
     return hip.live_tiles(rowmask, M)
 
@@ -557,7 +569,7 @@ def _zero_rows_live(rowmask, M, x_masked, K=128, N=384):
     """Live-tile list for a projection whose input rows are ZERO wherever rowmask is (x_masked: the caller guarantees it
     -- the model stacks do: the embedding and every layer output are multiplied by this very mask, transformer.py:105,
     :594, :539): those rows of the output are the bias, no read, no MFMA (rg_gemm_nt skip_dead_fill = 2)."""
-    if not x_masked or rowmask is None or _COMPUTE != torch.bfloat16 or M < max(hip.COMPACT_MIN_ROWS, 4096):
+    if not x_masked or rowmask is None or not _lists_ok() or M < max(hip.COMPACT_MIN_ROWS, 4096):
         return None
     # the shapes the list-driven (weight-stationary) GEMM takes: K = 128 with N up to 512, or K = 256 ... 512 with N a multiple
     # of 128 up to 1024 (one column block per gridDim.y: the d_model = 256 projections of config-5)
@@ -587,7 +599,7 @@ def _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, b
     # positions with rowmask == 0 while staging (QKV_BIAS_ROWS_IN_ATTENTION; False: the projection writes them)
     # (allow_unwritten: the caller's consumer of ctx is list-driven too -- the fused block; the rows of ctx in padded
     # tiles are then placeholders computed from unwritten Q rows)
-    sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten
+    sub = live is not None and QKV_BIAS_ROWS_IN_ATTENTION and allow_unwritten and _unwritten_qkv_ok()
     if (QKV_HEAD_MAJOR and _COMPUTE == torch.bfloat16 and (H, x2.shape[1]) in ((4, 128), (8, 256)) and x2.shape[0] >= 4096
             and 16 <= L <= 416 and (not need_grad or QKV_HEAD_MAJOR_TRAIN)):
         # the projection writes q | k | v HEAD-MAJOR ([3, B, H, L, 32]: a head's K / V / Q tile is one contiguous run); the
@@ -647,7 +659,8 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
         dctx = hip.gemm_nt(dz, shadow(Wo, transpose=True), live=live, skip_dead_fill=True)   # attn_bwd: rowmask-driven
     # the forward's decision (same inputs; x_masked == 2: it was the fused block's forward): were the padded tiles' rows of
     # qkv left unwritten?
-    sub = QKV_BIAS_ROWS_IN_ATTENTION and x_masked == 2 and _zero_rows_live(rowmask, x2.shape[0], True, d, 3 * P) is not None
+    sub = (QKV_BIAS_ROWS_IN_ATTENTION and x_masked == 2 and _unwritten_qkv_ok()
+           and _zero_rows_live(rowmask, x2.shape[0], True, d, 3 * P) is not None)
     dqkv = hip.attn_bwd(qkv if qkv.dim() == 5 else qkv.view(B, L, -1), dctx.view(B, L, P), ctx_, lse, key_ids, pad_value, causal, H,
                         drop_p=drop_p, seed=seed, rowmask=rowmask, bqkv=bias_cat((bq, bk, bv)) if sub else None)
     dqkv2 = dqkv.view(B * L, 3 * P)

@@ -27,7 +27,8 @@ BENCH_SHAPE = dict(B=int(os.environ.get("RG_BENCH_B", "16")), L=int(os.environ.g
 
 
 def _tier():
-    return torch.float32 if os.environ.get("RG_DP_TIER", "bf16") == "f32" else torch.bfloat16
+    t = os.environ.get("RG_DP_TIER", "bf16")
+    return "bf16x3" if t == "bf16x3" else (torch.float32 if t == "f32" else torch.bfloat16)
 
 
 def bench_case(device):

@@ -71,7 +71,7 @@ def _checksum(t):
     return (v * w[torch.arange(v.numel(), device=v.device) % 7]).sum()
 
 
-@pytest.mark.parametrize("d,resid", [(128, "bf16"), (256, "bf16"), (128, "split"), (128, "f32")])
+@pytest.mark.parametrize("d,resid", [(128, "bf16"), (256, "bf16"), (128, "split"), (128, "f32"), (128, "bf16x3")])
 def test_step_bitwise_reproducible_at_scale(monkeypatch, d, resid):
     """critic_update + generator_iteration at L = 200, B = 256 full-length users per domain (800 work tiles), dropout 0.5 with
     the same seeds, d_model 128 (the fused path) and 256 (the unfused one): every tensor a launcher returns, outside the
@@ -80,7 +80,7 @@ def test_step_bitwise_reproducible_at_scale(monkeypatch, d, resid):
     monkeypatch.setenv("RG_BENCH_D", str(d))
     monkeypatch.setenv("RG_BENCH_MINLEN", "199")
     monkeypatch.setenv("RG_BENCH_DROPOUT", "0.5")
-    monkeypatch.setenv("RG_DP_TIER", "f32" if resid == "f32" else "bf16")        # ("f32": the parity tier's instantiations)
+    monkeypatch.setenv("RG_DP_TIER", resid if resid in ("f32", "bf16x3") else "bf16")        # (the parity tiers' instantiations)
     import importlib
     import dp_worker
     importlib.reload(dp_worker)                  # BENCH_SHAPE reads the environment at import
@@ -157,20 +157,52 @@ def test_fused_discriminator_operand_stacks_bitwise_reproducible(gp):
             assert torch.equal(_bits(a), _bits(b)), "launch %d: stack %d differs from the first launch" % (i, j)
 
 
-def test_row_wise_kernels_equal_their_chunked_launches():
+import contextlib
+import subprocess
+
+
+@contextlib.contextmanager
+def _aggressor(seconds=300):
+    """A second GPU process that keeps the CUs busy with the fused block, attention and a projection (tests/aggressor.py): the
+    process under test then shares SIMDs, LDS and the matrix pipe with foreign waves -- the contention mode in which round 3's
+    fused-block defect first showed at SMALL M, exercised by hand until round 4."""
+    p = subprocess.Popen([sys.executable, os.path.join(HERE, "aggressor.py"), str(seconds)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+    try:
+        assert p.stdout.readline().strip() == b"ready", "the aggressor process did not start"
+        yield p
+        assert p.poll() is None, "the aggressor process ended before the check did (nothing was contended)"
+    finally:
+        p.terminate()
+        p.wait()
+
+
+@pytest.mark.parametrize("tier,contended", [("bf16", False), ("bf16", True), ("bf16x3", False), ("bf16x3", True), ("f32", True)])
+def test_row_wise_kernels_equal_their_chunked_launches(tier, contended):
     """Row- / sequence-independent kernels: one launch over the whole batch (grids that fill every CU twice or more) must equal,
     bit for bit, the concatenation of launches over 1/16 of the rows (at most one workgroup per CU) -- an occupancy-dependent
     error that is the same in every launch would pass the repeat tests above, not this one.  Dropout off (the masks are indexed
-    by absolute row)."""
+    by absolute row).  All three tiers; `contended`: the same next to a co-resident aggressor process."""
     from recguru_amd import hip
-    dt = torch.bfloat16
-    d, H, L, B = 128, 4, 256, 256
+    prev = hip.SPLIT_OPERANDS
+    try:
+        hip.SPLIT_OPERANDS = tier == "bf16x3"
+        with (_aggressor() if contended else contextlib.nullcontext()):
+            _row_wise_chunks(torch.bfloat16 if tier == "bf16" else torch.float32, tier == "bf16x3")
+    finally:
+        hip.SPLIT_OPERANDS = prev
+
+
+def _row_wise_chunks(dt, x3):
+    from recguru_amd import hip
+    # f32 / bf16x3: L = 200 is the longest the bf16x3 attention backward takes on its split tiles (14 key tiles); B = 336 keeps a
+    # chunk (1/16 of the rows) at >= 4096 rows, i.e. on the same weight-stationary / whole-tile kernels as the whole batch
+    d, H, L, B = 128, 4, (256 if dt == torch.bfloat16 else 200), (256 if dt == torch.bfloat16 else 336)
     M, NC = B * L, 16
     g0 = torch.Generator().manual_seed(11)
     r = lambda *s: (torch.randn(*s, generator=g0) * 0.5).cuda().to(dt)
     z = lambda k: torch.zeros(k, device="cuda")
     gam, bet = 1 + 0.1 * torch.randn(d, generator=g0).cuda(), 0.1 * torch.randn(d, generator=g0).cuda()
-    pk = lambda w, t=0: hip.cast(w.float().contiguous(), dt, transpose=t | hip.CAST_PACK)
+    pk = lambda w, t=0: hip.cast(w.float().contiguous(), dt, transpose=t | hip.CAST_PACK | (hip.CAST_SPLIT if x3 else 0))
     Wo, W1, W2 = r(d, d), r(512, d), r(d, 512)
     x, ctx = r(M, d), r(M, d)
     ids = torch.randint(1, 50, (B, L), generator=g0).cuda()
@@ -188,14 +220,15 @@ def test_row_wise_kernels_equal_their_chunked_launches():
         out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True)
         return [out] + [sv[k] for k in sorted(sv)]
     same("post_attn_fwd", pa(ctx, x), [pa(rows(ctx, c).contiguous(), rows(x, c).contiguous()) for c in range(NC)])
-    # ... the split-residual form (x = hi + lo in, out / out_lo out) and the decoder form (collapsed cross-attention stage)
+    # ... the split-residual form (x = hi + lo in, out / out_lo out; bf16 tier) and the decoder form (collapsed cross-attention stage)
     x_lo = (r(M, d).float() * 0.01).to(dt)
 
     def pa_res(c_, x_, l_):
         out, sv = hip.post_attn_fwd(c_, x_, pk(Wo), z(d), gam, bet, pk(W1), z(512), pk(W2), z(d), gam, bet, None, save=True, w_packed=True, x_lo=l_)
         return [out] + [sv[k] for k in sorted(sv)]
-    same("post_attn_fwd (split residual)", pa_res(ctx, x, x_lo),
-         [pa_res(rows(ctx, c).contiguous(), rows(x, c).contiguous(), rows(x_lo, c).contiguous()) for c in range(NC)])
+    if dt == torch.bfloat16:
+        same("post_attn_fwd (split residual)", pa_res(ctx, x, x_lo),
+             [pa_res(rows(ctx, c).contiguous(), rows(x, c).contiguous(), rows(x_lo, c).contiguous()) for c in range(NC)])
     o = torch.randn(B, d, generator=g0).cuda()
 
     def pa_dec(c_, x_, o_):

@@ -54,23 +54,6 @@ def _run_ranks(argv, world=2, backend="gloo", extra_env=None, timeout=900):
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
 
 
-def _twice(fn):
-    """The gloo tests put BOTH rank processes on this box's one GPU, where they time-share the CUs with each other and with the
-    test process -- the setting in which round 3's fused-block defect showed up once in ~15 suite runs, and in
-    which one further unexplained failure of the loss-curve test was seen in ~20.  A failure here must reproduce to count: the
-    check is run a second time on fresh rank processes, and the first failure is printed either way."""
-    import functools
-
-    @functools.wraps(fn)
-    def wrapped(*a, **k):
-        try:
-            return fn(*a, **k)
-        except AssertionError as e:
-            sys.stderr.write("\n[test_dp_hip_gpu] first attempt of %s failed, retrying once:\n%s\n" % (fn.__name__, str(e)[:2000]))
-            return fn(*a, **k)
-    return wrapped
-
-
 def _compare_grads(got, gD, gG, rtol, atol_of_max):
     n = 0
     for pre, ref in (("D.", gD), ("G.", gG)):
@@ -91,7 +74,6 @@ def _reset_ops():
 
 
 @pytest.mark.parametrize("name", ["case1"])
-@_twice
 def test_dp2_hip_matches_full_batch(name, tmp_path):
     from dp_worker import run_steps
     out = os.path.join(str(tmp_path), "rank0.npz")
@@ -106,7 +88,6 @@ def test_dp2_hip_matches_full_batch(name, tmp_path):
 
 
 @pytest.mark.parametrize("tier", ["bf16", "f32"])
-@_twice
 def test_dp2_hip_bench_shape(tier, tmp_path, capsys):
     """The measured tier under DP at the bench shape (L=200, d=128, N=3, V=100k, k=30; B=16 split 2 x 8): the two 51 MB
     embedding-table gradients go through DataParallel.begin_sync (asynchronous, under the other domain's backward) and the
@@ -136,11 +117,20 @@ def test_dp2_hip_bench_shape(tier, tmp_path, capsys):
     assert _compare_grads(got, gD, gG, 1e-3 if tier == "bf16" else 1e-4, 1e-4 if tier == "bf16" else 2e-5) > 40
 
 
-@_twice
 def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
     """"1 vs 2 ranks, same global batch, 20-step loss curve equal within fp32 tolerance (dropout 0)" -- 20
     steps of train_recon_x's body and 3 phase-2 iterations (15 critic updates + 3 generator updates) of the shipped
-    functions on the loss-curve fixture's batches, f32 tier."""
+    functions on the loss-curve fixture's batches, f32 tier.
+
+    What "equal" can mean here (round 4: profiles/r04/determinism/, tools/dp_curve_stress.py, tools/curve_trace.py).  The
+    parameter gradients and loss sums are float-atomic sums, so two runs of the SAME single-rank process differ in their last
+    bits; every other launcher returns identical bits on identical inputs (curve_trace: 0 exceptions in 4168 launches x 10 runs).
+    Phase 1 keeps those differences at 1e-6.  Phase 2 does not: the gradient penalty goes through ReLU masks [h > 0] and Adam
+    turns rounding-level gradients into +-lr steps, and 360 runs of this fixture fall into FOUR discrete trajectories -- D_cost
+    after the third iteration within 4e-7, 6e-6, 1.7e-5 or 1.45e-3 of run 0, the last one in 4 of 119 single-rank runs alone, 11 of
+    120 next to a second GPU process and 0 of 120 two-rank runs: the "one further unexplained failure in ~20" of round 3, which
+    the retry decorator of that round hid.  No retry now: phase 1 and the reconstruction losses are held tightly, the W-GAN scalars
+    and the discriminator's last hidden layer to twice the spread a single rank shows against itself."""
     from dp_worker import run_curve
     out = os.path.join(str(tmp_path), "curve.npz")
     _run_ranks(["curve", "curves1", out])
@@ -156,17 +146,19 @@ def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
     np.testing.assert_allclose(got["p1"], p1, rtol=2e-5, atol=1e-6)
     # phase 2: the gradient penalty goes through ReLU masks [h > 0] and Adam turns rounding-level gradients into +-lr
     # steps, so two f32 summation orders drift apart a little more than rounding ("loss curves")
-    np.testing.assert_allclose(got["p2"][:, 3:], p2[:, 3:], rtol=1e-4, atol=1e-6)
-    np.testing.assert_allclose(got["p2"][:, :3], p2[:, :3], rtol=0, atol=2e-4)
-    # parameters after the 20 + 18 optimizer steps.  Adam turns the rounding-level differences between two summation orders
-    # into different +-lr steps on elements whose gradient is within rounding of zero, so a small fraction of
-    # the elements may differ by a few lr (here: 0.1 % of the discriminator's last hidden layer, up to 8 lr after 15 steps);
-    # everything else agrees closely
+    np.testing.assert_allclose(got["p2"][:, 3:], p2[:, 3:], rtol=1e-4, atol=1e-6)      # (worst branch: 6.4e-5 absolute on losses of ~2)
+    np.testing.assert_allclose(got["p2"][:, :3], p2[:, :3], rtol=0, atol=3e-3)         # 2 x the widest single-rank branch (1.45e-3)
+    # parameters after the 20 + 18 optimizer steps.  The generator's are smooth (reconstruction gradients dominate: <= 9e-4 of max
+    # in the widest branch); the discriminator's are where the branches differ -- 15 Adam steps of +-lr on rounding-level
+    # gradients: 6.3e-3 of max in main.3.weight between two runs of ONE rank -- so they get a sanity bound only
     for k, w in keep.items():
         d = np.abs(got["w." + k] - w)
         scale = float(np.abs(w).max())
-        assert float((d > 2e-3 * scale).mean()) < 0.005, (k, float((d > 2e-3 * scale).mean()))
-        assert float(d.max()) <= 3.5e-3 + 2e-3 * scale, (k, float(d.max()))
+        if k.startswith("main."):
+            assert float(d.max()) <= 2e-2 * scale, (k, float(d.max()) / scale)
+        else:
+            assert float(d.max()) <= 3e-3 * scale, (k, float(d.max()) / scale)
+            assert float((d > 1e-3 * scale).mean()) < 0.005, (k, float((d > 1e-3 * scale).mean()))
 
 
 def _two_gpus():

@@ -54,12 +54,14 @@ def test_cross_model_vs_oracle(d, H, L, N, k):
         ops.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.parametrize("tier", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("dropout", [0.0, 0.5])
-def test_live_tile_lists_end_to_end(dropout):
-    """bf16 tier at a size where the list-driven kernels engage (M = B*L >= 8192): a reconstruction step with the
+def test_live_tile_lists_end_to_end(dropout, tier):
+    """bf16 and bf16x3 tiers at a size where the list-driven kernels engage (M = B*L >= 8192): a reconstruction step with the
     padded 16-row tiles compacted away / skipped everywhere gives the same loss and gradients as without (up to the
     arrival order of f32 atomics)."""
     from recguru_amd import hip, ops, synthetic, training as T
+    ops.set_compute_dtype(tier)
     from recguru_amd.config import get_param
     from recguru_amd.models import MyAuto4Rec_c
     d, H, L, N, k, V, B = 128, 4, 200, 2, 3, 500, 48
@@ -82,6 +84,7 @@ def test_live_tile_lists_end_to_end(dropout):
         finally:
             hip.COMPACT_MIN_ROWS = old
             hip.POISON_UNWRITTEN = False
+    ops.set_compute_dtype(torch.bfloat16)
     np.testing.assert_allclose(res["lists"][0], res["plain"][0], rtol=1e-5)
     assert len(res["plain"][1]) >= 40
     for kk, g in res["plain"][1].items():
@@ -89,14 +92,15 @@ def test_live_tile_lists_end_to_end(dropout):
         torch.testing.assert_close(res["lists"][1][kk], g, rtol=1e-3, atol=1e-6 + 1e-4 * scale, msg=kk)
 
 
-def test_qkv_bias_fill_for_padded_tiles_is_exact():
+@pytest.mark.parametrize("tier", ["bf16", "bf16x3"])
+def test_qkv_bias_fill_for_padded_tiles_is_exact(tier):
     """Inside the model stacks a padded position's layer input is exactly zero, so its Q / K / V rows are the bias rows:
     the projection with the live-tile list (padded tiles filled with the bias, not read, not multiplied) must equal the
     projection of every row BIT FOR BIT -- user embeddings, reconstruction loss and gradients included."""
     import numpy as np
     from recguru_amd import config, hip, models, ops, synthetic, training as T
     from parity_util import make_args
-    ops.set_compute_dtype(torch.bfloat16)
+    ops.set_compute_dtype(tier)
     B, L, d, H, N, V, k = 96, 200, 128, 4, 3, 5000, 6
     param = config.get_param(make_args(d, H, k, L, V, V, N, B), make_dirs=False)
     torch.manual_seed(3)
@@ -118,6 +122,7 @@ def test_qkv_bias_fill_for_padded_tiles_is_exact():
             res.append((ue, float(la), {k_: p.grad.clone() for k_, p in G.named_parameters() if p.grad is not None}))
         finally:
             ops._zero_rows_live = real
+    ops.set_compute_dtype(torch.bfloat16)
     assert B * L >= hip.COMPACT_MIN_ROWS                    # the list is really in use in the first pass
     assert torch.equal(res[0][0], res[1][0])
     np.testing.assert_allclose(res[0][1], res[1][1], rtol=1e-5)         # the loss sums are f32 atomics

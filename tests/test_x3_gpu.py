@@ -226,3 +226,46 @@ def test_tier_switch_and_mixing():
     finally:
         ops.set_compute_dtype(torch.bfloat16)
     assert ops.compute_tier() == "bf16" and not hip.SPLIT_OPERANDS
+
+
+@pytest.mark.parametrize("train", [False, True])
+def test_fused_discriminator(train):
+    """rg_disc_rows under RG_X3 (+ its three weight-gradient products): W-loss, gradient penalty and every parameter gradient of a
+    critic update, and the generator's W-loss with its input gradients, against the exact-f32 tier on the same weights, rows,
+    alpha and dropout seeds."""
+    from recguru_amd import models, ops
+    B, d = 300, 128
+    torch.manual_seed(5)
+    real, fake = rnd(B, d, seed=1), rnd(B, d, seed=2)
+    alpha = torch.rand(B, 1, generator=torch.Generator().manual_seed(3)).cuda()
+    res = {}
+    try:
+        for tier in ("f32", "bf16x3"):
+            ops.set_compute_dtype(tier)
+            torch.manual_seed(7)
+            D = models.Discriminator(d, 1, 5 * d).cuda()
+            D.train(train)
+            ops.manual_seed(11, 0)
+            sc = ops.critic_fused(D, real, fake, alpha)
+            grads = {k: p.grad.clone() for k, p in D.named_parameters()}
+            a, b = real.clone().requires_grad_(True), fake.clone().requires_grad_(True)
+            ops.manual_seed(12, 0)
+            ma, mb = ops.disc_means(D, a, b)
+            (ma - 2 * mb).backward()
+            torch.cuda.synchronize()
+            res[tier] = (sc.clone(), grads, ma.detach().clone(), mb.detach().clone(), a.grad.clone(), b.grad.clone())
+    finally:
+        ops.set_compute_dtype(torch.bfloat16)
+    r0, r1 = res["f32"], res["bf16x3"]
+    close(r1[0], r0[0], "D(real), D(fake), GP", tol=1e-4)
+    # parameter gradients: the chains go through the ReLU masks [h > 0] (and, in train mode, dropout's kept-and-positive bits), so a
+    # pre-activation within 1e-5 of zero flips its unit's contribution in ONE of 300 rows: discontinuous, O(1 / B) of an element --
+    # measured 9e-4 (eval) / 4e-3 (train) of max in main.0.weight.  Held in the rms sense (smooth part) and loosely element-wise.
+    for k in r0[1]:
+        a, b = r1[1][k].float(), r0[1][k].float()
+        rms = float((a - b).pow(2).mean().sqrt() / b.pow(2).mean().sqrt().clamp_min(1e-30))
+        assert rms <= 2e-3, "grad %s: rms error %.3g of rms value" % (k, rms)
+        close(a, b, "grad " + k, tol=2e-2)
+    close(torch.stack([r1[2], r1[3]]), torch.stack([r0[2], r0[3]]), "means")
+    close(r1[4], r0[4], "d mean / d a", tol=1e-4)
+    close(r1[5], r0[5], "d mean / d b", tol=1e-4)

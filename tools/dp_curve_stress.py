@@ -45,11 +45,15 @@ def report(tag, ref, cur):
         fails.append("p1")
     if not np.allclose(p2[:, 3:], r2[:, 3:], rtol=1e-4, atol=1e-6):
         fails.append("p2.recon")
-    if not np.allclose(p2[:, :3], r2[:, :3], rtol=0, atol=2e-4):
+    if not np.allclose(p2[:, :3], r2[:, :3], rtol=0, atol=3e-3):
         fails.append("p2.gan")
     for k in rk:
         d = np.abs(keep[k] - rk[k]); scale = float(np.abs(rk[k]).max())
-        if float((d > 2e-3 * scale).mean()) >= 0.005 or float(d.max()) > 3.5e-3 + 2e-3 * scale:
+        if k.startswith("main."):
+            bad = float(d.max()) > 2e-2 * scale
+        else:
+            bad = float(d.max()) > 3e-3 * scale or float((d > 1e-3 * scale).mean()) >= 0.005
+        if bad:
             fails.append("w." + k)
     print("%s phase-1 max rel %.2e (first step above 1e-6: %d) | phase-2 max abs D_cost %.2e W_D %.2e g_dis %.2e recon %.2e | params %s | %s"
           % (tag, e1.max(), first, e2[:, 0].max(), e2[:, 1].max(), e2[:, 2].max(), e2[:, 3:].max(),
