@@ -15,7 +15,7 @@
 // bf16x3 tier (T = x3): A and C are f32 in memory; the A tile is split ONCE while it is staged (a hi and a lo bf16 tile in
 // LDS, rg_common.hip.h), the weight slice is split once per workgroup (K = 128: stationary) or per tile and chunk (K > 128:
 // the slice of the current 128-wide chunk, re-read from L2 -- a stationary K = 384 slice would be 192 VGPRs), the C tile is raw
-// f32.  One 128-column block per workgroup (gridDim.y): HBM-bound at twice the bf16 tier's bytes.
+// f32.  One 128-column block per workgroup (gridDim.x): HBM-bound at twice the bf16 tier's bytes.
 #define WS_M 64
 #define WS_LD (128 + 8)
 #define RG_X3_PLANE (WS_M * WS_LD * 2)
@@ -40,14 +40,20 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   const int li = lane & 15, lg = lane >> 4;
   const T* __restrict__ A = reinterpret_cast<const T*>(a.A);
   const T* __restrict__ W = reinterpret_cast<const T*>(a.W);
-  const T* __restrict__ aux = reinterpret_cast<const T*>(a.aux);
-  T* __restrict__ C = reinterpret_cast<T*>(a.C);
+  // (no __restrict__ on aux / C: the split-K dx product accumulates in place, aux == C -- a tile's aux rows are read before its
+  // C rows are written, by the same threads)
+  const T* aux = reinterpret_cast<const T*>(a.aux);
+  T* C = reinterpret_cast<T*>(a.C);
   const int n0 = wave * 32;
   const DropCfg drop = make_drop(a.epilogue == RG_EPI_DROP_GELU ? a.drop_p : 0.f, a.drop_seed);
-  // blockIdx.y: first 128-column block of this workgroup (N > 128 with K > 128 -- the d_model = 256 shapes of config-5: a
+  // cby: first 128-column block of this workgroup (N > 128 with K > 128 -- the d_model = 256 shapes of config-5: a
   // workgroup keeps the K x 128 slice of W of ITS column block in registers and walks the row tiles; A is re-read per block
   // from L2 / Infinity Cache)
-  const int cby = (int)blockIdx.y;
+  // Grid (column blocks, walkers): the column blocks of one walker are CONSECUTIVE workgroups, so the N / 128 workgroups that
+  // read the same rows of A run at the same time and all but the first find them in the Infinity Cache (with the walkers on the
+  // fast axis the re-reads were a whole pass over A apart: 840 MB at config-5, 420 MB in the bf16x3 tier -- HBM every time)
+  const int cby = (int)blockIdx.x;
+  const int wg = (int)blockIdx.y, nwg = (int)gridDim.y;
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: N = 3 * H * 32
   // columns q | k | v -> three tensors [B][H][L][32]; a 128-column block is four heads of one tensor -- block cb = tensor
@@ -87,11 +93,11 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // of live 16-row tiles a.live16 (rg_live_tiles) -- 4 consecutive list entries; rows of the padded tiles are not read
   // and their rows of C are written as zeros at the end.  Thread tid stages chunk i = row 16 i + (tid >> 4).
   LiveWalk lw;
-  lw.init(a.live16, a.M);
+  lw.init(a.live16, a.M, wg, nwg);
   const int nwork = a.live16 ? (lw.nlive + 3) >> 2 : ntiles;
   auto group = [&](int k, int (&g)[4]) {                 // k-th work tile of this workgroup
     if (!a.live16) {
-      const int wt = (int)blockIdx.x + k * (int)gridDim.x;
+      const int wt = wg + k * nwg;
 #pragma unroll
       for (int rt = 0; rt < 4; ++rt) g[rt] = wt * WS_M + 16 * rt;
     } else {
@@ -118,14 +124,14 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
       load_frag(axn[i], aux + (size_t)m * a.ldaux + (cby + cb) * 128 + c8);
     }
   };
-  int tile = blockIdx.x, kt_ = 0;                         // kt_: index of `tile` among this workgroup's tiles
+  int tile = wg, kt_ = 0;                                 // kt_: index of `tile` among this workgroup's tiles
   int mb[4], mbn[4];
   if (tile < nwork) {
     group(0, mb);
     prefetch(mb, 0);
     if constexpr (AUX) aux_prefetch(mb, 0);
   }
-  for (; tile < nwork; tile += gridDim.x, ++kt_) {
+  for (; tile < nwork; tile += nwg, ++kt_) {
     group(kt_ + 1, mbn);
     f32x4 acc[2][4];
 #pragma unroll
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
         frag_zero(z[cb]);
       }
     }
-    for (int j = 4 * (int)blockIdx.x; j < ndead; j += 4 * (int)gridDim.x) {
+    for (int j = 4 * wg; j < ndead; j += 4 * nwg) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if (j + i < ndead) {
@@ -287,8 +293,8 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   int grid = ny > 1 ? (768 / ny > 96 ? 768 / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
-  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(grid, ny), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(grid, ny), dim3(256), 0, s, a);
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(ny, grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(ny, grid), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
 }
@@ -313,7 +319,7 @@ int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   const int nkc = a->K / 128, ncb = a->N / 128;
   if ((nkc == 1 && ncb >= 1 && ncb <= 4) || (ncb == 1 && nkc >= 2 && nkc <= 4)) return 10 * nkc + ncb;
   // K and N both beyond 128 (d_model = 256: 256 -> 768 / 512 / 256, 512 -> 256): the <K/128, 1> instantiation once per
-  // 128-column block (gridDim.y)
+  // 128-column block (gridDim.x)
   if (nkc >= 2 && nkc <= 4 && ncb >= 2 && ncb <= 8) return 10 * nkc + 1;
   return 0;
 }

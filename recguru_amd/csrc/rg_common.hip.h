@@ -488,7 +488,11 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 struct LiveWalk {
   const int* list;
   int nlive, cap, v, blk;
-  __device__ __forceinline__ void init(const int* live16, int M) {
+  int wg, nwg;                          // this workgroup's index among the walkers and their number (default: blockIdx.x of gridDim.x)
+  __device__ __forceinline__ void init(const int* live16, int M) { init(live16, M, (int)blockIdx.x, (int)gridDim.x); }
+  __device__ __forceinline__ void init(const int* live16, int M, int wg_, int nwg_) {
+    wg = wg_;
+    nwg = nwg_;
     list = live16;
     nlive = live16 ? live16[0] : 0;
     cap = ((M + 15) >> 4) - 1;          // last valid entry index (entries past nlive are never used)
@@ -497,11 +501,11 @@ struct LiveWalk {
   }
   // first rows of the 4 row tiles of work tile `wt` = blockIdx.x + k * gridDim.x (>= M: absent)
   __device__ __forceinline__ void group(int k, int (&g)[4], int M) {
-    const int wt = (int)blockIdx.x + k * (int)gridDim.x;
+    const int wt = wg + k * nwg;
     if ((k >> 4) != blk) {              // (uniform) next block of 16 tiles
       blk = k >> 4;
       const int lane = threadIdx.x & 63;
-      const long long idx = 4ll * ((long long)blockIdx.x + (long long)gridDim.x * (16 * blk + (lane >> 2))) + (lane & 3);
+      const long long idx = 4ll * ((long long)wg + (long long)nwg * (16 * blk + (lane >> 2))) + (lane & 3);
       v = list[1 + (int)(idx < (long long)cap ? idx : (long long)cap)];
     }
 #pragma unroll
@@ -514,11 +518,11 @@ struct LiveWalk {
   template <int RT>
   __device__ __forceinline__ void group_n(int k, int (&g)[RT], int M) {
     constexpr int PER = 64 / RT, SH = RT == 4 ? 4 : (RT == 2 ? 5 : 6);
-    const int wt = (int)blockIdx.x + k * (int)gridDim.x;
+    const int wt = wg + k * nwg;
     if ((k >> SH) != blk) {             // (uniform) next block of PER work tiles
       blk = k >> SH;
       const int lane = threadIdx.x & 63;
-      const long long idx = (long long)RT * ((long long)blockIdx.x + (long long)gridDim.x * (PER * blk + lane / RT)) + (lane % RT);
+      const long long idx = (long long)RT * ((long long)wg + (long long)nwg * (PER * blk + lane / RT)) + (lane % RT);
       v = list[1 + (int)(idx < (long long)cap ? idx : (long long)cap)];
     }
 #pragma unroll

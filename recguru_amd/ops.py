@@ -490,22 +490,22 @@ class EmbedPE(_Fn):
         return ret, None, None, None, None, None
 
 
-def _mask_tag(mask):
-    return (mask.data_ptr(), mask._version, mask.numel())
-
-
 def embed_pe(table, pe, ids, mask, skip_row=-1, drop_p=0.0):
     out = EmbedPE.run(table, pe, ids, mask, skip_row, float(drop_p))
-    out._rg_masked = _mask_tag(mask)        # rows of `out` are exactly zero wherever this very mask is (masked_by())
+    # rows of `out` are exactly zero wherever this very mask is (masked_by()): the tag holds the mask OBJECT weakly (an address can be
+    # reused by a later mask of the same size once this one is collected -- ADVICE r3) and the versions of both tensors at tagging time
+    out._rg_masked = (weakref.ref(mask), mask._version, out._version)
     return out
 
 
 def masked_by(x, rowmask):
     """True when x is known to have exactly-zero rows wherever rowmask is 0: it came out of embed_pe() with this very mask
-    tensor (same storage, not written since).  What lets the model stacks enter masked_input() from their FIRST layer on;
+    tensor object, and neither x nor the mask has been written in place since.  What lets the model stacks enter masked_input() from their FIRST layer on;
     a caller's arbitrary x (the reference's EncoderM / DecoderM accept any, transformer.py:587,:520) is not assumed to be.
     RG_DEBUG=1 verifies the claim on the device."""
-    ok = rowmask is not None and getattr(x, "_rg_masked", None) == _mask_tag(rowmask)
+    tag = getattr(x, "_rg_masked", None)
+    ok = (rowmask is not None and tag is not None and tag[0]() is rowmask and tag[1] == rowmask._version
+          and tag[2] == x._version)               # the same mask object, neither it nor x written since
     if ok and _DEBUG:
         m = rowmask.reshape(x.shape[0], x.shape[1], 1).to(x.dtype)
         assert float((x.detach() * (1 - m)).abs().max()) == 0.0, "masked_by: a padded row of x is not zero"

@@ -41,7 +41,12 @@ class Adam(object):
             self.state[p] = {"step": int(st["step"]), "exp_avg": st["exp_avg"].to(p.device, torch.float32).clone(),
                              "exp_avg_sq": st["exp_avg_sq"].to(p.device, torch.float32).clone()}
         for g, gs in zip(self.param_groups, sd.get("param_groups", [])):
-            g.update({k: v for k, v in gs.items() if k != "params"})
+            # only what step() implements is taken over; a torch.optim.Adam checkpoint that relies on anything else must not load
+            # silently into different semantics
+            if gs.get("weight_decay", 0) or gs.get("amsgrad", False) or gs.get("maximize", False):
+                raise ValueError("recguru_amd.optim.Adam: weight_decay / amsgrad / maximize are not implemented (checkpoint asks for %s)"
+                                 % {k: gs[k] for k in ("weight_decay", "amsgrad", "maximize") if gs.get(k)})
+            g.update({k: gs[k] for k in ("lr", "betas", "eps") if k in gs})
         self._tables = {}                                 # device tables are rebuilt from the restored state
 
     @torch.no_grad()
