@@ -45,20 +45,28 @@ PMC_FILES = ([os.environ["RG_PMC_TRAFFIC"]] if os.environ.get("RG_PMC_TRAFFIC") 
     [os.path.join(ROOT, "profiles", "pmc_traffic.json")]
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/pmc_traffic.json, written
+# bench.py's per-launcher names that stand for several device kernels of the counter profile (bytes of one call = their sum)
+PMC_ALIASES = {"item_loss_scatter_binned_kernel": ("bin_count_kernel", "bin_scan_kernel", "bin_fill_kernel", "bin_accumulate_kernel",
+                                                   "bin_accumulate_wide_kernel"),
+               "item_loss_train_rows_kernel": ("item_loss_train_rows_kernel", "item_loss_train_online_kernel")}
+
+
+def pmc_traffic(kernel, sub=None):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (profiles/rNN/[sub/]pmc_traffic.json, written
     by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE runs of this same command, with the gfx950
     correction of MI355X_MICROARCH.md: FETCH_SIZE counts 128-B requests as 64 B, so read bytes = 2 x FETCH_SIZE).
-    None when no counter profile of this kernel has been committed."""
-    for fn in PMC_FILES:                    # the current round's counter passes first
+    sub = "c5": the counter passes of the config-5 shape.  None when no counter profile of this kernel has been committed."""
+    files = PMC_FILES if sub is None else [os.path.join(os.path.dirname(f), sub, "pmc_traffic.json") for f in PMC_FILES]
+    for fn in files:                        # the current round's counter passes first
         try:
             with open(fn) as f:
                 t = json.load(f)
         except (OSError, ValueError):
             continue
-        e = t.get("kernels", {}).get(kernel)
-        if e is not None:
-            return e.get("hbm_bytes_per_launch")
+        ks = t.get("kernels", {})
+        hit = [ks[n]["hbm_bytes_per_launch"] for n in PMC_ALIASES.get(kernel, (kernel,)) if n in ks]
+        if hit:
+            return sum(hit)
     return None
 
 
@@ -353,7 +361,7 @@ def launch_ranks(args):
     return rc if rc >= 0 else 1
 
 
-def roofline_pass(step, dtype, rank):
+def roofline_pass(step, dtype, rank, pmc_sub=None):
     """One instrumented repetition of `step` on ONE stream (no critic overlap), so that a HIP-event pair brackets its kernel
     alone and the per-kernel averages agree with rocprofv3's.  Every rank runs the step (it contains collectives); rank 0
     returns the roofline object of the dominant kernel."""
@@ -394,7 +402,7 @@ def roofline_pass(step, dtype, rank):
 
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     roof = roofline_of(name, a)
-    roof["traffic"] = pmc_traffic(name)      # HBM bytes per launch from the committed rocprofv3 --pmc passes, or None
+    roof["traffic"] = pmc_traffic(name, pmc_sub)      # HBM bytes per launch from the committed rocprofv3 --pmc passes, or None
     roof["kernels_ms_per_step"] = {k: round(v["ms"], 3) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])}
     # the kernels the north-star names explicitly, plus everything above 2 % of the step
     roof["other_kernels"] = [roofline_of(k, v) for k, v in sorted(agg.items(), key=lambda kv: -kv[1]["ms"])
@@ -423,7 +431,7 @@ def config5_leg(args, device, rank, world, dp):
     param, G, D, opt_g, opt_d, opt_rec, loaders = build(a5, device, rank, world)
     step = make_step(param, G, D, opt_g, opt_d, loaders, device, dp, a5)
     dt, t_host, out = timed(step, 1, args.config5_steps, dp, device)
-    roof = None if args.no_roofline else roofline_pass(step, args.dtype, rank)
+    roof = None if args.no_roofline else roofline_pass(step, args.dtype, rank, pmc_sub="c5")
     per_step = 12 * a5.batch * world
     peak = torch.cuda.max_memory_allocated() / 2 ** 30
     del step, loaders, G, D, opt_g, opt_d, opt_rec

@@ -21,7 +21,6 @@
 // LDS (bf16): ctx tile + g chunk + y tile (+ the h1 staging tile when saving) = 3-4 x 16 KB, XOR-swizzled rows,
 // + 8 KB of parameters and row statistics: 56-72 KB per workgroup, 2 workgroups per CU (256 VGPRs per wave allow
 // two waves per SIMD in any case).
-#define RG_X3_PLANE (64 * 128 * 2)   // bf16x3 tier: a [64 x 128] activation tile is a bf16 hi tile + a bf16 lo tile (rg_common.hip.h)
 #include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
@@ -38,7 +37,7 @@
 // conflict-free under the hardware's 16-lane service groups ({0-3, 12-15, 20-27}, ...: lanes of two lg values land in
 // complementary chunk sets); a padded row (272 B) put two lanes of every group on one bank -- 43 % of the kernel's
 // LDS cycles were bank-conflict cycles (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE).  f32 (parity tier): padded rows.
-// bf16x3 tier: T = x3p, two bf16 tiles (hi, lo) of exactly the bf16 tier's layout, RG_X3_PLANE bytes apart.
+// bf16x3 tier: T = x3p<PL>, two bf16 tiles (hi, lo) of exactly the bf16 tier's layout, PL = rows x 256 bytes apart.
 template <typename T> struct Tile {
   static constexpr int LD = sizeof(T) == 2 ? FD : FLD;          // row pitch in elements
   static __device__ __forceinline__ int off(int row, int col) {  // col: any element whose 16-byte chunk holds it
@@ -106,9 +105,8 @@ __device__ __forceinline__ void load_wset(WSet<T>& w, const T* __restrict__ W, i
 }
 
 // acc[ct][rt] += W[row0 + ct*16 + i][k] . Act[rt*16 + j][k]   (weight = A operand, activation = B operand)
-template <typename T, int RT>
-__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, const typename LdsT<T>::type* __restrict__ Act, int li, int lg) {
-  typedef typename LdsT<T>::type LT;
+template <typename T, int RT, typename LT>
+__device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, const LT* __restrict__ Act, int li, int lg) {
   // the RT token-tile fragments of k-step ks+1 are read while the MFMAs of k-step ks run (one LDS latency per GEMM
   // step instead of RT)
   typename OpT<T>::type af[2][RT];
@@ -296,23 +294,24 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // so that three to four workgroups share a CU instead of two; the per-phase stamps show a wave at 2 per SIMD spending its
 // time on exposed LDS / VALU latencies, not on the matrix pipe or the weight stream)
 template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4>
-__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : 1)) void post_attn_fwd_kernel(rg_post_attn_args a) {
-  typedef typename LdsT<T>::type LT;  // element type of the LDS tiles (T, or x3p: a hi and a lo bf16 tile)
-  static_assert(!std::is_same<T, x3>::value || RT == 4, "the split tiles are [64 x 128] (RG_X3_PLANE)");
+__global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : ((std::is_same<T, x3>::value && RT == 2) ? 2 : 1)))
+void post_attn_fwd_kernel(rg_post_attn_args a) {
   constexpr int FTM = 16 * RT;        // tokens per work tile
+  constexpr int PL = FTM * FD * 2;    // bf16x3: bytes between the hi and the lo tile
+  typedef typename LdsT<T, PL>::type LT;  // element type of the LDS tiles (T, or x3p: a hi and a lo bf16 tile)
 #ifdef RG_STAMP
   unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long t0__ = __builtin_amdgcn_s_memtime();
 #endif
   // LDS: ctx tile (later: out staging) | x tile (later: g chunk) | y tile | params | row-stat exchange | [h1 chunk]
-  constexpr int ACT_BYTES = FTM * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
+  constexpr int ACT_BYTES = FTM * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T, PL>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
   LT* Actx = reinterpret_cast<LT*>(smem);
   LT* Ag = reinterpret_cast<LT*>(smem + ACT_BYTES);
   LT* Ay = reinterpret_cast<LT*>(smem + 2 * ACT_BYTES);
   // tiles that are not matrix operands -- the residual x (parked in the g-chunk buffer) and the output on its way to HBM (in
   // the ctx tile): raw f32 in the bf16x3 tier (exact residual stream, no split work), the ordinary tile otherwise
-  typedef typename ResT<T>::type XT;
+  typedef typename ResT<T, PL>::type XT;
   XT* Ax = reinterpret_cast<XT*>(Ag);
   XT* Aout = reinterpret_cast<XT*>(Actx);
   constexpr bool KEEPY = std::is_same<T, x3>::value;     // the LayerNorm-1 output stays in registers as the FFN's residual (exact)
@@ -716,18 +715,22 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   // measured SLOWER at the bench shape -- 277 -> 292 us (encoder inference), 337 -> 365, 413 -> 467 (decoder training): the
   // per-tile fixed costs (14 barriers, two LayerNorm exchanges, the weight sets) double per row, which the third wave per
   // SIMD does not buy back.  It is only instantiated in -DRG_PA_RT2 builds (RG_PA_RT=2 selects it there) for A/B timing.
+  // bf16x3: the 64-token form holds 96 KB of split tiles -- ONE workgroup per CU, one wave per SIMD, nothing to overlap the
+  // MFMA, VALU and LDS phases of a tile with; the 32-token form (48 KB) puts two workgroups on a CU (RG_X3_PA_RT=4: the 64-token
+  // form, for A/B timing)
+  static const int x3_rt = [] { const char* e = getenv("RG_X3_PA_RT"); return (e && atoi(e) == 4) ? 4 : 2; }();
 #ifdef RG_PA_RT2
   static const int rt_env = [] { const char* e = getenv("RG_PA_RT"); return e ? atoi(e) : 0; }();
-  const int rt = dtype != RG_BF16 ? 4 : (rt_env == 2 ? 2 : 4);
+  const int rt = dtype == RG_X3 ? x3_rt : (dtype != RG_BF16 ? 4 : (rt_env == 2 ? 2 : 4));
 #else
-  const int rt = 4;
+  const int rt = dtype == RG_X3 ? x3_rt : 4;
 #endif
   const int ftm = 16 * rt;
   const int ntiles = (a->M + ftm - 1) / ftm;
   const int act = act_tile_bytes(dtype, ftm);
   const int smem = 3 * act + (8 * FD + a->dff) * 4 + 2 * ftm * 4 * 4 + 64 * 4 + (a->h1_save ? act : 0);
   const int per_cu = (160 * 1024) / smem;
-  const int cap_cu = rt == 2 ? 3 : 3;                   // (RT == 2: 3 waves per SIMD by registers)
+  const int cap_cu = dtype == RG_X3 ? 2 : 3;            // (bf16 RT == 2: 3 waves per SIMD by registers; bf16x3: 256 VGPRs, two)
   int grid = 256 * (per_cu < 1 ? 1 : (per_cu > cap_cu ? cap_cu : per_cu));
   if (grid > ntiles) grid = ntiles;
   const int dm = a->drop_p <= 0.f ? 0 : (a->drop_p == 0.5f ? 1 : 2);
@@ -744,11 +747,15 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 #ifdef RG_PA_RT2
 #define RG_PA3(T, DM, C, S, R)                                                              \
   do {                                                                                      \
-    if constexpr (sizeof(T) == 2) { if (rt == 2) RG_PA4(T, DM, C, S, R, 2); else RG_PA4(T, DM, C, S, R, 4); } \
+    if constexpr (sizeof(T) == 2 || std::is_same<T, x3>::value) { if (rt == 2) RG_PA4(T, DM, C, S, R, 2); else RG_PA4(T, DM, C, S, R, 4); } \
     else RG_PA4(T, DM, C, S, R, 4);                                                         \
   } while (0)
 #else
-#define RG_PA3(T, DM, C, S, R) RG_PA4(T, DM, C, S, R, 4)
+#define RG_PA3(T, DM, C, S, R)                                                              \
+  do {                                                                                      \
+    if constexpr (std::is_same<T, x3>::value) { if (rt == 2) RG_PA4(T, DM, C, S, R, 2); else RG_PA4(T, DM, C, S, R, 4); } \
+    else RG_PA4(T, DM, C, S, R, 4);                                                         \
+  } while (0)
 #endif
 #define RG_PA2(T, DM, C, S)                                                                       \
   do {                                                                                            \
@@ -790,13 +797,14 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
 // arrive -- the staging layout (16 lanes x 8 features per row) is rg_ln_bwd's; dz never leaves the chip.
 template <typename T, bool LNF>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? 2 : 1)) void ffn_bwd_data_kernel(rg_ffn_bwd_args a) {
-  typedef typename LdsT<T>::type LT;
-  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
+  constexpr int PL = FT_M * FD * 2;
+  typedef typename LdsT<T, PL>::type LT;
+  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T, PL>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
   LT* Adl = reinterpret_cast<LT*>(smem);
   // dz (the residual gradient), the h1 chunk (read element-wise only) and dy on its way out are not matrix operands: raw f32
   // tiles in the bf16x3 tier (rg_common.hip.h x3r), the ordinary tile otherwise
-  typedef typename ResT<T>::type XT;
+  typedef typename ResT<T, PL>::type XT;
   XT* Adz = reinterpret_cast<XT*>(smem + ACT_BYTES);
   LT* Adh = reinterpret_cast<LT*>(smem + 2 * ACT_BYTES);
   XT* Ah = reinterpret_cast<XT*>(smem + 3 * ACT_BYTES);
@@ -1095,11 +1103,12 @@ extern "C" int rg_ffn_bwd_data(const rg_ffn_bwd_args* a, int dtype, void* stream
 // in registers (one weight set, loaded once per workgroup).  HBM-bound: 2 tiles of LDS, ~100 VGPRs, 4 workgroups per CU.
 template <typename T>
 __global__ __launch_bounds__(256, 2) void attn_out_bwd_kernel(rg_attn_out_bwd_args a) {
-  typedef typename LdsT<T>::type LT;
-  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T>::PLANES;
+  constexpr int PL = FT_M * FD * 2;
+  typedef typename LdsT<T, PL>::type LT;
+  constexpr int ACT_BYTES = FT_M * Tile<LT>::LD * (int)sizeof(LT) * LdsT<T, PL>::PLANES;
   extern __shared__ __align__(16) unsigned char smem[];
   LT* Adz = reinterpret_cast<LT*>(smem);
-  typedef typename ResT<T>::type XT;                     // dctx on its way out: not a matrix operand (raw f32 in the bf16x3 tier)
+  typedef typename ResT<T, PL>::type XT;                 // dctx on its way out: not a matrix operand (raw f32 in the bf16x3 tier)
   XT* Aout = reinterpret_cast<XT*>(smem + ACT_BYTES);
   float* lnp = reinterpret_cast<float*>(smem + 2 * ACT_BYTES);      // gamma | beta | 1 / gamma
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -18,7 +18,7 @@
 // f32.  One 128-column block per workgroup (gridDim.x): HBM-bound at twice the bf16 tier's bytes.
 #define WS_M 64
 #define WS_LD (128 + 8)
-#define RG_X3_PLANE (WS_M * WS_LD * 2)
+#define WS_PLANE (WS_M * WS_LD * 2)      // bf16x3: bytes between the hi and the lo image of the A tile
 #include <type_traits>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
@@ -31,10 +31,10 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   constexpr bool X3 = std::is_same<T, x3>::value;
   static_assert(!X3 || NCB == 1, "bf16x3: one column block per workgroup");
   constexpr bool STREAM = X3 && NKC > 1;          // the weight slice of ONE chunk in registers, reloaded per tile and chunk
-  typedef typename LdsT<T>::type LT;              // A tile: T, or a hi and a lo bf16 tile
+  typedef typename LdsT<T, WS_PLANE>::type LT;    // A tile: T, or a hi and a lo bf16 tile
   typedef typename ResT<T>::type XT;              // C tile: T, or raw f32
   typedef typename OpT<T>::type OP;
-  __shared__ __align__(16) LT As[WS_M * WS_LD * LdsT<T>::PLANES];
+  __shared__ __align__(16) LT As[WS_M * WS_LD * LdsT<T, WS_PLANE>::PLANES];
   __shared__ __align__(16) XT Cs[WS_M * WS_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;

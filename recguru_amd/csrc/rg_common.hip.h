@@ -280,14 +280,14 @@ template <> struct Precise<x3> { static constexpr bool value = false; };
 
 // ---- bf16x3 with operands split ONCE (the kernels that stage their operands through LDS) --------------------------------
 // An LDS tile of the x3 tier is a PAIR of bf16 tiles, hi and lo, laid out exactly like the bf16 tier's tile (same offsets, same
-// swizzles, same bank behaviour); the lo tile sits RG_X3_PLANE bytes behind the hi tile (a per-file constant, defined before
-// this header is included).  An element is split when it is WRITTEN to the tile (staging from HBM, an accumulator leaving
+// swizzles, same bank behaviour); the lo tile sits PL bytes behind the hi tile (a template argument of the tile's address
+// type x3p<PL>, so that kernels with different tile sizes share these helpers).  An element is split when it is WRITTEN to the tile (staging from HBM, an accumulator leaving
 // the registers) -- once -- and every wave's operand-fragment read is two plain 16-byte LDS reads with no VALU work behind
 // them; weights come from the fragment-packed presplit copy rg_cast writes (hi fragment, then lo fragment, 1 KB each).
-struct x3p { unsigned short u; };                      // one bf16 slot of a split tile (the address type of such a tile)
+template <int PL> struct x3p { unsigned short u; };     // one bf16 slot of a split tile whose lo image sits PL BYTES behind the hi image
 struct FragX3 { bf16x8_t hi, lo; };                    // operand fragment, already split
-template <typename T> struct LdsT { typedef T type; static constexpr int PLANES = 1; };
-template <> struct LdsT<x3> { typedef x3p type; static constexpr int PLANES = 2; };
+template <typename T, int PL = 0> struct LdsT { typedef T type; static constexpr int PLANES = 1; };
+template <int PL> struct LdsT<x3, PL> { typedef x3p<PL> type; static constexpr int PLANES = 2; };
 template <typename T> struct OpT { typedef Frag<T> type; };
 template <> struct OpT<x3> { typedef FragX3 type; };
 __device__ __forceinline__ void mma(const FragX3& a, const FragX3& b, f32x4& c) {
@@ -301,39 +301,38 @@ __device__ __forceinline__ void load_frag(FragX3& f, const x3* p) {
   load8(v, reinterpret_cast<const float*>(p));
   split_x3(v, f.hi, f.lo);
 }
-#ifdef RG_X3_PLANE
-__device__ __forceinline__ const x3p* lo_of(const x3p* p) { return reinterpret_cast<const x3p*>(reinterpret_cast<const char*>(p) + RG_X3_PLANE); }
-__device__ __forceinline__ x3p* lo_of(x3p* p) { return reinterpret_cast<x3p*>(reinterpret_cast<char*>(p) + RG_X3_PLANE); }
-__device__ __forceinline__ void load_frag(FragX3& f, const x3p* p) {
+template <int PL> __device__ __forceinline__ const x3p<PL>* lo_of(const x3p<PL>* p) { return reinterpret_cast<const x3p<PL>*>(reinterpret_cast<const char*>(p) + PL); }
+template <int PL> __device__ __forceinline__ x3p<PL>* lo_of(x3p<PL>* p) { return reinterpret_cast<x3p<PL>*>(reinterpret_cast<char*>(p) + PL); }
+template <int PL> __device__ __forceinline__ void load_frag(FragX3& f, const x3p<PL>* p) {
   f.hi = *reinterpret_cast<const bf16x8_t*>(p);
   f.lo = *reinterpret_cast<const bf16x8_t*>(lo_of(p));
 }
 // 8 raw elements (as loaded from HBM) -> the tile
-__device__ __forceinline__ void stage8(x3p* dst, const Frag<x3>& raw) {
+template <int PL> __device__ __forceinline__ void stage8(x3p<PL>* dst, const Frag<x3>& raw) {
   bf16x8_t hi, lo;
   split_x3(raw.v, hi, lo);
   *reinterpret_cast<bf16x8_t*>(dst) = hi;
   *reinterpret_cast<bf16x8_t*>(lo_of(dst)) = lo;
 }
 // ... and back: hi + lo (exact in f32: the two parts do not overlap)
-__device__ __forceinline__ void unstage8(Frag<x3>& raw, const x3p* src) {
+template <int PL> __device__ __forceinline__ void unstage8(Frag<x3>& raw, const x3p<PL>* src) {
   const bf16x8_t hi = *reinterpret_cast<const bf16x8_t*>(src), lo = *reinterpret_cast<const bf16x8_t*>(lo_of(src));
 #pragma unroll
   for (int j = 0; j < 8; ++j) raw.v[j] = (float)hi[j] + (float)lo[j];
 }
-__device__ __forceinline__ void store8(x3p* p, const float* v) {
+template <int PL> __device__ __forceinline__ void store8(x3p<PL>* p, const float* v) {
   Frag<x3> r;
 #pragma unroll
   for (int j = 0; j < 8; ++j) r.v[j] = v[j];
   stage8(p, r);
 }
-__device__ __forceinline__ void load8(float* o, const x3p* p) {
+template <int PL> __device__ __forceinline__ void load8(float* o, const x3p<PL>* p) {
   Frag<x3> r;
   unstage8(r, p);
 #pragma unroll
   for (int j = 0; j < 8; ++j) o[j] = r.v[j];
 }
-__device__ __forceinline__ void store4(x3p* p, const float* v) {
+template <int PL> __device__ __forceinline__ void store4(x3p<PL>* p, const float* v) {
   bf16x4_t hi, lo;
 #pragma unroll
   for (int j = 0; j < 4; j += 2) {
@@ -349,18 +348,17 @@ __device__ __forceinline__ void store4(x3p* p, const float* v) {
   *reinterpret_cast<bf16x4_t*>(p) = hi;
   *reinterpret_cast<bf16x4_t*>(lo_of(p)) = lo;
 }
-__device__ __forceinline__ void load4t(float* o, const x3p* p) {
+template <int PL> __device__ __forceinline__ void load4t(float* o, const x3p<PL>* p) {
   const bf16x4_t hi = *reinterpret_cast<const bf16x4_t*>(p), lo = *reinterpret_cast<const bf16x4_t*>(lo_of(p));
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = (float)hi[j] + (float)lo[j];
 }
-#endif
 // x3r: a raw f32 slot of the x3 tier -- for tiles that are NOT matrix operands (residuals, outputs on their way to HBM):
 // splitting those would cost VALU work and round a residual to 16 bits for nothing.  A [64 x 128] tile of them is exactly as
 // large as the split pair, so it can take the place of one.
 struct x3r { float f; };
-template <typename T> struct ResT { typedef typename LdsT<T>::type type; };
-template <> struct ResT<x3> { typedef x3r type; };
+template <typename T, int PL = 0> struct ResT { typedef typename LdsT<T, PL>::type type; };
+template <int PL> struct ResT<x3, PL> { typedef x3r type; };
 __device__ __forceinline__ void stage8(x3r* dst, const Frag<x3>& raw) {
   *reinterpret_cast<float4*>(dst) = make_float4(raw.v[0], raw.v[1], raw.v[2], raw.v[3]);
   *reinterpret_cast<float4*>(dst + 4) = make_float4(raw.v[4], raw.v[5], raw.v[6], raw.v[7]);

@@ -1,5 +1,6 @@
 """The fused post-attention block at the bench shape (pad mask, live-tile list, dropout 0.5): encoder inference / encoder
-training / decoder training (cross stage under dropout) launches, minimum of interleaved rounds."""
+training / decoder training (cross stage under dropout) launches, minimum of interleaved rounds.
+  python tools/kb_post_attn.py [bf16|f32|bf16x3]        (bf16x3: RG_X3_PA_RT=4 times the 64-token form instead of the 32-token one)"""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from recguru_amd import hip, synthetic
@@ -9,10 +10,12 @@ M = B * L
 dom = synthetic.make_domain(B, 100000, L, 1, seed=1)
 ids = torch.as_tensor(dom["enc_in"]).cuda()
 mask = (ids != 0).float().reshape(-1).contiguous()
-dt = torch.bfloat16
+tier = sys.argv[1] if len(sys.argv) > 1 else "bf16"
+dt = torch.bfloat16 if tier == "bf16" else torch.float32
+hip.SPLIT_OPERANDS = tier == "bf16x3"
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
 x, ctx = r(M, d) * mask[:, None].to(dt), r(M, d)
-pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK)
+pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK | (hip.CAST_SPLIT if tier == "bf16x3" else 0))
 wo, w1, w2 = pk(r(d, d)), pk(r(512, d)), pk(r(d, 512))
 z = lambda n: torch.zeros(n, device="cuda")
 g = torch.ones(d, device="cuda")
@@ -33,4 +36,4 @@ for rnd in range(4):
     for k, f in fns.items():
         best[k] = min(best[k], timeit(f, n=8, warm=2))
 for k, v in best.items():
-    print("post_attn_fwd %-55s %7.1f us" % (k, v))
+    print("post_attn_fwd [%s] %-55s %7.1f us" % (tier, k, v))
