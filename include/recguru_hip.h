@@ -109,6 +109,16 @@ typedef struct {
 int rg_gemm_tn(const rg_gemm_tn_args* args /* host */, int dtype, void* stream);
 /* bytes of `partials` scratch rg_gemm_tn can use for these arguments (0: the kernel it would run has no use for it) */
 size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* args /* host */, int dtype);
+/* The FOUR weight-gradient products of one transformer layer's backward (autograd of the nn.Linear members of
+ * MultiHeadAttention and PositionWiseFeedForwardNet, Transformer/transformer.py:136-188) in ONE launch + one reduce launch:
+ *   slot 0  dW2   [128 x 512] += dl2^T gelu(h1)   (prologue_x = RG_PRO_GELU)      slot 1  dW1 [512 x 128] += dh1^T y
+ *   slot 2  dWqkv [384 x 128] += dqkv^T x                                          slot 3  dWo [128 x 128] += dz^T ctx
+ * p[4] in that order (T = 0: empty slot), RG_BF16, T >= 8192, every used slot with `partials` of
+ * rg_gemm_tn_layer_workspace(slot, wgs[slot]) bytes; wgs[i] = workgroups dealt to slot i (sum <= 256).  colsum / live16 as in
+ * rg_gemm_tn.  Same sums as four rg_gemm_tn calls (different f32 summation order). */
+int rg_gemm_tn_layer_supported(const rg_gemm_tn_args* p /* host, 4 */, const int* wgs /* host, 4 */, int dtype);
+size_t rg_gemm_tn_layer_workspace(int slot, int wgs);
+int rg_gemm_tn_layer(const rg_gemm_tn_args* p /* host, 4 */, const int* wgs /* host, 4 */, int dtype, void* stream);
 /* Plan queries (no launch): the name of the kernel rg_gemm_nt / rg_gemm_tn would run for these arguments --
  * "gemm_ws_kernel<K/128,N/128>" (persistent weight-stationary), "gemm_nt_kernel<dtype,NTW>" (generic tiles),
  * "gemm_tn_dma_kernel<N1,N2>" / "gemm_tn_big_kernel<N1,N2>" (big shapes: LDS-DMA ring / register-staged) or

@@ -250,7 +250,7 @@ template <int N1, int N2> struct TnDma {
 };
 
 template <int N1, int N2, bool GELU_X>
-__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
+__device__ __forceinline__ void tn_dma_body(const rg_gemm_tn_args& a, const int bid, const int nb) {      // workgroup bid of nb
   typedef __bf16 T;
   typedef TnDma<N1, N2> C;
   constexpr bool SPLIT1 = N1 >= N2;
@@ -268,8 +268,8 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   const int m2 = SPLIT1 ? 0 : wave * NT * 16;
   const int nlive = a.live16 ? a.live16[0] : 0;
   const int nchunks = a.live16 ? (nlive + EPC - 1) / EPC : (a.T + CT - 1) / CT;
-  const int per = (nchunks + gridDim.x - 1) / gridDim.x;
-  const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
+  const int per = (nchunks + nb - 1) / nb;
+  const int c_beg = bid * per, c_end = min(nchunks, c_beg + per);
   if (c_beg >= c_end) return;
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
 
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
     }
     }
   }
-  float* __restrict__ part = a.partials ? a.partials + (size_t)blockIdx.x * (N1 * N2) + tid : nullptr;
+  float* __restrict__ part = a.partials ? a.partials + (size_t)bid * (N1 * N2) + tid : nullptr;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -451,18 +451,42 @@ __global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
   }
 }
 
+template <int N1, int N2, bool GELU_X>
+__global__ __launch_bounds__(512) void gemm_tn_dma_kernel(rg_gemm_tn_args a) {
+  tn_dma_body<N1, N2, GELU_X>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The FOUR weight-gradient products of a transformer layer's backward in ONE launch (rg_gemm_tn_layer): slot 0 dW2 +=
+// dl2^T gelu(h1) [128 x 512], slot 1 dW1 += dh1^T y [512 x 128], slot 2 dWqkv += dqkv^T x [384 x 128], slot 3 dWo += dz^T ctx
+// [128 x 128].  Each call of the single-product kernel pays ~35 us that do not scale with T -- the ramp of 192 one-workgroup
+// CUs, the tail, 192 partial dW tiles written and read back by a reduce launch -- 56 calls per step.  Here the workgroups of
+// one grid are dealt to the slots in proportion to their bytes (so every slot's token ranges are longer and its partial tiles
+// fewer), the four ramps and tails coincide, and one reduce launch sums all partial tiles.
+struct rg_tn_layer_args {
+  rg_gemm_tn_args p[4];
+  int end[4];                 // workgroups [end[i-1], end[i]) work on slot i (an empty slot has no workgroups)
+};
+__global__ __launch_bounds__(512) void gemm_tn_layer_kernel(rg_tn_layer_args m) {
+  const int bid = (int)blockIdx.x;
+  if (bid < m.end[0]) tn_dma_body<128, 512, true>(m.p[0], bid, m.end[0]);
+  else if (bid < m.end[1]) tn_dma_body<512, 128, false>(m.p[1], bid - m.end[0], m.end[1] - m.end[0]);
+  else if (bid < m.end[2]) tn_dma_body<384, 128, false>(m.p[2], bid - m.end[1], m.end[2] - m.end[1]);
+  else tn_dma_body<128, 128, false>(m.p[3], bid - m.end[2], m.end[3] - m.end[2]);
+}
+
 // dW += scale * sum over the active workgroups' slices.  Thread = one element e of the register-major slice layout
 // (coalesced across threads for every slice); blockIdx.y splits the slices so that small dW still fill the chip.
 template <int N1, int N2>
-__global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, int grid1, int ct) {     // ct: tokens per chunk of the first launch
+__device__ __forceinline__ void tn_reduce_body(const rg_gemm_tn_args& a, int grid1, int ct, const int bx, const int by, const int ny) {
   constexpr bool SPLIT1 = N1 >= N2;
   constexpr int NT = SPLIT1 ? N2 / 16 : N2 / 128;
   const int nchunks = a.live16 ? (a.live16[0] + ct / 16 - 1) / (ct / 16) : (a.T + ct - 1) / ct;
   if (nchunks <= 0) return;
   const int per = (nchunks + grid1 - 1) / grid1;
   const int nact = (nchunks + per - 1) / per;          // workgroups of the first launch that had a token range
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int b0 = (int)((long long)nact * blockIdx.y / gridDim.y), b1 = (int)((long long)nact * (blockIdx.y + 1) / gridDim.y);
+  const int e = bx * 256 + threadIdx.x;
+  const int b0 = (int)((long long)nact * by / ny), b1 = (int)((long long)nact * (by + 1) / ny);
   const float* __restrict__ p = a.partials + e;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   int b = b0;
@@ -478,6 +502,26 @@ __global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, i
   constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;
   const int m1 = SPLIT1 ? wave * MT * 16 : 0, m2 = SPLIT1 ? 0 : wave * NT * 16;
   atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, ((s0 + s1) + (s2 + s3)) * a.scale);
+}
+
+template <int N1, int N2>
+__global__ __launch_bounds__(256) void tn_big_reduce_kernel(rg_gemm_tn_args a, int grid1, int ct) {     // ct: tokens per chunk of the first launch
+  tn_reduce_body<N1, N2>(a, grid1, ct, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.y);
+}
+// one reduce launch for the four slots of gemm_tn_layer_kernel: blockIdx.x walks the slots' (element block, slice group) pairs
+struct rg_tn_layer_reduce_args {
+  rg_gemm_tn_args p[4];
+  int grid1[4], ct[4], gx[4], gy[4], end[4];
+};
+__global__ __launch_bounds__(256) void tn_layer_reduce_kernel(rg_tn_layer_reduce_args m) {
+  const int bid = (int)blockIdx.x;
+  const int i = (bid >= m.end[0]) + (bid >= m.end[1]) + (bid >= m.end[2]);
+  const int r = bid - (i ? m.end[i - 1] : 0);
+  const int bx = r % m.gx[i], by = r / m.gx[i];
+  if (i == 0) tn_reduce_body<128, 512>(m.p[0], m.grid1[0], m.ct[0], bx, by, m.gy[0]);
+  else if (i == 1) tn_reduce_body<512, 128>(m.p[1], m.grid1[1], m.ct[1], bx, by, m.gy[1]);
+  else if (i == 2) tn_reduce_body<384, 128>(m.p[2], m.grid1[2], m.ct[2], bx, by, m.gy[2]);
+  else tn_reduce_body<128, 128>(m.p[3], m.grid1[3], m.ct[3], bx, by, m.gy[3]);
 }
 
 static int tn_use_dma() {            // RG_TN_REGSTAGE=1: the register-staged kernel (kept for A/B timing, tools/kb_tn.py)
@@ -602,4 +646,74 @@ static int tn_big_native(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
   if (a->N1 == 256 && a->N2 == 128) return launch_big<256, 128>(*a, s);
   if (a->N1 == 128 && a->N2 == 128) return launch_big<128, 128>(*a, s);
   return 1;
+}
+
+// ---- the four weight-gradient products of a layer in one launch ---------------------------------------------------------------
+static const int LAYER_N1[4] = {128, 512, 384, 128}, LAYER_N2[4] = {512, 128, 128, 128};
+
+static int layer_ct(int i) { return i == 3 ? TnDma<128, 128>::CT : (i == 2 ? TnDma<384, 128>::CT : (i == 1 ? TnDma<512, 128>::CT : TnDma<128, 512>::CT)); }
+static int layer_ring(int i) {
+  return i == 3 ? TnDma<128, 128>::NST * TnDma<128, 128>::STG : (i == 2 ? TnDma<384, 128>::NST * TnDma<384, 128>::STG :
+         (i == 1 ? TnDma<512, 128>::NST * TnDma<512, 128>::STG : TnDma<128, 512>::NST * TnDma<128, 512>::STG));
+}
+// LDS of slot i with g workgroups: the DMA ring + this workgroup's slice of the live-tile list behind it
+static int layer_lds(const rg_gemm_tn_args& a, int i, int g) {
+  const int ct = layer_ct(i), nchunks = (a.T + ct - 1) / ct;
+  if (g > nchunks) g = nchunks;
+  const int per = (nchunks + g - 1) / g;
+  return layer_ring(i) + (ct / 16) * per * 4;
+}
+
+extern "C" int rg_gemm_tn_layer_supported(const rg_gemm_tn_args* p, const int* wgs, int dtype) {
+  if (!p || !wgs || dtype != RG_BF16 || !tn_use_dma()) return 0;
+  int tot = 0;
+  for (int i = 0; i < 4; ++i) {
+    const rg_gemm_tn_args& a = p[i];
+    if (a.T == 0) continue;                                          // empty slot
+    if (a.N1 != LAYER_N1[i] || a.N2 != LAYER_N2[i] || (a.prologue_x == RG_PRO_GELU) != (i == 0)) return 0;
+    if (!rg_gemm_tn_big_select(&a, dtype) || !a.partials || !a.Y || !a.X || !a.dW || wgs[i] <= 0) return 0;
+    if (layer_lds(a, i, wgs[i]) > 160 * 1024) return 0;
+    tot += wgs[i];
+  }
+  return tot <= 256;
+}
+
+// bytes of partial-tile scratch slot i needs when the launch deals `wgs` workgroups to it
+extern "C" size_t rg_gemm_tn_layer_workspace(int slot, int wgs) { return (size_t)wgs * LAYER_N1[slot] * LAYER_N2[slot] * sizeof(float); }
+
+// wgs[i]: workgroups for slot i (0 for an empty slot; sum <= 256); p[i].partials: >= rg_gemm_tn_layer_workspace(i, wgs[i]) bytes each
+extern "C" int rg_gemm_tn_layer(const rg_gemm_tn_args* p, const int* wgs, int dtype, void* stream) {
+  if (!rg_gemm_tn_layer_supported(p, wgs, dtype)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn_layer: needs the bf16 tier and the four layer "
+                                                                     "shapes (128x512 gelu, 512x128, 384x128, 128x128; T >= 8192; partials)");
+  hipStream_t s = (hipStream_t)stream;
+  rg_tn_layer_args m;
+  rg_tn_layer_reduce_args r;
+  int tot = 0, rtot = 0, smem = 0;
+  for (int i = 0; i < 4; ++i) {
+    m.p[i] = p[i];
+    r.p[i] = p[i];
+    const int ct = layer_ct(i);
+    int g = p[i].T > 0 ? wgs[i] : 0;
+    if (p[i].T > 0) {
+      const int nchunks = (p[i].T + ct - 1) / ct;
+      if (g > nchunks) g = nchunks;
+      const int need = layer_lds(p[i], i, g);
+      if (need > smem) smem = need;
+    }
+    tot += g;
+    m.end[i] = tot;
+    r.grid1[i] = g;
+    r.ct[i] = ct;
+    r.gx[i] = LAYER_N1[i] * LAYER_N2[i] / 256;
+    r.gy[i] = g == 0 ? 0 : (r.gx[i] >= 256 ? 4 : (r.gx[i] >= 128 ? 8 : 16));
+    rtot += r.gx[i] * r.gy[i];
+    r.end[i] = rtot;
+  }
+  if (tot == 0) return 0;
+  if (tot > 256 || smem > 160 * 1024) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_layer: more than 256 workgroups, or a token range too long for the list slice in LDS");
+  hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+  hipLaunchKernelGGL(gemm_tn_layer_kernel, dim3(tot), dim3(512), smem, s, m);
+  hipLaunchKernelGGL(tn_layer_reduce_kernel, dim3(rtot), dim3(256), 0, s, r);
+  RG_CHECK_LAUNCH();
+  return 0;
 }

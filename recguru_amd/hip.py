@@ -85,7 +85,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
-           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
+           "rg_cross_drop_scale", "rg_seq_wsum", "rg_gemm_nt_plan", "rg_gemm_tn_plan", "rg_gemm_tn_workspace", "rg_gemm_tn_layer", "rg_gemm_tn_layer_supported", "rg_gemm_tn_layer_workspace", "rg_ln_bwd_workspace", "rg_cast_multi",
            "rg_item_loss_bwd_binned_workspace", "rg_item_loss_bwd_binned", "rg_adam_multi", "rg_rank_scores",
            "rg_assemble_batch", "rg_sample_negatives", "rg_sample_negatives_alias", "rg_dropout", "rg_cross_rows", "rg_live_tiles",
            "rg_adam_multi_dev", "rg_disc_rows", "rg_disc_supported", "rg_attn_fwd_x_supported", "rg_pad_mask", "rg_last_rows",
@@ -235,6 +235,60 @@ def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0
         _note_plan(lib().rg_gemm_tn_plan, a, mt_of(Y))
     _check(lib().rg_gemm_tn(ctypes.byref(a), mt_of(Y), _stream()), "rg_gemm_tn")
     return dW
+
+
+LAYER_SLOTS = ((128, 512, PRO_GELU), (512, 128, PRO_NONE), (384, 128, PRO_NONE), (128, 128, PRO_NONE))      # (N1, N2, prologue) of rg_gemm_tn_layer
+LAYER_WGS = int(os.environ.get("RG_TN_LAYER_WGS", "256"))     # workgroups of the merged launch (one per CU: ~159 KB of LDS each)
+
+
+class _TnLayerArgs(ctypes.Structure):
+    _fields_ = [("p", GemmTnArgs * 4)]
+
+
+def gemm_tn_layer_slot(Y, X, prologue_x):
+    """Slot of rg_gemm_tn_layer that takes dW += Y^T pro(X), or None."""
+    key = (Y.shape[1], X.shape[1], prologue_x)
+    return LAYER_SLOTS.index(key) if (key in LAYER_SLOTS and Y.dtype == torch.bfloat16 and Y.shape[0] >= 8192) else None
+
+
+def gemm_tn_layer(probs):
+    """The four weight-gradient products of one transformer layer's backward in ONE launch (+ one reduce launch):
+    probs[i] = None or (Y, X, dW, colsum, live) for slot i of LAYER_SLOTS.  Workgroups are dealt in proportion to the bytes a slot
+    streams (listed slots: ~0.6 of their rows at the synthetic length distribution).  Returns False (nothing launched) when the
+    library does not take the set (tier, shapes, sizes): the caller then issues the products one by one."""
+    args = _TnLayerArgs()
+    w = [0.0] * 4
+    for i, pr in enumerate(probs):
+        if pr is None:
+            continue
+        Y, X, dW, colsum, live = pr
+        N1, N2, pro = LAYER_SLOTS[i]
+        assert Y.shape[1] == N1 and X.shape == (Y.shape[0], N2) and Y.dtype == X.dtype
+        args.p[i] = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), Y.shape[0], N1, N2,
+                               pro, 1.0, 0, 1, _p(live), None, 0)
+        w[i] = Y.shape[0] * (N1 + N2) * (0.6 if live is not None else 1.0)
+    tot = sum(w)
+    if tot == 0:
+        return True
+    wgs = [max(8, int(round(LAYER_WGS * x / tot))) if x > 0 else 0 for x in w]
+    while sum(wgs) > LAYER_WGS:
+        wgs[wgs.index(max(wgs))] -= 1
+    fn = lib().rg_gemm_tn_layer_workspace
+    fn.restype = ctypes.c_size_t
+    need = [int(fn(i, wgs[i])) for i in range(4)]
+    dev = next(pr[0].device for pr in probs if pr is not None)
+    ws = _tn_workspace(dev, sum(need), "tn_layer")
+    off = 0
+    for i in range(4):
+        if wgs[i]:
+            args.p[i].partials = ws.data_ptr() + off
+            off += need[i]
+    dt = dt_of(next(pr[0] for pr in probs if pr is not None))
+    cw = (ctypes.c_int * 4)(*wgs)
+    if not lib().rg_gemm_tn_layer_supported(ctypes.byref(args), cw, dt):
+        return False
+    _check(lib().rg_gemm_tn_layer(ctypes.byref(args), cw, dt, _stream()), "rg_gemm_tn_layer")
+    return True
 
 
 def attn_fwd(qkv, key_ids, pad_value, causal, H, need_lse=True, drop_p=0.0, seed=0, rowmask=None, x_masked=False, bqkv=None,
@@ -1150,7 +1204,7 @@ def _work_item_loss_scatter(h, table_rows, pos, neg, mask, k, coef, gout, dE, *a
 _WORK = {"item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
          "ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["gemm_tn_layer", "attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
           "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse", "cross_add_ln"]
 

@@ -285,6 +285,51 @@ def _live_tn(rowmask, M, n1, n2):
 
 TN_LIST_WIDE = True
 
+# The weight-gradient products of a layer's backward are collected and issued as ONE launch (rg_gemm_tn_layer: the four products
+# of a d_model = 128 transformer layer) when the layer function opens a _tn_layer() context; products that do not fit a slot, and
+# everything outside such a context, go out one by one as before.
+import os as _os1
+TN_PER_LAYER = not _os1.environ.get("RG_NO_TN_LAYER")      # RG_NO_TN_LAYER=1: one launch per product (A/B timing)
+_TN_BATCH = None
+
+
+class _tn_layer(object):
+    def __enter__(self):
+        global _TN_BATCH
+        self.prev, _TN_BATCH = _TN_BATCH, ([] if TN_PER_LAYER else None)
+        return self
+
+    def __exit__(self, et, ev, tb):
+        global _TN_BATCH
+        batch, _TN_BATCH = _TN_BATCH, self.prev
+        if et is None and batch:
+            _flush_tn(batch)
+
+
+def _flush_tn(batch):
+    slots, rest = [None] * 4, []
+    for e in batch:
+        Y, X, dW, colsum, pro, live = e
+        i = hip.gemm_tn_layer_slot(Y, X, pro)
+        if i is None or slots[i] is not None:
+            rest.append(e)
+        else:
+            slots[i] = (Y, X, dW, colsum, live)
+    if sum(x is not None for x in slots) >= 2 and hip.gemm_tn_layer(slots):
+        slots = [None] * 4
+    for i, x in enumerate(slots):
+        if x is not None:
+            hip.gemm_tn(x[0], x[1], x[2], x[3], prologue_x=hip.LAYER_SLOTS[i][2], live=x[4])
+    for Y, X, dW, colsum, pro, live in rest:
+        hip.gemm_tn(Y, X, dW, colsum, prologue_x=pro, live=live)
+
+
+def _tn(Y, X, dW, colsum=None, prologue_x=hip.PRO_NONE, live=None):
+    """dW += Y^T pro(X), colsum += column sums of Y -- now, or with the enclosing layer's other products (_tn_layer)."""
+    if _TN_BATCH is None:
+        return hip.gemm_tn(Y, X, dW, colsum, prologue_x=prologue_x, live=live)
+    _TN_BATCH.append((Y, X, dW, colsum, prologue_x, live))
+
 
 # ------------------------------------------------------------------------------------------------
 # Parameter gradients are accumulated IN PLACE: the weight-gradient kernels (gemm_tn, colsum, ln_bwd, the
@@ -652,7 +697,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
         # LayerNorm backward + dctx = dz Wo in ONE launch (dz is read back only by the weight-gradient product)
         dz, dctx = hip.attn_out_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe,
                                     shadow(Wo, transpose=True, pack=True, split=True), live=live, w_packed=True)
-        hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
+        _tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live)
     else:
         dz = hip.ln_bwd(dy, y, rstd, g.detach(), be.detach(), rowmask, dg, dbe, live=live)
         hip.gemm_tn(dz, ctx_.view(B * L, P), dWo, dbo, live=live if live is not None else _live_tn(rowmask, dz.shape[0], P, d))
@@ -665,7 +710,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
                         drop_p=drop_p, seed=seed, rowmask=rowmask, bqkv=bias_cat((bq, bk, bv)) if sub else None)
     dqkv2 = dqkv.view(B * L, 3 * P)
     (dWqkv, rW), (dbqkv, rb) = _gt_cat((Wq, Wk, Wv)), _gt_cat((bq, bk, bv))
-    hip.gemm_tn(dqkv2, x2, dWqkv, dbqkv)                 # every row: a padded position that is a live key has dK, dV != 0
+    _tn(dqkv2, x2, dWqkv, dbqkv)                         # every row: a padded position that is a live key has dK, dV != 0
     # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
     # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
     Wt = shadow_cat((Wq, Wk, Wv), transpose=True)          # [d, 3P]
@@ -738,8 +783,8 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
         dh1, dy, dl2 = hip.ffn_bwd_data(None, None, h1, shadow(W2, transpose=True, pack=True, split=True), shadow(W1, transpose=True, pack=True, split=True),
                                         nz_scale=_inv_keep(drop_p), live=live, w_packed=True,
                                         ln=(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out))
-        hip.gemm_tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
-        hip.gemm_tn(dh1, y, dW1, db1, live=live)
+        _tn(dl2, h1, dW2, db2, prologue_x=hip.PRO_GELU, live=live)
+        _tn(dh1, y, dW1, db1, live=live)
         return dy, (rW1, rb1, rW2, rb2, rg, rbe)
     if drop_p > 0:
         dz, dl2 = hip.ln_bwd(dout, out, rstd, g.detach(), be.detach(), rowmask, dg, dbe, drop_p, seed_out, live=live)
@@ -800,10 +845,11 @@ class EncoderLayerFn(_Fn):
         x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2 = ctx.saved_tensors
         B, L, pad_value, causal, H, drop_p, seeds, xm = ctx.meta
         d = x2.shape[1]
-        dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, ctx.prm[10:],
-                                drop_p, seeds[1], seeds[2])
-        dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
-                                 ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
+        with _tn_layer():               # the layer's four weight-gradient products leave as one launch
+            dy, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y, out, (h1, rstd2), rowmask, ctx.prm[10:],
+                                    drop_p, seeds[1], seeds[2])
+            dx, ga = _attn_block_bwd(dy, x2, y, (qkv, ctx_, lse, rstd1), B, L, key_ids, pad_value, causal, H,
+                                     ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
         return (dx.view(B, L, d), None, None, None, None, None, None) + ga + gf
 
 
@@ -978,33 +1024,34 @@ class DecoderLayerFn(_Fn):
         d = x2.shape[1]
         P = cWv.shape[0]
         dev = dout.device
-        dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, ctx.prm[16:],
-                                 drop_p, seeds[1], seeds[2])
-        (dcg, rcg), (dcbe, rcbe) = _gt(cg), _gt(cbe)
-        (dcWo, rcWo), (dcbo, rcbo) = _gt(cWo), _gt(cbo)
-        # residual: dz == dy1; under dropout the cross-attention output bias gradient is the column sum of dy1, which
-        # the same kernel accumulates
-        dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), rowmask, dcg, dcbe,
-                         dz_colsum=dcbo if s_cross is not None else None)
-        if s_cross is None:
-            do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype
-            hip.gemm_tn(do, c, dcWo, dcbo)
-            dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                            # [B, P]
-        else:
-            doh = hip.seq_wsum(dy1, s_cross, B, L, H)                                    # [B, H, d]
-            # all heads at once (see the forward): dWo[:, block h] += doh[:, h, :]^T c[:, block h] is one TN product
-            # against the head-masked stack of c; dc's block h is the diagonal block of doh[:, h, :] @ Wo
-            eye = _head_eye(H, c)
-            cm = (c.view(B, 1, H, 32) * eye).view(B * H, P)
-            doh2 = doh.reshape(B * H, d)
-            hip.gemm_tn(doh2, cm, dcWo)
-            full = hip.gemm_nt(doh2, shadow(cWo, transpose=True))                         # [B*H, P] = doh @ Wo
-            dc = (full.view(B, H, H, 32) * eye).sum(1).view(B, P)
-        (dcWv, rcWv), (dcbv, rcbv) = _gt(cWv), _gt(cbv)
-        hip.gemm_tn(dc, u, dcWv, dcbv)
-        du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
-        dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
-                                 ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
+        with _tn_layer():               # the layer's four big weight-gradient products leave as one launch
+            dy2, gf = _ffn_block_bwd(dout.contiguous().view(B * L, d), y2, out, (h1, rstd2), rowmask, ctx.prm[16:],
+                                     drop_p, seeds[1], seeds[2])
+            (dcg, rcg), (dcbe, rcbe) = _gt(cg), _gt(cbe)
+            (dcWo, rcWo), (dcbo, rcbo) = _gt(cWo), _gt(cbo)
+            # residual: dz == dy1; under dropout the cross-attention output bias gradient is the column sum of dy1, which
+            # the same kernel accumulates
+            dy1 = hip.ln_bwd(dy2, y2, rstd_c, cg.detach(), cbe.detach(), rowmask, dcg, dcbe,
+                             dz_colsum=dcbo if s_cross is not None else None)
+            if s_cross is None:
+                do = hip.seq_sum(dy1, B, L)                                                  # [B, d] tier dtype
+                hip.gemm_tn(do, c, dcWo, dcbo)
+                dc = hip.gemm_nt(do, shadow(cWo, transpose=True))                            # [B, P]
+            else:
+                doh = hip.seq_wsum(dy1, s_cross, B, L, H)                                    # [B, H, d]
+                # all heads at once (see the forward): dWo[:, block h] += doh[:, h, :]^T c[:, block h] is one TN product
+                # against the head-masked stack of c; dc's block h is the diagonal block of doh[:, h, :] @ Wo
+                eye = _head_eye(H, c)
+                cm = (c.view(B, 1, H, 32) * eye).view(B * H, P)
+                doh2 = doh.reshape(B * H, d)
+                hip.gemm_tn(doh2, cm, dcWo)
+                full = hip.gemm_nt(doh2, shadow(cWo, transpose=True))                         # [B*H, P] = doh @ Wo
+                dc = (full.view(B, H, H, 32) * eye).sum(1).view(B, P)
+            (dcWv, rcWv), (dcbv, rcbv) = _gt(cWv), _gt(cbv)
+            hip.gemm_tn(dc, u, dcWv, dcbv)
+            du = hip.gemm_nt(dc, shadow(cWv, transpose=True))                                # [B, d]
+            dx, ga = _attn_block_bwd(dy1, x2, y1, (qkv, ctx_, lse, rstd1), B, L, key_ids, 0, True, H,
+                                     ctx.prm[:10], drop_p, seeds[0], rowmask, xm)
         return ((dx.view(B, L, d), du.to(ctx.u_dtype), None, None, None, None, None) + ga + (rcWv, rcbv, rcWo, rcbo, rcg, rcbe) + gf)
 
 

@@ -1526,3 +1526,39 @@ def test_attn_out_bwd_equals_ln_bwd_plus_projection(dt, M, listed):
     torch.testing.assert_close(db1, db0, rtol=2e-4, atol=2e-4 * float(db0.abs().max()))
     dz2, dctx2 = hip.attn_out_bwd(dy, y, rstd, g, be, mask, None, None, Wot, live=live, w_packed=False)      # row-major weights
     assert torch.equal(dctx2[rows], dctx1[rows])
+
+
+@pytest.mark.parametrize("listed", [False, True])
+@pytest.mark.parametrize("present", [(1, 1, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1), (1, 0, 1, 0)])
+def test_gemm_tn_layer_equals_four_products(listed, present):
+    """rg_gemm_tn_layer: the four weight-gradient products of a layer (dW2 with the GELU prologue, dW1, dWqkv, dWo) and their
+    bias gradients in one launch + one reduce launch == the four rg_gemm_tn calls (different f32 summation order only); with a
+    live-tile list on the slots that take one (dWqkv sums every row), with empty slots, and accumulating into existing dW."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    T = 9000
+    mask = _pad_mask(T // 120, 120, T + 7) if listed else None
+    live = hip.live_tiles(mask, T) if listed else None
+    probs, refs = [], []
+    for i, (N1, N2, pro) in enumerate(hip.LAYER_SLOTS):
+        if not present[i]:
+            probs.append(None)
+            refs.append(None)
+            continue
+        Y, X = rnd(T, N1, dt=dt, seed=10 + i), rnd(T, N2, dt=dt, seed=20 + i)
+        lv = live if (listed and i != 2) else None
+        if lv is not None:
+            Y = Y * mask[:, None].to(dt)
+        dW0 = rnd(N1, N2, dt=torch.float32, seed=30 + i)
+        dW_a, dW_b = dW0.clone(), dW0.clone()
+        cs_a, cs_b = torch.zeros(N1, device="cuda"), torch.zeros(N1, device="cuda")
+        hip.gemm_tn(Y, X, dW_a, cs_a, prologue_x=pro, live=lv)
+        probs.append((Y, X, dW_b, cs_b, lv))
+        refs.append((dW_a, cs_a, dW_b, cs_b))
+    assert hip.gemm_tn_layer(probs)
+    for i, r in enumerate(refs):
+        if r is None:
+            continue
+        scale = float(r[0].abs().max())
+        torch.testing.assert_close(r[2], r[0], rtol=1e-4, atol=1e-5 * scale, msg="slot %d dW" % i)
+        torch.testing.assert_close(r[3], r[1], rtol=1e-4, atol=1e-5 * float(r[1].abs().max()) + 1e-6, msg="slot %d colsum" % i)
