@@ -113,7 +113,7 @@ size_t rg_gemm_tn_workspace(const rg_gemm_tn_args* args /* host */, int dtype);
  * MultiHeadAttention and PositionWiseFeedForwardNet, Transformer/transformer.py:136-188) in ONE launch + one reduce launch:
  *   slot 0  dW2   [128 x 512] += dl2^T gelu(h1)   (prologue_x = RG_PRO_GELU)      slot 1  dW1 [512 x 128] += dh1^T y
  *   slot 2  dWqkv [384 x 128] += dqkv^T x                                          slot 3  dWo [128 x 128] += dz^T ctx
- * p[4] in that order (T = 0: empty slot), RG_BF16, T >= 8192, every used slot with `partials` of
+ * p[4] in that order (T = 0: empty slot), RG_BF16 or RG_X3, T >= 8192, every used slot with `partials` of
  * rg_gemm_tn_layer_workspace(slot, wgs[slot]) bytes; wgs[i] = workgroups dealt to slot i (sum <= 256).  colsum / live16 as in
  * rg_gemm_tn.  Same sums as four rg_gemm_tn calls (different f32 summation order). */
 int rg_gemm_tn_layer_supported(const rg_gemm_tn_args* p /* host, 4 */, const int* wgs /* host, 4 */, int dtype);

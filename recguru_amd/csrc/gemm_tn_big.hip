@@ -54,7 +54,7 @@ __device__ __forceinline__ void mma_ones(const FragX3& a, const Frag<__bf16>& on
 // they are staged -- 2.5 VALU operations per element, once -- and every product is three MFMAs; chunks of 32 tokens, the bytes
 // of the bf16 tier's 64)
 template <typename T, int N1, int N2, bool GELU_X>
-__global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
+__device__ __forceinline__ void tn_big_body(const rg_gemm_tn_args& a, const int bid, const int nwg) {      // workgroup bid of nwg
   constexpr bool X3 = std::is_same<T, x3>::value;
   constexpr int TB_T = X3 ? TB_T_X3 : TB_T_BF16;
   typedef typename OpT<T>::type OP;
@@ -77,8 +77,8 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
   // a.live16 (optional): the list of live 16-row tiles (rg_live_tiles) -- a chunk is then 4 consecutive LIST entries
   // instead of 64 consecutive tokens; rows of padded tiles carry zero upstream gradient and are never read
   const int nchunks = a.live16 ? (a.live16[0] + TB_T / 16 - 1) / (TB_T / 16) : (a.T + TB_T - 1) / TB_T;
-  const int per = (nchunks + gridDim.x - 1) / gridDim.x;
-  const int c_beg = blockIdx.x * per, c_end = min(nchunks, c_beg + per);
+  const int per = (nchunks + nwg - 1) / nwg;
+  const int c_beg = bid * per, c_end = min(nchunks, c_beg + per);
   const bool do_cs = a.colsum != nullptr && (SPLIT1 || wave == 0);
 
   f32x4 acc[MT][NT];
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
     lds_barrier();
   }
   if (c_beg >= c_end) return;
-  float* __restrict__ part = a.partials ? a.partials + (size_t)blockIdx.x * (N1 * N2) + tid : nullptr;
+  float* __restrict__ part = a.partials ? a.partials + (size_t)bid * (N1 * N2) + tid : nullptr;
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -219,6 +219,11 @@ __global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
       for (int r = 0; r < 4; ++r) atomicAdd(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
     }
   }
+}
+
+template <typename T, int N1, int N2, bool GELU_X>
+__global__ __launch_bounds__(512) void gemm_tn_big_kernel(rg_gemm_tn_args a) {
+  tn_big_body<T, N1, N2, GELU_X>(a, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -467,6 +472,14 @@ struct rg_tn_layer_args {
   rg_gemm_tn_args p[4];
   int end[4];                 // workgroups [end[i-1], end[i]) work on slot i (an empty slot has no workgroups)
 };
+// bf16x3 tier: the register-staged bodies (rows split into hi / lo images on the way to LDS)
+__global__ __launch_bounds__(512) void gemm_tn_layer_x3_kernel(rg_tn_layer_args m) {
+  const int bid = (int)blockIdx.x;
+  if (bid < m.end[0]) tn_big_body<x3, 128, 512, true>(m.p[0], bid, m.end[0]);
+  else if (bid < m.end[1]) tn_big_body<x3, 512, 128, false>(m.p[1], bid - m.end[0], m.end[1] - m.end[0]);
+  else if (bid < m.end[2]) tn_big_body<x3, 384, 128, false>(m.p[2], bid - m.end[1], m.end[2] - m.end[1]);
+  else tn_big_body<x3, 128, 128, false>(m.p[3], bid - m.end[2], m.end[3] - m.end[2]);
+}
 __global__ __launch_bounds__(512) void gemm_tn_layer_kernel(rg_tn_layer_args m) {
   const int bid = (int)blockIdx.x;
   if (bid < m.end[0]) tn_dma_body<128, 512, true>(m.p[0], bid, m.end[0]);
@@ -651,13 +664,14 @@ static int tn_big_native(const rg_gemm_tn_args* a, int dtype, hipStream_t s) {
 // ---- the four weight-gradient products of a layer in one launch ---------------------------------------------------------------
 static const int LAYER_N1[4] = {128, 512, 384, 128}, LAYER_N2[4] = {512, 128, 128, 128};
 
-static int layer_ct(int i) { return i == 3 ? TnDma<128, 128>::CT : (i == 2 ? TnDma<384, 128>::CT : (i == 1 ? TnDma<512, 128>::CT : TnDma<128, 512>::CT)); }
+static int layer_ct(int i, int dtype = RG_BF16) { return dtype == RG_X3 ? TB_T_X3 : i == 3 ? TnDma<128, 128>::CT : (i == 2 ? TnDma<384, 128>::CT : (i == 1 ? TnDma<512, 128>::CT : TnDma<128, 512>::CT)); }
 static int layer_ring(int i) {
   return i == 3 ? TnDma<128, 128>::NST * TnDma<128, 128>::STG : (i == 2 ? TnDma<384, 128>::NST * TnDma<384, 128>::STG :
          (i == 1 ? TnDma<512, 128>::NST * TnDma<512, 128>::STG : TnDma<128, 512>::NST * TnDma<128, 512>::STG));
 }
 // LDS of slot i with g workgroups: the DMA ring + this workgroup's slice of the live-tile list behind it
-static int layer_lds(const rg_gemm_tn_args& a, int i, int g) {
+static int layer_lds(const rg_gemm_tn_args& a, int i, int g, int dtype) {
+  if (dtype == RG_X3) return TB_T_X3 * (a.N1 + 8 + a.N2 + 8) * 2 * 2;        // hi | lo images of the Y and X chunks (the list rides in registers)
   const int ct = layer_ct(i), nchunks = (a.T + ct - 1) / ct;
   if (g > nchunks) g = nchunks;
   const int per = (nchunks + g - 1) / g;
@@ -665,14 +679,14 @@ static int layer_lds(const rg_gemm_tn_args& a, int i, int g) {
 }
 
 extern "C" int rg_gemm_tn_layer_supported(const rg_gemm_tn_args* p, const int* wgs, int dtype) {
-  if (!p || !wgs || dtype != RG_BF16 || !tn_use_dma()) return 0;
+  if (!p || !wgs || (dtype != RG_BF16 && dtype != RG_X3) || (dtype == RG_BF16 && !tn_use_dma())) return 0;
   int tot = 0;
   for (int i = 0; i < 4; ++i) {
     const rg_gemm_tn_args& a = p[i];
     if (a.T == 0) continue;                                          // empty slot
     if (a.N1 != LAYER_N1[i] || a.N2 != LAYER_N2[i] || (a.prologue_x == RG_PRO_GELU) != (i == 0)) return 0;
     if (!rg_gemm_tn_big_select(&a, dtype) || !a.partials || !a.Y || !a.X || !a.dW || wgs[i] <= 0) return 0;
-    if (layer_lds(a, i, wgs[i]) > 160 * 1024) return 0;
+    if (layer_lds(a, i, wgs[i], dtype) > 160 * 1024) return 0;
     tot += wgs[i];
   }
   return tot <= 256;
@@ -683,7 +697,7 @@ extern "C" size_t rg_gemm_tn_layer_workspace(int slot, int wgs) { return (size_t
 
 // wgs[i]: workgroups for slot i (0 for an empty slot; sum <= 256); p[i].partials: >= rg_gemm_tn_layer_workspace(i, wgs[i]) bytes each
 extern "C" int rg_gemm_tn_layer(const rg_gemm_tn_args* p, const int* wgs, int dtype, void* stream) {
-  if (!rg_gemm_tn_layer_supported(p, wgs, dtype)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn_layer: needs the bf16 tier and the four layer "
+  if (!rg_gemm_tn_layer_supported(p, wgs, dtype)) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_tn_layer: needs the bf16 / bf16x3 tier and the four layer "
                                                                      "shapes (128x512 gelu, 512x128, 384x128, 128x128; T >= 8192; partials)");
   hipStream_t s = (hipStream_t)stream;
   rg_tn_layer_args m;
@@ -692,12 +706,12 @@ extern "C" int rg_gemm_tn_layer(const rg_gemm_tn_args* p, const int* wgs, int dt
   for (int i = 0; i < 4; ++i) {
     m.p[i] = p[i];
     r.p[i] = p[i];
-    const int ct = layer_ct(i);
+    const int ct = layer_ct(i, dtype);
     int g = p[i].T > 0 ? wgs[i] : 0;
     if (p[i].T > 0) {
       const int nchunks = (p[i].T + ct - 1) / ct;
       if (g > nchunks) g = nchunks;
-      const int need = layer_lds(p[i], i, g);
+      const int need = layer_lds(p[i], i, g, dtype);
       if (need > smem) smem = need;
     }
     tot += g;
@@ -711,8 +725,13 @@ extern "C" int rg_gemm_tn_layer(const rg_gemm_tn_args* p, const int* wgs, int dt
   }
   if (tot == 0) return 0;
   if (tot > 256 || smem > 160 * 1024) return rg_set_error_msg(RG_ERR_INVALID, "gemm_tn_layer: more than 256 workgroups, or a token range too long for the list slice in LDS");
-  hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-  hipLaunchKernelGGL(gemm_tn_layer_kernel, dim3(tot), dim3(512), smem, s, m);
+  if (dtype == RG_X3) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_layer_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(gemm_tn_layer_x3_kernel, dim3(tot), dim3(512), smem, s, m);
+  } else {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_layer_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    hipLaunchKernelGGL(gemm_tn_layer_kernel, dim3(tot), dim3(512), smem, s, m);
+  }
   hipLaunchKernelGGL(tn_layer_reduce_kernel, dim3(rtot), dim3(256), 0, s, r);
   RG_CHECK_LAUNCH();
   return 0;

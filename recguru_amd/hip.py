@@ -248,7 +248,8 @@ class _TnLayerArgs(ctypes.Structure):
 def gemm_tn_layer_slot(Y, X, prologue_x):
     """Slot of rg_gemm_tn_layer that takes dW += Y^T pro(X), or None."""
     key = (Y.shape[1], X.shape[1], prologue_x)
-    return LAYER_SLOTS.index(key) if (key in LAYER_SLOTS and Y.dtype == torch.bfloat16 and Y.shape[0] >= 8192) else None
+    ok = Y.dtype == torch.bfloat16 or (Y.dtype == torch.float32 and SPLIT_OPERANDS)        # bf16 and bf16x3 tiers
+    return LAYER_SLOTS.index(key) if (key in LAYER_SLOTS and ok and Y.shape[0] >= 8192) else None
 
 
 def gemm_tn_layer(probs):
@@ -283,7 +284,7 @@ def gemm_tn_layer(probs):
         if wgs[i]:
             args.p[i].partials = ws.data_ptr() + off
             off += need[i]
-    dt = dt_of(next(pr[0] for pr in probs if pr is not None))
+    dt = mt_of(next(pr[0] for pr in probs if pr is not None))
     cw = (ctypes.c_int * 4)(*wgs)
     if not lib().rg_gemm_tn_layer_supported(ctypes.byref(args), cw, dt):
         return False

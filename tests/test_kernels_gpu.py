@@ -1528,14 +1528,23 @@ def test_attn_out_bwd_equals_ln_bwd_plus_projection(dt, M, listed):
     assert torch.equal(dctx2[rows], dctx1[rows])
 
 
+@pytest.mark.parametrize("tier", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("listed", [False, True])
 @pytest.mark.parametrize("present", [(1, 1, 1, 1), (1, 1, 0, 0), (0, 0, 1, 1), (1, 0, 1, 0)])
-def test_gemm_tn_layer_equals_four_products(listed, present):
+def test_gemm_tn_layer_equals_four_products(listed, present, tier):
     """rg_gemm_tn_layer: the four weight-gradient products of a layer (dW2 with the GELU prologue, dW1, dWqkv, dWo) and their
     bias gradients in one launch + one reduce launch == the four rg_gemm_tn calls (different f32 summation order only); with a
     live-tile list on the slots that take one (dWqkv sums every row), with empty slots, and accumulating into existing dW."""
     from recguru_amd import hip
-    dt = torch.bfloat16
+    dt = torch.bfloat16 if tier == "bf16" else torch.float32
+    hip.SPLIT_OPERANDS = tier == "bf16x3"
+    try:
+        _tn_layer_case(hip, dt, listed, present)
+    finally:
+        hip.SPLIT_OPERANDS = False
+
+
+def _tn_layer_case(hip, dt, listed, present):
     T = 9000
     mask = _pad_mask(T // 120, 120, T + 7) if listed else None
     live = hip.live_tiles(mask, T) if listed else None
