@@ -144,13 +144,25 @@ struct QLive {
 // One (b, h) head's dropout bits, p == 0.5 mode: word w of query row q covers keys 32w..32w+31 and equals
 // rg_hash(seed, idx >> 5) for idx = ((b*H + h)*L + q) * LPAD + key -- exactly what rg_keep() would hash,
 // computed once per head instead of once per lane and element.  Layout [word][query].
+// row0 (a multiple of 16): query rows in front of it belong to 16-row tiles of padded positions only (the forward skips those
+// tiles, the backward's dctx rows there are zeros by contract) -- their words are never looked at and are not hashed: 44 % of the
+// rows at the bench's lengths.  A group of 32 lanes takes 32 consecutive rows of one word index (consecutive LDS banks); the
+// (word, row block) units of the live rows are dealt round-robin to the NTH / 32 groups.
 template <int NW, int LPK, int NTH = 256>
-__device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, const DropCfg& drop, int b, int h, int H, int L, int tid) {
+__device__ __forceinline__ void fill_dmask(unsigned int* __restrict__ dmask, const DropCfg& drop, int b, int h, int H, int L, int tid,
+                                           int row0 = 0) {
   const unsigned int nw = rg_lpad(L) >> 5;
   const unsigned int wbase = ((unsigned int)b * H + h) * L * nw;
-  for (int i = tid; i < NW * LPK; i += NTH) {
-    const int w = i / LPK, row = i - w * LPK;
-    dmask[i] = (row < L && (unsigned int)w < nw) ? rg_hash(drop.seed, wbase + (unsigned int)row * nw + w) : 0u;
+  const int nblk = (L - row0 + 31) >> 5;
+  constexpr int G = NTH / 32, DW = G % NW, DB = G / NW;      // unit u = blk * NW + w, u += G per round: no division in the loop
+  int blk = (tid >> 5) / NW, w = (tid >> 5) - blk * NW;
+  while (blk < nblk) {
+    const int row = row0 + 32 * blk + (tid & 31);
+    if (row < LPK)
+      dmask[w * LPK + row] = (row < L && (unsigned int)w < nw) ? rg_hash(drop.seed, wbase + __umul24((unsigned int)row, nw) + w) : 0u;
+    w += DW;
+    blk += DB;
+    if (w >= NW) { w -= NW; ++blk; }
   }
 }
 
@@ -278,9 +290,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   const T* __restrict__ qkv = XIN ? nullptr : reinterpret_cast<const T*>(a.qkv) + (HM ? (size_t)0 : (size_t)b * L * ld);
   // head-major: tensor w of head (b, h) starts at ((w * B + b) * H + h) * L * 32
   const size_t hm_head = ((size_t)b * a.H + h) * L * DK, hm_tensor = (size_t)a.B * a.H * L * DK;
-  int first_hm = 0;                    // HM + x_masked == 2: rows before it are bias rows (loaded FIRST: the DMA addresses need it)
+  // first position with rowmask != 0 (loaded FIRST: the DMA addresses and the dropout-word fill need it); HM + x_masked == 2: rows
+  // before it are bias rows
+  int first_q = 0, first_hm = 0;
+  if (a.rowmask != nullptr && a.first_live) first_q = min(a.first_live[b], L);
   if constexpr (HM) {
-    if (a.x_masked == 2 && a.rowmask != nullptr && a.first_live) first_hm = min(a.first_live[b], L);
+    if (a.x_masked == 2) first_hm = first_q;
   }
   const int nkt = (L + 31) / 32 * 2;  // live key tiles (wave-uniform)
   const int nqt = (L + 15) / 16;
@@ -339,24 +354,43 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
     const T* __restrict__ kb_row = padr + (a.H + h) * DK;
     const T* __restrict__ vb_row = padr + (2 * a.H + h) * DK;
     const T* __restrict__ z_row = padr + 3 * a.H * DK;
+    // A piece = 16 rows = one wave instruction per tensor.  The per-lane part of the source address does not depend on the piece
+    // (pieces start at multiples of 16 rows; the swizzles look at (row >> 2) & 3 only), and all but the (at most two) pieces that
+    // straddle first_live or L read ONE run -- the head's rows, the bias row or the zero row: scalar base + per-lane offset, no
+    // per-lane selects (they were 35 VALU instructions per piece: with the hash fill, half of this kernel's VALU work per head)
+    const int wv = __builtin_amdgcn_readfirstlane(wave);
+    const int lr = lane >> 2, cp = lane & 3;
+    const int ck = cp ^ ((-(lr >> 2)) & 3), cv = cp ^ (((lr >> 2) & 1) << 1);
+    const unsigned int o_row = (unsigned int)lr * DK * (unsigned int)sizeof(T);
 #pragma unroll
     for (int j0 = 0; j0 < NKT; j0 += 4) {
-      const int j = j0 + wave;                       // 16-row piece of the tiles (wave-uniform)
+      const int j = j0 + wv;                         // 16-row piece of the tiles (wave-uniform)
       if (j < NKT) {
-        const int row = j * 16 + (lane >> 2), cp = lane & 3;
-        const int ck = cp ^ ((-(row >> 2)) & 3), cv = cp ^ (((row >> 2) & 1) << 1);
-        const T* ksrc = row >= L ? z_row : (row < first_hm ? kb_row : kh + (size_t)row * DK);
-        const T* vsrc = row >= L ? z_row : (row < first_hm ? vb_row : vh + (size_t)row * DK);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + 8 * ck),
-                                         (__attribute__((address_space(3))) void*)(Ks + j * 16 * DK), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + 8 * cv),
-                                         (__attribute__((address_space(3))) void*)(Vs + j * 16 * DK), 16, 0, 0);
+        const int r0 = j * 16;
+        const bool beyond = r0 >= L, biasrun = r0 + 16 <= first_hm, liverun = r0 >= first_hm && r0 + 16 <= L;
+        if (beyond || biasrun || liverun) {
+          const char* kb = reinterpret_cast<const char*>(beyond ? z_row : biasrun ? kb_row : kh + (size_t)r0 * DK);
+          const char* vb = reinterpret_cast<const char*>(beyond ? z_row : biasrun ? vb_row : vh + (size_t)r0 * DK);
+          const unsigned int ro = liverun ? o_row : 0u;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(kb + (size_t)(ro + 16u * ck)),
+                                           (__attribute__((address_space(3))) void*)(Ks + j * 16 * DK), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vb + (size_t)(ro + 16u * cv)),
+                                           (__attribute__((address_space(3))) void*)(Vs + j * 16 * DK), 16, 0, 0);
+        } else {
+          const int row = r0 + lr;
+          const T* ksrc = row >= L ? z_row : (row < first_hm ? kb_row : kh + (size_t)row * DK);
+          const T* vsrc = row >= L ? z_row : (row < first_hm ? vb_row : vh + (size_t)row * DK);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ksrc + 8 * ck),
+                                           (__attribute__((address_space(3))) void*)(Ks + j * 16 * DK), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(vsrc + 8 * cv),
+                                           (__attribute__((address_space(3))) void*)(Vs + j * 16 * DK), 16, 0, 0);
+        }
       }
     }
   }
   // the head's dropout words: hashed HERE, under the latency of the mask / key-id loads above (at the top of the kernel,
   // with nothing in flight, the fill was exposed time: 1 us per head)
-  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid);
+  if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid, first_q & ~15);
   unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
 #pragma unroll
   for (int rd = 0; rd < NRD; ++rd) {
@@ -1103,28 +1137,52 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
       }
     }
     // the head's dropout words are hashed under the latency of the staging loads just issued
-    if constexpr (DM == 1) { if (i0 == 0) fill_dmask<NW, LPK, NTH>(dmask, drop, b, h, a.H, L, tid); }
+    if constexpr (DM == 1) { if (i0 == 0) fill_dmask<NW, LPK, NTH>(dmask, drop, b, h, a.H, L, tid, first & ~15); }
     // dctx rows with rowmask == 0 are zero by contract (rg_attn_bwd_args.rowmask) and are TAKEN as zero whatever the
     // buffer holds: its producer may leave the rows of padded 16-row tiles unwritten (rg_gemm_nt_args.skip_dead_fill).
     // The qkv / ctx rows of such positions are real data (a padded position is still a key unless its id is pad_value).
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = (tid + NTH * (i0 + i)) >> 2;
-      if (i0 + i >= NCH || row >= L) { frag_zero(qr[i]); frag_zero(kr[i]); frag_zero(vr[i]); frag_zero(gr[i]); frag_zero(orow[i]); }
-      else if (rmr[i] == 0.f || row < first) {
-        frag_zero(gr[i]);
-        // x_masked == 2: the qkv rows of such positions may be unwritten -- bias rows; ctx rows of padded query tiles are
-        // placeholders either way and only meet dO = 0
-        if (sub) { qr[i] = qbf; kr[i] = kbf; vr[i] = vbf; frag_zero(orow[i]); }
-      }
-    }
+    // A wave's 64 chunks of one round are 16 consecutive rows.  Three wave-uniform cases take no per-lane selects at all -- all
+    // 16 rows live (raw rows, delta, scaled dO), all 16 dead (rowmask == 0 or in front of first_live: bias rows or raw rows,
+    // delta = 0, dO = 0 -- no products), all 16 beyond L (zeros); only a piece that straddles first_live or L takes the general
+    // path.  (The selects, the delta of rows whose dO is zero and the scaling of zeros were a quarter of this kernel's VALU
+    // work per head.)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
       if (i0 + i < NCH && c < LPK * 4) {
-        stage_op<PL>(Qs + row * LDR + c8, qr[i]);
-        stage_op<PL>(Ks + row * LDR + c8, kr[i]);
-        stage_op<PL>(Vs + row * LDR + c8, vr[i]);
+        const bool in = row < L, dead = rmr[i] == 0.f || row < first;
+        const bool all_live = __all(in && !dead), all_dead = __all(in && dead), all_beyond = __all(!in);
+        Frag<G> zf;
+        frag_zero(zf);
+        if (all_live || all_dead) {
+          if (all_dead && sub) { qr[i] = qbf; kr[i] = kbf; vr[i] = vbf; }
+          stage_op<PL>(Qs + row * LDR + c8, qr[i]);
+          stage_op<PL>(Ks + row * LDR + c8, kr[i]);
+          stage_op<PL>(Vs + row * LDR + c8, vr[i]);
+          if (all_dead) {
+            if ((c & 3) == 0) dl_s[row] = 0.f;
+            stage_op<PL>(Gs + row * LDR + c8, zf);
+            continue;
+          }
+        } else if (all_beyond) {
+          stage_op<PL>(Qs + row * LDR + c8, zf);
+          stage_op<PL>(Ks + row * LDR + c8, zf);
+          stage_op<PL>(Vs + row * LDR + c8, zf);
+          if ((c & 3) == 0) dl_s[row] = 0.f;
+          stage_op<PL>(Gs + row * LDR + c8, zf);
+          continue;
+        } else {
+          if (!in) { qr[i] = zf; kr[i] = zf; vr[i] = zf; gr[i] = zf; orow[i] = zf; }
+          else if (dead) {
+            gr[i] = zf;
+            // x_masked == 2: the qkv rows of such positions may be unwritten -- bias rows; ctx rows of padded query tiles are
+            // placeholders either way and only meet dO = 0
+            if (sub) { qr[i] = qbf; kr[i] = kbf; vr[i] = vbf; orow[i] = zf; }
+          }
+          stage_op<PL>(Qs + row * LDR + c8, qr[i]);
+          stage_op<PL>(Ks + row * LDR + c8, kr[i]);
+          stage_op<PL>(Vs + row * LDR + c8, vr[i]);
+        }
         float d = 0.f;
 #pragma unroll
         for (int j = 0; j < 8; ++j) d += (float)gr[i].v[j] * (float)orow[i].v[j];

@@ -20,6 +20,7 @@
 #define WS_LD (128 + 8)
 #define WS_PLANE (WS_M * WS_LD * 2)      // bf16x3: bytes between the hi and the lo image of the A tile
 #include <type_traits>
+#include <cstdlib>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -291,7 +292,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
 template <int NKC, int NCB, typename T = __bf16>
 static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   const int ntiles = (a.M + WS_M - 1) / WS_M;
-  int grid = ny > 1 ? (768 / ny > 96 ? 768 / ny : 96) : 512;
+  // walkers per column block: ny * grid workgroups must fit the chip at once (persistent walkers: a second round of workgroups
+  // would run with half the CUs idle).  bf16: 35 KB of LDS, <= 128 VGPRs -- up to four per CU (768 measured best); bf16x3: two A
+  // planes + an f32 C tile = 70 KB -- two per CU, 512 slots
+  const int slots = std::is_same<T, x3>::value ? 512 : 768;
+  static const int slots_env = getenv("RG_WS_SLOTS") ? atoi(getenv("RG_WS_SLOTS")) : 0;
+  int grid = ny > 1 ? ((slots_env ? slots_env : slots) / ny > 96 ? (slots_env ? slots_env : slots) / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
   if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(ny, grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(ny, grid), dim3(256), 0, s, a);
