@@ -525,6 +525,12 @@ def main():
                            "arithmetic": {"bf16x3": "f32 activations; every MFMA operand split into a bf16 pair, three bf16 MFMAs per "
                                                     "product (user embeddings 7.5e-6 of max against the oracle at this shape)",
                                           "f32": "f32 activations, exact-f32 MFMA (1.7e-6 of max)"}[tier]}
+            if not args.no_roofline and tier == "bf16x3":           # the dominant kernel of the tolerance-meeting tier, compactly
+                rt = roofline_pass(step, tier, rank)
+                if rt:
+                    tiers[tier]["roofline"] = {k: rt[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_nominal",
+                                                                   "launches_per_step", "avg_launch_us", "share_of_kernel_time") if k in rt}
+                    tiers[tier]["kernels_ms_per_step"] = dict(list(rt["kernels_ms_per_step"].items())[:8])
             del step
         ops.set_compute_dtype(args.dtype)
 
