@@ -1076,13 +1076,15 @@ class Profiler(object):
         agg, cache = {}, {}
         for name, fl, by, e0, e1, ref in self.records:
             a = agg.setdefault(name, {"launches": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0, "flops_exec": 0.0, "bytes_exec": 0.0})
-            lf = self._live_frac(ref, cache)
             a["launches"] += 1
             a["ms"] += e0.elapsed_time(e1)
-            a["flops"] += fl
-            a["bytes"] += by
-            a["flops_exec"] += fl * lf
-            a["bytes_exec"] += by * lf
+            # one launch = one (flops, bytes, list) triple, or several (rg_gemm_tn_layer: one per product, each with its own list)
+            for f1, b1, r1 in (zip(fl, by, ref) if isinstance(fl, list) else ((fl, by, ref),)):
+                lf = self._live_frac(r1, cache)
+                a["flops"] += f1
+                a["bytes"] += b1
+                a["flops_exec"] += f1 * lf
+                a["bytes_exec"] += b1 * lf
         return agg
 
 
@@ -1202,10 +1204,26 @@ def _work_item_loss_scatter(h, table_rows, pos, neg, mask, k, coef, gout, dE, *a
     return "item_loss_scatter_binned_kernel", 2.0 * pairs * d, pairs * (d * _esize(h) + 2 * 12 + 2 * 8)
 
 
-_WORK = {"item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
+def _work_gemm_tn_layer(probs):
+    """Per product: X and Y rows read once (the tier's element size), dW written in f32 (the per-workgroup partial tiles and their
+    reduce are not algorithmic bytes)."""
+    fl, by, refs = [], [], []
+    for i, pr in enumerate(probs):
+        if pr is None:
+            continue
+        Y, X, dW, colsum, live = pr
+        T, N1, N2 = Y.shape[0], Y.shape[1], X.shape[1]
+        fl.append(2.0 * T * N1 * N2)
+        by.append(T * (N1 + N2) * _esize(Y) + N1 * N2 * 4)
+        refs.append(live)
+    x3 = any(pr is not None and pr[0].dtype == torch.float32 for pr in probs)
+    return "gemm_tn_layer_x3_kernel" if x3 else "gemm_tn_layer_kernel", fl, by, refs
+
+
+_WORK = {"gemm_tn_layer": _work_gemm_tn_layer, "item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
          "ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["gemm_tn_layer", "attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
           "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse", "cross_add_ln"]
 
@@ -1221,7 +1239,8 @@ def start_profile():
         def timed(*a, **k):
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            kname, fl, by = work(*a, **k) if work else (name + "_kernel", 0.0, 0.0)
+            wk = work(*a, **k) if work else (name + "_kernel", 0.0, 0.0)
+            kname, fl, by = wk[:3]
             if name in ("item_loss_fwd", "item_loss_bwd"):      # d = 64/128/256 run the row-group kernels (loss.hip)
                 rows = "_rows" if a[0].shape[1] in (64, 128, 256) else ""
                 kname = "%s%s_kernel" % (name, rows)
@@ -1244,6 +1263,8 @@ def start_profile():
                     ref = None
             if ref is None and name == "ln_bwd" and len(a) > 5 and k.get("live") is None:
                 ref = None                  # without a list ln_bwd walks every row
+            if len(wk) > 3:                 # the work function names the lists itself
+                ref = wk[3]
             _PROF.records.append((kname, fl, by, e0, e1, ref))
             return out
         return timed
