@@ -53,8 +53,21 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // Grid (column blocks, walkers): the column blocks of one walker are CONSECUTIVE workgroups, so the N / 128 workgroups that
   // read the same rows of A run at the same time and all but the first find them in the Infinity Cache (with the walkers on the
   // fast axis the re-reads were a whole pass over A apart: 840 MB at config-5, 420 MB in the bf16x3 tier -- HBM every time)
-  const int cby = (int)blockIdx.x;
-  const int wg = (int)blockIdx.y, nwg = (int)gridDim.y;
+  // XCD-aware (round 4): workgroups are dealt round-robin to the 8 XCDs (blocks b and b + 8 share one, each XCD has its own
+  // 4 MB L2), so the ny column blocks of ONE walker are consecutive rounds of the SAME XCD: the first fetches a row tile of A over
+  // the fabric, the other ny - 1 read it from that XCD's L2 (with consecutive block ids they sat on ny different XCDs and every one
+  // of them fetched A over the fabric: FETCH_SIZE 2.3 x the algorithmic bytes on the 256 -> 768 projection of config-5).
+  // Block i: xcd = i & 7, round r = i >> 3 -> column block r % ny of walker (r / ny) * 8 + xcd.  Only speed depends on it.
+  const int ny = (a.N >> 7) / NCB, nwg = (int)gridDim.x / ny;
+  int cby, wg;
+  if (ny > 1 && (nwg & 7) == 0) {
+    const int i = (int)blockIdx.x, r = i >> 3;
+    cby = r % ny;
+    wg = (r / ny) * 8 + (i & 7);
+  } else {
+    cby = (int)blockIdx.x % ny;
+    wg = (int)blockIdx.x / ny;
+  }
   const int ntiles = (a.M + WS_M - 1) / WS_M;
   // element offset of the 16-byte chunk (row m, block cb, columns c8..c8+7) of C: row-major, or head-major (c_hm_L: N = 3 * H * 32
   // columns q | k | v -> three tensors [B][H][L][32]; a 128-column block is four heads of one tensor -- block cb = tensor
@@ -299,8 +312,10 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   static const int slots_env = getenv("RG_WS_SLOTS") ? atoi(getenv("RG_WS_SLOTS")) : 0;
   int grid = ny > 1 ? ((slots_env ? slots_env : slots) / ny > 96 ? (slots_env ? slots_env : slots) / ny : 96) : 512;
   if (grid > ntiles) grid = ntiles;
-  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(ny, grid), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(ny, grid), dim3(256), 0, s, a);
+  static const int no_xcd = getenv("RG_WS_NO_XCD") ? atoi(getenv("RG_WS_NO_XCD")) : 0;
+  if (ny > 1 && grid >= 16) grid = (grid & ~7) - (no_xcd ? 1 : 0);     // walkers in multiples of 8: the XCD-aware block mapping (RG_WS_NO_XCD=1: one walker fewer = the plain mapping, for A/B)
+  if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(ny * grid), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(ny * grid), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
   return 0;
 }
