@@ -76,14 +76,23 @@ def _screen_and_record(isa_files, verbose):
                 return                           # this very library has been screened
     except (OSError, ValueError):
         pass
-    flagged, warnings = [], 0
+    flagged, warnings, opsel = [], 0, []
     for fn in isa_files:
         bad, warn = isa_screen.screen(fn)
         warnings += len(warn)
         flagged += [(os.path.basename(fn), kernel, no, block, len(ins)) for kernel, no, block, ins in bad]
+        opsel += [(os.path.basename(fn), kernel, no, text) for kernel, no, text in isa_screen.packed_opsel(fn)]
     ver = subprocess.run(["hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode().strip().splitlines()
     info = {"hipcc": ver[:3], "flags": FLAGS, "library_sha256": sha, "isa_files": len(isa_files), "screen": "recguru_amd/isa_screen.py",
-            "flagged_join_blocks": [list(x) for x in flagged], "spill_in_front_of_exec_restore_warnings": warnings}
+            "flagged_join_blocks": [list(x) for x in flagged], "spill_in_front_of_exec_restore_warnings": warnings,
+            "packed_f32_high_half_selects": [list(x) for x in opsel]}
+    if opsel and not os.environ.get("RG_BUILD_NO_SCREEN"):
+        msg = "\n".join("  %s: %s: line %d: %s" % x for x in opsel[:12])
+        raise RuntimeError("hipcc emitted a packed-f32 operation that feeds a LOW result from the HIGH half of a source pair (%d site(s); "
+                           "recguru_amd/isa_screen.py, DESIGN.md 2a finding 1): on gfx950 that form returns wrong values in lanes 48-63 "
+                           "when a second wave shares the SIMD.  Keep per-row statistics out of one register pair (scalar temporaries, "
+                           "-fno-slp-vectorize on the function) until the pattern is gone (RG_BUILD_NO_SCREEN=1 builds anyway):\n%s"
+                           % (len(opsel), msg))
     if flagged and not os.environ.get("RG_BUILD_NO_SCREEN"):
         msg = "\n".join("  %s: %s: %d vector instruction(s) in front of the exec restore at line %d (join block %s)" % (f, k, n, no, b)
                         for f, k, no, b, n in flagged)
@@ -93,7 +102,7 @@ def _screen_and_record(isa_files, verbose):
     with open(info_path, "w") as f:
         json.dump(info, f, indent=1)
     if verbose:
-        print("ISA screen: %d files, %d flagged join blocks, %d warnings" % (len(isa_files), len(flagged), warnings))
+        print("ISA screen: %d files, %d flagged join blocks, %d packed-f32 high-half selects, %d warnings" % (len(isa_files), len(flagged), len(opsel), warnings))
 
 
 def _drain(procs):

@@ -22,8 +22,18 @@ global_* / scratch_* / buffer_*) in front of its `s_or_b64 exec, exec, sX` -- wh
 (or empty) exec.  Spill-like copies directly in front of any other exec restore are listed as warnings (branch-free `if` bodies have
 no join label; there the copies can also be the body's own code).
 
-recguru_amd/build.py keeps the device ISA of every source (-save-temps) and calls screen() on it: a flagged kernel fails the
-build.  tools/isa_exec_screen.py is the command-line front.
+Second screen (round 4, DESIGN.md 2a finding 1): `v_pk_add_f32 vD, vA, vB op_sel:[0,1]` -- a packed-f32 operation whose LOW result
+takes the HIGH half of its second source pair.  On gfx950 the low result of that form intermittently comes out as if the selected
+source were 0, in lanes 48-63 only, whenever a second wave shares the SIMD (two workgroups per CU, or another process on the GPU):
+the fused block's LayerNorm subtracted a mean of 0 from one element of a row in 4 % of the rows of every bench-shape launch for
+three rounds.  Established on the ISA of the faulty kernel (tools/hazard/isa_variants.py, 720 instances): dropping the op_sel,
+replacing the instruction by two v_sub_f32, or moving the selection to src0 of a v_pk_fma_f32 (op_sel:[1,0,0]) removes the defect;
+wait states, sleeps, waits on LDS and a copied source do not.  hipcc forms the instruction by itself when two per-row statistics end
+up in one register pair (SLP vectorisation).  packed_opsel() flags every packed-f32 operation with an op_sel bit on its second or
+third source (and on src0 of anything but v_pk_fma_f32, the one such form measured clean): the build fails on it.
+
+recguru_amd/build.py keeps the device ISA of every source (-save-temps) and calls screen() and packed_opsel() on it: a flagged
+kernel fails the build.  tools/isa_exec_screen.py is the command-line front.
 """
 import glob
 import os
@@ -103,6 +113,24 @@ def screen(path):
     return bad, warn
 
 
+PK_F32 = re.compile(r"^\s*(v_pk_(?:add|mul|fma)_f32)\s+.*?\bop_sel:\[([01,]+)\]")
+
+
+def packed_opsel(path):
+    """[(kernel, line, text)]: packed-f32 operations that feed a LOW result from the HIGH half of a source pair in a form not
+    measured clean (module docstring): any op_sel bit on src1 / src2, or on src0 of v_pk_add_f32 / v_pk_mul_f32."""
+    out = []
+    for kernel, ins in kernels(path).items():
+        for no, s in ins:
+            m = PK_F32.match(s)
+            if not m:
+                continue
+            bits = [int(b) for b in m.group(2).split(",")]
+            if any(bits[1:]) or (bits[0] and m.group(1) != "v_pk_fma_f32"):
+                out.append((kernel, no, s))
+    return out
+
+
 def build_isa(outdir):
     srcs = sorted(glob.glob(os.path.join(ROOT, "recguru_amd", "csrc", "*.hip")))
     procs = []
@@ -137,8 +165,13 @@ def main():
                     print("      " + i)
                 if len(ins) > 4:
                     print("      ... %d more" % (len(ins) - 4))
-        print("%-24s %s" % (os.path.basename(fn), ("FLAGGED: %d join block(s)" % len(bad)) if bad else ("clean (%d warnings)" % len(warn))))
-    print("join blocks that run vector instructions under the narrowed exec: %d" % total)
+        pk = packed_opsel(fn)
+        total += len(pk)
+        for kernel, no, text in pk[:6]:
+            print("%s: %s: HIGH-HALF SELECT ON A PACKED-F32 SOURCE, line %d: %s" % (os.path.basename(fn), kernel, no, text))
+        print("%-24s %s" % (os.path.basename(fn), ("FLAGGED: %d join block(s), %d packed-f32 op_sel form(s)" % (len(bad), len(pk))) if bad or pk
+                            else ("clean (%d warnings)" % len(warn))))
+    print("flagged (join blocks under a narrowed exec + packed-f32 high-half selects): %d" % total)
     sys.exit(1 if total else 0)
 
 

@@ -192,6 +192,47 @@ _Z6kernelv:
             assert flagged[0][0] == "_Z6kernelv" and flagged[0][2] == ".LBB0_2" and "a144" in flagged[0][3][0]
 
 
+def test_isa_screen_flags_the_packed_f32_high_half_select(tmp_path):
+    """Second rule of recguru_amd/isa_screen.py (finding 1): `v_pk_add_f32 ... op_sel:[0,1]` -- the form that made the
+    fused block's LayerNorm subtract a mean of 0 in lanes 48-63 at two workgroups per CU -- and its relatives are flagged; the
+    broadcasts of a LOW half (op_sel_hi) and the one high-half form measured clean (src0 of v_pk_fma_f32) are not.  The fixture's
+    first instruction is a line of the faulty kernel's ISA (profiles/r04/determinism/post_attn_fwd_old_rsqrtf_form.s.gz)."""
+    from recguru_amd import isa_screen
+    text = """
+_Z6kernelv:
+	v_pk_add_f32 v[38:39], v[44:45], v[78:79] op_sel:[0,1] neg_lo:[0,1] neg_hi:[0,1]
+	v_pk_add_f32 v[42:43], v[42:43], v[86:87] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,1]
+	v_pk_mul_f32 v[38:39], v[80:81], v[38:39] op_sel_hi:[0,1]
+	v_pk_fma_f32 v[40:41], v[40:41], v[72:73], v[76:77]
+	v_pk_fma_f32 v[40:41], v[82:83], v[250:251], v[40:41] op_sel:[1,0,0]
+	v_pk_fma_f32 v[40:41], v[82:83], v[250:251], v[40:41] op_sel:[0,0,1]
+	v_pk_mul_f32 v[38:39], v[80:81], v[38:39] op_sel:[1,0]
+	s_endpgm
+"""
+    p = tmp_path / "pk.s"
+    p.write_text(text)
+    hits = isa_screen.packed_opsel(str(p))
+    assert [h[1] for h in hits] == [3, 8, 9], hits
+    assert all(h[0] == "_Z6kernelv" for h in hits)
+
+
+def test_the_faulty_fused_block_of_rounds_1_to_3_is_flagged():
+    """The kept ISA of the kernel that carried finding 1 (rsqrtf() form, rebuilt with this round's hipcc) holds the flagged form --
+    16 sites in the encoder kernel -- and passes the exec-restore screen: the two rules are independent."""
+    import gzip
+    import tempfile
+    from recguru_amd import isa_screen
+    src = os.path.join(ROOT, "profiles", "r04", "determinism", "post_attn_fwd_old_rsqrtf_form.s.gz")
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as f:
+        f.write(gzip.open(src, "rt").read())
+    try:
+        hits = isa_screen.packed_opsel(f.name)
+        assert len(hits) == 16 and all("op_sel:[0,1]" in h[2] and h[2].startswith("v_pk_add_f32") for h in hits)
+        assert isa_screen.screen(f.name)[0] == []
+    finally:
+        os.unlink(f.name)
+
+
 def test_built_library_passes_the_isa_screen():
     """The device ISA the build kept (recguru_amd/build/isa/*.s) has no join block that runs vector instructions under a narrowed exec,
     and BUILD_INFO.json records the compiler and the hash of the library that was screened."""
@@ -206,6 +247,7 @@ def test_built_library_passes_the_isa_screen():
     for fn in isa:
         flagged, _ = isa_screen.screen(fn)
         assert not flagged, (fn, flagged[:2])
+        assert isa_screen.packed_opsel(fn) == [], fn
     info = json.load(open(os.path.join(ROOT, "recguru_amd", "build", "BUILD_INFO.json")))
-    assert info["flagged_join_blocks"] == [] and "clang" in " ".join(info["hipcc"])
+    assert info["flagged_join_blocks"] == [] and info["packed_f32_high_half_selects"] == [] and "clang" in " ".join(info["hipcc"])
     assert info["library_sha256"] == hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()
