@@ -24,7 +24,8 @@ no join label; there the copies can also be the body's own code).
 
 Second screen (round 4, DESIGN.md 2a finding 1): `v_pk_add_f32 vD, vA, vB op_sel:[0,1]` -- a packed-f32 operation whose LOW result
 takes the HIGH half of its second source pair.  On gfx950 the low result of that form intermittently comes out as if the selected
-source were 0, in lanes 48-63 only, whenever a second wave shares the SIMD (two workgroups per CU, or another process on the GPU):
+source were 0, in lanes 48-63 only, whenever ANOTHER wave on the SIMD is issuing MFMAs (two workgroups per CU, or another process
+on the GPU; stand-alone reproducer: tools/hazard/opsel_repro.hip):
 the fused block's LayerNorm subtracted a mean of 0 from one element of a row in 4 % of the rows of every bench-shape launch for
 three rounds.  Established on the ISA of the faulty kernel (tools/hazard/isa_variants.py, 720 instances): dropping the op_sel,
 replacing the instruction by two v_sub_f32, or moving the selection to src0 of a v_pk_fma_f32 (op_sel:[1,0,0]) removes the defect;
