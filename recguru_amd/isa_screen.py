@@ -30,8 +30,10 @@ the fused block's LayerNorm subtracted a mean of 0 from one element of a row in 
 three rounds.  Established on the ISA of the faulty kernel (tools/hazard/isa_variants.py, 720 instances): dropping the op_sel,
 replacing the instruction by two v_sub_f32, or moving the selection to src0 of a v_pk_fma_f32 (op_sel:[1,0,0]) removes the defect;
 wait states, sleeps, waits on LDS and a copied source do not.  hipcc forms the instruction by itself when two per-row statistics end
-up in one register pair (SLP vectorisation).  packed_opsel() flags every packed-f32 operation with an op_sel bit on its second or
-third source (and on src0 of anything but v_pk_fma_f32, the one such form measured clean): the build fails on it.
+up in one register pair (SLP vectorisation).  The stand-alone probe maps the hazard to the SECOND source operand: v_pk_add_f32 and
+v_pk_mul_f32 with op_sel:[0,1] and v_pk_fma_f32 with op_sel:[0,1,0] fail (src1 read as 0); op_sel:[1,0] (src0) of v_pk_add_f32 /
+v_pk_mov_b32, op_sel:[1,0,0] and op_sel:[0,0,1] (src0, src2) of v_pk_fma_f32 and every op_sel_hi form do not.
+packed_opsel() flags every packed-f32 operation with the op_sel bit of its second source set: the build fails on it.
 
 recguru_amd/build.py keeps the device ISA of every source (-save-temps) and calls screen() and packed_opsel() on it: a flagged
 kernel fails the build.  tools/isa_exec_screen.py is the command-line front.
@@ -118,8 +120,8 @@ PK_F32 = re.compile(r"^\s*(v_pk_(?:add|mul|fma)_f32)\s+.*?\bop_sel:\[([01,]+)\]"
 
 
 def packed_opsel(path):
-    """[(kernel, line, text)]: packed-f32 operations that feed a LOW result from the HIGH half of a source pair in a form not
-    measured clean (module docstring): any op_sel bit on src1 / src2, or on src0 of v_pk_add_f32 / v_pk_mul_f32."""
+    """[(kernel, line, text)]: packed-f32 operations that feed a LOW result from the HIGH half of their SECOND source (module
+    docstring)."""
     out = []
     for kernel, ins in kernels(path).items():
         for no, s in ins:
@@ -127,7 +129,7 @@ def packed_opsel(path):
             if not m:
                 continue
             bits = [int(b) for b in m.group(2).split(",")]
-            if any(bits[1:]) or (bits[0] and m.group(1) != "v_pk_fma_f32"):
+            if len(bits) > 1 and bits[1]:      # src1 (a bit on src0 measured clean for add, fma and v_pk_mov_b32; on src2 for fma)
                 out.append((kernel, no, s))
     return out
 

@@ -194,8 +194,9 @@ _Z6kernelv:
 
 def test_isa_screen_flags_the_packed_f32_high_half_select(tmp_path):
     """Second rule of recguru_amd/isa_screen.py (finding 1): `v_pk_add_f32 ... op_sel:[0,1]` -- the form that made the
-    fused block's LayerNorm subtract a mean of 0 in lanes 48-63 at two workgroups per CU -- and its relatives are flagged; the
-    broadcasts of a LOW half (op_sel_hi) and the one high-half form measured clean (src0 of v_pk_fma_f32) are not.  The fixture's
+    fused block's LayerNorm subtract a mean of 0 in lanes 48-63 at two workgroups per CU -- and every other high-half select on a
+    SECOND source (add, mul, fma: all three measured faulty) are flagged; broadcasts of a LOW half (op_sel_hi) and high-half selects on
+    src0 / src2 (measured clean, tools/hazard/opsel_repro.hip) are not.  The fixture's
     first instruction is a line of the faulty kernel's ISA (profiles/r04/determinism/post_attn_fwd_old_rsqrtf_form.s.gz)."""
     from recguru_amd import isa_screen
     text = """
@@ -207,12 +208,14 @@ _Z6kernelv:
 	v_pk_fma_f32 v[40:41], v[82:83], v[250:251], v[40:41] op_sel:[1,0,0]
 	v_pk_fma_f32 v[40:41], v[82:83], v[250:251], v[40:41] op_sel:[0,0,1]
 	v_pk_mul_f32 v[38:39], v[80:81], v[38:39] op_sel:[1,0]
+	v_pk_fma_f32 v[40:41], v[82:83], v[250:251], v[40:41] op_sel:[0,1,0]
+	v_pk_mul_f32 v[38:39], v[80:81], v[38:39] op_sel:[0,1]
 	s_endpgm
 """
     p = tmp_path / "pk.s"
     p.write_text(text)
     hits = isa_screen.packed_opsel(str(p))
-    assert [h[1] for h in hits] == [3, 8, 9], hits
+    assert [h[1] for h in hits] == [3, 10, 11], hits     # (lines 7 - 9: selects on src0 / src2 alone -- measured clean, not flagged)
     assert all(h[0] == "_Z6kernelv" for h in hits)
 
 
