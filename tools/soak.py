@@ -9,7 +9,7 @@ from recguru_amd import ops
 
 args = bench.parse()
 device = "cuda:0"
-ops.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+ops.set_compute_dtype(args.dtype)
 ops.set_data_parallel(None)
 ops.manual_seed(0, 0)
 n_ae = args.ae_steps if args.ae_steps > 10 else 500
