@@ -1220,10 +1220,21 @@ def _work_gemm_tn_layer(probs):
     return "gemm_tn_layer_x3_kernel" if x3 else "gemm_tn_layer_kernel", fl, by, refs
 
 
-_WORK = {"gemm_tn_layer": _work_gemm_tn_layer, "item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
+def _work_attn_out_bwd(dy, y, rstd, *a, **k):
+    """LayerNorm backward + dctx = dz . Wo: dy and y rows read, dz and dctx rows written, the row rstd."""
+    M, d = dy.shape
+    return "attn_out_bwd_kernel", 2.0 * M * d * d, 4 * M * d * _esize(dy) + M * 4
+
+
+def _work_ln_bwd(dy, y, rstd, *a, **k):
+    M, N = dy.shape
+    return "ln_bwd_kernel", 0.0, 3 * M * N * _esize(dy) + M * 4
+
+
+_WORK = {"attn_out_bwd": _work_attn_out_bwd, "ln_bwd": _work_ln_bwd, "gemm_tn_layer": _work_gemm_tn_layer, "item_loss_scatter_binned": _work_item_loss_scatter, "attn_lastq_x_fwd": _work_lastq_x_fwd, "attn_lastq_x_bwd": _work_lastq_x_bwd, "item_loss_train": _work_item_loss_train,
          "ffn_bwd_data": _work_ffn_bwd, "attn_fwd_x": _work_attn_fwd_x, "post_attn_fwd": _work_post_attn, "gemm_nt": _work_gemm_nt, "gemm_tn": _work_gemm_tn, "attn_fwd": _work_attn_fwd, "attn_bwd": _work_attn_bwd,
          "embed_pe_fwd": _work_embed_fwd, "item_loss_fwd": _work_item_loss, "item_loss_bwd": _work_item_loss}
-_PLAIN = ["attn_out_bwd", "dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "ln_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
+_PLAIN = ["dropout_", "cross_rows", "adam_multi", "adam_multi_dev", "disc_rows", "item_loss_bwd_binned", "embed_scatter_bwd", "bcast_add_ln", "seq_sum", "colsum", "outer_posmask", "interpolate",
           "gp_penalty", "sum_into", "adam", "cast", "attn_lastq_fwd", "attn_lastq_bwd", "cross_drop_scale", "seq_wsum",
           "embed_scatter_bwd_binned", "scale_dev", "dropout_gelu", "add_drop_ln", "mse", "cross_add_ln"]
 
