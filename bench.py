@@ -35,7 +35,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 # MI355X_MICROARCH.md, dense.  bf16x3: a product is three bf16 MFMAs, so its ALGORITHMIC flops are priced at a third of the bf16 peak
-MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3}
+MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3, "bf16x3": 2500.0 / 3, "mixed": 2500.0 / 3}
 HBM_PEAK_GBS = 8000.0
 MFMA_KERNELS = ("gemm", "attn", "post_attn")           # kernels priced against the MFMA peak; the rest against HBM
 # counter passes of the newest round first (profiles/rNN/pmc_traffic.json, written by tools/profile_round.sh rNN);
@@ -93,7 +93,7 @@ def parse():
     ap.add_argument("--n_blocks", type=int, default=3)
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--n_negs", type=int, default=30)
-    ap.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16",
+    ap.add_argument("--dtype", choices=["bf16", "f32", "bf16x3", "mixed"], default="bf16",
                     help="bf16: bf16 operands and activations (the headline tier); f32: exact-f32 MFMA; bf16x3: f32 activations, every "
                          "MFMA operand split into a bf16 pair, three MFMAs per product (inside rtol 1e-3 / atol 1e-5 like f32)")
     ap.add_argument("--residual", choices=["bf16", "split"], default="bf16",
@@ -282,19 +282,17 @@ def cpu_baseline(args):
                 O.critic_step(pG, pD, cfg, bt[0][0], bt[1][0], opt_d, torch.rand(B, 1))
             O.generator_step(pG, pD, cfg, bt[0], bt[1], opt_g)
         return time.perf_counter() - t0
-    def median3(drop, drop_d, budget):
-        """Up to three iterations (one setting's times spread by 1.7x from run to run on a shared host); stops early once the
-        setting has used `budget` seconds so that the default bench run stays within minutes."""
-        ts = []
-        while len(ts) < 3 and sum(ts) < budget:
-            ts.append(iteration(drop, drop_d))
-        return sorted(ts)[len(ts) // 2], ts
+    def median3(drop, drop_d):
+        """ALWAYS three iterations per setting (one setting's times spread by 1.7x from run to run on a shared host; VERDICT r4
+        item 8): the leg runs after every timed region, ~2 minutes of host time at B = 64."""
+        ts = [iteration(drop, drop_d) for _ in range(3)]
+        return sorted(ts)[1], ts
     try:
-        dt, ts = median3(args.dropout, 0.2 if args.dropout > 0 else 0.0, 70.0)
-        dt0, ts0 = (dt, ts) if args.dropout == 0 else (median3(0.0, 0.0, 30.0) if sum(ts) < 110.0 else (None, []))
+        dt, ts = median3(args.dropout, 0.2 if args.dropout > 0 else 0.0)
+        dt0, ts0 = (dt, ts) if args.dropout == 0 else median3(0.0, 0.0)
     finally:
         O.DROPOUT, O.DROPOUT_D = 0.0, 0.0
-    fmt = lambda t: "median %.1f s of %d (min %.1f, max %.1f)" % (sorted(t)[len(t) // 2], len(t), min(t), max(t))
+    fmt = lambda t: "MEDIAN %.1f s of %d iterations (min %.1f, max %.1f)" % (sorted(t)[len(t) // 2], len(t), min(t), max(t))
     return {"value": per_step / dt, "unit": "user-sequences/sec", "cores": torch.get_num_threads(), "kind": "port",
             "value_dropout0": (per_step / dt0) if dt0 else None,
             "iterations_s": [round(t, 2) for t in ts], "iterations_dropout0_s": [round(t, 2) for t in ts0],

@@ -198,6 +198,11 @@ int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream
  * dE[rows,d]; skip_row (e.g. padding_idx 0 of AutoEnc4Rec.py:153) receives nothing (-1 = none). */
 int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
                     long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* The same with a second, bf16 copy of the output rows, out2 [ntok,d] (NULL: none) -- the "mixed" tier (f32 forward tensors, bf16
+ * backward operands: DESIGN.md 2) keeps the layer input twice, f32 for the forward and bf16 as the X operand of the first layer's
+ * weight-gradient product.  out2 needs d in {128, 256}. */
+int rg_embed_pe_fwd2(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out, void* out2,
+                     long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
 /* Split-residual form (bf16 tier, see rg_post_attn_args.x_lo): the rows are gathered from the F32 MASTER table
  * (table_f32 [rows,d]; the embedding feeds the residual stream directly, so rounding the table to bf16 first would cap its
  * precision at 8 bits) and leave as the pair out = bf16(v), out_lo = bf16(v - out). */

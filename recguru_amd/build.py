@@ -56,7 +56,13 @@ def build(force=False, verbose=False, jobs=4):
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
-    _screen_and_record([_isa_of(o) for o in objs], verbose)
+    try:
+        _screen_and_record([_isa_of(o) for o in objs], verbose)
+    except RuntimeError:
+        # a library whose ISA the screen refuses must not stay loadable (hip.lib() loads whatever is on disk -- ADVICE r4)
+        if os.path.exists(LIB):
+            os.remove(LIB)
+        raise
     return LIB
 
 
@@ -83,9 +89,16 @@ def _screen_and_record(isa_files, verbose):
         flagged += [(os.path.basename(fn), kernel, no, block, len(ins)) for kernel, no, block, ins in bad]
         opsel += [(os.path.basename(fn), kernel, no, text) for kernel, no, text in isa_screen.packed_opsel(fn)]
     ver = subprocess.run(["hipcc", "--version"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT).stdout.decode().strip().splitlines()
+    bypass = bool(os.environ.get("RG_BUILD_NO_SCREEN"))
     info = {"hipcc": ver[:3], "flags": FLAGS, "library_sha256": sha, "isa_files": len(isa_files), "screen": "recguru_amd/isa_screen.py",
             "flagged_join_blocks": [list(x) for x in flagged], "spill_in_front_of_exec_restore_warnings": warnings,
             "packed_f32_high_half_selects": [list(x) for x in opsel]}
+    if bypass and (flagged or opsel):
+        # a flagged library kept on purpose (RG_BUILD_NO_SCREEN=1): never record its hash as "screened", so that the next
+        # ordinary build screens -- and refuses -- it again instead of returning early on a matching hash
+        info["screen_bypassed"] = True
+        info["library_sha256"] = None
+        info["bypassed_library_sha256"] = sha
     if opsel and not os.environ.get("RG_BUILD_NO_SCREEN"):
         msg = "\n".join("  %s: %s: line %d: %s" % x for x in opsel[:12])
         raise RuntimeError("hipcc emitted a packed-f32 operation that feeds a LOW result from the HIGH half of a source pair (%d site(s); "

@@ -1,6 +1,7 @@
 // HBM-bound kernels of the path: embedding gather / scatter, LayerNorm backward, the collapsed
 // cross-attention broadcast+LayerNorm, gradient-penalty helpers, Adam, casts and reductions.
 // All of them move 8-16 bytes per lane per access with lanes on consecutive addresses.
+#include <stdlib.h>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -46,6 +47,69 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_kernel(const T* __restr
       for (int j = 0; j < 8; ++j) v[j] = 0.f;
     }
     store8(out + (size_t)tok * d + c8, v);
+  }
+}
+
+// Row form for d_model 128 / 256 (round 5): a row is D / 8 lanes x 8 elements, a wave takes 64 consecutive tokens at a time -- ids and
+// mask values arrive by ONE coalesced load per wave (lane t: token t0 + t) and reach the lane groups through ds_bpermute --, U rows
+// per lane group are in flight together, and every index is 32-bit (the element-per-thread form above pays two 64-bit divisions
+// per 16 bytes).  On-box ceiling for this access pattern (tools/peaks.hip, gather_copy_512B: random 512-B rows of a 1 GiB table copied
+// out): 5.3 - 5.4 TB/s.  M2: a second, bf16 copy of the output rows (mixed tier: the operand copy the bf16 backward reads).
+template <typename T, int D, int U, bool M2>
+__global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_rows_kernel(const T* __restrict__ table, const float* __restrict__ pe,
+                                                                    const int64_t* __restrict__ ids, const float* __restrict__ mask,
+                                                                    T* __restrict__ out, __bf16* __restrict__ out2, int ntok, int L, DropCfg drop) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR;           // lanes per row, rows per wave instruction
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * EW_BLOCK + threadIdx.x) >> 6), nwave = (int)gridDim.x * (EW_BLOCK / 64);
+  const int lr = lane / LPR, c8 = (lane % LPR) * 8;
+  for (int t0 = wave * 64; t0 < ntok; t0 += nwave * 64) {
+    const int tl = min(t0 + lane, ntok - 1);
+    const int64_t idl = ids[tl];
+    const float ml = (t0 + lane < ntok) ? mask[tl] : 0.f;
+    const int idlo = (int)(idl & 0xFFFFFFFFll), idhi = (int)(idl >> 32);
+    const int p0 = __builtin_amdgcn_readfirstlane(t0) % L;           // (uniform: one scalar division per 64 tokens)
+#pragma unroll 1
+    for (int g = 0; g < 64; g += RPW * U) {
+      float m[U];
+      int64_t id[U];
+      int pos[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int src = g + u * RPW + lr;
+        m[u] = __shfl(ml, src);
+        id[u] = ((int64_t)__shfl(idhi, src) << 32) | (unsigned int)__shfl(idlo, src);
+        pos[u] = (p0 + src) % L;
+      }
+      float v[U][8], pp[U][8];
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+        if (m[u] != 0.f) {
+          load8(v[u], table + (size_t)id[u] * D + c8);
+          load8(pp[u], pe + (unsigned int)pos[u] * D + c8);
+        }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int tok = t0 + g + u * RPW + lr;
+        if (m[u] != 0.f) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] + pp[u][j]) * m[u];
+          if (drop.thresh) {
+            float k8[8];
+            rg_keep8(drop, (unsigned int)tok * (unsigned int)D + (unsigned int)c8, k8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[u][j] *= k8[j];
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] = 0.f;
+        }
+        if (tok < ntok) {
+          store8(out + (size_t)tok * D + c8, v[u]);
+          if constexpr (M2) store8(out2 + (size_t)tok * D + c8, v[u]);
+        }
+      }
+    }
   }
 }
 
@@ -1130,17 +1194,43 @@ extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, f
   return 0;
 }
 
-extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
-                               long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {
-  const DropCfg drop = make_drop(drop_p, seed);
-  if (ntok <= 0) return 0;
-  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
-  hipStream_t s = (hipStream_t)stream;
+static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out, void* out2,
+                               long long ntok, int L, int d, const DropCfg& drop, int dtype, hipStream_t s) {
+  static const int old_form = getenv("RG_EMBED_OLD") ? atoi(getenv("RG_EMBED_OLD")) : 0;      // A/B: the element-per-thread kernel
+  if ((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d && (!old_form || out2)) {
+    // persistent-ish: one wave per 64-token block, at most 8 workgroups per CU
+    long long g = (ntok + 255) / 256;
+    const int grid = (int)(g < 1 ? 1 : (g > 256LL * 8 ? 256LL * 8 : g));
+#define RG_EMB(T, D, M2) hipLaunchKernelGGL((embed_pe_fwd_rows_kernel<T, D, 4, M2>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)out2, (int)ntok, L, drop)
+#define RG_EMB_T(T) do { if (d == 128) { if (out2) RG_EMB(T, 128, true); else RG_EMB(T, 128, false); } else { if (out2) RG_EMB(T, 256, true); else RG_EMB(T, 256, false); } } while (0)
+    DISPATCH_T(dtype, RG_EMB_T(__bf16), RG_EMB_T(float), "embed_pe_fwd")
+#undef RG_EMB_T
+#undef RG_EMB
+  }
   const int grid = ew_grid(ntok * (d >> 3), EW_BLOCK);
   DISPATCH_T(dtype,
              hipLaunchKernelGGL(embed_pe_fwd_kernel<__bf16>, dim3(grid), dim3(EW_BLOCK), 0, s, (const __bf16*)table, pe, ids, mask, (__bf16*)out, ntok, L, d, drop),
              hipLaunchKernelGGL(embed_pe_fwd_kernel<float>, dim3(grid), dim3(EW_BLOCK), 0, s, (const float*)table, pe, ids, mask, (float*)out, ntok, L, d, drop),
              "embed_pe_fwd")
+}
+
+extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
+                               long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  const DropCfg drop = make_drop(drop_p, seed);
+  if (ntok <= 0) return 0;
+  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
+  return embed_pe_fwd_launch(table, pe, ids, mask, out, nullptr, ntok, L, d, drop, dtype, (hipStream_t)stream);
+}
+
+// ... with a second, bf16 copy of the rows (rg_embed_pe_fwd2: the mixed tier's operand copy for the bf16 backward; out2 may be NULL)
+extern "C" int rg_embed_pe_fwd2(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out, void* out2,
+                                long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  const DropCfg drop = make_drop(drop_p, seed);
+  if (ntok <= 0) return 0;
+  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd2: d must be a multiple of 8");
+  if (out2 && !((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d))
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd2: the second output needs d in {128, 256} and ntok * d < 2^31");
+  return embed_pe_fwd_launch(table, pe, ids, mask, out, out2, ntok, L, d, drop, dtype, (hipStream_t)stream);
 }
 
 extern "C" int rg_embed_pe_fwd_split(const float* table_f32, const float* pe, const int64_t* ids, const float* mask, void* out,

@@ -94,7 +94,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
            "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse",
-           "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln"]
+           "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln", "rg_embed_pe_fwd2"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -111,12 +111,35 @@ class ItemLossArgs(ctypes.Structure):
                 ("mode", c_i), ("skip_row", c_ll)]
 
 
+def _check_screened(path):
+    """Refuse the in-tree library when build/BUILD_INFO.json says its ISA screen was bypassed or belongs to another build
+    (recguru_amd/build.py, DESIGN.md 2a: a flagged kernel returns wrong values silently).  RG_ALLOW_UNSCREENED=1 or an explicit
+    RG_HIP_LIB (A/B variant builds) skip the check; a missing BUILD_INFO.json (library built by hand) does too."""
+    if os.environ.get("RG_ALLOW_UNSCREENED") or os.environ.get("RG_HIP_LIB"):
+        return
+    info_path = os.path.join(_HERE, "build", "BUILD_INFO.json")
+    try:
+        import json
+        with open(info_path) as f:
+            info = json.load(f)
+    except (OSError, ValueError):
+        return
+    import hashlib
+    with open(path, "rb") as f:
+        sha = hashlib.sha256(f.read()).hexdigest()
+    if info.get("screen_bypassed") or info.get("library_sha256") != sha:
+        raise RuntimeError("recguru_amd: %s is not the library the ISA screen passed (build/BUILD_INFO.json: %s) -- rebuild with "
+                           "`python -m recguru_amd.build` (RG_ALLOW_UNSCREENED=1 loads it anyway)"
+                           % (path, "screen bypassed" if info.get("screen_bypassed") else "hash mismatch"))
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("recguru_amd: %s is missing -- run `python -m recguru_amd.build` "
                                "(there is no CPU fallback)" % LIB_PATH)
+        _check_screened(LIB_PATH)
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.rg_last_error.restype = ctypes.c_char_p
         for name in SYMBOLS:
@@ -354,12 +377,17 @@ def _vp(t):
     return ctypes.c_void_p(_p(t))
 
 
-def embed_pe_fwd(table, pe, ids, mask, L, drop_p=0.0, seed=0):
+def embed_pe_fwd(table, pe, ids, mask, L, drop_p=0.0, seed=0, mirror=False):
     """(table[ids] + pe[t]) * mask -> [ntok, d] in table.dtype."""
     ntok, d = ids.numel(), table.shape[1]
     assert ids.dtype == torch.int64 and ids.is_contiguous() and mask.dtype == torch.float32 and mask.numel() == ntok
     assert pe.dtype == torch.float32 and pe.shape[1] == d and pe.is_contiguous() and table.is_contiguous()
     out = torch.empty(ntok, d, device=table.device, dtype=table.dtype)
+    if mirror:          # a second, bf16 copy of the rows (mixed tier: the X operand of the first layer's weight gradient)
+        out2 = torch.empty(ntok, d, device=table.device, dtype=torch.bfloat16)
+        _check(lib().rg_embed_pe_fwd2(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), _vp(out2), c_ll(ntok), L, d, c_f(drop_p),
+                                      c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd2")
+        return out, out2
     _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, c_f(drop_p),
                                  c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd")
     return out
@@ -1080,9 +1108,13 @@ class Profiler(object):
             a["ms"] += e0.elapsed_time(e1)
             # one launch = one (flops, bytes, list) triple, or several (rg_gemm_tn_layer: one per product, each with its own list)
             for f1, b1, r1 in (zip(fl, by, ref) if isinstance(fl, list) else ((fl, by, ref),)):
-                lf = self._live_frac(r1, cache)
                 a["flops"] += f1
                 a["bytes"] += b1
+                if isinstance(r1, tuple) and r1 and r1[0] == "exec":     # the work function priced the executed work itself
+                    a["flops_exec"] += r1[1]
+                    a["bytes_exec"] += r1[2]
+                    continue
+                lf = self._live_frac(r1, cache)
                 a["flops_exec"] += f1 * lf
                 a["bytes_exec"] += b1 * lf
         return agg
@@ -1145,8 +1177,13 @@ def _work_attn_bwd(qkv, dctx, ctx, lse, key_ids, pad_value, causal, H, *a, **k):
 
 
 def _work_embed_fwd(table, pe, ids, mask, L, *a, **k):
+    """Nominal: a table row read and an output row written per position + id (8 B) and mask (4 B).  Executed: the kernel reads a
+    table row only where mask != 0 (padded positions get a zero row written without a gather), so the row READS are priced for
+    the live positions alone; every output row is still written and every id / mask read."""
     n, d = ids.numel(), table.shape[1]
-    return "embed_pe_fwd_kernel", 0.0, n * d * 2 * _esize(table) + n * 12
+    es = _esize(table)
+    nl = float((mask.reshape(-1) != 0).sum())
+    return "embed_pe_fwd_kernel", 0.0, n * d * 2 * es + n * 12, ("exec", 0.0, nl * d * es + n * d * es + n * 12)
 
 
 def _work_item_loss(h, table, pos, neg, mask, k, mode, *a, **kw):

@@ -22,8 +22,9 @@ def set_compute_dtype(dt):
     """torch.bfloat16 (bf16 tier), torch.float32 (exact-f32 tier) or "bf16x3": the f32 tier's tensors and elementwise arithmetic
     with every matrix product on split bf16 operands (hip.SPLIT_OPERANDS; include/recguru_hip.h RG_X3) -- inside the north-star
     tolerance like the f32 tier at a third of its matrix-pipe time."""
-    global _COMPUTE
-    x3 = dt == "bf16x3"
+    global _COMPUTE, _MIXED
+    _MIXED = dt == "mixed"
+    x3 = dt in ("bf16x3", "mixed")
     if x3:
         dt = torch.float32
     elif dt == "bf16":
@@ -43,7 +44,37 @@ def compute_dtype():
 
 
 def compute_tier():
-    return "bf16" if _COMPUTE == torch.bfloat16 else ("bf16x3" if hip.SPLIT_OPERANDS else "f32")
+    return "bf16" if _COMPUTE == torch.bfloat16 else (("mixed" if _MIXED else "bf16x3") if hip.SPLIT_OPERANDS else "f32")
+
+
+# "mixed" tier: the FORWARD is the bf16x3 tier's (f32 tensors, every product on split bf16 operands: the outputs the north star
+# names -- user embeddings, reconstruction loss, discriminator loss -- carry ~16-bit operands), the BACKWARD of the transformer
+# layers runs the bf16 tier's kernels on bf16 copies of the saved activations (single-MFMA products, f32 accumulation; parameter
+# gradients accumulate in f32 as everywhere).  DESIGN.md 2.
+_MIXED = False
+
+
+def mixed():
+    return _MIXED
+
+
+class _bf16_backward(object):
+    """Context of a layer's backward in the mixed tier: the bf16 tier's kernel selection (tensor dtype bf16, no operand split)."""
+
+    def __enter__(self):
+        global _COMPUTE
+        self.prev = (_COMPUTE, hip.SPLIT_OPERANDS)
+        _COMPUTE, hip.SPLIT_OPERANDS = torch.bfloat16, False
+        return self
+
+    def __exit__(self, *a):
+        global _COMPUTE
+        _COMPUTE, hip.SPLIT_OPERANDS = self.prev
+
+
+def _b16(t):
+    """bf16 copy of an f32 activation saved for the mixed tier's backward (None and non-f32 tensors pass through)."""
+    return t.to(torch.bfloat16) if (t is not None and t.dtype == torch.float32) else t
 
 
 # Residual stream of the bf16 tier: torch.bfloat16 = one bf16 tensor per layer input / output (8 significant bits);
@@ -290,18 +321,22 @@ TN_LIST_WIDE = True
 # everything outside such a context, go out one by one as before.
 import os as _os1
 TN_PER_LAYER = not _os1.environ.get("RG_NO_TN_LAYER")      # RG_NO_TN_LAYER=1: one launch per product (A/B timing)
-_TN_BATCH = None
+import threading as _threading
+# The open batch belongs to the THREAD that opened it (autograd runs backward nodes on per-device worker threads; a re-entrant or
+# concurrent backward must not append to another layer's batch -- ADVICE r4).  The deferred products keep their operands
+# (dl2, dh1 [M, 512], dz, dqkv) alive until the layer's context exits: + M * (128 + 512 + 128 + 384) elements of peak activation
+# memory per layer backward in flight (1.9 GB in the bf16 tier at the bench shape).
+_TN_TLS = _threading.local()
 
 
 class _tn_layer(object):
     def __enter__(self):
-        global _TN_BATCH
-        self.prev, _TN_BATCH = _TN_BATCH, ([] if TN_PER_LAYER else None)
+        self.prev = getattr(_TN_TLS, "batch", None)
+        _TN_TLS.batch = [] if TN_PER_LAYER else None
         return self
 
     def __exit__(self, et, ev, tb):
-        global _TN_BATCH
-        batch, _TN_BATCH = _TN_BATCH, self.prev
+        batch, _TN_TLS.batch = _TN_TLS.batch, self.prev
         if et is None and batch:
             _flush_tn(batch)
 
@@ -326,9 +361,10 @@ def _flush_tn(batch):
 
 def _tn(Y, X, dW, colsum=None, prologue_x=hip.PRO_NONE, live=None):
     """dW += Y^T pro(X), colsum += column sums of Y -- now, or with the enclosing layer's other products (_tn_layer)."""
-    if _TN_BATCH is None:
+    batch = getattr(_TN_TLS, "batch", None)
+    if batch is None:
         return hip.gemm_tn(Y, X, dW, colsum, prologue_x=prologue_x, live=live)
-    _TN_BATCH.append((Y, X, dW, colsum, prologue_x, live))
+    batch.append((Y, X, dW, colsum, prologue_x, live))
 
 
 # ------------------------------------------------------------------------------------------------
@@ -834,14 +870,27 @@ class EncoderLayerFn(_Fn):
             y, sa = _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, need,
                                     drop_p, seeds[0], rowmask, xm)
             out, sf = _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
+        ctx.mixed = _MIXED
         if need:
-            ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
+            if _MIXED:              # the backward runs the bf16 tier's kernels on bf16 copies (every q | k | v row was written)
+                ctx.save_for_backward(_b16(x2), key_ids, rowmask, _b16(y), _b16(out), _b16(sa[0]), _b16(sa[1]), sa[2], sa[3],
+                                      _b16(sf[0]), sf[1])          # (lse and the rstd vectors stay f32 in every tier)
+                xm = 1 if xm else 0
+            else:
+                ctx.save_for_backward(x2, key_ids, rowmask, y, out, *sa, *sf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, pad_value, causal, H, drop_p, seeds, xm)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.mixed:
+            with _bf16_backward():
+                return EncoderLayerFn._backward(ctx, dout.to(torch.bfloat16))
+        return EncoderLayerFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x2, key_ids, rowmask, y, out, qkv, ctx_, lse, rstd1, h1, rstd2 = ctx.saved_tensors
         B, L, pad_value, causal, H, drop_p, seeds, xm = ctx.meta
         d = x2.shape[1]
@@ -905,8 +954,13 @@ class EncoderLastLayerFn(_Fn):
             y = hip.gemm_nt(c_last, shadow(Wo), bo.detach(), epilogue=hip.EPI_RESID_LN, aux=x_last,
                             gamma=g1.detach(), beta=be1.detach(), rstd_out=rstd1, eps=LN_EPS)
             out, sf = _ffn_block_fwd(y, rm_last, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
+        ctx.mixed = _MIXED
         if need:
-            ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf, rmf)
+            if _MIXED:
+                ctx.save_for_backward(_b16(x2), _b16(x_last), key_ids, rm_last, _b16(kv), _b16(q_last), _b16(c_last), _b16(y), _b16(out),
+                                      rstd1, _b16(sf[0]), sf[1], rmf)
+            else:
+                ctx.save_for_backward(x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, *sf, rmf)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, pad_value, H, drop_p, seeds, fold, from_x, bool(_X_MASKED))
         if out_lo is not None:
@@ -916,6 +970,13 @@ class EncoderLastLayerFn(_Fn):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.mixed:
+            with _bf16_backward():
+                return EncoderLastLayerFn._backward(ctx, dout.to(torch.bfloat16))
+        return EncoderLastLayerFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         x2, x_last, key_ids, rm_last, kv, q_last, c_last, y, out, rstd1, h1, rstd2, rmf = ctx.saved_tensors
         Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1 = ctx.prm[:10]
         B, L, pad_value, H, drop_p, seeds, fold, from_x, xm = ctx.meta
@@ -1007,15 +1068,28 @@ class DecoderLayerFn(_Fn):
             else:
                 y2, rstd_c = hip.bcast_add_ln(y1, o, cg.detach(), cbe.detach(), L, LN_EPS)
             out, sf = _ffn_block_fwd(y2, rowmask, W1, b1, W2, b2, g2, be2, drop_p, seeds[1], seeds[2])
+        ctx.mixed = _MIXED
         if need:
             extra = (s_cross,) if s_cross is not None else ()
-            ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf, *extra)
+            if _MIXED:
+                ctx.save_for_backward(_b16(x2), _b16(u), key_ids, rowmask, _b16(y1), _b16(y2), _b16(out), _b16(c), rstd_c,
+                                      _b16(sa[0]), _b16(sa[1]), sa[2], sa[3], _b16(sf[0]), sf[1], *extra)
+                xm_d = 1 if xm_d else 0
+            else:
+                ctx.save_for_backward(x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, *sa, *sf, *extra)
             ctx.prm = (Wq, bq, Wk, bk, Wv, bv, Wo, bo, g1, be1, cWv, cbv, cWo, cbo, cg, cbe, W1, b1, W2, b2, g2, be2)
             ctx.meta = (B, L, H, drop_p, seeds, xm_d)
         return out.view(B, L, d)
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.mixed:
+            with _bf16_backward():
+                return DecoderLayerFn._backward(ctx, dout.to(torch.bfloat16))
+        return DecoderLayerFn._backward(ctx, dout)
+
+    @staticmethod
+    def _backward(ctx, dout):
         B, L, H, drop_p, seeds, xm = ctx.meta
         sav = ctx.saved_tensors
         x2, u, key_ids, rowmask, y1, y2, out, c, rstd_c, qkv, ctx_, lse, rstd1, h1, rstd2 = sav[:15]

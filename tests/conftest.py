@@ -25,3 +25,19 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _restore_default_tier():
+    """Every test leaves the process in the default tier (bf16, bf16 residual stream, no operand split) even when it FAILS in the
+    middle of a tier switch -- otherwise one failing tier-parametrized test leaks its tier into the tests that follow."""
+    yield
+    try:
+        import torch
+        from recguru_amd import hip, ops
+    except Exception:
+        return
+    if ops.compute_tier() != "bf16" or hip.SPLIT_OPERANDS or ops.residual_dtype() != torch.bfloat16:
+        ops.set_compute_dtype(torch.bfloat16)
+        ops.set_residual_dtype(torch.bfloat16)
+        hip.SPLIT_OPERANDS = False

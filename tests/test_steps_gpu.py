@@ -27,8 +27,8 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEAD = ("dec_enc_attn.WQ", "dec_enc_attn.WK")
 NOISE = DEAD + ("WK.bias",)
-TIERS = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16_split_resid": torch.bfloat16, "bf16x3": "bf16x3"}
-EXACT = ("f32", "bf16x3")            # the tiers held to the north-star tolerance rtol 1e-3 / atol 1e-5
+TIERS = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16_split_resid": torch.bfloat16, "bf16x3": "bf16x3", "mixed": "mixed"}
+EXACT = ("f32", "bf16x3", "mixed")   # the tiers held to the north-star tolerance rtol 1e-3 / atol 1e-5 on the OUTPUTS
 
 
 @pytest.fixture(autouse=True)
@@ -116,7 +116,7 @@ def _moved_frac_bad(new, ref, old, lr, tol):
     return float((np.abs((new - old) - (ref - old)) > tol * lr).mean())
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "mixed", "bf16", "bf16_split_resid"])
 def test_bench_shape_steps_vs_oracle(tier, capsys):
     from recguru_amd import ops, training as T
     from recguru_amd.optim import Adam
@@ -161,7 +161,7 @@ def test_bench_shape_steps_vs_oracle(tier, capsys):
         np.testing.assert_allclose([float(d_cost), float(w_d), float(g_dis)], [ref["D_cost"], ref["W_D"], ref["g_dis"]],
                                    rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(gp, ref["gp"], rtol=1e-3, atol=1e-5)
-        assert bad_d <= 0.005 and bad_g <= 0.01
+        assert bad_d <= 0.005 and bad_g <= (0.05 if tier == "mixed" else 0.01)
         if tier == "bf16x3":
             assert ue_err <= 1e-4         # (<= 1e-3 of max; the CPU emulation of the split predicts 7e-6)
     else:
@@ -212,7 +212,7 @@ def _curve_models(z, device="cuda"):
     return m, param, G.to(device), D.to(device)
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "mixed", "bf16", "bf16_split_resid"])
 def test_loss_curves_replay(tier, capsys):
     """20 train_recon_x steps + train_gan_all(iterations=9) = 5 phase-2 + 5 phase-3 iterations, as the reference's
     drivers ran them (oracle/gen_golden_curves.py).  f32: rtol 1e-3 per point in phase 1; in phases 2 / 3 the
@@ -251,7 +251,7 @@ def test_loss_curves_replay(tier, capsys):
     if tier in EXACT:
         # bf16x3: the band (the spread of the SAME arithmetic under another rounding) is entered twice -- 16-bit operands are one
         # more rounding choice on this rounding-chaotic trajectory (measured: D_cost 3.5e-4 against a band of 3.1e-4)
-        w = 2.0 if tier == "bf16x3" else 1.0
+        w = 2.0 if tier in ("bf16x3", "mixed") else 1.0
         np.testing.assert_allclose(p1, z["phase1.loss"], rtol=1e-3, atol=1e-5)
         for i, n in enumerate(names2):
             np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=w * bands["phase2." + n], err_msg=n)
@@ -576,7 +576,7 @@ def _bench_shape_curve_oracle(steps, its):
     return _ORACLE_CURVE
 
 
-@pytest.mark.parametrize("tier", ["f32", "bf16x3", "bf16", "bf16_split_resid"])
+@pytest.mark.parametrize("tier", ["f32", "bf16x3", "mixed", "bf16", "bf16_split_resid"])
 def test_bench_shape_loss_curve_vs_oracle(tier, capsys):
     """North-star: "loss curves matching the CPU reference within tolerance" AT the metric's shape (seq_len 200, hidden 128,
     100k-item domains): 6 steps of the shipped train_recon_x (Noam learning rates up to 0.03) followed by the shipped

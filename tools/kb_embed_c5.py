@@ -32,9 +32,10 @@ for V, d, B, L, k in ((2_000_000, 256, 1024, 400, 64), (100_000, 128, 4096, 200,
     for nm, idt, mk in (("zipf ids, 44 %% padded", ids, mask), ("uniform ids, no padding", uni, torch.ones(B * L, device=dev))):
         t = timeit(lambda: hip.embed_pe_fwd(table, pe, idt, mk, L))
         live = float(mk.mean())
-        by = ntok * d * 2 * 2 + ntok * 12
-        print("V=%d d=%d B=%d L=%d  embed_pe_fwd  %-26s %7.1f us  %6.0f GB/s algorithmic (%.2f of 8 TB/s); rows actually gathered: %.0f %%"
-              % (V, d, B, L, nm, t * 1e6, by / t / 1e9, by / t / 8e12, 100 * live))
+        by = ntok * d * 2 * 2 + ntok * 12                       # nominal: a row read + a row written per position
+        bx = live * ntok * d * 2 + ntok * d * 2 + ntok * 12     # executed: rows are gathered for the live positions only
+        print("V=%d d=%d B=%d L=%d  embed_pe_fwd  %-26s %7.1f us  %6.0f GB/s executed bytes (%.2f of 8 TB/s; rows gathered: %.0f %%); "
+              "nominal bytes %6.0f GB/s" % (V, d, B, L, nm, t * 1e6, bx / t / 1e9, bx / t / 8e12, 100 * live, by / t / 1e9))
     h = (torch.randn(ntok, d, device=dev) * 0.1).bfloat16()
     pos = uni.view(-1)
     neg = torch.randint(1, V + 1, (ntok * k,), device=dev)

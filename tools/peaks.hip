@@ -1,0 +1,220 @@
+// peaks.hip -- the denominators of bench.py's rooflines re-derived ON THE BOX:
+//
+//   * HBM: device-to-device copy (hipMemcpyAsync and a float4 copy kernel), read-only and write-only streams and a triad
+//     over buffers far beyond the 256 MiB Infinity Cache;
+//   * random row gather: uniformly drawn rows of 256 B / 512 B / 1 KiB from a 1 GiB table (the config-5 embedding table is
+//     2 M x 256 bf16 = 1 GiB of 512-B rows), as a read-only gather (rows summed in registers) and as the embedding kernel's
+//     gather-copy (row read + contiguous row write + 8-B id read);
+//   * matrix pipe: v_mfma_f32_16x16x32_bf16 issue loop, 4 independent accumulators per wave, at 1 / 2 / 4 waves per SIMD.
+//
+// Build + run (tools/peaks.py does both):   hipcc --offload-arch=gfx950 -O3 -o tools/peaks_probe tools/peaks.hip && tools/peaks_probe
+// Prints one "name value unit" line per probe and a JSON object on the last line.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#define CK(x)                                                                      \
+  do {                                                                             \
+    hipError_t e_ = (x);                                                           \
+    if (e_ != hipSuccess) {                                                        \
+      fprintf(stderr, "%s:%d: %s\n", __FILE__, __LINE__, hipGetErrorString(e_));   \
+      exit(1);                                                                     \
+    }                                                                              \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+
+// ---- streams -------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) copy_kernel(const float4* __restrict__ a, float4* __restrict__ b, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = a[i];
+}
+__global__ void __launch_bounds__(256) read_kernel(const float4* __restrict__ a, float* __restrict__ out, size_t n) {
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 v = a[i];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  if (s.x + s.y + s.z + s.w == 12345.678f) out[0] = s.x;      // (never true: keeps the loads)
+}
+__global__ void __launch_bounds__(256) write_kernel(float4* __restrict__ b, size_t n, float x) {
+  const float4 v = make_float4(x, x, x, x);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) b[i] = v;
+}
+__global__ void __launch_bounds__(256) triad_kernel(const float4* __restrict__ b, const float4* __restrict__ c, float4* __restrict__ a,
+                                                    size_t n, float s) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float4 x = b[i], y = c[i];
+    a[i] = make_float4(x.x + s * y.x, x.y + s * y.y, x.z + s * y.z, x.w + s * y.w);
+  }
+}
+
+// ---- random row gather ---------------------------------------------------------------------------------------------------
+// A row of RB bytes is RB / 16 lanes x 16 B; a wave instruction therefore fetches 64 * 16 / RB rows.  Every lane group keeps U
+// rows in flight.  COPY: the row is written to out[t] (the embedding kernel's shape); otherwise it is summed in registers.
+template <int RB, int U, bool COPY>
+__global__ void __launch_bounds__(256) gather_kernel(const float4* __restrict__ table, const int* __restrict__ ids, float4* __restrict__ out,
+                                                     float* __restrict__ sink, int n) {
+  constexpr int LPR = RB / 16;                 // lanes per row
+  const int lane_in_row = threadIdx.x % LPR;
+  const int groups = (gridDim.x * blockDim.x) / LPR;
+  const int g = (blockIdx.x * blockDim.x + threadIdx.x) / LPR;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t0 = g * U; t0 < n; t0 += groups * U) {
+    int id[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) id[u] = ids[min(t0 + u, n - 1)];
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = table[(size_t)id[u] * LPR + lane_in_row];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (COPY) {
+        if (t0 + u < n) out[(size_t)(t0 + u) * LPR + lane_in_row] = v[u];
+      } else {
+        s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      }
+    }
+  }
+  if (!COPY && s.x + s.y + s.z + s.w == 12345.678f) sink[0] = s.x;
+}
+
+// ---- MFMA issue loop -----------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) mfma_kernel(float* __restrict__ out, int iters) {
+  bf16x8_t a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x & 7)); b[j] = (__bf16)(0.002f * (j + 1)); }
+  f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+  for (int i = 0; i < iters; ++i) {
+    c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c0, 0, 0, 0);
+    c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c1, 0, 0, 0);
+    c2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c2, 0, 0, 0);
+    c3 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c3, 0, 0, 0);
+  }
+  const f32x4 c = c0 + c1 + c2 + c3;
+  if (c[0] == 12345.678f) out[threadIdx.x] = c[0] + c[1] + c[2] + c[3];
+}
+
+// ---- harness -------------------------------------------------------------------------------------------------------------
+struct Res { std::string name; double value; std::string unit; std::string note; };
+static std::vector<Res> results;
+
+template <typename F>
+static double time_ms(F launch, int reps = 7) {
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  launch();                                         // warm-up
+  CK(hipDeviceSynchronize());
+  std::vector<float> ts;
+  for (int r = 0; r < reps; ++r) {
+    CK(hipEventRecord(e0, 0));
+    launch();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ts.push_back(ms);
+  }
+  std::sort(ts.begin(), ts.end());
+  CK(hipEventDestroy(e0));
+  CK(hipEventDestroy(e1));
+  return ts[ts.size() / 2];                         // median
+}
+
+static void report(const char* name, double v, const char* unit, const char* note) {
+  printf("%-44s %10.1f %-8s %s\n", name, v, unit, note);
+  fflush(stdout);
+  results.push_back({name, v, unit, note});
+}
+
+template <int RB, int U>
+static void gather_probe(const float4* table, size_t table_bytes, const int* ids, float4* out, float* sink, int n, int grid) {
+  char nm[96], note[160];
+  const double rows_b = (double)n * RB;
+  double ms = time_ms([&] { gather_kernel<RB, U, false><<<grid, 256>>>(table, ids, out, sink, n); });
+  snprintf(nm, sizeof nm, "gather_read_%dB_rows_u%d", RB, U);
+  snprintf(note, sizeof note, "%d uniformly random %d-B rows of a %.2f GiB table summed in registers, %d rows in flight per lane group", n, RB,
+           table_bytes / 1073741824.0, U);
+  report(nm, (rows_b + 4.0 * n) / ms * 1e-6, "GB/s", note);
+  ms = time_ms([&] { gather_kernel<RB, U, true><<<grid, 256>>>(table, ids, out, sink, n); });
+  snprintf(nm, sizeof nm, "gather_copy_%dB_rows_u%d", RB, U);
+  snprintf(note, sizeof note, "the same rows copied to a contiguous [n, %d B] output: row read + row write + id read", RB);
+  report(nm, (2.0 * rows_b + 4.0 * n) / ms * 1e-6, "GB/s", note);
+}
+
+int main(int argc, char** argv) {
+  hipDeviceProp_t prop;
+  CK(hipGetDeviceProperties(&prop, 0));
+  printf("device: %s, %d CUs, clock %.0f MHz, memory clock %.0f MHz, bus %d bit\n", prop.name, prop.multiProcessorCount,
+         prop.clockRate * 1e-3, prop.memoryClockRate * 1e-3, prop.memoryBusWidth);
+  const int CUS = prop.multiProcessorCount;
+  const size_t GB = (size_t)1 << 30;
+  const size_t NB = 2 * GB;                      // 2 GiB per stream buffer: 8 x the Infinity Cache
+  float4 *a, *b, *c;
+  float* sink;
+  CK(hipMalloc(&a, NB));
+  CK(hipMalloc(&b, NB));
+  CK(hipMalloc(&c, NB));
+  CK(hipMalloc(&sink, 4096));
+  CK(hipMemset(a, 0, NB));
+  CK(hipMemset(b, 0, NB));
+  CK(hipMemset(c, 0, NB));
+  const size_t n4 = NB / 16;
+  const int grid = CUS * 8;
+  double ms;
+  ms = time_ms([&] { CK(hipMemcpyAsync(b, a, NB, hipMemcpyDeviceToDevice, 0)); });
+  report("hbm_memcpy_d2d", 2.0 * NB / ms * 1e-6, "GB/s", "hipMemcpyAsync device-to-device, 2 GiB; read + write bytes");
+  ms = time_ms([&] { copy_kernel<<<grid, 256>>>(a, b, n4); });
+  report("hbm_copy_kernel", 2.0 * NB / ms * 1e-6, "GB/s", "float4 grid-stride copy kernel, 2 GiB; read + write bytes");
+  ms = time_ms([&] { read_kernel<<<grid, 256>>>(a, sink, n4); });
+  report("hbm_read_only", 1.0 * NB / ms * 1e-6, "GB/s", "float4 read-only stream (register sum), 2 GiB");
+  ms = time_ms([&] { write_kernel<<<grid, 256>>>(b, n4, 1.f); });
+  report("hbm_write_only", 1.0 * NB / ms * 1e-6, "GB/s", "float4 write-only stream, 2 GiB");
+  ms = time_ms([&] { triad_kernel<<<grid, 256>>>(b, c, a, n4, 0.5f); });
+  report("hbm_triad", 3.0 * NB / ms * 1e-6, "GB/s", "a = b + s c over 2 GiB buffers; two reads + one write");
+  // ---- random rows of a 1 GiB table (buffer a); ids in c, outputs in b
+  const int n = 819200 * 2;                       // two bench batches of B * L = 4096 * 200 positions
+  std::vector<int> h(n);
+  uint64_t st = 0x9E3779B97F4A7C15ull;
+  auto rnd = [&]() { st ^= st << 13; st ^= st >> 7; st ^= st << 17; return st; };
+  int* ids = reinterpret_cast<int*>(c);
+  const size_t TB = GB;
+  for (int rb : {256, 512, 1024}) {
+    const uint64_t rows = TB / rb;
+    for (int i = 0; i < n; ++i) h[i] = (int)(rnd() % rows);
+    CK(hipMemcpy(ids, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    if (rb == 256) { gather_probe<256, 2>(a, TB, ids, b, sink, n, CUS * 8); gather_probe<256, 4>(a, TB, ids, b, sink, n, CUS * 8); gather_probe<256, 8>(a, TB, ids, b, sink, n, CUS * 8); }
+    if (rb == 512) { gather_probe<512, 2>(a, TB, ids, b, sink, n, CUS * 8); gather_probe<512, 4>(a, TB, ids, b, sink, n, CUS * 8); gather_probe<512, 8>(a, TB, ids, b, sink, n, CUS * 8); }
+    if (rb == 1024) { gather_probe<1024, 2>(a, TB, ids, b, sink, n, CUS * 8); gather_probe<1024, 4>(a, TB, ids, b, sink, n, CUS * 8); }
+  }
+  // the bench table: 100 002 rows x 256 B = 25.6 MB (Infinity-Cache / L2 resident)
+  {
+    const uint64_t rows = 100002;
+    for (int i = 0; i < n; ++i) h[i] = (int)(rnd() % rows);
+    CK(hipMemcpy(ids, h.data(), (size_t)n * 4, hipMemcpyHostToDevice));
+    char note[160];
+    ms = time_ms([&] { gather_kernel<256, 4, true><<<CUS * 8, 256>>>(a, ids, b, sink, n); });
+    snprintf(note, sizeof note, "%d random 256-B rows of a 25.6 MB table (cache resident) copied out: row read + write + id", n);
+    report("gather_copy_256B_rows_25MB_table", (2.0 * n * 256 + 4.0 * n) / ms * 1e-6, "GB/s", note);
+  }
+  // ---- matrix pipe
+  for (int wps : {1, 2, 4}) {
+    const int iters = 20000;
+    ms = time_ms([&] { mfma_kernel<<<CUS * wps, 256>>>(sink, iters); }, 5);
+    const double flops = (double)CUS * wps * 4 /*waves*/ * iters * 4.0 * (2.0 * 16 * 16 * 32);
+    char nm[64], note[128];
+    snprintf(nm, sizeof nm, "mfma_16x16x32_bf16_%dwave_per_simd", wps);
+    snprintf(note, sizeof note, "issue loop, 4 independent accumulators per wave, %d workgroups of 256 threads per CU", wps);
+    report(nm, flops / ms * 1e-9, "TFLOP/s", note);
+  }
+  printf("{");
+  for (size_t i = 0; i < results.size(); ++i)
+    printf("%s\"%s\": {\"value\": %.1f, \"unit\": \"%s\"}", i ? ", " : "", results[i].name.c_str(), results[i].value, results[i].unit.c_str());
+  printf("}\n");
+  return 0;
+}
