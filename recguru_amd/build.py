@@ -93,7 +93,7 @@ def _screen_and_record(isa_files, verbose):
     info = {"hipcc": ver[:3], "flags": FLAGS, "library_sha256": sha, "isa_files": len(isa_files), "screen": "recguru_amd/isa_screen.py",
             "flagged_join_blocks": [list(x) for x in flagged], "spill_in_front_of_exec_restore_warnings": warnings,
             "packed_f32_high_half_selects": [list(x) for x in opsel]}
-    if bypass and (flagged or opsel):
+    if bypass and (flagged or opsel or warnings):
         # a flagged library kept on purpose (RG_BUILD_NO_SCREEN=1): never record its hash as "screened", so that the next
         # ordinary build screens -- and refuses -- it again instead of returning early on a matching hash
         info["screen_bypassed"] = True
@@ -106,6 +106,13 @@ def _screen_and_record(isa_files, verbose):
                            "when a second wave shares the SIMD.  Keep per-row statistics out of one register pair (scalar temporaries, "
                            "-fno-slp-vectorize on the function) until the pattern is gone (RG_BUILD_NO_SCREEN=1 builds anyway):\n%s"
                            % (len(opsel), msg))
+    if warnings and not os.environ.get("RG_BUILD_NO_SCREEN"):
+        # (round 5) the copies that are a conditional body's own masked writes -- source defined inside the block -- are recognised and
+        # dropped by the screen's dataflow triage; what is left is a VGPR <-> AGPR / scratch copy of a value that was live BEFORE the
+        # narrowed region, executed under the narrowed exec: the spill defect without a join label
+        raise RuntimeError("hipcc placed %d spill-like copy run(s) of live-in registers in front of an exec restore (recguru_amd/isa_screen.py, "
+                           "DESIGN.md 2a; `python tools/isa_exec_screen.py recguru_amd/build/isa/*.s` lists them; RG_BUILD_NO_SCREEN=1 builds anyway)"
+                           % warnings)
     if flagged and not os.environ.get("RG_BUILD_NO_SCREEN"):
         msg = "\n".join("  %s: %s: %d vector instruction(s) in front of the exec restore at line %d (join block %s)" % (f, k, n, no, b)
                         for f, k, no, b, n in flagged)

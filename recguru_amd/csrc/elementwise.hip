@@ -81,13 +81,14 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_rows_kernel(const T* __
         id[u] = ((int64_t)__shfl(idhi, src) << 32) | (unsigned int)__shfl(idlo, src);
         pos[u] = (p0 + src) % L;
       }
+      // UNCONDITIONAL loads (a load under a divergent condition gets a vmcnt(0) at its join: the U rows would arrive one after the
+      // other): a padded position reads row 0 of the table -- one hot line set, no HBM traffic -- and its result is discarded
       float v[U][8], pp[U][8];
 #pragma unroll
-      for (int u = 0; u < U; ++u)
-        if (m[u] != 0.f) {
-          load8(v[u], table + (size_t)id[u] * D + c8);
-          load8(pp[u], pe + (unsigned int)pos[u] * D + c8);
-        }
+      for (int u = 0; u < U; ++u) {
+        load8(v[u], table + (size_t)(m[u] != 0.f ? id[u] : 0) * D + c8);
+        load8(pp[u], pe + (unsigned int)pos[u] * D + c8);
+      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const int tok = t0 + g + u * RPW + lr;

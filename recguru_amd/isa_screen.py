@@ -52,7 +52,7 @@ VEC = re.compile(r"^\s*(?!v_writelane_b32|v_readlane_b32|v_readfirstlane_b32)(v_
 LABEL = re.compile(r"^([.\w$]+):")
 RESTORE = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value", "-Wno-pass-failed"]
-SAVEEXEC = re.compile(r"^\s*s_and_saveexec_b64\s+(s\[\d+:\d+\])")
+SAVEEXEC = re.compile(r"^\s*s_(?:and|andn2)_saveexec_b64\s+(s\[\d+:\d+\])")     # the exec-NARROWING saveexec forms
 EXECZ = re.compile(r"^\s*s_cbranch_execz\s+([.\w$]+)")
 RESTORE_OF = re.compile(r"^\s*s_or_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\])")
 SPILL = re.compile(r"^\s*(v_accvgpr_write_b32\s+a\d+,\s*v\d+|v_accvgpr_read_b32|scratch_store|scratch_load|buffer_store_dword.*offen|buffer_load_dword.*offen)")
@@ -89,7 +89,11 @@ def screen(path):
             m = SAVEEXEC.match(s)
             if m and i + 1 < len(ins):
                 saved = m.group(1)
-                mb = EXECZ.match(ins[i + 1][1])
+                nx = i + 1                      # scalar instructions may be scheduled between the saveexec and its branch
+                while nx + 1 < len(ins) and ins[nx][1].startswith("s_") and not ins[nx][1].startswith(STOP + ("s_or_b64 exec",)) \
+                        and saved not in ins[nx][1].split(None, 1)[-1].split(",")[0]:
+                    nx += 1
+                mb = EXECZ.match(ins[nx][1])
                 if mb and mb.group(1) in labels:
                     j = labels[mb.group(1)] + 1
                     pending = []
@@ -109,11 +113,54 @@ def screen(path):
                 j, run = i - 1, []
                 while j >= 0 and (SPILL.match(ins[j][1]) or (ins[j][1].startswith("s_") and not ins[j][1].startswith(STOP + ("s_or_b64 exec",)))):
                     if SPILL.match(ins[j][1]):
-                        run.append("%d: %s" % ins[j])
+                        run.append(j)
                     j -= 1
-                if run:
-                    warn.append((kernel, no, "-", run[::-1]))
+                # Triage (round 5): a VGPR -> AGPR copy under a narrowed exec is the conditional body's OWN masked write when the
+                # source VGPR was DEFINED inside the same straight-line block (after the block's label / the exec-narrowing
+                # instruction): the lanes outside exec keep the variable's previous value in the AGPR, as the source says.  It is
+                # a SPILL (the defect: lanes outside exec keep whatever the slot held) when the source was live before the block.
+                # Copies of the first kind are dropped; the rest stay warnings -- and `unresolved` marks them for the build.
+                left = []
+                for jj in run:
+                    mw = ACC_WRITE.match(ins[jj][1])
+                    if mw and _defined_in_block(ins, jj, int(mw.group(1))):
+                        continue
+                    mr = ACC_READ.match(ins[jj][1])              # AGPR -> VGPR of a value this very block computed (an MFMA result)
+                    if mr and _defined_in_block(ins, jj, int(mr.group(1)), "a"):
+                        continue
+                    left.append("%d: %s" % ins[jj])
+                if left:
+                    warn.append((kernel, no, "-", left[::-1]))
     return bad, warn
+
+
+ACC_READ = re.compile(r"^\s*v_accvgpr_read_b32\s+v\d+,\s*a(\d+)\s*$")
+ADEST = re.compile(r"^\s*(?:v_mfma|v_smfmac|v_accvgpr_write)\S*\s+(a\d+|a\[\d+:\d+\])")
+ACC_WRITE = re.compile(r"^\s*v_accvgpr_write_b32\s+a\d+,\s*v(\d+)\s*$")
+DEST = re.compile(r"^\s*(?:v_|ds_read|ds_load|global_load|buffer_load|scratch_load|flat_load)\S*\s+(v\d+|v\[\d+:\d+\])")
+BLOCK_START = ("s_and_saveexec", "s_or_saveexec", "s_andn2_saveexec", "s_xor_saveexec", "s_or_b64 exec", "s_and_b64 exec", "s_andn2_b64 exec",
+               "s_xor_b64 exec", "s_mov_b64 exec")
+
+
+def _defined_in_block(ins, at, vreg, bank="v"):
+    """True when register `vreg` of the VGPR ("v") or AGPR ("a") bank is written by an instruction between the start of the
+    straight-line block that holds ins[at] (the nearest label or exec-changing instruction in front of it) and ins[at]."""
+    j = at - 1
+    while j >= 0:
+        t = ins[j][1]
+        if LABEL.match(t) or t.startswith(BLOCK_START) or t.startswith(("s_cbranch", "s_branch", "s_endpgm", "s_setpc", "s_swappc")):
+            return False
+        m = (ADEST if bank == "a" else DEST).match(t)
+        if m and (bank == "a" or not t.startswith(("v_cmp", "v_cmpx", "v_accvgpr_write"))):
+            d = m.group(1)
+            if d[1] == "[":
+                lo, hi = (int(x) for x in d[2:-1].split(":"))
+            else:
+                lo = hi = int(d[1:])
+            if lo <= vreg <= hi:
+                return True
+        j -= 1
+    return False
 
 
 PK_F32 = re.compile(r"^\s*(v_pk_(?:add|mul|fma)_f32)\s+.*?\bop_sel:\[([01,]+)\]")

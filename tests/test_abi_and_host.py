@@ -192,6 +192,53 @@ _Z6kernelv:
             assert flagged[0][0] == "_Z6kernelv" and flagged[0][2] == ".LBB0_2" and "a144" in flagged[0][3][0]
 
 
+def test_isa_screen_triage_separates_a_body_s_own_masked_write_from_a_spill(tmp_path):
+    """Round 5: a VGPR -> AGPR copy in front of an exec restore is the conditional body's own masked write when
+    its source was DEFINED inside the block (dropped), and a spill of a live-in value otherwise (stays a warning: the build fails on
+    it); the same for AGPR -> VGPR reads of an MFMA result of the block.  The join rule follows scalar instructions scheduled
+    between the saveexec and its branch, and the s_andn2 form."""
+    from recguru_amd import isa_screen
+    own = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[18:19], s[4:5]
+	v_and_b32_e32 v35, v61, v35
+	v_accvgpr_write_b32 a9, v35
+	s_or_b64 exec, exec, s[18:19]
+	s_endpgm
+"""
+    spill = own.replace("\tv_and_b32_e32 v35, v61, v35\n", "")
+    mfma_own = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[18:19], s[4:5]
+	v_mfma_f32_16x16x4_f32 a[48:51], v15, a47, a[52:55]
+	s_nop 9
+	v_accvgpr_read_b32 v9, a51
+	s_or_b64 exec, exec, s[18:19]
+	s_endpgm
+"""
+    mfma_spill = mfma_own.replace("\tv_mfma_f32_16x16x4_f32 a[48:51], v15, a47, a[52:55]\n", "")
+    for name, text, n_warn in (("own.s", own, 0), ("spill.s", spill, 1), ("mfma_own.s", mfma_own, 0), ("mfma_spill.s", mfma_spill, 1)):
+        p = tmp_path / name
+        p.write_text(text)
+        flagged, warn = isa_screen.screen(str(p))
+        assert flagged == [] and len(warn) == n_warn, (name, flagged, warn)
+    sched = """
+_Z6kernelv:
+	s_andn2_saveexec_b64 s[18:19], s[4:5]
+	s_mov_b64 s[80:81], s[24:25]
+	s_cbranch_execz .LBB0_2
+	ds_write_b32 v1, v2
+.LBB0_2:
+	v_accvgpr_write_b32 a144, v119
+	s_or_b64 exec, exec, s[18:19]
+	s_endpgm
+"""
+    p = tmp_path / "sched.s"
+    p.write_text(sched)
+    flagged, _ = isa_screen.screen(str(p))
+    assert len(flagged) == 1 and flagged[0][2] == ".LBB0_2"
+
+
 def test_isa_screen_flags_the_packed_f32_high_half_select(tmp_path):
     """Second rule of recguru_amd/isa_screen.py (finding 1): `v_pk_add_f32 ... op_sel:[0,1]` -- the form that made the
     fused block's LayerNorm subtract a mean of 0 in lanes 48-63 at two workgroups per CU -- and every other high-half select on a
@@ -248,9 +295,11 @@ def test_built_library_passes_the_isa_screen():
         pytest.skip("no device ISA beside the objects (library built elsewhere)")
     assert len(isa) >= 10
     for fn in isa:
-        flagged, _ = isa_screen.screen(fn)
+        flagged, warn = isa_screen.screen(fn)
         assert not flagged, (fn, flagged[:2])
+        assert not warn, (fn, warn[:2])          # (round 5) no spill-like copy of a live-in register in front of an exec restore
         assert isa_screen.packed_opsel(fn) == [], fn
     info = json.load(open(os.path.join(ROOT, "recguru_amd", "build", "BUILD_INFO.json")))
     assert info["flagged_join_blocks"] == [] and info["packed_f32_high_half_selects"] == [] and "clang" in " ".join(info["hipcc"])
+    assert info["spill_in_front_of_exec_restore_warnings"] == 0 and not info.get("screen_bypassed")
     assert info["library_sha256"] == hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()

@@ -244,6 +244,22 @@ def _row_wise_chunks(dt, x3):
     fw = lambda q_, i_: list(hip.attn_fwd(q_, i_, 51, False, H, need_lse=True))
     whole = fw(qkv, ids)
     same("attn_fwd", whole, [fw(seqs(qkv, c).contiguous(), seqs(ids, c).contiguous()) for c in range(NC)])
+    # ... the CAUSAL forward (the decoder's form; in the f32 / bf16x3 tiers the instantiations whose conditional bodies write
+    # their masked scores to AGPRs under a narrowed exec: the copies the ISA screen's triage lets through as the body's own -- held
+    # here to the same bits at both occupancies, alone and contended: VERDICT r4 item 7a), at this L and at L = 400 (26 key tiles)
+    ids0 = ids.clone()
+    ids0[:, : L // 3] = 0                                     # a left-padded prefix: key-pad value 0 masks it in the decoder
+    fwc = lambda q_, i_: list(hip.attn_fwd(q_, i_, 0, True, H, need_lse=True))
+    same("attn_fwd (causal)", fwc(qkv, ids0), [fwc(seqs(qkv, c).contiguous(), seqs(ids0, c).contiguous()) for c in range(NC)])
+    if dt != torch.bfloat16:
+        L4, B4 = 400, 64
+        qkv4 = r(B4, L4, 3 * d)
+        ids4 = torch.randint(1, 50, (B4, L4), generator=g0).cuda()
+        ids4[:, :150] = 0
+        sq4 = lambda t, c: t[c * (B4 // NC):(c + 1) * (B4 // NC)]
+        for causal, padv in ((True, 0), (False, 51)):
+            f4 = lambda q_, i_: list(hip.attn_fwd(q_, i_, padv, causal, H, need_lse=True))
+            same("attn_fwd (L = 400, causal %s)" % causal, f4(qkv4, ids4), [f4(sq4(qkv4, c).contiguous(), sq4(ids4, c).contiguous()) for c in range(NC)])
     dctx = r(B, L, d)
     bw = lambda q_, g_, c_, l_, i_: [hip.attn_bwd(q_, g_, c_, l_, i_, 51, False, H)]
     same("attn_bwd", bw(qkv, dctx, whole[0], whole[1], ids),
