@@ -1199,9 +1199,11 @@ static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t
                                long long ntok, int L, int d, const DropCfg& drop, int dtype, hipStream_t s) {
   static const int old_form = getenv("RG_EMBED_OLD") ? atoi(getenv("RG_EMBED_OLD")) : 0;      // A/B: the element-per-thread kernel
   if ((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d && (!old_form || out2)) {
-    // persistent-ish: one wave per 64-token block, at most 8 workgroups per CU
-    long long g = (ntok + 255) / 256;
-    const int grid = (int)(g < 1 ? 1 : (g > 256LL * 8 ? 256LL * 8 : g));
+    // one wave per 64-token block, at most 8 workgroups (32 waves) per CU -- and every wave the SAME number of blocks: with 12 800
+    // blocks on 8 192 waves a third of the waves took two blocks and the launch lasted two block times for 1.56 of work
+    const long long nblk = (ntok + 63) / 64, cap = 256LL * 8 * (EW_BLOCK / 64);
+    const long long iters = (nblk + cap - 1) / cap, waves = (nblk + iters - 1) / iters;
+    const int grid = (int)((waves + EW_BLOCK / 64 - 1) / (EW_BLOCK / 64));
 #define RG_EMB(T, D, M2) hipLaunchKernelGGL((embed_pe_fwd_rows_kernel<T, D, 4, M2>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)out2, (int)ntok, L, drop)
 #define RG_EMB_T(T) do { if (d == 128) { if (out2) RG_EMB(T, 128, true); else RG_EMB(T, 128, false); } else { if (out2) RG_EMB(T, 256, true); else RG_EMB(T, 256, false); } } while (0)
     DISPATCH_T(dtype, RG_EMB_T(__bf16), RG_EMB_T(float), "embed_pe_fwd")

@@ -148,8 +148,10 @@ __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][RT], const float* __res
 // live VGPRs in AGPRs at the top of that branch's join block IN FRONT of its exec restore, i.e. for lanes 0-15 only
 // (recguru_amd/isa_screen.py).  The bf16x3 instantiations (512 registers: the ones that spill to AGPRs) use it.
 template <int RT, bool ALLST = false>
-__device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], const float* __restrict__ gamma_lds,
-                                        const float* __restrict__ beta_lds, float* __restrict__ redA, float* __restrict__ redB,
+// (no __restrict__ on the LDS pointers: the exchange crosses the inline-asm workgroup barrier, and hipcc may move stores through a
+// noalias pointer past an asm statement that does not name it -- it did in the first build of fused256.hip's copy of this function)
+__device__ __forceinline__ void ln_regs(f32x4 (&v)[2][RT], float (&rstd)[RT], const float* gamma_lds,
+                                        const float* beta_lds, float* redA, float* redB,
                                         float eps, int n0, int wave, int li, int lg) {
   float s[RT], m2[RT];
 #pragma unroll
@@ -702,8 +704,11 @@ static int act_tile_bytes(int dtype, int rows) {
   return dtype == RG_BF16 ? rows * FD * 2 : (dtype == RG_X3 ? rows * FD * 2 * 2 : rows * FLD * 4);
 }
 
+int rg_post_attn_fwd256(const rg_post_attn_args* a, int dtype, hipStream_t s);      // fused256.hip: d_model == n_heads * 32 == 256
+
 extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;
+  if (a->d == 256) return rg_post_attn_fwd256(a, dtype, (hipStream_t)stream);
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
   if ((long long)a->M * a->dff * (dtype == RG_BF16 ? 2 : 4) >= (1ll << 32))

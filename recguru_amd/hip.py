@@ -926,8 +926,15 @@ def attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, key_ids, pad_value, dbv, d
     return dx, dq, ops4[0], ops4[1], ops4[2], ops4[3]
 
 
-def post_attn_supported(d, P, dff):
-    return d == 128 and P == 128 and dff % 128 == 0 and dff > 0
+FUSE_BLOCK_256 = not os.environ.get("RG_NO_PA256")      # RG_NO_PA256=1: d_model 256 takes the unfused launches (A/B timing)
+
+
+def post_attn_supported(d, P, dff, dtype=None):
+    """The fused post-attention block takes d_model == n_heads * 32 == 128 in every tier (csrc/fused.hip) and, in the bf16 tier,
+    d_model == 256 with d_ff a multiple of 256 (csrc/fused256.hip: BASELINE configs[4])."""
+    if d == 128 and P == 128 and dff % 128 == 0 and dff > 0:
+        return True
+    return bool(FUSE_BLOCK_256 and d == 256 and P == 256 and dff % 256 == 0 and dff > 0 and dtype == torch.bfloat16 and not SPLIT_OPERANDS)
 
 
 _LIVE = {}

@@ -293,7 +293,7 @@ def _lists_everywhere(W1, M):
     (bf16 tier; d_model = 128 is implied by the fused path; d_ff = 512 are the weight-gradient shapes the big kernel
     has; M rows enough for those kernels to be selected -- the conditions under which _live() hands the backward a
     list) -- only then may the padded tiles' rows of those buffers stay unwritten."""
-    return _lists_ok() and W1.shape[0] == 512 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
+    return _lists_ok() and W1.shape[0] == 512 and W1.shape[1] == 128 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
 
 
 def _live(rowmask, M, shapes_ok=True):
@@ -612,7 +612,7 @@ def _zero_row(n, dev):
 
 
 def _fusable(x2, Wo, W1):
-    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0])
+    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0], x2.dtype) and not (x2.shape[1] == 256 and _split_resid())
 
 
 def _lo_in(x2, rows=None):
@@ -855,9 +855,12 @@ class EncoderLayerFn(_Fn):
         seeds = (_draw(), _draw(), _draw()) if drop_p > 0 else (0, 0, 0)
         xm = _X_MASKED
         if _fusable(x2, Wo, W1):
+            # (d_model 256, csrc/fused256.hip: the backward there is the unfused one, which reads every row -- q | k | v rows of
+            # padded tiles are written, as in the unfused forward)
+            unw = d == 128
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv, bv, need,
-                                           drop_p, seeds[0], rowmask, xm, allow_unwritten=True)
-            xm = 2 if xm else 0
+                                           drop_p, seeds[0], rowmask, xm, allow_unwritten=unw)
+            xm = (2 if xm else 0) if unw else xm
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True, split=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True, split=True), b1.detach(), shadow(W2, pack=True, split=True), b2.detach(), g2.detach(),
                                         be2.detach(),
@@ -1043,9 +1046,10 @@ class DecoderLayerFn(_Fn):
             o = hip.gemm_nt(c, shadow(cWo), cbo.detach(), out_f32=True)      # [B, d] f32
             cross_kw = dict(cross=(o, cg.detach(), cbe.detach()))
         if _fusable(x2, Wo, W1):
+            unw = d == 128                               # (see EncoderLayerFn)
             qkv, ctx_, lse = _qkv_attn_fwd(x2, B, L, key_ids, 0, True, H, Wq, bq, Wk, bk, Wv, bv, need, drop_p, seeds[0],
-                                           rowmask, _X_MASKED, allow_unwritten=True)
-            xm_d = 2 if _X_MASKED else 0
+                                           rowmask, _X_MASKED, allow_unwritten=unw)
+            xm_d = (2 if _X_MASKED else 0) if unw else (1 if _X_MASKED else 0)
             out, sv = hip.post_attn_fwd(ctx_.view(B * L, -1), x2, shadow(Wo, pack=True, split=True), bo.detach(), g1.detach(), be1.detach(),
                                         shadow(W1, pack=True, split=True), b1.detach(), shadow(W2, pack=True, split=True), b2.detach(), g2.detach(),
                                         be2.detach(),

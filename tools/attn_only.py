@@ -17,12 +17,19 @@ dt = torch.bfloat16
 p = float(sys.argv[1]) if len(sys.argv) > 1 else 0.5
 causal = "causal" in sys.argv[2:]
 tm = "tm" in sys.argv[2:]
+x3 = "x3" in sys.argv[2:]          # the bf16x3 tier's kernels: f32 token-major qkv (bias rows written), split operands
+if x3:
+    dt, tm = torch.float32, True
+    hip.SPLIT_OPERANDS = True
 x = ((torch.randn(M, d, device="cuda") * 0.5) * mask[:, None]).to(dt)
 w = (torch.randn(3 * P, d, device="cuda") / d ** 0.5).to(dt)
 bias = torch.randn(3 * P, device="cuda") * 0.1
 pad_rows = torch.cat([bias.view(3 * H, 32), torch.zeros(1, 32, device="cuda")], 0).to(dt).contiguous()
 live = hip.live_tiles(mask, M)
-if tm:
+if x3:
+    qkv = hip.gemm_nt(x, w, bias, live=live, skip_dead_fill=2).view(B, L, 3 * P)
+    kwf = dict(drop_p=p, seed=7, rowmask=mask, x_masked=True)
+elif tm:
     qkv = hip.gemm_nt(x, w, bias, live=live, skip_dead_fill=1).view(B, L, 3 * P)
     kwf = dict(drop_p=p, seed=7, rowmask=mask, x_masked=True, bqkv=bias)
 else:
@@ -31,5 +38,5 @@ else:
 dctx = (torch.randn(B, L, P, device="cuda") * 0.5 * mask.view(B, L, 1)).to(dt)
 for _ in range(3):
     ctx, lse = hip.attn_fwd(qkv, ids, 100001, causal, H, **kwf)
-    hip.attn_bwd(qkv, dctx, ctx, lse, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask, bqkv=bias)
+    hip.attn_bwd(qkv, dctx, ctx, lse, ids, 100001, causal, H, drop_p=p, seed=7, rowmask=mask, bqkv=None if x3 else bias)
 torch.cuda.synchronize()

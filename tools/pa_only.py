@@ -8,11 +8,13 @@ M = B * L
 dom = synthetic.make_domain(B, 100000, L, 1, seed=1)
 ids = torch.as_tensor(dom["enc_in"]).cuda()
 mask = (ids != 0).float().reshape(-1).contiguous()
-dt = torch.bfloat16
+x3 = "x3" in sys.argv[1:]          # the bf16x3 tier's kernel (f32 tensors, presplit fragment-packed weights): python tools/pa_only.py train 3 x3
+dt = torch.float32 if x3 else torch.bfloat16
+hip.SPLIT_OPERANDS = x3
 r = lambda *s: (torch.randn(*s, device="cuda") * 0.5).to(dt)
 x, ctx = r(M, d), r(M, d)
 # fragment-packed operand copies, as ops.shadow(..., pack=True) hands them to the kernel in production
-pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK)
+pk = lambda w: hip.cast(w.float().contiguous(), dt, transpose=hip.CAST_PACK | (hip.CAST_SPLIT if x3 else 0))
 wo, w1, w2 = pk(r(d, d)), pk(r(512, d)), pk(r(d, 512))
 z = lambda n: torch.zeros(n, device="cuda")
 g = torch.ones(d, device="cuda")

@@ -9,7 +9,7 @@ for grp in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
            "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_INST_CYCLES_VMEM_RD SQ_LDS_DATA_FIFO_FULL" \
            "SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS SQ_VALU_MFMA_COEXEC_CYCLES"; do
   i=$((i+1))
-  timeout 120 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_pa/g$i -- python3 $R/tools/pa_only.py ${1:-train} 3 > /dev/null 2>&1
+  timeout 120 rocprofv3 --pmc $grp --output-format csv -d $R/gpurun_out/pmc_pa/g$i -- python3 $R/tools/pa_only.py ${1:-train} 3 $2 > /dev/null 2>&1
 done
 python3 - <<PY
 import csv, glob, collections

@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round 5: everything profiles/r05/ holds, in one GPU-box call:  bash tools/profile_round5.sh
+# New against tools/profile_round.sh: the on-box peaks probe, FETCH_SIZE / WRITE_SIZE and SQ counter passes for the bf16x3 tier's
+# kernels too, config-5 with the fused d_model = 256 forward block and without it.  Counter passes never share a
+# run with a trace domain; the program itself stands behind `--`.
+RD=r05
+cd /tmp && export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$RD
+rm -rf $O && mkdir -p $O
+NB="--no_cpu_baseline --ae_steps 0 --full_length_steps 0 --tier_steps 0 --config5_steps 0 --host_only_steps 0"
+python3 $R/tools/peaks.py $O/peaks.txt > /dev/null 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 $R/bench.py --steps 4 --warmup 1 $NB > $O/bench_under_rocprof.json 2> $O/kt.err
+find $O/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
+rm -rf $O/kt
+timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcF -- python3 $R/bench.py --steps 1 --warmup 1 --no_roofline $NB > /dev/null 2> $O/pmcF.err
+timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcW -- python3 $R/bench.py --steps 1 --warmup 1 --no_roofline $NB > /dev/null 2> $O/pmcW.err
+(cd $R && python3 tools/pmc_traffic.py $O/pmcF $O/pmcW $O/pmc_traffic.json > $O/pmc_summary.txt 2>&1)
+rm -rf $O/pmcF $O/pmcW
+mkdir -p $R/profiles/$RD && cp $O/pmc_traffic.json $R/profiles/$RD/pmc_traffic.json      # bench.py reads roofline.traffic from here
+# ---- the bf16x3 tier: kernel stats, traffic counters, SQ counters
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/x3kt -- python3 $R/bench.py --dtype bf16x3 --steps 3 --warmup 1 --no_roofline $NB > /dev/null 2> $O/x3kt.err
+find $O/x3kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats_bf16x3.csv
+rm -rf $O/x3kt
+timeout 400 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmcF3 -- python3 $R/bench.py --dtype bf16x3 --steps 1 --warmup 1 --no_roofline $NB > /dev/null 2> $O/pmcF3.err
+timeout 400 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmcW3 -- python3 $R/bench.py --dtype bf16x3 --steps 1 --warmup 1 --no_roofline $NB > /dev/null 2> $O/pmcW3.err
+(cd $R && python3 tools/pmc_traffic.py $O/pmcF3 $O/pmcW3 $O/pmc_traffic_bf16x3.json > $O/pmc_summary_bf16x3.txt 2>&1)
+rm -rf $O/pmcF3 $O/pmcW3
+cd $R
+rm -rf gpurun_out/pmc_pa gpurun_out/pmc_attn
+bash tools/pmc_pa.sh train > $O/sq_post_attn.txt 2>&1
+rm -rf gpurun_out/pmc_pa
+bash tools/pmc_pa.sh train x3 > $O/sq_post_attn_bf16x3.txt 2>&1
+rm -rf gpurun_out/pmc_pa
+bash tools/pmc_attn.sh 0.5 > $O/sq_attention.txt 2>&1
+rm -rf gpurun_out/pmc_attn
+bash tools/pmc_attn.sh 0.5 x3 > $O/sq_attention_bf16x3.txt 2>&1
+rm -rf gpurun_out/pmc_attn
+# ---- the plain lines
+timeout 900 python3 bench.py 2> $O/bench.err | tail -1 > $O/bench.json
+timeout 300 python3 bench.py --dropout 0 --no_cpu_baseline --tier_steps 0 --config5_steps 0 --host_only_steps 0 2>> $O/bench.err | tail -1 > $O/bench_dropout0.json
+timeout 300 python3 bench.py --device_sampler --no_cpu_baseline --tier_steps 0 --config5_steps 0 --host_only_steps 0 2>> $O/bench.err | tail -1 > $O/bench_device_sampler.json
+timeout 300 python3 bench.py --mode ae --no_cpu_baseline --tier_steps 0 --config5_steps 0 --host_only_steps 0 2>> $O/bench.err | tail -1 > $O/bench_ae_step.json
+timeout 600 python3 bench.py --dtype bf16x3 --steps 5 --warmup 2 --no_cpu_baseline --ae_steps 0 --full_length_steps 0 2>> $O/bench.err | tail -1 > $O/bench_bf16x3_tier.json
+timeout 300 python3 tools/hostprof.py > $O/hostprof.txt 2>&1
+timeout 300 python3 tools/hostprof2.py > $O/hostprof_torch_kernels.txt 2>&1
+timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table.txt 2>&1
+RG_EMBED_OLD=1 timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table_element_per_thread_kernel.txt 2>&1
+# ---- config-5 (2 M items, L = 400, d = 256, k = 1024) at B = 4096: with the fused d_model = 256 forward block and without
+C5="--items 2000000 --seq_len 400 --d_model 256 --n_head 8 --n_negs 1024 --batch 4096 --batches_per_domain 1 --ae_steps 0 --full_length_steps 0 --tier_steps 0 --config5_steps 0 --host_only_steps 0 --no_cpu_baseline"
+mkdir -p $O/c5
+timeout 900 python3 bench.py $C5 --steps 3 --warmup 1 2> $O/c5/bench.err | tail -1 > $O/c5/bench.json
+RG_NO_PA256=1 timeout 900 python3 bench.py $C5 --steps 3 --warmup 1 2>> $O/c5/bench.err | tail -1 > $O/c5/bench_unfused_block.json
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5/kt -- python3 $R/bench.py $C5 --steps 2 --warmup 1 --no_roofline > $O/c5/bench_under_rocprof.json 2> $O/c5/kt.err)
+find $O/c5/kt -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/c5/kernel_stats.csv
+rm -rf $O/c5/kt
+(cd /tmp && timeout 900 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/c5/pmcF -- python3 $R/bench.py $C5 --steps 1 --warmup 1 --no_roofline > /dev/null 2> $O/c5/pmcF.err)
+(cd /tmp && timeout 900 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/c5/pmcW -- python3 $R/bench.py $C5 --steps 1 --warmup 1 --no_roofline > /dev/null 2> $O/c5/pmcW.err)
+python3 tools/pmc_traffic.py $O/c5/pmcF $O/c5/pmcW $O/c5/pmc_traffic.json > $O/c5/pmc_summary.txt 2>&1
+rm -rf $O/c5/pmcF $O/c5/pmcW
+ls -la $O $O/c5
