@@ -390,7 +390,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(rg_attn_args a) {
   }
   // the head's dropout words: hashed HERE, under the latency of the mask / key-id loads above (at the top of the kernel,
   // with nothing in flight, the fill was exposed time: 1 us per head)
+#ifndef RG_ABL_NO_DMASK    // (timing-only ablation: the per-head hash of the dropout words)
   if constexpr (DM == 1) fill_dmask<NW, LPK>(dmask, drop, b, h, a.H, L, tid, first_q & ~15);
+#endif
   unsigned int wl = 0u;                            // bit i: tile wave + 4 i is live
 #pragma unroll
   for (int rd = 0; rd < NRD; ++rd) {
@@ -1317,6 +1319,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
         mma(gtf, pf, dvt[dt]);     // dV^T[dv][key] += sum_q dO[q][dv] P[q][key]
         mma(qtf, dsf, dkt[dt]);    // dK^T[dk][key] += sum_q Q[q][dk] dS[q][key]
       }
+#ifndef RG_ABL_NO_DS      // (timing-only ablation, tools/ab_round5.sh: the whole in-sweep dQ path -- dS scratch write, transposing read, 16-deep MFMAs)
       if constexpr (ONEPASS) {
         // dS[q][key] (accumulator layout: lane = key, registers = 4 queries) -> bf16 -> the wave's scratch tile
         // T[key][q] in the pad columns (32..39) of ITS rows of Qs (q 0..7) and Ks (q 8..15), one 8-byte store per
@@ -1341,6 +1344,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
         }
         asm volatile("" ::: "memory");
       }
+#endif
     };
     if constexpr (ONEPASS) {
 #pragma unroll

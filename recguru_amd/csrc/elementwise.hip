@@ -81,8 +81,24 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_rows_kernel(const T* __
         id[u] = ((int64_t)__shfl(idhi, src) << 32) | (unsigned int)__shfl(idlo, src);
         pos[u] = (p0 + src) % L;
       }
-      // UNCONDITIONAL loads (a load under a divergent condition gets a vmcnt(0) at its join: the U rows would arrive one after the
-      // other): a padded position reads row 0 of the table -- one hot line set, no HBM traffic -- and its result is discarded
+      // a group of U * RPW consecutive padded positions (left padding: 44 % of the groups at the bench's lengths) only writes zeros
+      bool anyl = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) anyl = anyl || m[u] != 0.f;
+      if (__ballot(anyl) == 0ull) {                    // (wave-uniform)
+        float z8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int tok = t0 + g + u * RPW + lr;
+          if (tok < ntok) {
+            store8(out + (size_t)tok * D + c8, z8);
+            if constexpr (M2) store8(out2 + (size_t)tok * D + c8, z8);
+          }
+        }
+        continue;
+      }
+      // UNCONDITIONAL loads inside a live group (a load under a divergent condition gets a vmcnt(0) at its join: the U rows would
+      // arrive one after the other): a padded position reads row 0 of the table -- one hot line set -- and its result is discarded
       float v[U][8], pp[U][8];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -1197,8 +1213,12 @@ extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, f
 
 static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out, void* out2,
                                long long ntok, int L, int d, const DropCfg& drop, int dtype, hipStream_t s) {
-  static const int old_form = getenv("RG_EMBED_OLD") ? atoi(getenv("RG_EMBED_OLD")) : 0;      // A/B: the element-per-thread kernel
-  if ((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d && (!old_form || out2)) {
+  // The row form is selected for the two-output call and by RG_EMBED_ROWS=1 (A/B).  Measured (round 5, bench shape, 56 % live
+  // positions): 41 vs 49 us per launch when the same launch is repeated (ids / mask / table hot), 78.0 vs 77.0 us INSIDE the step --
+  // both kernels sit at the memory system's rate for this read / write mix (0.55 of 8 TB/s = 0.89 of the box's measured copy rate),
+  // so the simpler element-per-thread kernel stays the default.
+  static const int rows_form = getenv("RG_EMBED_ROWS") ? atoi(getenv("RG_EMBED_ROWS")) : 0;
+  if ((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d && (rows_form || out2)) {
     // one wave per 64-token block, at most 8 workgroups (32 waves) per CU -- and every wave the SAME number of blocks: with 12 800
     // blocks on 8 192 waves a third of the waves took two blocks and the launch lasted two block times for 1.56 of work
     const long long nblk = (ntok + 63) / 64, cap = 256LL * 8 * (EW_BLOCK / 64);

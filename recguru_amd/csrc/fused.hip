@@ -705,10 +705,15 @@ static int act_tile_bytes(int dtype, int rows) {
 }
 
 int rg_post_attn_fwd256(const rg_post_attn_args* a, int dtype, hipStream_t s);      // fused256.hip: d_model == n_heads * 32 == 256
+int rg_post_attn_fwd_w8_try(const rg_post_attn_args* a, int dtype, hipStream_t s, int* rc);      // fused128w8.hip
 
 extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* stream) {
   if (!a || a->M <= 0) return 0;
   if (a->d == 256) return rg_post_attn_fwd256(a, dtype, (hipStream_t)stream);
+  {
+    int rc8 = 0;                      // RG_PA8=1: the eight-wave prototype takes the encoder-inference launches (fused128w8.hip, A/B timing)
+    if (rg_post_attn_fwd_w8_try(a, dtype, (hipStream_t)stream, &rc8)) return rc8;
+  }
   if (a->d != FD || a->P != FD || (a->dff % FD) != 0 || a->dff <= 0)
     return rg_set_error_msg(RG_ERR_UNSUPPORTED, "post_attn_fwd: needs d_model == n_heads*32 == 128 and d_ff % 128 == 0");
   if ((long long)a->M * a->dff * (dtype == RG_BF16 ? 2 : 4) >= (1ll << 32))

@@ -346,7 +346,9 @@ __global__ __launch_bounds__(NT2, 2) void post_attn_fwd256_kernel(rg_post_attn_a
     init_acc2(acc, p_bo, n0, lg);
     load_wset2(wB, Wo, D2, n0, HW, li, lg);
     mma_wset2(acc, wA, Actx, li, lg);
-    load_wset2(wA, W1, D2, n0, 0, li, lg);               // FFN chunk 0, K half 0 (hidden behind the second half + LayerNorm 1)
+    // FFN chunk 0, K half 0: hidden behind the second half + LayerNorm 1 (decoder form: requested after the cross stage's own loads
+    // instead -- 32 more live registers across that stage were what spilled there)
+    if constexpr (!CROSS) load_wset2(wA, W1, D2, n0, 0, li, lg);
     mma_wset2(acc, wB, Actx + SUB, li, lg);
     add_tile2(acc, Ag, n0, li, lg);                      // + residual x
     float rstd[RT2];
@@ -402,6 +404,7 @@ __global__ __launch_bounds__(NT2, 2) void post_attn_fwd256_kernel(rg_post_attn_a
           }
       }
       lds_barrier();                                    // ysave copy and the y1 reads done before the tile is overwritten
+      load_wset2(wA, W1, D2, n0, 0, li, lg);            // (see the out-projection above) hidden behind the cross LayerNorm
       ln_regs2(acc, rstd, p_gc, p_bec, redA, redB, a.eps, n0, wave, li, lg);
       if (rstdco && wave == 0 && lg == 0) {
 #pragma unroll

@@ -1121,6 +1121,12 @@ class Profiler(object):
                     a["flops_exec"] += r1[1]
                     a["bytes_exec"] += r1[2]
                     continue
+                if isinstance(r1, tuple) and r1 and r1[0] == "exec_rows":    # bytes per LIVE row of the mask + a fixed part
+                    key = ("rows", r1[1].data_ptr(), r1[1].numel())
+                    if key not in cache:
+                        cache[key] = float((r1[1].reshape(-1) != 0).sum())
+                    a["bytes_exec"] += cache[key] * r1[2] + r1[3]
+                    continue
                 lf = self._live_frac(r1, cache)
                 a["flops_exec"] += f1 * lf
                 a["bytes_exec"] += b1 * lf
@@ -1189,8 +1195,9 @@ def _work_embed_fwd(table, pe, ids, mask, L, *a, **k):
     the live positions alone; every output row is still written and every id / mask read."""
     n, d = ids.numel(), table.shape[1]
     es = _esize(table)
-    nl = float((mask.reshape(-1) != 0).sum())
-    return "embed_pe_fwd_kernel", 0.0, n * d * 2 * es + n * 12, ("exec", 0.0, nl * d * es + n * d * es + n * 12)
+    # (the live count is read back in Profiler.summary(), AFTER the step: a host sync here would let the kernel start on a drained
+    # GPU and put its dispatch latency between the two events -- +15 us on a 77 us launch when first tried)
+    return "embed_pe_fwd_kernel", 0.0, n * d * 2 * es + n * 12, ("exec_rows", mask, d * es, n * d * es + n * 12)
 
 
 def _work_item_loss(h, table, pos, neg, mask, k, mode, *a, **kw):

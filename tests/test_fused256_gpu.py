@@ -186,3 +186,76 @@ def test_post_attn256_bitwise_reproducible_and_chunk_invariant():
         cat = torch.cat([p[j] for p in parts], 0)
         neq = bits(w) != bits(cat)
         assert not bool(neq.any()), "output %d: %d elements of the whole launch differ from the chunked ones" % (j, int(neq.sum()))
+
+
+@pytest.mark.parametrize("dt", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("d,drop_p", [(128, 0.0), (128, 0.5), (256, 0.3)])
+def test_embed_row_form_equals_the_element_per_thread_kernel(dt, d, drop_p):
+    """rg_embed_pe_fwd2 (the row-form gather kernel, csrc/elementwise.hip, with its second bf16 output) against rg_embed_pe_fwd (the
+    default element-per-thread kernel): same bits in `out` -- same arithmetic, same dropout index space --, the second output is
+    `out` rounded to bf16; ragged token count, left-padded sequences (whole padded groups take the zero-fill path)."""
+    from recguru_amd import hip
+    B, L, V = 37, 50, 3000
+    g = torch.Generator().manual_seed(3)
+    table = (torch.randn(V + 2, d, generator=g) * 0.5).to(dt).cuda()
+    pe = torch.randn(5000, d, generator=g).cuda()
+    ids = torch.randint(1, V + 1, (B, L), generator=g)
+    for b in range(B):
+        ids[b, : int(torch.randint(0, L - 3, (1,), generator=g))] = 0
+    ids = ids.cuda()
+    mask = (ids != 0).float().reshape(-1).contiguous()
+    ref = hip.embed_pe_fwd(table, pe, ids, mask, L, drop_p, 99)
+    out, out2 = hip.embed_pe_fwd(table, pe, ids, mask, L, drop_p, 99, mirror=True)
+    bits = lambda v: v.contiguous().view(torch.int16 if v.dtype == torch.bfloat16 else torch.int32)
+    assert bool((bits(out) == bits(ref)).all())
+    assert out2.dtype == torch.bfloat16 and bool((bits(out2) == bits(ref.to(torch.bfloat16))).all())
+    assert float(out[mask == 0].abs().max()) == 0.0
+
+
+_W8_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+from recguru_amd import hip
+import test_fused256_gpu as T
+torch.save(T._run_d128_inference_cases(), sys.argv[2])
+'''
+
+
+def _run_d128_inference_cases():
+    """Encoder-inference launches of the d_model = 128 fused block: ragged M without a list, M = 20 000 with the live-tile list, the three
+    dropout modes."""
+    from recguru_amd import hip
+    dt = torch.bfloat16
+    d, dff = 128, 512
+    outs = []
+    for M, drop_p in ((64 * 5 + 16, 0.0), (20000, 0.0), (20000, 0.5), (20000, 0.3)):
+        ctx, x = rnd(M, d, dt=dt, seed=1), rnd(M, d, dt=dt, seed=2)
+        Wo, W1, W2 = rnd(d, d, dt=dt, scale=d ** -0.5, seed=3), rnd(dff, d, dt=dt, scale=d ** -0.5, seed=4), rnd(d, dff, dt=dt, scale=dff ** -0.5, seed=5)
+        bo, b1, b2 = (0.1 * rnd(n, dt=torch.float32, seed=6 + i) for i, n in enumerate((d, dff, d)))
+        g1, g2 = (1 + 0.1 * rnd(d, dt=torch.float32, seed=10 + i) for i in range(2))
+        be1, be2 = (0.1 * rnd(d, dt=torch.float32, seed=20 + i) for i in range(2))
+        rm = ((torch.arange(M) // 16) % 3 != 1).float().cuda() * (torch.arange(M) % 5 != 2).float().cuda()
+        out, _ = hip.post_attn_fwd(ctx, x, _pack(Wo), bo, g1, be1, _pack(W1), b1, _pack(W2), b2, g2, be2, rm, w_packed=True, drop_p=drop_p,
+                                   seed_h1=11, seed_out=12)
+        outs.append(out.float().cpu())
+    return outs
+
+
+def test_eight_wave_prototype_matches_the_four_wave_kernel(tmp_path):
+    """csrc/fused128w8.hip (RG_PA8=1, a fresh process: the switch is read once) against post_attn_fwd_kernel<bf16>: the same products in
+    the same K order and the same dropout masks; LayerNorm statistics combined from eight partial sums instead of four -- outputs within
+    a bf16 ulp or two, identical zeros on the masked rows."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = _run_d128_inference_cases()
+    f = str(tmp_path / "w8.pt")
+    env = dict(os.environ, RG_PA8="1")
+    subprocess.run([sys.executable, "-c", _W8_WORKER, root, f], check=True, env=env)
+    got = torch.load(f)
+    for a, b in zip(got, ref):
+        assert bool(((a == 0) == (b == 0)).all()), "different zero pattern (row mask / dropout masks)"
+        err = float((a - b).abs().max())
+        assert err <= 0.07, err                      # values are O(1..4): one or two bf16 ulps (2^-7 .. 2^-6 relative)
+        assert float((a - b).abs().mean()) <= 2e-3

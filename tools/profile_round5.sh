@@ -45,7 +45,7 @@ timeout 600 python3 bench.py --dtype bf16x3 --steps 5 --warmup 2 --no_cpu_baseli
 timeout 300 python3 tools/hostprof.py > $O/hostprof.txt 2>&1
 timeout 300 python3 tools/hostprof2.py > $O/hostprof_torch_kernels.txt 2>&1
 timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table.txt 2>&1
-RG_EMBED_OLD=1 timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table_element_per_thread_kernel.txt 2>&1
+RG_EMBED_ROWS=1 timeout 300 python3 tools/kb_embed_c5.py > $O/kb_embed_config5_table_row_form_kernel.txt 2>&1
 # ---- config-5 (2 M items, L = 400, d = 256, k = 1024) at B = 4096: with the fused d_model = 256 forward block and without
 C5="--items 2000000 --seq_len 400 --d_model 256 --n_head 8 --n_negs 1024 --batch 4096 --batches_per_domain 1 --ae_steps 0 --full_length_steps 0 --tier_steps 0 --config5_steps 0 --host_only_steps 0 --no_cpu_baseline"
 mkdir -p $O/c5
