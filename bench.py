@@ -587,7 +587,9 @@ def main():
             tiers[tier] = {"value": round(per_step * args.tier_steps / dtt, 1), "ms_per_step": round(dtt / args.tier_steps * 1e3, 3),
                            "steps": args.tier_steps, "warmup": 1,
                            "arithmetic": {"bf16x3": "f32 activations; every MFMA operand split into a bf16 pair, three bf16 MFMAs per "
-                                                    "product (user embeddings 7.5e-6 of max against the oracle at this shape)",
+                                                    "product (user embeddings 7.5e-6 of max against the oracle at this shape, element-wise inside rtol 1e-3 / atol 1e-5; "
+                                                    "bench-shape loss curve 8.7e-5; the rounding-chaotic W-GAN series of the 16-position fixture are "
+                                                    "held to 2 x the fixture's float64-replay band: DESIGN.md 2)",
                                           "mixed": "EXPERIMENT (DESIGN.md 2): the bf16x3 forward (user embeddings / losses of a step as in "
                                                    "bf16x3: 7.5e-6 of max) with the bf16 tier's BACKWARD on bf16 copies of the saved "
                                                    "activations -- gradients carry 8-bit operands and the bench-shape loss curve leaves the "

@@ -28,7 +28,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEAD = ("dec_enc_attn.WQ", "dec_enc_attn.WK")
 NOISE = DEAD + ("WK.bias",)
 TIERS = {"f32": torch.float32, "bf16": torch.bfloat16, "bf16_split_resid": torch.bfloat16, "bf16x3": "bf16x3", "mixed": "mixed"}
-EXACT = ("f32", "bf16x3", "mixed")   # the tiers held to the north-star tolerance rtol 1e-3 / atol 1e-5 on the OUTPUTS
+EXACT = ("f32", "bf16x3")            # the tiers held to the north-star tolerance rtol 1e-3 / atol 1e-5
+# "mixed" (round 5 experiment): the bf16x3 FORWARD -- the outputs of a step are held to the same tolerance -- with the bf16
+# tier's BACKWARD: its gradients, and therefore its loss curves, are held to the bf16 tier's bounds (measured: 1.2e-3 at the bench shape)
+FWD_EXACT = EXACT + ("mixed",)
 
 
 @pytest.fixture(autouse=True)
@@ -154,14 +157,14 @@ def test_bench_shape_steps_vs_oracle(tier, capsys):
     with capsys.disabled():
         print("\n[bench shape, %s tier] user_embed err rel-to-max %.3g | loss_ae rel %.3g | D_cost/W_D/g_dis abs %.3g | "
               "GP rel %.3g | Adam-step mismatch fraction D %.3g G %.3g" % (tier, ue_err, l_rel, dc_abs, gp_rel, bad_d, bad_g))
-    if tier in EXACT:
+    if tier in FWD_EXACT:
         np.testing.assert_allclose(ue_a, ref["ue_a"], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(ue_b, ref["ue_b"], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose([float(la), float(lb)], [ref["la"], ref["lb"]], rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose([float(d_cost), float(w_d), float(g_dis)], [ref["D_cost"], ref["W_D"], ref["g_dis"]],
                                    rtol=1e-3, atol=1e-5)
         np.testing.assert_allclose(gp, ref["gp"], rtol=1e-3, atol=1e-5)
-        assert bad_d <= 0.005 and bad_g <= (0.05 if tier == "mixed" else 0.01)
+        assert bad_d <= 0.005 and bad_g <= (0.04 if tier == "mixed" else 0.01)      # mixed: bf16 gradients (measured 1.6 %, as the bf16 tier)
         if tier == "bf16x3":
             assert ue_err <= 1e-4         # (<= 1e-3 of max; the CPU emulation of the split predicts 7e-6)
     else:
@@ -251,7 +254,7 @@ def test_loss_curves_replay(tier, capsys):
     if tier in EXACT:
         # bf16x3: the band (the spread of the SAME arithmetic under another rounding) is entered twice -- 16-bit operands are one
         # more rounding choice on this rounding-chaotic trajectory (measured: D_cost 3.5e-4 against a band of 3.1e-4)
-        w = 2.0 if tier in ("bf16x3", "mixed") else 1.0
+        w = 2.0 if tier == "bf16x3" else 1.0
         np.testing.assert_allclose(p1, z["phase1.loss"], rtol=1e-3, atol=1e-5)
         for i, n in enumerate(names2):
             np.testing.assert_allclose(p2[:, i], z["phase2." + n], rtol=1e-3, atol=w * bands["phase2." + n], err_msg=n)
