@@ -111,7 +111,7 @@ def parse():
     ap.add_argument("--mode", choices=["gan", "ae"], default="gan",
                     help="gan: the AE+GAN step = one phase-2 iteration of train_gan_all (BASELINE.json's metric); "
                          "ae: the AE step = one train_recon_x iteration (SURVEY 8d (i))")
-    ap.add_argument("--ae_steps", type=int, default=5, help="gan mode: AE steps timed after the main region for the "
+    ap.add_argument("--ae_steps", type=int, default=8, help="gan mode: AE steps timed after the main region for the "
                     "`ae_step` object of the line (0: skip)")
     ap.add_argument("--full_length_steps", type=int, default=4, help="gan mode: steps timed with full-length users (no "
                     "padding to skip) for `value_full_length` (0: skip)")
@@ -568,7 +568,7 @@ def main():
         loaders = make_loaders(args, device, rank, args.min_len)       # back to the default length distribution
     if not ae and args.ae_steps > 0:
         step = make_ae_step(param, G, opt_rec, loaders, device, dp)
-        dta, _, outa = timed(step, 2, args.ae_steps, dp, device)
+        dta, _, outa = timed(step, 3, args.ae_steps, dp, device)      # (3 untimed steps: the allocator regrows after the full-length leg)
         ae_line = {"metric": "user-sequences/sec (AE step)", "value": round(2 * args.batch * world * args.ae_steps / dta, 1),
                    "ms_per_step": round(dta / args.ae_steps * 1e3, 3), "steps": args.ae_steps,
                    "sequences_per_step": 2 * args.batch * world,

@@ -12,6 +12,7 @@
 // Backward recomputes the dots (rows come from L2 / Infinity Cache), forms
 // c_j = dl_t/dlogit_j * mask_t * gout / sum(mask), accumulates dh_t = sum_j c_j E[j] in registers and
 // scatters c_j * h_t into the dense f32 table gradient with full-row (256 B per instruction) atomics.
+#include <stdlib.h>
 #include "rg_common.hip.h"
 #include "../../include/recguru_hip.h"
 
@@ -508,6 +509,132 @@ __global__ __launch_bounds__(64 * LW) void item_loss_train_online_kernel(rg_item
 }
 
 
+// The same kernel with the gather PIPELINED (round 5): per 64 rows the item ids arrive by ONE coalesced load (lane l: row i0 + l; the next
+// 64 are requested a block ahead) and reach the lane groups through ds_bpermute -- the id load was a second dependent memory latency in
+// front of every batch of rows --, and the rows of batch s + 1 are requested BEFORE batch s is reduced (two register buffers), so a wave
+// keeps 2 x RG_U x G rows in flight instead of RG_U x G.  The rows of a lane group pass through the online recurrence in the same order:
+// bit-identical logits, lse, loss and dh (tests/test_kernels_gpu.py::test_item_loss_online_pipelined_equals_plain).  RG_ITEM_ONLINE_PLAIN=1
+// selects the plain kernel above (A/B).
+template <typename T, int LPR>
+__global__ __launch_bounds__(64 * LW) void item_loss_train_online2_kernel(rg_item_loss_args a, float* __restrict__ cbuf) {
+  constexpr int G = 64 / LPR, RS = G * RG_U, NS = 64 / RS;          // rows per step, steps per block of 64 rows (even)
+  static_assert(NS % 2 == 0, "two register buffers alternate inside a block of 64 rows");
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gi = lane / LPR, li = lane % LPR;
+  const T* __restrict__ H = reinterpret_cast<const T*>(a.h);
+  const T* __restrict__ E = reinterpret_cast<const T*>(a.table);
+  T* __restrict__ dH = reinterpret_cast<T*>(a.dh);
+  const int d = a.d, k = a.k, n = a.k + 1;
+  const float gs = 1.f / a.sums[1];
+  float lsum = 0.f;
+  for (long long t = (long long)blockIdx.x * LW + wave; t < a.ntok; t += (long long)gridDim.x * LW) {
+    const float m = a.mask[t];
+    float dh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dh[j] = 0.f;
+    if (m != 0.f) {
+      float h[8], e0[8], A[8];
+      load8(h, H + (size_t)t * d + 8 * li);
+      const long long pos = a.pos[t];
+      const int64_t* __restrict__ negt = a.neg + (size_t)t * k;
+      // lane l: the item of row i0 + l (row 0 = the positive; rows >= n read the positive's row again and are ignored)
+      auto load_ids = [&](int i0) -> long long {
+        const int idx = i0 + lane;
+        const long long v = negt[min(max(idx - 1, 0), k - 1)];       // unconditional load from a clamped address
+        return (idx == 0 || idx >= n) ? pos : v;
+      };
+      Frag<T> e[2][RG_U];                                 // RAW rows (bf16: 4 registers each) until they are reduced
+      auto issue = [&](Frag<T> (&eb)[RG_U], long long ids, int j0) {
+        const int idlo = (int)(ids & 0xFFFFFFFFll), idhi = (int)(ids >> 32);
+#pragma unroll
+        for (int u = 0; u < RG_U; ++u) {
+          const int src = j0 + u * G + gi;
+          const long long item = ((long long)__shfl(idhi, src) << 32) | (unsigned int)__shfl(idlo, src);
+          load_frag(eb[u], E + (size_t)item * d + 8 * li);
+        }
+      };
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { A[j] = 0.f; e0[j] = 0.f; }
+      float mx = -INFINITY, sm = 0.f, l0 = 0.f;          // per row group
+      long long idn = load_ids(0);
+      issue(e[0], idn, 0);
+      for (int i0 = 0; i0 < n; i0 += 64) {
+        const long long idc = idn;
+        idn = load_ids(min(i0 + 64, n - 1));             // (unconditional; unused past the last block)
+#pragma unroll 1
+        for (int sp = 0; sp < NS; sp += 2) {               // two steps per trip: the register buffers keep compile-time indices
+#pragma unroll
+          for (int half = 0; half < 2; ++half) {
+            const int s = sp + half;
+            // the next batch of rows -- the next step of this block, or the first step of the next block -- before this one is
+            // reduced; ONE unconditional load sequence from selected ids (a load under a branch is waited for at its join)
+            const bool wrap = s + 1 >= NS;
+            issue(e[(half + 1) & 1], wrap ? idn : idc, wrap ? 0 : (s + 1) * RS);
+            Frag<T> (&eb)[RG_U] = e[half];
+#pragma unroll
+            for (int u = 0; u < RG_U; ++u) {
+              const int idx = i0 + s * RS + u * G + gi;
+              float ev[8];
+#pragma unroll
+              for (int j = 0; j < 8; ++j) ev[j] = (float)eb[u].v[j];
+              float dot = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) dot += ev[j] * h[j];
+              dot = group_sum<LPR>(dot);
+              if (idx < n) {
+                if (idx == 0) {
+                  l0 = dot;
+#pragma unroll
+                  for (int j = 0; j < 8; ++j) e0[j] = ev[j];
+                }
+                if (li == 0) cbuf[t * n + idx] = dot;
+                const float nm = fmaxf(mx, dot);
+                const float r = __expf(mx - nm), p = __expf(dot - nm);     // (mx == -inf: r = 0, sm and A are still 0)
+                sm = sm * r + p;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) A[j] = A[j] * r + p * ev[j];
+                mx = nm;
+              }
+            }
+          }
+        }
+      }
+      float M = mx;
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o));
+      const float wg = mx == -INFINITY ? 0.f : __expf(mx - M);
+      sm *= wg;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) A[j] *= wg;
+#pragma unroll
+      for (int o = LPR; o < 64; o <<= 1) {
+        sm += __shfl_xor(sm, o);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) A[j] += __shfl_xor(A[j], o);
+      }
+      l0 = __shfl(l0, 0);
+      const float lse = M + __logf(sm);
+      lsum += (lse - l0) * m;
+      if (lane == 0) a.aux_tok[t] = lse;
+      const float w = m * gs, inv = 1.f / sm;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dh[j] = (A[j] * inv - e0[j]) * w;
+    } else if (lane == 0) {
+      a.aux_tok[t] = 0.f;
+    }
+    if (gi == 0) store8(dH + (size_t)t * d + 8 * li, dh);
+  }
+  __shared__ float red[LW];
+  if (lane == 0) red[wave] = lsum;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s0 = 0.f;
+    for (int w = 0; w < LW; ++w) s0 += red[w];
+    if (s0 != 0.f) atomicAdd(a.sums, s0);
+  }
+}
+
+
 template <typename T>
 static int launch(const rg_item_loss_args& a, bool bwd, hipStream_t s) {
   long long g = (a.ntok + LW - 1) / LW;
@@ -900,12 +1027,18 @@ __global__ __launch_bounds__(256) void bin_accumulate_kernel(rg_item_loss_args a
 // float-atomic unit takes at full rate).  Per (position, item) pair the table gradient then costs one gather of h[t]
 // (2 bytes per element) plus 1 / (entries per row and chunk) of a 4-byte atomic per element.
 #define RG_WIDE_LOG 8
+#ifndef RG_WIDE_U_OF
+#define RG_WIDE_U_OF(G) 4          // (round 5: 16 / 8 rows per lane group in flight -- 32 per wave -- measured 187 -> 264 ms per config-5 step)
+#endif
 #define RG_WIDE_RPB 256
 #define RG_CHUNK_WIDE 8192
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void bin_accumulate_wide_kernel(rg_item_loss_args a, BinWs w, long long table_rows) {
   constexpr int CH = RG_CHUNK_WIDE, RB = RG_WIDE_RPB;
-  constexpr int G = 64 / LPR, D = LPR * 8, U = 4;
+  // U rows of h in flight per lane group.  The kernel already moves 6.7 TB/s of L2 <-> fabric bytes (PMC, profiles/r05/c5: h rows are
+  // re-read ~1 000 times, a quarter from the Infinity Cache): a deeper gather (U = 16: 32 rows per wave, the registers are free at two
+  // workgroups per CU) made it SLOWER, 187 -> 264 ms per config-5 step -- it is at the memory system's rate, not short of loads
+  constexpr int G = 64 / LPR, D = LPR * 8, U = RG_WIDE_U_OF(G);
   extern __shared__ float sm[];                     // sorted t [CH] | sorted c [CH] | row buffers [4][D]
   int* st = reinterpret_cast<int*>(sm);
   float* sc = sm + CH;
@@ -1053,7 +1186,8 @@ static int launch_binned(const rg_item_loss_args& a, const float* coef, void* ws
   else if (a.d == 128) hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 16, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   else hipLaunchKernelGGL((item_loss_bwd_rows_kernel<T, 32, true>), dim3((int)g), dim3(64 * LW), 0, s, a, w.c);
   // K2..K4
-  w.ppw = w.nbins > 4096 ? RG_PPW_WIDE : RG_PPW;
+  static const int ppw_wide_env = [] { const char* e = getenv("RG_PPW_WIDE"); return e ? atoi(e) : 0; }();      // (A/B: pairs per workgroup of count / fill)
+  w.ppw = w.nbins > 4096 ? (ppw_wide_env >= 8192 ? ppw_wide_env : RG_PPW_WIDE) : RG_PPW;
   const int gp = (int)((npairs + w.ppw - 1) / w.ppw);
   hipLaunchKernelGGL(bin_count_kernel, dim3(gp), dim3(256), (size_t)w.nbins * 4, s, a, w);
   hipLaunchKernelGGL(bin_scan_kernel, dim3(1), dim3(1024), 0, s, w);
@@ -1126,9 +1260,16 @@ static int launch_train(const rg_item_loss_args& a, float* coef, hipStream_t s) 
   if (!nit) {       // more rows than four register batches: the online form
     if (a.mode != RG_LOSS_SAMPLED_CE || !a.aux_tok)
       return rg_set_error_msg(RG_ERR_UNSUPPORTED, "item_loss_train: 1+k beyond 4 row batches takes the online form: sampled softmax only, aux_tok [ntok] required");
-    if (a.d == 64) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 8>), grid, block, 0, s, a, coef);
-    else if (a.d == 128) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 16>), grid, block, 0, s, a, coef);
-    else hipLaunchKernelGGL((item_loss_train_online_kernel<T, 32>), grid, block, 0, s, a, coef);
+    static const int plain = [] { const char* e = getenv("RG_ITEM_ONLINE_PLAIN"); return e ? atoi(e) : 0; }();
+    if (plain) {
+      if (a.d == 64) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 8>), grid, block, 0, s, a, coef);
+      else if (a.d == 128) hipLaunchKernelGGL((item_loss_train_online_kernel<T, 16>), grid, block, 0, s, a, coef);
+      else hipLaunchKernelGGL((item_loss_train_online_kernel<T, 32>), grid, block, 0, s, a, coef);
+    } else {
+      if (a.d == 64) hipLaunchKernelGGL((item_loss_train_online2_kernel<T, 8>), grid, block, 0, s, a, coef);
+      else if (a.d == 128) hipLaunchKernelGGL((item_loss_train_online2_kernel<T, 16>), grid, block, 0, s, a, coef);
+      else hipLaunchKernelGGL((item_loss_train_online2_kernel<T, 32>), grid, block, 0, s, a, coef);
+    }
     RG_CHECK_LAUNCH();
     return 0;
   }

@@ -259,3 +259,50 @@ def test_eight_wave_prototype_matches_the_four_wave_kernel(tmp_path):
         err = float((a - b).abs().max())
         assert err <= 0.07, err                      # values are O(1..4): one or two bf16 ulps (2^-7 .. 2^-6 relative)
         assert float((a - b).abs().mean()) <= 2e-3
+
+
+_ONLINE_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import test_fused256_gpu as T
+torch.save(T._run_online_item_loss_cases(), sys.argv[2])
+'''
+
+
+def _run_online_item_loss_cases():
+    from recguru_amd import hip
+    outs = []
+    for dt, d, k, V, ntok in ((torch.bfloat16, 256, 200, 5000, 3000), (torch.bfloat16, 128, 300, 900, 2000), (torch.float32, 64, 1024, 5000, 700),
+                              (torch.float32, 256, 1024, 20000, 500)):
+        assert hip.item_loss_train_supported(k, d) == 2
+        g = torch.Generator().manual_seed(k)
+        table = (torch.randn(V + 2, d, generator=g) * 0.3).to(dt).cuda()
+        h = (torch.randn(ntok, d, generator=g) * 0.5).to(dt).cuda()
+        pos = torch.randint(1, V + 1, (ntok,), generator=g).cuda()
+        neg = torch.randint(1, V + 1, (ntok * k,), generator=g).cuda()
+        mask = (torch.rand(ntok, generator=g) < 0.7).float().cuda()
+        sums = torch.zeros(2, device="cuda")
+        sums[1] = mask.sum()
+        lse = torch.empty(ntok, device="cuda")
+        coef, dh = hip.item_loss_train(h, table, pos, neg, mask, k, hip.LOSS_SAMPLED_CE, sums, lse=lse)
+        live = mask.bool()
+        outs.append([coef.view(ntok, k + 1)[live].cpu(), dh.float().cpu(), lse.cpu(), sums.cpu()])
+    return outs
+
+
+def test_item_loss_online_pipelined_equals_plain(tmp_path):
+    """item_loss_train_online2_kernel (round 5: ids by one coalesced load per 64 rows + ds_bpermute, the next batch of rows requested before
+    the current one is reduced) against the plain online kernel (RG_ITEM_ONLINE_PLAIN=1, a fresh process): every lane group sees its rows
+    in the same order, so logits, lse and dh carry the same bits; the loss sum (float atomics over blocks) agrees to rounding."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = _run_online_item_loss_cases()
+    f = str(tmp_path / "plain.pt")
+    subprocess.run([sys.executable, "-c", _ONLINE_WORKER, root, f], check=True, env=dict(os.environ, RG_ITEM_ONLINE_PLAIN="1"))
+    ref = torch.load(f)
+    for (c1, d1, l1, s1), (c0, d0, l0, s0) in zip(got, ref):
+        assert torch.equal(c1, c0) and torch.equal(d1, d0) and torch.equal(l1, l0)
+        assert float(s1[1]) == float(s0[1]) and abs(float(s1[0]) - float(s0[0])) <= 1e-5 * abs(float(s0[0]))
+        assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(d1).all())
