@@ -272,6 +272,11 @@ def _head_eye(H, like):
     return e
 
 
+def _os_env(name):
+    import os
+    return os.environ.get(name)
+
+
 def _z(n, like):
     return torch.zeros(n, device=like.device, dtype=torch.float32)
 
@@ -293,7 +298,8 @@ def _lists_everywhere(W1, M):
     (bf16 tier; d_model = 128 is implied by the fused path; d_ff = 512 are the weight-gradient shapes the big kernel
     has; M rows enough for those kernels to be selected -- the conditions under which _live() hands the backward a
     list) -- only then may the padded tiles' rows of those buffers stay unwritten."""
-    return _lists_ok() and W1.shape[0] == 512 and W1.shape[1] == 128 and M >= max(hip.COMPACT_MIN_ROWS, 8192)
+    wide = LISTS_256 and W1.shape[1] == 256 and _COMPUTE == torch.bfloat16       # (d_model 256: round 5, see _attn_block_bwd)
+    return _lists_ok() and W1.shape[0] == 512 and (W1.shape[1] == 128 or wide) and M >= max(hip.COMPACT_MIN_ROWS, 8192)
 
 
 def _live(rowmask, M, shapes_ok=True):
@@ -315,6 +321,7 @@ def _live_tn(rowmask, M, n1, n2):
 
 
 TN_LIST_WIDE = True
+LISTS_256 = not _os_env("RG_NO_LISTS_256")      # d_model 256: list-driven unfused backward (RG_NO_LISTS_256=1: every row, A/B)
 
 # The weight-gradient products of a layer's backward are collected and issued as ONE launch (rg_gemm_tn_layer: the four products
 # of a d_model = 128 transformer layer) when the layer function opens a _tn_layer() context; products that do not fit a slot, and
@@ -726,7 +733,9 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     P = Wo.shape[1]
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     # rowmask here only lets the kernel skip the padded rows (their dy is already zero; the mask values are 0 / 1)
-    live = _live(rowmask, dy.shape[0], d == 128 and P == 128)
+    # (d_model 256, round 5: the unfused backward of that width is list-driven too -- LayerNorm backward, the weight-stationary products and
+    # the weight gradients all take the list --: 44 % of the rows of BASELINE configs[4]'s backward passes are padding)
+    live = _live(rowmask, dy.shape[0], (d == 128 and P == 128) or (LISTS_256 and d == 256 and P == 256 and _COMPUTE == torch.bfloat16))
     # every consumer of dz below is list-driven: the padded tiles' rows of dz are never written nor read
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     if FUSE_ATTN_OUT_BWD and d == 128 and P == 128:
@@ -750,13 +759,13 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
     # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
     Wt = shadow_cat((Wq, Wk, Wv), transpose=True)          # [d, 3P]
-    if (WS_SPLIT_K_DX and _COMPUTE == torch.bfloat16 and live is None and dqkv2.shape[0] >= 4096 and 3 * P == 768 and d % 128 == 0
+    if (WS_SPLIT_K_DX and _COMPUTE == torch.bfloat16 and dqkv2.shape[0] >= 4096 and 3 * P == 768 and d % 128 == 0
             and 128 < d <= 1024):
         # K = 768 is beyond the weight-stationary kernel's four 128-deep K blocks (the generic tile kernel ran this product at
         # 2.1 TB/s): two K halves instead, the second accumulating onto the first's output in place (the partial sum is rounded
         # to bf16 once in between)
-        dx = hip.gemm_nt(dqkv2[:, :384], Wt[:, :384], epilogue=hip.EPI_ADD, aux=dz)
-        dx = hip.gemm_nt(dqkv2[:, 384:], Wt[:, 384:], epilogue=hip.EPI_ADD, aux=dx, out=dx)
+        dx = hip.gemm_nt(dqkv2[:, :384], Wt[:, :384], epilogue=hip.EPI_ADD, aux=dz, live=live)
+        dx = hip.gemm_nt(dqkv2[:, 384:], Wt[:, 384:], epilogue=hip.EPI_ADD, aux=dx, out=dx, live=live)
     else:
         dx = hip.gemm_nt(dqkv2, Wt, epilogue=hip.EPI_ADD, aux=dz, live=live)
     return dx, (rW[0], rb[0], rW[1], rb[1], rW[2], rb[2], rWo, rbo, rg, rbe)
@@ -810,7 +819,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     W1, b1, W2, b2, g, be = prm
     h1, rstd = saved
     d, dff = W2.shape
-    live = _live(rowmask, dout.shape[0], d == 128 and dff == 512)   # padded 16-row tiles: zero upstream gradient, skipped
+    live = _live(rowmask, dout.shape[0], (d == 128 and dff == 512) or (LISTS_256 and d == 256 and dff == 512 and _COMPUTE == torch.bfloat16))   # padded 16-row tiles: zero upstream gradient, skipped
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)

@@ -54,6 +54,44 @@ def test_cross_model_vs_oracle(d, H, L, N, k):
         ops.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.parametrize("dropout", [0.0, 0.5])
+def test_live_tile_lists_end_to_end_d256(dropout):
+    """The same at d_model = 256 (BASELINE configs[4]'s width; round 5: fused forward block + list-driven unfused backward): with the
+    lists forced on and every buffer a list-driven kernel may leave unwritten pre-filled with NaN, a reconstruction step gives the loss and
+    gradients of the plain (every row) path."""
+    from recguru_amd import hip, ops, synthetic, training as T
+    from recguru_amd.config import get_param
+    from recguru_amd.models import MyAuto4Rec_c
+    ops.set_compute_dtype("bf16")
+    d, H, L, N, k, V, B = 256, 8, 200, 2, 3, 500, 48
+    dom = synthetic.make_domain(B, V, L, k, seed=3)
+    res = {}
+    old, old256 = hip.COMPACT_MIN_ROWS, ops.LISTS_256
+    for mode, thr in (("lists", 0), ("plain", 1 << 30)):
+        hip.COMPACT_MIN_ROWS = thr
+        ops.LISTS_256 = mode == "lists"
+        hip.POISON_UNWRITTEN = mode == "lists"
+        try:
+            torch.manual_seed(1)
+            param = get_param(make_args(d, H, k, L, V, V, N, B, dropout=dropout), make_dirs=False)
+            G = MyAuto4Rec_c("cuda", param).to(torch.float32).cuda()
+            cb = tuple(torch.as_tensor(dom[n]).cuda() for n in ("enc_in", "dec_in", "dec_out", "n_items"))
+            ops.manual_seed(5)
+            mask = T.get_pad_mask(cb[2], 0, "cuda")
+            la = T.loss_ae(G, *cb, True, B, L, param, mask, "cuda", domain="a")
+            la.backward()
+            res[mode] = (float(la.detach()), {kk: p.grad.detach().clone() for kk, p in G.named_parameters() if p.grad is not None})
+        finally:
+            hip.COMPACT_MIN_ROWS, ops.LISTS_256 = old, old256
+            hip.POISON_UNWRITTEN = False
+    np.testing.assert_allclose(res["lists"][0], res["plain"][0], rtol=1e-5)
+    assert len(res["plain"][1]) >= 40
+    for kk, g in res["plain"][1].items():
+        scale = float(g.abs().max())
+        assert bool(torch.isfinite(res["lists"][1][kk]).all()), kk
+        torch.testing.assert_close(res["lists"][1][kk], g, rtol=1e-3, atol=1e-6 + 1e-4 * scale, msg=kk)
+
+
 @pytest.mark.parametrize("tier", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("dropout", [0.0, 0.5])
 def test_live_tile_lists_end_to_end(dropout, tier):
