@@ -618,6 +618,15 @@ def _zero_row(n, dev):
     return z
 
 
+def _ws_tier():
+    """The tiers that have the weight-stationary GEMM (bf16; bf16x3 since round 5 for the d_model = 256 restructurings below: the row passes
+    around it -- rg_bcast_add_ln, rg_dropout_gelu, rg_add_drop_ln -- take f32 tensors as they are)."""
+    return _COMPUTE == torch.bfloat16 or (hip.SPLIT_OPERANDS and WS_WIDE_X3)
+
+
+WS_WIDE_X3 = not _os_env("RG_NO_WS_WIDE_X3")      # RG_NO_WS_WIDE_X3=1: the bf16x3 tier keeps the generic LayerNorm-epilogue products at d_model 256 (A/B)
+
+
 def _fusable(x2, Wo, W1):
     return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0], x2.dtype) and not (x2.shape[1] == 256 and _split_resid())
 
@@ -709,7 +718,7 @@ def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv,
                                    rowmask, x_masked)
     M, d = x2.shape
     P = Wo.shape[1]
-    if (WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d % 128 == 0 and P % 128 == 0 and d > 128
+    if (WS_PROJ_PLUS_LN and _ws_tier() and M >= 4096 and d % 128 == 0 and P % 128 == 0 and d > 128
             and P // 128 <= 4 and d // 128 <= 8):
         # d_model = 256 (config-5): the whole-row LayerNorm epilogue only exists in the generic 64 x 256 tile kernel, which runs
         # this product at 7 % of the HBM rate; the weight-stationary kernel (+ bias + residual, one column block per gridDim.y)
@@ -759,7 +768,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     # dx of the padded rows is never used (the producer of x multiplies its incoming gradient by the same pad mask; the
     # embedding scatter skips masked positions), so those tiles are skipped and written as zeros
     Wt = shadow_cat((Wq, Wk, Wv), transpose=True)          # [d, 3P]
-    if (WS_SPLIT_K_DX and _COMPUTE == torch.bfloat16 and dqkv2.shape[0] >= 4096 and 3 * P == 768 and d % 128 == 0
+    if (WS_SPLIT_K_DX and _ws_tier() and dqkv2.shape[0] >= 4096 and 3 * P == 768 and d % 128 == 0
             and 128 < d <= 1024):
         # K = 768 is beyond the weight-stationary kernel's four 128-deep K blocks (the generic tile kernel ran this product at
         # 2.1 TB/s): two K halves instead, the second accumulating onto the first's output in place (the partial sum is rounded
@@ -777,8 +786,8 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
     passes over the GEMM outputs (h1 keeps the DROPPED pre-activation, as the fused kernel saves it)."""
     M, d = y.shape
     dff = W1.shape[0]
-    wide = WS_PROJ_PLUS_LN and _COMPUTE == torch.bfloat16 and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4
-    if wide and WS_DROP_GELU_EPILOGUE:
+    wide = WS_PROJ_PLUS_LN and _ws_tier() and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4
+    if wide and WS_DROP_GELU_EPILOGUE and _COMPUTE == torch.bfloat16:      # (the dropout + GELU epilogue exists in the bf16 kernel only)
         # ... with the activation pass folded into the first product's epilogue (both of its outputs leave the same LDS tile)
         gact = torch.empty(M, dff, device=y.device, dtype=y.dtype)
         h1 = hip.gemm_nt(y, shadow(W1), b1.detach(), epilogue=hip.EPI_DROP_GELU, drop_p=drop_p, drop_seed=seed_h1, out2=gact)

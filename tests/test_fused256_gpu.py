@@ -306,3 +306,60 @@ def test_item_loss_online_pipelined_equals_plain(tmp_path):
         assert torch.equal(c1, c0) and torch.equal(d1, d0) and torch.equal(l1, l0)
         assert float(s1[1]) == float(s0[1]) and abs(float(s1[0]) - float(s0[0])) <= 1e-5 * abs(float(s0[0]))
         assert bool(torch.isfinite(c1).all()) and bool(torch.isfinite(d1).all())
+
+
+@pytest.mark.parametrize("decoder", [False, True])
+@pytest.mark.parametrize("drop_p", [0.0, 0.5])
+def test_x3_d256_weight_stationary_restructuring_equals_generic_path(decoder, drop_p):
+    """bf16x3 tier at d_model = 256 (round 5): out-projection + residual and the FFN's second product through the weight-stationary kernel
+    between row passes (rg_bcast_add_ln / rg_dropout_gelu / rg_add_drop_ln on f32 tensors, the dx product as two K = 384 halves) against
+    the generic tile kernel's LayerNorm-epilogue products (ops.WS_WIDE_X3 = False), same dropout seeds: outputs and every gradient to
+    1e-4 of max (both are split-operand products with f32 storage: only summation orders differ)."""
+    from recguru_amd import ops
+    d, H, dff, B, L = 256, 8, 512, 24, 200
+    torch.manual_seed(5)
+    lens = torch.randint(20, L + 1, (B,))
+    ids = torch.zeros(B, L, dtype=torch.long)
+    for b in range(B):
+        ids[b, L - int(lens[b]):] = torch.randint(1, 5000, (int(lens[b]),))
+    ids = ids.cuda()
+    rowmask = (ids != 0).float()
+    x0 = (torch.randn(B, L, d) * 0.7).cuda() * rowmask[..., None]
+    u0 = (torch.randn(B, d) * 0.7).cuda()
+    gout = (torch.randn(B, L, d) * 0.1).cuda() * rowmask[..., None]
+    res = []
+    prev = ops.WS_WIDE_X3
+    try:
+        ops.set_compute_dtype("bf16x3")
+        for wide in (True, False):
+            ops.WS_WIDE_X3 = wide
+            prm = _layer_params(d, H, dff, 77, decoder)
+            x = x0.clone().requires_grad_(True)
+            ops.manual_seed(123)
+            with ops.masked_input(True):
+                if decoder:
+                    u = u0.clone().requires_grad_(True)
+                    out = ops.DecoderLayerFn.run(x, u, ids, ids, rowmask, H, drop_p, *prm)
+                else:
+                    u = None
+                    out = ops.EncoderLayerFn.run(x, ids, rowmask, 5001, False, H, drop_p, *prm)
+            out.backward(gout)
+            torch.cuda.synchronize()
+            res.append((out.detach().clone(), x.grad.clone(), None if u is None else u.grad.clone(), [p.grad.clone() if p.grad is not None else None for p in prm]))
+    finally:
+        ops.WS_WIDE_X3 = prev
+        ops.set_compute_dtype(torch.bfloat16)
+
+    def close(a, b, what, tol=1e-4):
+        err = float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+        assert err <= tol, "%s: restructured vs generic differ by %.3g of max" % (what, err)
+    (o1, dx1, du1, g1), (o2, dx2, du2, g2) = res
+    close(o1, o2, "layer output")
+    close(dx1, dx2, "input gradient")
+    if decoder:
+        close(du1, du2, "user-embedding gradient")
+    for i, (a, b) in enumerate(zip(g1, g2)):
+        assert (a is None) == (b is None), i
+        if i == 3 or a is None:
+            continue
+        close(a, b, "parameter gradient %d" % i, 2e-4)
