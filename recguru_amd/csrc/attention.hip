@@ -190,6 +190,9 @@ template <int PL> __device__ __forceinline__ void vstage_op(FragX3& f, const __b
   f.hi = h.v;
   f.lo = l.v;
 }
+// a raw row fragment as loaded from memory -> operand fragment (bf16x3: split on the way)
+__device__ __forceinline__ void raw_to_op(Frag<__bf16>& f, const Frag<__bf16>& raw) { f = raw; }
+__device__ __forceinline__ void raw_to_op(FragX3& f, const Frag<x3>& raw) { split_x3(raw.v, f.hi, f.lo); }
 __device__ __forceinline__ void acc_to_op(Frag<__bf16>& f, const f32x4& lo, const f32x4& hi) { acc_to_frag(f, lo, hi); }
 __device__ __forceinline__ void acc_to_op(FragX3& f, const f32x4& lo, const f32x4& hi) {
   const float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
@@ -1040,23 +1043,30 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(rg_attn_bwd_args a) {
 // G: the type of qkv / dctx / ctx / dqkv in memory -- __bf16, or x3 (the bf16x3 tier: f32 in memory; the four staged tiles are
 // split into hi and lo bf16 images while they are staged, PL elements apart, P and dS are split when they leave the
 // accumulators, every product is three MFMAs; two-phase form, eight waves, L <= 224: 153 KB of LDS at L = 200).
-template <int NKT, bool CAUSAL, int DM, bool ONEPASS, int NTH = 256, typename G = __bf16>
+// RESTAGE (round 5, bf16x3 beyond L = 224: config-5's L = 400): only TWO of the four operand tiles live in LDS at a time -- phase 1 (dK, dV)
+// sweeps Q and dO from LDS and takes the K / V fragments of a wave's own key tile straight from memory; K and V are then staged INTO THE
+// SAME SPACE and phase 2 (dQ) sweeps them with the Q / dO fragments of the wave's own query tile from memory.  hi + lo images of two
+// [416, 40] tiles are 133 KB (with the dropout bit table 161.5 KB: one workgroup per CU) where four are 266 KB -- the split-operand
+// product at L = 400 instead of the generic exact-f32-layout kernel (860 of 2 425 ms of config-5's bf16x3 step).
+template <int NKT, bool CAUSAL, int DM, bool ONEPASS, int NTH = 256, typename G = __bf16, bool RESTAGE = false>
 __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(rg_attn_bwd_args a) {
   static_assert(!ONEPASS || NKT >= 8, "the dS scratch tiles need 4 x 32 rows of pad columns");
   static_assert(!ONEPASS || NTH == 256, "the one-pass dQ reduction is written for four waves");
   constexpr bool X3 = std::is_same<G, x3>::value;
   static_assert(!X3 || !ONEPASS, "bf16x3: two-phase form");
+  static_assert(!RESTAGE || !ONEPASS, "restaging between the phases: two-phase form");
   constexpr int NWV = NTH / 64;
   typedef __bf16 T;                                           // element of the LDS tiles
   typedef typename OpT<G>::type OP;                           // operand fragment
   constexpr int LPK = NKT * 16;
   constexpr int LDR = DK + 8;
-  constexpr int PL = X3 ? 4 * LPK * LDR : 0;                  // bf16x3: the lo images sit PL elements behind the hi images
-  __shared__ __align__(16) T QKVG[4 * LPK * LDR * (X3 ? 2 : 1)];   // one block: reused as f32 scratch by the ONEPASS reduction
+  constexpr int NTILE = RESTAGE ? 2 : 4;                      // operand tiles resident at a time
+  constexpr int PL = X3 ? NTILE * LPK * LDR : 0;              // bf16x3: the lo images sit PL elements behind the hi images
+  __shared__ __align__(16) T QKVG[NTILE * LPK * LDR * (X3 ? 2 : 1)];   // one block: reused as f32 scratch by the ONEPASS reduction
   T* const Qs = QKVG;
-  T* const Ks = QKVG + LPK * LDR;
-  T* const Vs = QKVG + 2 * LPK * LDR;
-  T* const Gs = QKVG + 3 * LPK * LDR;           // dO
+  T* const Ks = RESTAGE ? QKVG : QKVG + LPK * LDR;                     // RESTAGE: K takes Q's place, V takes dO's
+  T* const Vs = RESTAGE ? QKVG + LPK * LDR : QKVG + 2 * LPK * LDR;
+  T* const Gs = RESTAGE ? QKVG + LPK * LDR : QKVG + 3 * LPK * LDR;     // dO
   __shared__ __align__(16) float lse2_s[LPK];   // lse * log2(e)   (+inf marks a fully masked row)
   __shared__ __align__(16) float dl_s[LPK];     // delta = rowsum(dO * O)
   __shared__ __align__(16) float rowp_s[LPK];   // 1/L for fully masked rows, else 0
@@ -1105,6 +1115,59 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
 
   // a batch's 5 x 4 global loads are all issued before its first LDS store (one HBM latency per 4 chunks per thread)
   constexpr int NCH = (LPK * 4 + NTH - 1) / NTH;
+  // RESTAGE: a pair of tiles at a time -- (Q, dO) with the row deltas, later (K, V): plain rows, zeros beyond L (no bias-row substitution
+  // in this tier); dO rows of positions with rowmask == 0 are TAKEN as zero, and carry the 1 / (1 - p) in the p == 0.5 mode, as below
+  auto stage_pair = [&](const G* __restrict__ r0, int ld0, const G* __restrict__ r1, int ld1, T* __restrict__ t0, T* __restrict__ t1, bool grad) {
+#pragma unroll
+    for (int i0 = 0; i0 < NCH; i0 += 4) {
+      Frag<G> ar[4], br[4], orow[4];
+      float rmr[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+        const int rc = min(row, L - 1);
+        rmr[i] = 1.f;
+        if (i0 + i < NCH) {
+          load_frag(ar[i], r0 + (size_t)rc * ld0 + c8);
+          load_frag(br[i], r1 + (size_t)rc * ld1 + c8);
+          if (grad) {
+            load_frag(orow[i], O + (size_t)rc * P + c8);
+            const float x = rmp[a.rowmask ? (size_t)b * L + rc : 0];
+            rmr[i] = a.rowmask ? x : 1.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int c = tid + NTH * (i0 + i), row = c >> 2, c8 = (c & 3) * 8;
+        if (i0 + i < NCH && c < LPK * 4) {
+          Frag<G> zf;
+          frag_zero(zf);
+          const bool in = row < L;
+          if (!in) { ar[i] = zf; br[i] = zf; }
+          if (grad) {
+            if (!in || rmr[i] == 0.f) { br[i] = zf; orow[i] = zf; }
+            float d = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) d += (float)br[i].v[j] * (float)orow[i].v[j];
+            d += __shfl_xor(d, 1);
+            d += __shfl_xor(d, 2);
+            if ((c & 3) == 0) dl_s[row] = d;
+            if constexpr (DM == 1) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) br[i].v[j] = (G)((float)br[i].v[j] * drop.inv_keep);
+            }
+          }
+          stage_op<PL>(t0 + row * LDR + c8, ar[i]);
+          stage_op<PL>(t1 + row * LDR + c8, br[i]);
+        }
+      }
+    }
+  };
+  if constexpr (RESTAGE) {
+    if constexpr (DM == 1) fill_dmask<NW, LPK, NTH>(dmask, drop, b, h, a.H, L, tid, 0);
+    stage_pair(qrow, qld, dO, P, Qs, Gs, true);
+  } else {
   const bool sub = a.x_masked == 2 && a.rowmask != nullptr && a.bqkv != nullptr;
   const int first = (sub && a.first_live) ? min(a.first_live[b], L - 1) : 0;      // see the forward
   Frag<G> qbf, kbf, vbf;              // bias rows of this head, this thread's chunk (tid & 3)
@@ -1199,6 +1262,7 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
       }
     }
   }
+  }       // (!RESTAGE)
   ql.publish(qlive, tid);
 #pragma unroll
   for (int i = 0; i < QLive<NKT, NTH>::NR; ++i) {
@@ -1236,8 +1300,17 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
   for (int kt = wave; kt < nkeyt; kt += NWV) {
     const int key = kt * 16 + li;                   // this lane's key (column of S)
     OP kf, vf;
-    load_op<PL>(kf, Ks + key * LDR + 8 * lg);
-    load_op<PL>(vf, Vs + key * LDR + 8 * lg);
+    if constexpr (RESTAGE) {          // this wave's key tile straight from memory (K / V are not in LDS during phase 1)
+      Frag<G> kr, vr;
+      load_frag(kr, krow + (size_t)min(key, L - 1) * qld + 8 * lg);
+      load_frag(vr, vrow + (size_t)min(key, L - 1) * qld + 8 * lg);
+      if (key >= L) { frag_zero(kr); frag_zero(vr); }
+      raw_to_op(kf, kr);
+      raw_to_op(vf, vr);
+    } else {
+      load_op<PL>(kf, Ks + key * LDR + 8 * lg);
+      load_op<PL>(vf, Vs + key * LDR + 8 * lg);
+    }
     const float kb = kbias[key];
     f32x4 dkt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
     f32x4 dvt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1365,12 +1438,33 @@ __global__ __launch_bounds__(NTH, NTH == 512 ? 1 : 2) void attn_bwd_bf16_kernel(
   }
 
   if constexpr (!ONEPASS) {
+  if constexpr (RESTAGE) {
+    __syncthreads();                                // every wave is done with Q / dO
+    stage_pair(krow, qld, vrow, qld, Ks, Vs, false);
+    __syncthreads();
+  }
   // ---------------------------------------------------------------- phase 2: dQ^T
   for (int qt = wave; qt < nt; qt += NWV) {
     const int q = qt * 16 + li;                     // this lane's query (column of S^T)
     OP qf, gf;
-    load_op<PL>(qf, Qs + q * LDR + 8 * lg);
-    load_op<PL>(gf, Gs + q * LDR + 8 * lg);
+    if constexpr (RESTAGE) {          // this wave's query tile straight from memory, dO as staged in phase 1 (zero where rowmask == 0, x 1/(1-p))
+      Frag<G> qr, gr;
+      const int qc = min(q, L - 1);
+      load_frag(qr, qrow + (size_t)qc * qld + 8 * lg);
+      load_frag(gr, dO + (size_t)qc * P + 8 * lg);
+      const float rmq = a.rowmask ? a.rowmask[(size_t)b * L + qc] : 1.f;
+      if (q >= L) frag_zero(qr);
+      if (q >= L || rmq == 0.f) frag_zero(gr);
+      if constexpr (DM == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gr.v[j] = (G)((float)gr.v[j] * drop.inv_keep);
+      }
+      raw_to_op(qf, qr);
+      raw_to_op(gf, gr);
+    } else {
+      load_op<PL>(qf, Qs + q * LDR + 8 * lg);
+      load_op<PL>(gf, Gs + q * LDR + 8 * lg);
+    }
     const float lse_q = lse2_s[q], dl_q = dl_s[q];
     const int qrel = q - 4 * lg;
     f32x4 dqt[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
@@ -1625,6 +1719,24 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
         else RG_BWDX(14);
 #undef RG_BWDX
 #undef RG_BWDX2
+        RG_CHECK_LAUNCH();
+        return 0;
+      }
+      // bf16x3, 224 < L <= 416 (round 5): the same kernel with two of the four split tiles resident at a time (RESTAGE);
+      // RG_ATTN_BWD_X3_GENERIC=1: the generic two-image kernel below (A/B)
+      static const bool generic_long = getenv("RG_ATTN_BWD_X3_GENERIC") != nullptr;
+      if (nkt <= 26 && !a.qkv_hm && !generic_long) {
+        const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+        const dim3 block8(512);
+#define RG_BWDR2(N, C)                                                                                                  \
+  do {                                                                                                                  \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 0, false, 512, x3, true>), grid, block8, 0, s, a);        \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 1, false, 512, x3, true>), grid, block8, 0, s, a);   \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<N, C, 2, false, 512, x3, true>), grid, block8, 0, s, a);                \
+  } while (0)
+        if (nkt <= 16) { if (a.causal) RG_BWDR2(16, true); else RG_BWDR2(16, false); }
+        else { if (a.causal) RG_BWDR2(26, true); else RG_BWDR2(26, false); }
+#undef RG_BWDR2
         RG_CHECK_LAUNCH();
         return 0;
       }

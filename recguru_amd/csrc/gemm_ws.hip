@@ -323,11 +323,12 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
 // 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
 int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
   if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no head-major form
-    if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->epilogue == RG_EPI_DROP_GELU || a->c_hm_L > 0) return 0;
+    if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->c_hm_L > 0) return 0;
+    if (a->epilogue == RG_EPI_DROP_GELU && (!a->C2 || a->aux || a->live16)) return 0;      // (round 5: the dropout + GELU epilogue on f32 tiles too)
     if (a->epilogue == RG_EPI_RELU && a->drop_p > 0.f) return 0;
     if ((a->K & 127) || (a->N & 127) || a->M < 4096 || a->K > 512 || a->N > 1024) return 0;
     if ((a->lda & 7) || (a->ldw & 7) || (a->ldc & 7) || (a->aux && (a->ldaux & 7))) return 0;
-    if (a->epilogue != RG_EPI_NONE && a->epilogue != RG_EPI_RELU && !a->aux) return 0;
+    if (a->epilogue != RG_EPI_NONE && a->epilogue != RG_EPI_RELU && a->epilogue != RG_EPI_DROP_GELU && !a->aux) return 0;
     return 10 * (a->K / 128) + 1;
   }
   if (dtype != RG_BF16 || a->c_is_f32 || a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN) return 0;

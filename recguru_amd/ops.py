@@ -723,7 +723,10 @@ def _attn_block_fwd(x2, B, L, key_ids, pad_value, causal, H, Wq, bq, Wk, bk, Wv,
         # d_model = 256 (config-5): the whole-row LayerNorm epilogue only exists in the generic 64 x 256 tile kernel, which runs
         # this product at 7 % of the HBM rate; the weight-stationary kernel (+ bias + residual, one column block per gridDim.y)
         # followed by a LayerNorm pass over its bf16 output is 3x faster (the sum is rounded to bf16 once before the LayerNorm)
-        z = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_ADD, aux=x2)
+        # (round 5) list-driven where the backward is: the rows of padded 16-row tiles come out as zeros (their LayerNorm is the bias row:
+        # finite) -- every later stage is row-wise and the layer output is multiplied by the pad mask, so nothing live depends on them
+        lf = _live(rowmask, M, LISTS_256 and d == 256 and P == 256)
+        z = hip.gemm_nt(ctx_.view(B * L, -1), shadow(Wo), bo.detach(), epilogue=hip.EPI_ADD, aux=x2, live=lf)
         y, rstd = hip.bcast_add_ln(z, _zero_row(d, z.device), g.detach(), be.detach(), M, LN_EPS)
         return y, (qkv, ctx_, lse, rstd)
     rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
@@ -744,7 +747,7 @@ def _attn_block_bwd(dy, x2, y, saved, B, L, key_ids, pad_value, causal, H, prm, 
     # rowmask here only lets the kernel skip the padded rows (their dy is already zero; the mask values are 0 / 1)
     # (d_model 256, round 5: the unfused backward of that width is list-driven too -- LayerNorm backward, the weight-stationary products and
     # the weight gradients all take the list --: 44 % of the rows of BASELINE configs[4]'s backward passes are padding)
-    live = _live(rowmask, dy.shape[0], (d == 128 and P == 128) or (LISTS_256 and d == 256 and P == 256 and _COMPUTE == torch.bfloat16))
+    live = _live(rowmask, dy.shape[0], (d == 128 and P == 128) or (LISTS_256 and d == 256 and P == 256 and _ws_tier()))
     # every consumer of dz below is list-driven: the padded tiles' rows of dz are never written nor read
     (dWo, rWo), (dbo, rbo) = _gt(Wo), _gt(bo)
     if FUSE_ATTN_OUT_BWD and d == 128 and P == 128:
@@ -787,11 +790,12 @@ def _ffn_block_fwd(y, rowmask, W1, b1, W2, b2, g, be, drop_p=0.0, seed_h1=0, see
     M, d = y.shape
     dff = W1.shape[0]
     wide = WS_PROJ_PLUS_LN and _ws_tier() and M >= 4096 and d == 256 and dff % 128 == 0 and dff // 128 <= 4
-    if wide and WS_DROP_GELU_EPILOGUE and _COMPUTE == torch.bfloat16:      # (the dropout + GELU epilogue exists in the bf16 kernel only)
+    if wide and WS_DROP_GELU_EPILOGUE:
         # ... with the activation pass folded into the first product's epilogue (both of its outputs leave the same LDS tile)
         gact = torch.empty(M, dff, device=y.device, dtype=y.dtype)
         h1 = hip.gemm_nt(y, shadow(W1), b1.detach(), epilogue=hip.EPI_DROP_GELU, drop_p=drop_p, drop_seed=seed_h1, out2=gact)
-        l2 = hip.gemm_nt(gact, shadow(W2), b2.detach())
+        lf = _live(rowmask, M, LISTS_256 and dff == 512)          # (see _attn_block_fwd: the output rows of padded tiles are zeros either way)
+        l2 = hip.gemm_nt(gact, shadow(W2), b2.detach(), live=lf)
         out, rstd = hip.add_drop_ln(y, l2, g.detach(), be.detach(), rowmask, drop_p, seed_out, LN_EPS)
         return out, (h1, rstd)
     h1 = hip.gemm_nt(y, shadow(W1), b1.detach())
@@ -828,7 +832,7 @@ def _ffn_block_bwd(dout, y, out, saved, rowmask, prm, drop_p=0.0, seed_h1=0, see
     W1, b1, W2, b2, g, be = prm
     h1, rstd = saved
     d, dff = W2.shape
-    live = _live(rowmask, dout.shape[0], (d == 128 and dff == 512) or (LISTS_256 and d == 256 and dff == 512 and _COMPUTE == torch.bfloat16))   # padded 16-row tiles: zero upstream gradient, skipped
+    live = _live(rowmask, dout.shape[0], (d == 128 and dff == 512) or (LISTS_256 and d == 256 and dff == 512 and _ws_tier()))   # padded 16-row tiles: zero upstream gradient, skipped
     (dg, rg), (dbe, rbe) = _gt(g), _gt(be)
     (dW2, rW2), (db2, rb2) = _gt(W2), _gt(b2)
     (dW1, rW1), (db1, rb1) = _gt(W1), _gt(b1)

@@ -54,15 +54,16 @@ def test_cross_model_vs_oracle(d, H, L, N, k):
         ops.set_compute_dtype(torch.bfloat16)
 
 
+@pytest.mark.parametrize("tier", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("dropout", [0.0, 0.5])
-def test_live_tile_lists_end_to_end_d256(dropout):
+def test_live_tile_lists_end_to_end_d256(dropout, tier):
     """The same at d_model = 256 (BASELINE configs[4]'s width; round 5: fused forward block + list-driven unfused backward): with the
     lists forced on and every buffer a list-driven kernel may leave unwritten pre-filled with NaN, a reconstruction step gives the loss and
     gradients of the plain (every row) path."""
     from recguru_amd import hip, ops, synthetic, training as T
     from recguru_amd.config import get_param
     from recguru_amd.models import MyAuto4Rec_c
-    ops.set_compute_dtype("bf16")
+    ops.set_compute_dtype(tier)
     d, H, L, N, k, V, B = 256, 8, 200, 2, 3, 500, 48
     dom = synthetic.make_domain(B, V, L, k, seed=3)
     res = {}

@@ -85,11 +85,13 @@ def test_gemm_tn(T, N1, N2, gelu):
 
 
 @pytest.mark.parametrize("B,L,H,causal", [(3, 12, 2, True), (2, 16, 4, False), (2, 50, 1, True), (3, 200, 4, True), (3, 200, 4, False),
-                                          (2, 224, 2, False), (1, 250, 2, True), (1, 400, 2, False)])
+                                          (2, 224, 2, False), (1, 250, 2, True), (1, 400, 2, False), (2, 400, 8, True), (2, 256, 4, False),
+                                          (3, 330, 2, True)])
 @pytest.mark.parametrize("p", [0.0, 0.5, 0.3])
 def test_attention(B, L, H, causal, p):
     """Forward (ctx, lse) and backward (dqkv) with a left-padding row mask, pad keys and dropout: the bf16x3 backward is the
-    two-phase kernel on split tiles up to L = 224 and the generic kernel beyond."""
+    two-phase kernel on split tiles up to L = 224 and, beyond (round 5), the same kernel with two of the four tiles resident at a
+    time (K / V restaged into Q / dO's space between the phases: 16 and 26 key tiles)."""
     from recguru_amd import hip
     P = H * 32
     qkv = rnd(B, L, 3 * P, seed=1)
