@@ -1698,7 +1698,24 @@ static int launch_bwd(const rg_attn_bwd_args& a, hipStream_t s) {
 #undef RG_BWD16_2
   } else {
     if constexpr (std::is_same<T, x3>::value) {
-      // bf16x3, L <= 224: the bf16 tier's two-phase kernel on split operand tiles (eight waves, one workgroup per CU)
+      // bf16x3, 128 < L <= 224 (round 5): the two-tiles-at-a-time form (RESTAGE) -- its 81.6 KB of LDS let TWO workgroups share a CU
+      // (four waves per SIMD) where the four-tile form's 153 KB allow one: 18.9 -> 14.9 ms per bench-shape step
+      // (profiles/r05/ab/bench_bf16x3_attention_backward_*.json); RG_ATTN_BWD_X3_NO_RESTAGE=1: the four-tile form (A/B)
+      static const bool restage_short = getenv("RG_ATTN_BWD_X3_NO_RESTAGE") == nullptr;
+      if (nkt > 8 && nkt <= 14 && !a.qkv_hm && restage_short) {
+        const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
+        const dim3 block8(512);
+#define RG_BWDS2(C)                                                                                                      \
+  do {                                                                                                                  \
+    if (dm == 0) hipLaunchKernelGGL((attn_bwd_bf16_kernel<14, C, 0, false, 512, x3, true>), grid, block8, 0, s, a);       \
+    else if (dm == 1) hipLaunchKernelGGL((attn_bwd_bf16_kernel<14, C, 1, false, 512, x3, true>), grid, block8, 0, s, a);  \
+    else hipLaunchKernelGGL((attn_bwd_bf16_kernel<14, C, 2, false, 512, x3, true>), grid, block8, 0, s, a);               \
+  } while (0)
+        if (a.causal) RG_BWDS2(true); else RG_BWDS2(false);
+#undef RG_BWDS2
+        RG_CHECK_LAUNCH();
+        return 0;
+      }
       if (nkt <= 14 && !a.qkv_hm) {            // (16 key tiles: 168 KB of split tiles -- beyond a CU's LDS; the generic form below)
         const int dm = a.drop_p <= 0.f ? 0 : (a.drop_p == 0.5f ? 1 : 2);
         const dim3 block8(512);
