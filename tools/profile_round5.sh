@@ -59,3 +59,9 @@ rm -rf $O/c5/kt
 python3 tools/pmc_traffic.py $O/c5/pmcF $O/c5/pmcW $O/c5/pmc_traffic.json > $O/c5/pmc_summary.txt 2>&1
 rm -rf $O/c5/pmcF $O/c5/pmcW
 ls -la $O $O/c5
+# ---- config-5 in the bf16x3 tier: the line and its kernel stats
+timeout 900 python3 bench.py $C5 --dtype bf16x3 --steps 2 --warmup 1 2>> $O/c5/bench.err | tail -1 > $O/c5/bench_bf16x3.json
+(cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c5/kt3 -- python3 $R/bench.py $C5 --dtype bf16x3 --steps 1 --warmup 1 --no_roofline > /dev/null 2> $O/c5/kt3.err)
+find $O/c5/kt3 -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/c5/kernel_stats_bf16x3.csv
+rm -rf $O/c5/kt3
+ls -la $O/c5
