@@ -36,6 +36,22 @@ extern "C" {
 const char* rg_last_error(void);
 int rg_version(void);
 
+/* ---- deterministic reductions (SURVEY.md 5.2 "offer sorted segmented-reduce mode for tests"; no reference counterpart: torch's own
+ * index_add / scatter backward on the reference's path are float atomics too, GURU/AutoEnc4Rec_cross.py:98-102 through autograd).
+ * librecguru_hip.so sums parameter gradients, loss sums and the discriminator's scalars with float atomics (order = workgroup
+ * schedule).  librecguru_hip_det.so -- the same sources built with -DRG_DETERMINISTIC -- sends every such add to a 64-bit fixed-point
+ * shadow instead (integer atomics: any order gives the same bits).  Destinations must then lie in one of two arenas the host
+ * registers: a float buffer [bytes] at fbase (still readable by the kernels) whose shadow of long long [2 * bytes] starts at sbase,
+ * in units of 2^-bits; the host converts shadow -> float after the launch (recguru_amd/hip.py `_DetArena`).
+ *   rg_det_enabled()  number of translation units built deterministic (0: this is the float-atomic library)
+ *   rg_det_set_arenas()  arena 0: gradients, arena 1: loss sums / scalars (current device)
+ *   rg_det_fault(clear)  0 = every add so far went to a shadow; 1 = a destination outside the arenas was added to with a float
+ *                        atomic (host omission); 2 = a contribution outside the fixed-point range (or NaN); -1 = HIP error */
+int rg_det_enabled(void);
+int rg_det_set_arenas(void* fbase0, void* sbase0, unsigned long long bytes0, int bits0,
+                      void* fbase1, void* sbase1, unsigned long long bytes1, int bits1);
+int rg_det_fault(int clear);
+
 /* ---- generic Linear-shaped GEMMs --------------------------------------------------------------
  * replaces nn.Linear forward / backward in MultiHeadAttention (Transformer/transformer.py:136-161),
  * PositionWiseFeedForwardNet (:173-188) and Discriminator (tools/utils.py:41-57). */

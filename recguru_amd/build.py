@@ -15,6 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librecguru_hip.so")
+LIB_DET = os.path.join(HERE, "librecguru_hip_det.so")
 # -Wno-pass-failed: the L > 224 attention instantiations hold > 80 KB of LDS per workgroup, so their launch-bounds
 # occupancy hint (2 waves per SIMD) cannot be met -- expected, not worth a warning per instantiation
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value", "-Wno-pass-failed"]
@@ -27,17 +28,14 @@ def _stale(target, sources):
     return any(os.path.getmtime(s) > t for s in sources)
 
 
-def build(force=False, verbose=False, jobs=4):
-    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
-    hdrs = glob.glob(os.path.join(CSRC, "*.hip.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
-    objdir = os.path.join(HERE, "build")
+def _compile(srcs, hdrs, objdir, extra, force, verbose, jobs):
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for s in srcs:
         o = os.path.join(objdir, os.path.basename(s)[:-4] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + hdrs) or not os.path.exists(_isa_of(o)):
-            cmd = ["hipcc"] + FLAGS + ["-save-temps=obj", "-c", s, "-o", o]
+            cmd = ["hipcc"] + FLAGS + extra + ["-save-temps=obj", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
@@ -51,19 +49,53 @@ def build(force=False, verbose=False, jobs=4):
             os.replace(tmp, _isa_of(o))
         for junk in glob.glob(stem + "-hip-amdgcn-*") + glob.glob(stem + "-host-*") + glob.glob(stem + ".hip-hip-*"):
             os.remove(junk)
-    if force or _stale(LIB, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    return objs
+
+
+def _link_and_screen(target, objs, screened_objs, info_name, force, verbose):
+    if force or _stale(target, objs):
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", target] + objs
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
     try:
-        _screen_and_record([_isa_of(o) for o in objs], verbose)
+        _screen_and_record([_isa_of(o) for o in screened_objs], verbose, target, info_name)
     except RuntimeError:
         # a library whose ISA the screen refuses must not stay loadable (hip.lib() loads whatever is on disk -- ADVICE r4)
-        if os.path.exists(LIB):
-            os.remove(LIB)
+        if os.path.exists(target):
+            os.remove(target)
         raise
+    return target
+
+
+def _sources():
+    srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    hdrs = glob.glob(os.path.join(CSRC, "*.hip.h")) + glob.glob(os.path.join(HERE, "..", "include", "*.h"))
+    return srcs, hdrs
+
+
+def build(force=False, verbose=False, jobs=4, det=True):
+    """librecguru_hip.so, and (det) librecguru_hip_det.so beside it."""
+    srcs, hdrs = _sources()
+    objs = _compile(srcs, hdrs, os.path.join(HERE, "build"), [], force, verbose, jobs)
+    _link_and_screen(LIB, objs, objs, "BUILD_INFO.json", force, verbose)
+    if det:
+        build_det(force, verbose, jobs)
     return LIB
+
+
+def build_det(force=False, verbose=False, jobs=4):
+    """The deterministic-reduction library (csrc/rg_det.hip.h): the translation units that accumulate are compiled a second time
+    with -DRG_DETERMINISTIC into build/det/, the others' objects are shared with librecguru_hip.so.  Same ISA screen."""
+    srcs, hdrs = _sources()
+    acc = [s for s in srcs if '#include "rg_det.hip.h"' in open(s).read()]
+    dobjs = _compile(acc, hdrs, os.path.join(HERE, "build", "det"), ["-DRG_DETERMINISTIC=1"], force, verbose, jobs)
+    names = set(os.path.basename(o) for o in dobjs)
+    shared = [os.path.join(HERE, "build", os.path.basename(s)[:-4] + ".o") for s in srcs if os.path.basename(s)[:-4] + ".o" not in names]
+    missing = [o for o in shared if not os.path.exists(o)]
+    if missing:
+        raise RuntimeError("build_det: build() first (%s missing)" % ", ".join(missing))
+    return _link_and_screen(LIB_DET, dobjs + shared, dobjs, "BUILD_INFO_det.json", force, verbose)
 
 
 def _isa_of(obj):
@@ -72,10 +104,11 @@ def _isa_of(obj):
     return os.path.join(d, os.path.basename(obj)[:-2] + ".s")
 
 
-def _screen_and_record(isa_files, verbose):
+def _screen_and_record(isa_files, verbose, lib_path=None, info_name="BUILD_INFO.json"):
     from . import isa_screen
-    info_path = os.path.join(HERE, "build", "BUILD_INFO.json")
-    sha = hashlib.sha256(open(LIB, "rb").read()).hexdigest()
+    lib_path = lib_path or LIB
+    info_path = os.path.join(HERE, "build", info_name)
+    sha = hashlib.sha256(open(lib_path, "rb").read()).hexdigest()
     try:
         with open(info_path) as f:
             if json.load(f).get("library_sha256") == sha:

@@ -20,6 +20,7 @@
 // 16 columns hold q'_h split into bf16 high + low parts (4 + 4 columns; backward: dxbar_h in the other 8), so the f32
 // vectors lose nothing to the bf16 operand format.  bf16 tier, d_model = H*32 = 128, L <= 256.
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define LX_D 128
@@ -507,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
       }
     }
   }
-  if (a.dbv && lane < 32) atomicAdd(a.dbv + h * LX_DK + lane, dbv);
+  if (a.dbv && lane < 32) rg_acc(a.dbv + h * LX_DK + lane, dbv);
 }
 
 static size_t lx_smem_bytes(int L, bool bwd) {

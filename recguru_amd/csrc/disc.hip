@@ -29,6 +29,7 @@
 // launch with the MFMAs and every other memory access ablated away); packed, it is one contiguous 1 KB read.  8 waves per workgroup; a wave takes PAIRS of
 // 16-feature blocks so that every activation fragment read from LDS feeds two MFMAs per row block.
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define DNW 8                // waves per workgroup
@@ -322,13 +323,13 @@ __global__ __launch_bounds__(DTHREADS, 1) void disc_rows_kernel(rg_disc_args a) 
           }
         }
         if (lane == 0 && a.scalars) {
-          if (sr != 0.f) atomicAdd(a.scalars + 0, sr / (float)a.B);
-          if (sf != 0.f) atomicAdd(a.scalars + 1, sf / (float)a.B);
+          if (sr != 0.f) rg_acc(a.scalars + 0, sr / (float)a.B);
+          if (sf != 0.f) rg_acc(a.scalars + 1, sf / (float)a.B);
         }
         if (wg && tid == 0 && a.db4) {
           float s = 0.f;
           for (int t = 0; t < nvalid; ++t) s += rowf[t];
-          if (s != 0.f) atomicAdd(a.db4, s);
+          if (s != 0.f) rg_acc(a.db4, s);
         }
       }
       __syncthreads();
@@ -341,7 +342,7 @@ __global__ __launch_bounds__(DTHREADS, 1) void disc_rows_kernel(rg_disc_args a) 
           dsum += cf * h;
           bufB[t * ldB + f] = (T)(h > 0.f ? cf * wv : 0.f);
         }
-        if (!gp_tile && wg && a.dw4 && dsum != 0.f) atomicAdd(a.dw4 + f, dsum);
+        if (!gp_tile && wg && a.dw4 && dsum != 0.f) rg_acc(a.dw4 + f, dsum);
       }
       __syncthreads();
       disc_flush(bufB, ldB, at(Y3, srow, n3), n3, n3, TR, nvf);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(DTHREADS, 1) void disc_rows_kernel(rg_disc_args a) 
       if (tid == 0 && a.scalars) {
         float s = 0.f;
         for (int w = 0; w < DNW; ++w) s += red[w];
-        if (s != 0.f) atomicAdd(a.scalars + 2, s * a.gp_coef / (float)a.B);
+        if (s != 0.f) rg_acc(a.scalars + 2, s * a.gp_coef / (float)a.B);
       }
       for (int c = tid; c < TR * d; c += DTHREADS) {
         const int t = c / d, k = c - t * d;
@@ -379,7 +380,7 @@ __global__ __launch_bounds__(DTHREADS, 1) void disc_rows_kernel(rg_disc_args a) 
       for (int f = tid; f < n3; f += DTHREADS) {
         float s = 0.f;
         for (int t = 0; t < TR; ++t) s += (float)bufB[t * ldB + f];
-        if (s != 0.f) atomicAdd(a.dw4 + f, s);
+        if (s != 0.f) rg_acc(a.dw4 + f, s);
       }
     }
   }

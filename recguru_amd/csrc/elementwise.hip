@@ -3,6 +3,7 @@
 // All of them move 8-16 bytes per lane per access with lanes on consecutive addresses.
 #include <stdlib.h>
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define EW_BLOCK 256
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
     for (int u = 0; u < ES_UNROLL; ++u) {
       if (m[u] == 0.f || row[u] == skip_row) continue;
       int slot = -1;
-      if (row[u] >= 0 && row[u] < 0x7fffffffLL) {
+      if (!RG_DET && row[u] >= 0 && row[u] < 0x7fffffffLL) {     // (deterministic build: no first-come LDS slots, every add goes to the fixed-point shadow)
         const unsigned int h = ((unsigned int)row[u] * 2654435761u) >> 26;       // 6 bits
         int got = -1;
         if (lane == 0) {
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
           float v = (float)g[u][j] * m[u];
           if (drop.thresh) v *= rg_keep(drop, (unsigned int)(t0 + u) * (unsigned int)d + (unsigned int)e);
           if (slot >= 0) atomicAdd(es_acc + slot * d + e, v);
-          else atomicAdd(dE + (size_t)row[u] * d + e, v);
+          else rg_acc(dE + (size_t)row[u] * d + e, v);
         }
       }
     }
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_scatter_bwd_kernel(const T* __
   for (int sl = tid >> 6; sl < ES_SLOTS; sl += EW_BLOCK / 64) {
     const int row = es_tag[sl];
     if (row < 0) continue;
-    for (int e = lane; e < d; e += 64) atomicAdd(dE + (size_t)row * d + e, es_acc[sl * d + e]);
+    for (int e = lane; e < d; e += 64) rg_acc(dE + (size_t)row * d + e, es_acc[sl * d + e]);
   }
 }
 
@@ -359,9 +360,9 @@ __global__ __launch_bounds__(EW_BLOCK) void ln_bwd_kernel(rg_ln_bwd_args a) {
       a.partials[((size_t)blockIdx.x * 3 + 1) * N + n] = sb;
       a.partials[((size_t)blockIdx.x * 3 + 2) * N + n] = sc;
     } else {
-      if (a.dgamma) atomicAdd(a.dgamma + n, sg);
-      if (a.dbeta) atomicAdd(a.dbeta + n, sb);
-      if (a.dz_colsum) atomicAdd(a.dz_colsum + n, sc);
+      if (a.dgamma) rg_acc(a.dgamma + n, sg);
+      if (a.dbeta) rg_acc(a.dbeta + n, sb);
+      if (a.dz_colsum) rg_acc(a.dz_colsum + n, sc);
     }
   }
 }
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(256) void ln_bwd_reduce_kernel(const float* __restr
       s1 += partials[(size_t)(b + gridDim.x) * 3 * N + c];
     }
     if (b < nblocks) s0 += partials[(size_t)b * 3 * N + c];
-    atomicAdd(dst + (c % N), s0 + s1);
+    rg_acc(dst + (c % N), s0 + s1);
   }
 }
 
@@ -543,7 +544,7 @@ __global__ __launch_bounds__(EW_BLOCK) void colsum_kernel(const T* __restrict__ 
     }
   red[part][threadIdx.x & 63] = s;
   __syncthreads();
-  if (part == 0 && n < N) atomicAdd(out + n, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+  if (part == 0 && n < N) rg_acc(out + n, (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
 }
 
 // out[m,n] = coef[m] * w[n] * [aux[m,n] > 0]      (seed of the ReLU-mask chains, tools/utils.py:41-52)
@@ -587,7 +588,7 @@ __global__ __launch_bounds__(EW_BLOCK) void gp_penalty_kernel(const float* __res
     for (int e = lane; e < d; e += 64) dg[(size_t)b * d + e] = (T)(c * g[(size_t)b * d + e]);
     acc += (nrm - 1.f) * (nrm - 1.f);
   }
-  if (lane == 0 && acc != 0.f) atomicAdd(gp, acc * lambda / (float)B);
+  if (lane == 0 && acc != 0.f) rg_acc(gp, acc * lambda / (float)B);
 }
 
 // out[0] += scale * sum(x)
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(EW_BLOCK) void sum_kernel(const float* __restrict__
   float s = 0.f;
   for (long long i = (long long)blockIdx.x * EW_BLOCK + threadIdx.x; i < n; i += (long long)gridDim.x * EW_BLOCK) s += x[i];
   s = wave_sum(s);
-  if ((threadIdx.x & 63) == 0 && s != 0.f) atomicAdd(out, s * scale);
+  if ((threadIdx.x & 63) == 0 && s != 0.f) rg_acc(out, s * scale);
 }
 
 // torch.optim.Adam (no amsgrad, no weight decay), one tensor; optionally refreshes the operand-tier
@@ -1447,7 +1448,7 @@ __global__ __launch_bounds__(EW_BLOCK) void mse_kernel(const T* __restrict__ a, 
   if (threadIdx.x == 0) {
     float t = 0.f;
     for (int w = 0; w < EW_BLOCK / 64; ++w) t += red[w];
-    atomicAdd(out, t * inv_n);
+    rg_acc(out, t * inv_n);
   }
 }
 

@@ -23,6 +23,7 @@
 // two waves per SIMD in any case).
 #include <type_traits>
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define FT_M 64      // tokens per tile (the backward kernels; the forward block: 16 * RT)
@@ -1062,7 +1063,7 @@ __global__ __launch_bounds__(256) void ffn_bwd_ln_reduce_kernel(const float* __r
     s1 += partials[(size_t)(b + gridDim.x) * 2 * FD + c];
   }
   if (b < nblocks) s0 += partials[(size_t)b * 2 * FD + c];
-  atomicAdd(dst + (c & (FD - 1)), s0 + s1);
+  rg_acc(dst + (c & (FD - 1)), s0 + s1);
 }
 
 extern "C" int rg_ffn_bwd_data_supported(int d, int dff) { return d == FD && dff > 0 && (dff % FD) == 0; }

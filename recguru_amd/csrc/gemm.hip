@@ -10,6 +10,7 @@
 // The residual+LayerNorm epilogue needs whole rows and therefore a tile that spans N.
 #include <stdio.h>
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define TM 64
@@ -460,14 +461,14 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(rg_gemm_tn_args a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n1 = n1_0 + wave * 16 + 4 * lg + r;
-      if (n1 < a.N1 && n2 < a.N2) atomicAdd(a.dW + (size_t)n1 * a.lddw + n2, acc[j][r] * a.scale);
+      if (n1 < a.N1 && n2 < a.N2) rg_acc(a.dW + (size_t)n1 * a.lddw + n2, acc[j][r] * a.scale);
     }
   }
   if (do_colsum && li == 0) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int n1 = n1_0 + wave * 16 + 4 * lg + r;
-      if (n1 < a.N1) atomicAdd(a.colsum + n1, csum[r] * a.scale);
+      if (n1 < a.N1) rg_acc(a.colsum + n1, csum[r] * a.scale);
     }
   }
 }

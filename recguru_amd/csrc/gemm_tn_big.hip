@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <type_traits>
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define TB_T_BF16 64 // tokens per chunk (bf16): two MFMA k-steps per barrier pair and >= 80 KB of loads in flight per CU
@@ -212,11 +213,11 @@ __device__ __forceinline__ void tn_big_body(const rg_gemm_tn_args& a, const int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (part) part[((i * NT + j) * 4 + r) * 512] = acc[i][j][r];     // element e = slot * 512 + tid of this workgroup's slice
-        else atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
+        else rg_acc(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
       }
     if (do_cs && li == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
+      for (int r = 0; r < 4; ++r) rg_acc(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
     }
   }
 }
@@ -447,11 +448,11 @@ __device__ __forceinline__ void tn_dma_body(const rg_gemm_tn_args& a, const int 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (part) part[((i * NT + j) * 4 + r) * 512] = acc[i][j][r];     // element e = slot * 512 + tid of this workgroup's slice
-        else atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
+        else rg_acc(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, acc[i][j][r] * a.scale);
       }
     if (do_cs && li == 0) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) atomicAdd(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
+      for (int r = 0; r < 4; ++r) rg_acc(a.colsum + m1 + i * 16 + 4 * lg + r, cs[i][r] * a.scale);
     }
   }
 }
@@ -514,7 +515,7 @@ __device__ __forceinline__ void tn_reduce_body(const rg_gemm_tn_args& a, int gri
   const int wave = tid >> 6, li = tid & 15, lg = (tid >> 4) & 3;
   constexpr int MT = SPLIT1 ? N1 / 128 : N1 / 16;
   const int m1 = SPLIT1 ? wave * MT * 16 : 0, m2 = SPLIT1 ? 0 : wave * NT * 16;
-  atomicAdd(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, ((s0 + s1) + (s2 + s3)) * a.scale);
+  rg_acc(a.dW + (size_t)(m1 + i * 16 + 4 * lg + r) * a.lddw + m2 + j * 16 + li, ((s0 + s1) + (s2 + s3)) * a.scale);
 }
 
 template <int N1, int N2>

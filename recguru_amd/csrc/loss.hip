@@ -14,6 +14,7 @@
 // scatters c_j * h_t into the dense f32 table gradient with full-row (256 B per instruction) atomics.
 #include <stdlib.h>
 #include "rg_common.hip.h"
+#include "rg_det.hip.h"
 #include "../../include/recguru_hip.h"
 
 #define LW 4  // waves per block
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_fwd_kernel(rg_item_loss_arg
   if (threadIdx.x == 0) {
     float s0 = 0.f, s1 = 0.f;
     for (int w = 0; w < LW; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
-    if (s1 != 0.f) { atomicAdd(a.sums, s0); atomicAdd(a.sums + 1, s1); }
+    if (s1 != 0.f) { rg_acc(a.sums, s0); rg_acc(a.sums + 1, s1); }
   }
 }
 
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_kernel(rg_item_loss_arg
         for (int q = 0; q < NPL; ++q) {
           const int e = lane + 64 * q;
           dh[q] += c * row[q];
-          if (e < d && item != a.skip_row) atomicAdd(a.dE + (size_t)item * d + e, c * h[q]);
+          if (e < d && item != a.skip_row) rg_acc(a.dE + (size_t)item * d + e, c * h[q]);
         }
       }
     }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_fwd_rows_kernel(rg_item_los
   if (threadIdx.x == 0) {
     float s0 = 0.f, s1 = 0.f;
     for (int w = 0; w < LW; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
-    if (s1 != 0.f) { atomicAdd(a.sums, s0); atomicAdd(a.sums + 1, s1); }
+    if (s1 != 0.f) { rg_acc(a.sums, s0); rg_acc(a.sums + 1, s1); }
   }
 }
 
@@ -286,7 +287,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_bwd_rows_kernel(rg_item_los
           } else if (idx < n && item[u] != a.skip_row) {
             float* __restrict__ dst = a.dE + (size_t)item[u] * d + li;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) atomicAdd(dst + LPR * j, c * ht[j]);
+            for (int j = 0; j < 8; ++j) rg_acc(dst + LPR * j, c * ht[j]);
           }
         }
       }
@@ -403,7 +404,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_train_rows_kernel(rg_item_l
   if (threadIdx.x == 0) {
     float s0 = 0.f;
     for (int w = 0; w < LW; ++w) s0 += red[w];
-    if (s0 != 0.f) atomicAdd(a.sums, s0);
+    if (s0 != 0.f) rg_acc(a.sums, s0);
   }
 }
 
@@ -504,7 +505,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_train_online_kernel(rg_item
   if (threadIdx.x == 0) {
     float s0 = 0.f;
     for (int w = 0; w < LW; ++w) s0 += red[w];
-    if (s0 != 0.f) atomicAdd(a.sums, s0);
+    if (s0 != 0.f) rg_acc(a.sums, s0);
   }
 }
 
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(64 * LW) void item_loss_train_online2_kernel(rg_ite
   if (threadIdx.x == 0) {
     float s0 = 0.f;
     for (int w = 0; w < LW; ++w) s0 += red[w];
-    if (s0 != 0.f) atomicAdd(a.sums, s0);
+    if (s0 != 0.f) rg_acc(a.sums, s0);
   }
 }
 
@@ -1141,6 +1142,7 @@ static int bin_log_of(long long table_rows) {      // rows per bin: 64, or 256 f
   return 0;
 }
 extern "C" size_t rg_item_loss_bwd_binned_workspace(long long ntok, int k, int d, long long table_rows) {
+  if (RG_DET) return 0;     // the binned kernels sum rows in the order the counting sort's cursors were claimed: not offered by the deterministic build
   const int bl = bin_log_of(table_rows);
   if (!bl) return 0;
   const long long nbins = (table_rows + (1LL << bl) - 1) >> bl;

@@ -10,7 +10,11 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RG_HIP_LIB") or os.path.join(_HERE, "librecguru_hip.so")   # RG_HIP_LIB: another build of the SAME library (A/B kernel experiments, tools/ab_variants.sh)
+# RG_DETERMINISTIC=1: the deterministic-reduction build of the same sources (csrc/rg_det.hip.h: every floating-point accumulation that
+# more than one wave can reach is an integer atomic on a 64-bit fixed-point shadow -- any summation order gives the same bits).
+# The wrappers below that hand a kernel an accumulator are marked @_det_accum / use _DetScope; in the default mode those are no-ops.
+DETERMINISTIC = os.environ.get("RG_DETERMINISTIC", "0") not in ("", "0")
+LIB_PATH = os.environ.get("RG_HIP_LIB") or os.path.join(_HERE, "librecguru_hip_det.so" if DETERMINISTIC else "librecguru_hip.so")   # RG_HIP_LIB: another build of the SAME library (A/B kernel experiments, tools/ab_variants.sh)
 _lib = None
 
 F32, BF16, X3 = 0, 1, 2
@@ -94,7 +98,8 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
            "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
            "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse",
-           "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln", "rg_embed_pe_fwd2"]
+           "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln", "rg_embed_pe_fwd2",
+           "rg_det_enabled", "rg_det_set_arenas", "rg_det_fault"]
 LOSS_SAMPLED_CE, LOSS_BPR, LOSS_BPR_SAS = 0, 1, 2
 c_ll = ctypes.c_longlong
 
@@ -117,7 +122,7 @@ def _check_screened(path):
     RG_HIP_LIB (A/B variant builds) skip the check; a missing BUILD_INFO.json (library built by hand) does too."""
     if os.environ.get("RG_ALLOW_UNSCREENED") or os.environ.get("RG_HIP_LIB"):
         return
-    info_path = os.path.join(_HERE, "build", "BUILD_INFO.json")
+    info_path = os.path.join(_HERE, "build", "BUILD_INFO_det.json" if os.path.basename(path) == "librecguru_hip_det.so" else "BUILD_INFO.json")
     try:
         import json
         with open(info_path) as f:
@@ -183,6 +188,131 @@ def _rowmajor(t):
     return t.stride(0)
 
 
+# ------------------------------------------------------------------------------------------------
+# deterministic reductions (RG_DETERMINISTIC=1, librecguru_hip_det.so)
+# ------------------------------------------------------------------------------------------------
+DET_BITS = {"g": 46, "s": 30}        # gradients: 2^-46 units (|sum| < 131072); loss sums / scalars: 2^-30 units (|sum| < 8.6e9)
+
+
+class _DetArena(object):
+    """Per device: for each kind a float32 buffer (what the kernel is handed; it may read it) and an int64 buffer of the same
+    element count (where the deterministic library's rg_acc() really adds, at sbase + 2 * byte offset).  A bump allocator: a
+    wrapper takes slices for its accumulators, launches, converts shadow -> float into the real destinations and gives the
+    slices back -- all on the launch stream, so the next taker is ordered behind the conversion."""
+    _per_device = {}
+
+    def __init__(self, dev):
+        ng = int(os.environ.get("RG_DET_ARENA_MFLOATS", "96")) << 20          # gradients: 96 M floats (384 MB + 768 MB of shadow)
+        self.n = {"g": ng, "s": 4096}
+        self.f = {k: torch.zeros(n, device=dev, dtype=torch.float32) for k, n in self.n.items()}
+        self.s = {k: torch.zeros(n, device=dev, dtype=torch.int64) for k, n in self.n.items()}
+        self.top = {"g": 0, "s": 0}
+        self.last_stream = None
+        fn = lib().rg_det_set_arenas
+        fn.argtypes = [c_p, c_p, ctypes.c_ulonglong, c_i, c_p, c_p, ctypes.c_ulonglong, c_i]
+        with torch.cuda.device(dev):
+            _check(fn(self.f["g"].data_ptr(), self.s["g"].data_ptr(), self.n["g"] * 4, DET_BITS["g"],
+                      self.f["s"].data_ptr(), self.s["s"].data_ptr(), self.n["s"] * 4, DET_BITS["s"]), "rg_det_set_arenas")
+
+    @classmethod
+    def of(cls, dev):
+        a = cls._per_device.get(dev.index)
+        if a is None:
+            if not lib().rg_det_enabled():
+                raise RuntimeError("recguru_amd: RG_DETERMINISTIC needs librecguru_hip_det.so, %s is the float-atomic build" % LIB_PATH)
+            a = cls._per_device[dev.index] = cls(dev)
+        return a
+
+    def holds(self, t):
+        p = t.data_ptr()
+        return any(f.data_ptr() <= p < f.data_ptr() + f.numel() * 4 for f in self.f.values())
+
+
+class _DetScope(object):
+    """The accumulators of one launch: take(t, kind) -> a contiguous float32 tensor of t's shape inside the arena to hand to the
+    kernel in t's place (load=True: with t's values, for destinations the kernel also reads -- the mask count beside a loss sum);
+    commit() adds the exact fixed-point sums, rounded once to float32, into the real tensors."""
+    def __init__(self):
+        self.arena, self.items, self.mark = None, [], None
+
+    def take(self, t, kind="g", load=False):
+        if t is None:
+            return None
+        assert t.dtype == torch.float32 and t.is_cuda
+        if self.arena is None:
+            self.arena = _DetArena.of(t.device)
+            self.mark = dict(self.arena.top)
+        a = self.arena
+        if a.holds(t):
+            return t                                                   # already redirected by an enclosing wrapper
+        cur = torch.cuda.current_stream(t.device)
+        if a.last_stream is not None and a.last_stream != cur:         # slices are recycled in host order: a launch on another
+            cur.wait_stream(a.last_stream)                             # stream (critic-phase overlap) goes behind the previous taker
+        a.last_stream = cur
+        n = t.numel()
+        off = a.top[kind]
+        if off + n > a.n[kind]:
+            raise RuntimeError("recguru_amd: deterministic arena exhausted (%d + %d of %d floats; RG_DET_ARENA_MFLOATS)" % (off, n, a.n[kind]))
+        a.top[kind] = off + ((n + 63) & ~63)
+        f = a.f[kind][off:off + n].view(t.shape)
+        if load:
+            f.copy_(t)
+        a.s[kind][off:off + n].zero_()
+        self.items.append((t, kind, off, n, f))
+        return f
+
+    def commit(self):
+        for t, kind, off, n, f in self.items:
+            t.add_(self.arena.s[kind][off:off + n].to(torch.float64).mul_(2.0 ** -DET_BITS[kind]).to(torch.float32).view(t.shape))
+        if self.arena is not None:
+            self.arena.top.update(self.mark)
+        self.items = []
+
+    def back(self, r):
+        """Results that ARE an arena stand-in map back to the tensor they stood for."""
+        if isinstance(r, torch.Tensor):
+            for t, _, _, _, f in self.items:
+                if r is f:
+                    return t
+            return r
+        if isinstance(r, tuple):
+            return tuple(self.back(x) for x in r)
+        return r
+
+
+def _det_accum(**spec):
+    """Decorator: the named tensor arguments are accumulators of the wrapped launch.  spec value: "g" (gradient), "s" (loss sum /
+    scalar), "S" (scalar the kernel also reads).  The float-atomic mode returns the function unchanged."""
+    def deco(fn):
+        if not DETERMINISTIC:
+            return fn
+        import functools
+        import inspect
+        sig = inspect.signature(fn)
+
+        @functools.wraps(fn)
+        def wrapped(*args, **kw):
+            ba = sig.bind(*args, **kw)
+            ba.apply_defaults()
+            sc = _DetScope()
+            for name, kind in spec.items():
+                ba.arguments[name] = sc.take(ba.arguments.get(name), kind.lower(), load=kind == "S")
+            try:
+                r = fn(*ba.args, **ba.kwargs)
+                r = sc.back(r)
+            finally:
+                sc.commit()
+            return r
+        return wrapped
+    return deco
+
+
+def det_fault(clear=True):
+    """0, or what went wrong since the last call in deterministic mode (include/recguru_hip.h rg_det_fault)."""
+    torch.cuda.synchronize()
+    return int(lib().rg_det_fault(1 if clear else 0))
+
+
 # test knob: outputs whose padded-tile rows a kernel is allowed to leave unwritten start as NaN, so that any consumer
 # that still reads such a row shows up in the results
 POISON_UNWRITTEN = False
@@ -239,11 +369,16 @@ def _tn_workspace(dev, nbytes, kind="tn"):
 def gemm_tn(Y, X, dW=None, colsum=None, prologue_x=PRO_NONE, scale=1.0, splits=0, use_tr=1, live=None, partials=True,
             colsum_rows=0):
     """dW[N1,N2] += Y[T,N1].T @ pro(X[T,N2]) (f32, accumulated); colsum[N1] += Y.sum(0)."""
+    if dW is None:
+        dW = torch.zeros(Y.shape[1], X.shape[1], device=Y.device, dtype=torch.float32)
+    return _gemm_tn(Y, X, dW, colsum, prologue_x, scale, splits, use_tr, live, partials, colsum_rows)
+
+
+@_det_accum(dW="g", colsum="g")
+def _gemm_tn(Y, X, dW, colsum, prologue_x, scale, splits, use_tr, live, partials, colsum_rows):
     T, N1 = Y.shape
     N2 = X.shape[1]
     assert X.shape[0] == T and X.dtype == Y.dtype
-    if dW is None:
-        dW = torch.zeros(N1, N2, device=Y.device, dtype=torch.float32)
     if T == 0:
         return dW
     a = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), T, N1, N2,
@@ -282,10 +417,13 @@ def gemm_tn_layer(probs):
     library does not take the set (tier, shapes, sizes): the caller then issues the products one by one."""
     args = _TnLayerArgs()
     w = [0.0] * 4
+    sc = _DetScope() if DETERMINISTIC else None
     for i, pr in enumerate(probs):
         if pr is None:
             continue
         Y, X, dW, colsum, live = pr
+        if sc is not None:
+            dW, colsum = sc.take(dW), sc.take(colsum)
         N1, N2, pro = LAYER_SLOTS[i]
         assert Y.shape[1] == N1 and X.shape == (Y.shape[0], N2) and Y.dtype == X.dtype
         args.p[i] = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), Y.shape[0], N1, N2,
@@ -310,8 +448,14 @@ def gemm_tn_layer(probs):
     dt = mt_of(next(pr[0] for pr in probs if pr is not None))
     cw = (ctypes.c_int * 4)(*wgs)
     if not lib().rg_gemm_tn_layer_supported(ctypes.byref(args), cw, dt):
+        if sc is not None:
+            sc.commit()
         return False
-    _check(lib().rg_gemm_tn_layer(ctypes.byref(args), cw, dt, _stream()), "rg_gemm_tn_layer")
+    try:
+        _check(lib().rg_gemm_tn_layer(ctypes.byref(args), cw, dt, _stream()), "rg_gemm_tn_layer")
+    finally:
+        if sc is not None:
+            sc.commit()
     return True
 
 
@@ -406,6 +550,7 @@ def embed_pe_fwd_split(table_f32, pe, ids, mask, L, drop_p=0.0, seed=0):
     return out, lo
 
 
+@_det_accum(dE="g")
 def embed_scatter_bwd(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0):
     ntok, d = ids.numel(), dx.shape[-1]
     assert dx.is_contiguous() and dE.dtype == torch.float32 and dE.is_contiguous()
@@ -438,6 +583,7 @@ def embed_scatter_bwd_binned(dx, ids, mask, dE, skip_row=-1, drop_p=0.0, seed=0)
     return dE
 
 
+@_det_accum(dgamma="g", dbeta="g", dz_colsum="g")
 def ln_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p=0.0, drop_seed=0, live=None, dz_colsum=None):
     """dz = LayerNorm backward from the saved output; dgamma/dbeta accumulated in place.
     With drop_p > 0 also returns dz * dropmask/(1-p) (backward of a dropout feeding the LN input).
@@ -548,6 +694,7 @@ def seq_sum(x, B, L):
     return out
 
 
+@_det_accum(out="g")
 def colsum(x, out, aux=None, scale=1.0, coef=None):
     M, N = x.shape
     _check(lib().rg_colsum(_vp(x), _vp(aux), _vp(coef), _vp(out), c_ll(M), N, _rowmajor(x), c_f(scale), dt_of(x),
@@ -591,6 +738,7 @@ def interpolate(alpha, real, fake):
     return out
 
 
+@_det_accum(gp="s")
 def gp_penalty(g, gp, lam, dtype):
     B, d = g.shape
     assert g.dtype == torch.float32 and g.is_contiguous()
@@ -599,6 +747,7 @@ def gp_penalty(g, gp, lam, dtype):
     return dg
 
 
+@_det_accum(out="s")
 def sum_into(x, out, scale=1.0):
     assert x.dtype == torch.float32 and x.is_contiguous()
     _check(lib().rg_sum(_vp(x), _vp(out), c_ll(x.numel()), c_f(scale), _stream()), "rg_sum")
@@ -664,9 +813,14 @@ def item_loss_fwd(h, table, pos, neg, mask, k, mode):
     assert pos.dtype == torch.int64 and neg.dtype == torch.int64 and pos.numel() == ntok and neg.numel() == ntok * k
     aux = torch.empty(ntok, device=h.device, dtype=torch.float32)
     sums = torch.zeros(2, device=h.device, dtype=torch.float32)
-    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(aux), _p(sums), None, None, None, ntok, d, k,
-                     mode, -1)
-    _check(lib().rg_item_loss_fwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_fwd")
+    sc = _DetScope() if DETERMINISTIC else None
+    a = ItemLossArgs(_p(h), _p(table), _p(pos), _p(neg), _p(mask), _p(aux), _p(sc.take(sums, "s") if sc else sums), None, None, None,
+                     ntok, d, k, mode, -1)
+    try:
+        _check(lib().rg_item_loss_fwd(ctypes.byref(a), dt_of(h), _stream()), "rg_item_loss_fwd")
+    finally:
+        if sc is not None:
+            sc.commit()
     return sums, aux
 
 
@@ -755,6 +909,7 @@ def item_loss_train_supported(k, d):
     return int(lib().rg_item_loss_train_supported(int(k), int(d)))
 
 
+@_det_accum(sums="S")
 def item_loss_train(h, table, pos, neg, mask, k, mode, sums, lse=None):
     """Loss sum into sums[0] (sums[1] = the mask count, set by the caller) plus, for an upstream gradient of 1,
     the coefficients [ntok*(1+k)] f32 and dh [ntok,d]: one gather of the rows instead of two.
@@ -794,7 +949,12 @@ def mse(a, b, want_grads=True):
     out = torch.zeros(1, device=a.device, dtype=torch.float32)
     da = torch.empty_like(a) if want_grads else None
     db = torch.empty_like(b) if want_grads else None
-    _check(lib().rg_mse(_vp(a), _vp(b), _vp(out), _vp(da), _vp(db), c_ll(a.numel()), dt_of(a), _stream()), "rg_mse")
+    sc = _DetScope() if DETERMINISTIC else None
+    try:
+        _check(lib().rg_mse(_vp(a), _vp(b), _vp(sc.take(out, "s") if sc else out), _vp(da), _vp(db), c_ll(a.numel()), dt_of(a), _stream()), "rg_mse")
+    finally:
+        if sc is not None:
+            sc.commit()
     return out, da, db
 
 
@@ -805,6 +965,7 @@ def scale_dev(x, s):
     return x
 
 
+@_det_accum(dE="g")
 def item_loss_bwd(h, table, pos, neg, mask, k, mode, aux, sums, gout, dE, skip_row=-1):
     ntok, d = h.shape
     dh = torch.empty_like(h)
@@ -841,13 +1002,21 @@ def disc_rows(real, fake, alpha, W, Wt, biases, w4, b4, drop_p, seeds_w, seeds_g
     assert all(w.is_contiguous() for w in W) and all(w.is_contiguous() for w in Wt)
     Y1, X1, Y2, X2, Y3, X3 = ops_xy
     bg = bias_grads if bias_grads is not None else (None,) * 5
+    sc = _DetScope() if DETERMINISTIC else None
+    if sc is not None:
+        scalars = sc.take(scalars, "s")
+        bg = tuple(bg[:3]) + (sc.take(bg[3]), sc.take(bg[4]))
     a = DiscArgs(_p(real), _p(fake), _p(alpha), _p(W[0]), _p(W[1]), _p(W[2]), _p(Wt[0]), _p(Wt[1]), _p(Wt[2]),
                  _p(biases[0]), _p(biases[1]), _p(biases[2]), _p(w4), _p(b4), B, d, n1, n2, n3, drop_p,
                  (c_u64 * 3)(*seeds_w), (c_u64 * 3)(*seeds_g), coef_real, coef_fake, gp_coef,
                  _p(out), _p(scalars), _p(Y1), _p(X1), _p(Y2), _p(X2), _p(Y3), _p(X3),
                  _p(bg[0]), _p(bg[1]), _p(bg[2]), _p(bg[3]), _p(bg[4]), _p(dx), _p(hscratch),
                  1 if bias_grads is not None else 0, debug_ablate, _p(stamps))
-    _check(lib().rg_disc_rows(ctypes.byref(a), mt_of(real), _stream()), "rg_disc_rows")
+    try:
+        _check(lib().rg_disc_rows(ctypes.byref(a), mt_of(real), _stream()), "rg_disc_rows")
+    finally:
+        if sc is not None:
+            sc.commit()
 
 
 def _lastq_fold(rowmask, bkv, B, L):
@@ -912,6 +1081,7 @@ def attn_lastq_x_fwd(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p=0.0, 
     return ctx
 
 
+@_det_accum(dbv="g")
 def attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, key_ids, pad_value, dbv, drop_p=0.0, seed=0, rowmask=None):
     """-> (dx [B,L,128], dq [B,128], ym_v, xbar, ym_q, dqp [B*4,128]): dWV += ym_v^T xbar, dWK += ym_q^T dqp; dbv accumulated."""
     a, keep = _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, rowmask)
@@ -1021,6 +1191,7 @@ def post_attn_fwd(ctx, x, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2, rowmask, sav
     return out, sv
 
 
+@_det_accum(dgamma="g", dbeta="g")
 def attn_out_bwd(dy, y, rstd, gamma, beta, rowmask, dgamma, dbeta, Wot, live=None, w_packed=False):
     """Backward of the attention block's tail y = LayerNorm(ctx Wo^T + bo + x) with respect to ctx, in one launch
     (rg_attn_out_bwd): returns (dz [M,d], dctx [M,P]); dgamma / dbeta accumulated in place.  Wot = Wo^T [P,d] (operand
@@ -1063,9 +1234,12 @@ def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False,
     dy = torch.empty(M, d, device=src.device, dtype=src.dtype)
     a = FfnBwdArgs(_p(dl2), _p(dz), _p(h1), _p(W2t), _p(W1t), _p(dh1), _p(dy), M, d, dff, 1 if w_packed else 0,
                    float(nz_scale), _p(live))
-    dl2o = None
+    dl2o, sc = None, None
     if ln is not None:
         dout, out, rstd, gamma, beta, rowmask, dgamma, dbeta, drop_p, drop_seed = ln
+        if DETERMINISTIC:
+            sc = _DetScope()
+            dgamma, dbeta = sc.take(dgamma), sc.take(dbeta)
         assert dout.is_contiguous() and out.is_contiguous() and dout.dtype == out.dtype
         dl2o = torch.empty(M, d, device=src.device, dtype=src.dtype)
         if POISON_UNWRITTEN and live is not None:
@@ -1076,7 +1250,11 @@ def ffn_bwd_data(dl2, dz, h1, W2t, W1t, nz_scale=0.0, live=None, w_packed=False,
         a.ln_dout, a.ln_out, a.ln_rstd, a.ln_gamma, a.ln_beta, a.ln_rowmask = _p(dout), _p(out), _p(rstd), _p(gamma), _p(beta), _p(rowmask)
         a.dl2_out, a.ln_dgamma, a.ln_dbeta, a.ln_partials = _p(dl2o), _p(dgamma), _p(dbeta), _p(ws)
         a.ln_drop_p, a.ln_drop_seed = float(drop_p), int(drop_seed)
-    _check(lib().rg_ffn_bwd_data(ctypes.byref(a), mt_of(src), _stream()), "rg_ffn_bwd_data")
+    try:
+        _check(lib().rg_ffn_bwd_data(ctypes.byref(a), mt_of(src), _stream()), "rg_ffn_bwd_data")
+    finally:
+        if sc is not None:
+            sc.commit()
     return (dh1, dy, dl2o) if ln is not None else (dh1, dy)
 
 

@@ -203,6 +203,9 @@ def main():
         dp.barrier()
         if dp.rank == 0:
             np.savez(out_path, p1=t1.numpy(), p2=t2.numpy(), **{"w." + k: v for k, v in keep.items()})
+    from recguru_amd import hip
+    if hip.DETERMINISTIC:                                     # (tests/test_det_gpu.py) every accumulation went to a fixed-point shadow
+        assert hip.det_fault() == 0, "an accumulator outside the deterministic arenas"
     torch.distributed.destroy_process_group()
 
 

@@ -1,0 +1,125 @@
+"""RG_DETERMINISTIC=1 ("offer sorted segmented-reduce mode for tests"): librecguru_hip_det.so sends every floating-point
+accumulation that more than one wave can reach -- weight gradients and their column sums, LayerNorm dgamma / dbeta, embedding-table
+gradients, loss sums, the discriminator's scalars, the gradient penalty -- to a 64-bit fixed-point shadow (csrc/rg_det.hip.h), so the
+order workgroups happen to run in no longer reaches the bits.
+
+  * two fresh processes of one rank return the SAME BITS: 20 phase-1 steps + 3 phase-2 iterations (15 critic + 3 generator
+    updates) of the loss-curve fixture -- the run whose float-atomic form falls into four discrete trajectories
+    (tests/test_dp_hip_gpu.py) -- and every gradient of a critic update + generator iteration at the bench shape in
+    the bf16, bf16x3 and f32 tiers with dropout on;
+  * no accumulator was missed (rg_det_fault() == 0: an add to a destination outside the arenas raises the flag);
+  * the deterministic results agree with the float-atomic library's inside that library's own run-to-run spread;
+  * 2 ranks == 1 rank through phase 2 at a bound the float-atomic mode cannot hold (there: 3e-3 on the W-GAN scalars).
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _worker(argv, det, extra_env=None, timeout=900):
+    env = dict(os.environ)
+    env.pop("RG_DETERMINISTIC", None)
+    if det:
+        env["RG_DETERMINISTIC"] = "1"
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(HERE, "det_worker.py")] + argv, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=timeout)
+    assert p.returncode == 0, p.stdout.decode()[-4000:]
+    return dict(np.load(argv[-1]))
+
+
+def _same_bits(a, b):
+    assert a.keys() == b.keys()
+    return [k for k in a if a[k].tobytes() != b[k].tobytes()]
+
+
+def test_deterministic_library_is_built_and_separate():
+    import ctypes
+    from recguru_amd import build, hip
+    assert os.path.exists(build.LIB_DET), "python -m recguru_amd.build builds librecguru_hip_det.so beside librecguru_hip.so"
+    det = ctypes.CDLL(build.LIB_DET)
+    assert det.rg_det_enabled() >= 7                       # translation units that accumulate
+    if not hip.DETERMINISTIC:
+        assert hip.lib().rg_det_enabled() == 0             # the shipped library: float atomics, nothing registered
+
+
+def test_single_rank_curve_is_bit_reproducible(tmp_path, capsys):
+    a = _worker(["curve", "curves1", str(tmp_path / "a.npz")], det=True)
+    b = _worker(["curve", "curves1", str(tmp_path / "b.npz")], det=True)
+    assert int(a["det_enabled"]) >= 7 and int(a["det_fault"]) == 0 and int(b["det_fault"]) == 0
+    assert _same_bits(a, b) == []
+    # against the float-atomic library: the bounds tests/test_dp_hip_gpu.py holds two float-atomic runs to
+    f = _worker(["curve", "curves1", str(tmp_path / "f.npz")], det=False)
+    assert int(f["det_enabled"]) == 0
+    with capsys.disabled():
+        print("\n[deterministic vs float-atomic library, 1 rank] phase-1 max rel diff %.3g | phase-2 max abs diff %s"
+              % (float(np.abs(a["p1"] / f["p1"] - 1).max()), np.array2string(np.abs(a["p2"] - f["p2"]).max(0), precision=2)))
+    np.testing.assert_allclose(a["p1"], f["p1"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(a["p2"][:, 3:], f["p2"][:, 3:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(a["p2"][:, :3], f["p2"][:, :3], rtol=0, atol=3e-3)
+
+
+@pytest.mark.parametrize("tier", ["bf16", "bf16x3", "f32"])
+def test_bench_shape_gradients_are_bit_reproducible(tier, tmp_path, capsys):
+    """B = 64 users per domain x L = 200 (12 800 positions: the merged weight-gradient launch, the two-stage LayerNorm column sums,
+    the 100k-row table gradients), dropout 0.5 / 0.2."""
+    env = {"RG_BENCH_B": "64", "RG_BENCH_DROPOUT": "0.5"}
+    a = _worker(["bench", tier, str(tmp_path / "a.npz")], det=True, extra_env=env)
+    b = _worker(["bench", tier, str(tmp_path / "b.npz")], det=True, extra_env=env)
+    assert int(a["det_fault"]) == 0 and int(b["det_fault"]) == 0
+    assert _same_bits(a, b) == []
+    f = _worker(["bench", tier, str(tmp_path / "f.npz")], det=False, extra_env=env)
+    g = _worker(["bench", tier, str(tmp_path / "g.npz")], det=False, extra_env=env)
+    drift = _same_bits(f, g)
+    worst = []
+    for k in a:
+        if k.startswith(("D.", "G.")) and not any(s in k for s in ("dec_enc_attn.WQ", "dec_enc_attn.WK", "WK.bias")):
+            scale = max(float(np.abs(f[k]).max()), 1e-12)
+            worst.append((float(np.abs(a[k] - f[k]).max()) / scale, float(np.abs(g[k] - f[k]).max()) / scale, k))
+    worst.sort(reverse=True)
+    with capsys.disabled():
+        print("\n[%s, bench shape B=64] float-atomic library: %d of %d arrays differ between two runs; deterministic vs float-atomic, "
+              "worst |diff| / max|g| (float-atomic run-to-run beside it): %s"
+              % (tier, len(drift), len(f), ", ".join("%s %.2g (%.2g)" % (k, d, s) for d, s, k in worst[:3])))
+    lim = 2e-3 if tier == "bf16" else 2e-5
+    assert worst[0][0] <= lim, worst[0]
+
+
+def test_dp2_equals_single_rank_deterministic(tmp_path, capsys):
+    """tests/test_dp_hip_gpu.py::test_dp2_hip_loss_curve_equals_single_rank with both sides deterministic: the remaining difference
+    is one float rounding per gradient element (a rank's sum is rounded before the all-reduce adds two of them), not a
+    summation order -- and it is the same on every run."""
+    from test_dp_hip_gpu import _run_ranks
+    out = str(tmp_path / "dp.npz")
+    _run_ranks(["curve", "curves1", out], extra_env={"RG_DETERMINISTIC": "1"})
+    got = dict(np.load(out))
+    one = _worker(["curve", "curves1", str(tmp_path / "one.npz")], det=True)
+    e1 = float(np.abs(got["p1"] / one["p1"] - 1).max())
+    e2 = np.abs(got["p2"] - one["p2"]).max(0)
+    with capsys.disabled():
+        print("\n[DP x2 vs 1 rank, both deterministic] phase-1 max rel diff %.3g | phase-2 max abs diff (D_cost, W_D, g_dis, recon_a, "
+              "recon_b) %s" % (e1, np.array2string(e2, precision=2)))
+    np.testing.assert_allclose(got["p1"], one["p1"], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["p2"][:, 3:], one["p2"][:, 3:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["p2"][:, :3], one["p2"][:, :3], rtol=0, atol=DP_SCALAR_ATOL)
+    wd = {k: float(np.abs(got[k] - one[k]).max() / np.abs(one[k]).max()) for k in one if k.startswith("w.")}
+    with capsys.disabled():
+        print("[DP x2 vs 1 rank, both deterministic] parameters after 20 + 18 optimizer steps, max |diff| / max |w|: %s"
+              % ", ".join("%s %.2g" % (k[2:], v) for k, v in sorted(wd.items())))
+    for k, v in wd.items():
+        assert v <= DP_WEIGHT_TOL, (k, v)
+    _run_ranks(["curve", "curves1", str(tmp_path / "dp2.npz")], extra_env={"RG_DETERMINISTIC": "1"})
+    again = dict(np.load(str(tmp_path / "dp2.npz")))
+    assert _same_bits(got, again) == []                    # and the two-rank run repeats bit for bit
+
+
+# measured (MI355X, this fixture): 1.7e-5 / 6.2e-6 / 6.2e-6 on D_cost / Wasserstein_D / g_dis -- the same on every run.  The float-atomic
+# library needs 3e-3 here (its widest single-rank branch is 1.45e-3)
+DP_SCALAR_ATOL = 1e-4
+DP_WEIGHT_TOL = 2e-3         # provisional
