@@ -202,15 +202,22 @@ class _DetArena(object):
     _per_device = {}
 
     def __init__(self, dev):
-        ng = int(os.environ.get("RG_DET_ARENA_MFLOATS", "96")) << 20          # gradients: 96 M floats (384 MB + 768 MB of shadow)
-        self.n = {"g": ng, "s": 4096}
-        self.f = {k: torch.zeros(n, device=dev, dtype=torch.float32) for k, n in self.n.items()}
-        self.s = {k: torch.zeros(n, device=dev, dtype=torch.int64) for k, n in self.n.items()}
+        self.dev = dev
         self.top = {"g": 0, "s": 0}
         self.last_stream = None
+        self.resize(int(os.environ.get("RG_DET_ARENA_MFLOATS", "32")) << 20)   # gradients: 32 M floats to start with (128 MB + 256 MB of shadow)
+
+    def resize(self, ng):
+        """(Re)allocate and register the arenas; only with no slice taken.  Grows on demand: config-5's table gradient is 512 M floats."""
+        assert self.top["g"] == 0 and self.top["s"] == 0
+        torch.cuda.synchronize(self.dev)                                      # nothing in flight still adds into the old buffers
+        self.n = {"g": ng, "s": 4096}
+        self.f = self.s = None
+        self.f = {k: torch.zeros(n, device=self.dev, dtype=torch.float32) for k, n in self.n.items()}
+        self.s = {k: torch.zeros(n, device=self.dev, dtype=torch.int64) for k, n in self.n.items()}
         fn = lib().rg_det_set_arenas
         fn.argtypes = [c_p, c_p, ctypes.c_ulonglong, c_i, c_p, c_p, ctypes.c_ulonglong, c_i]
-        with torch.cuda.device(dev):
+        with torch.cuda.device(self.dev):
             _check(fn(self.f["g"].data_ptr(), self.s["g"].data_ptr(), self.n["g"] * 4, DET_BITS["g"],
                       self.f["s"].data_ptr(), self.s["s"].data_ptr(), self.n["s"] * 4, DET_BITS["s"]), "rg_det_set_arenas")
 
@@ -251,6 +258,8 @@ class _DetScope(object):
         a.last_stream = cur
         n = t.numel()
         off = a.top[kind]
+        if off + n > a.n[kind] and kind == "g" and a.top["g"] == 0 and a.top["s"] == 0:
+            a.resize(max(2 * a.n["g"], (n + (1 << 20)) & ~((1 << 20) - 1)))
         if off + n > a.n[kind]:
             raise RuntimeError("recguru_amd: deterministic arena exhausted (%d + %d of %d floats; RG_DET_ARENA_MFLOATS)" % (off, n, a.n[kind]))
         a.top[kind] = off + ((n + 63) & ~63)

@@ -28,6 +28,32 @@ def test_library_exports_every_declared_symbol():
     assert lib.rg_version() == 1
 
 
+def test_deterministic_library_exports_the_same_abi():
+    """librecguru_hip_det.so (RG_DETERMINISTIC=1, csrc/rg_det.hip.h): every declared symbol, the accumulating translation units
+    registered, its own ISA-screen record; the shipped library registers none and refuses arenas without touching the GPU."""
+    import ctypes
+    import json
+    from recguru_amd import build, hip
+    build.build()
+    assert os.path.exists(build.LIB_DET)
+    det = ctypes.CDLL(build.LIB_DET)
+    for name in hip.SYMBOLS:
+        assert hasattr(det, name), "librecguru_hip_det.so does not export %s" % name
+    acc = [f for f in os.listdir(build.CSRC) if f.endswith(".hip") and '#include "rg_det.hip.h"' in open(os.path.join(build.CSRC, f)).read()]
+    assert det.rg_det_enabled() == len(acc) >= 7
+    plain = hip.lib() if not hip.DETERMINISTIC else ctypes.CDLL(build.LIB)
+    assert plain.rg_det_enabled() == 0
+    plain.rg_det_set_arenas.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ulonglong, ctypes.c_int] * 2
+    assert plain.rg_det_set_arenas(None, None, 0, 46, None, None, 0, 30) == -2          # RG_ERR_UNSUPPORTED
+    info = json.load(open(os.path.join(os.path.dirname(build.LIB), "build", "BUILD_INFO_det.json")))
+    assert info["flagged_join_blocks"] == [] and info["spill_in_front_of_exec_restore_warnings"] == 0 and not info.get("screen_bypassed")
+    # no float atomic left outside rg_acc() in a file that accumulates (the binned kernels, which the deterministic build does not offer, excepted)
+    for f in acc:
+        src = open(os.path.join(build.CSRC, f)).read()
+        left = [ln for ln in src.splitlines() if re.search(r"\batomicAdd\(", ln) and not re.search(r"&\s*(lh|cnt|w\.hist|w\.cursor|nlive_s)\b|es_acc", ln)]
+        assert all("loss.hip" == f and ("a.dE + row * D" in ln or "dst + lane" in ln) for ln in left), (f, left)
+
+
 def test_no_cpu_fallback():
     from recguru_amd import hip
     if torch.cuda.is_available():

@@ -113,7 +113,7 @@ def test_dp2_equals_single_rank_deterministic(tmp_path, capsys):
         print("[DP x2 vs 1 rank, both deterministic] parameters after 20 + 18 optimizer steps, max |diff| / max |w|: %s"
               % ", ".join("%s %.2g" % (k[2:], v) for k, v in sorted(wd.items())))
     for k, v in wd.items():
-        assert v <= DP_WEIGHT_TOL, (k, v)
+        assert v <= (DP_WEIGHT_TOL_D if k.startswith("w.main.") else DP_WEIGHT_TOL), (k, v)
     _run_ranks(["curve", "curves1", str(tmp_path / "dp2.npz")], extra_env={"RG_DETERMINISTIC": "1"})
     again = dict(np.load(str(tmp_path / "dp2.npz")))
     assert _same_bits(got, again) == []                    # and the two-rank run repeats bit for bit
@@ -122,4 +122,7 @@ def test_dp2_equals_single_rank_deterministic(tmp_path, capsys):
 # measured (MI355X, this fixture): 1.7e-5 / 6.2e-6 / 6.2e-6 on D_cost / Wasserstein_D / g_dis -- the same on every run.  The float-atomic
 # library needs 3e-3 here (its widest single-rank branch is 1.45e-3)
 DP_SCALAR_ATOL = 1e-4
-DP_WEIGHT_TOL = 2e-3         # provisional
+# parameters after the 20 + 18 optimizer steps, measured: generator 4.7e-6 ... 3.0e-4 of max |w| (float-atomic test: 3e-3); the discriminator's
+# last hidden layer 4.2e-3 (float-atomic: 2e-2) -- Adam turns a gradient element that is zero up to its last bit into a +-lr step, 15 times
+DP_WEIGHT_TOL = 1e-3
+DP_WEIGHT_TOL_D = 1e-2
