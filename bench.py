@@ -522,7 +522,8 @@ def main():
         sys.exit("bench.py: no GPU visible -- the HIP path has no CPU fallback")
     from recguru_amd import dist as rdist, hip, ops
     # RG_BENCH_BACKEND=gloo + RG_BENCH_SINGLE_DEVICE=1: debug aid to exercise the multi-process path on a 1-GPU box
-    dp = rdist.init_from_env(os.environ.get("RG_BENCH_BACKEND", "nccl")) if world > 1 else None
+    # RG_DP_FORCE=1 at N = 1: a process group of one rank -- the step's collectives run through RCCL on a 1-GPU box (`exchange` record)
+    dp = rdist.init_from_env(os.environ.get("RG_BENCH_BACKEND", "nccl")) if (world > 1 or os.environ.get("RG_DP_FORCE")) else None
     local = 0 if os.environ.get("RG_BENCH_SINGLE_DEVICE") else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     device = "cuda:%d" % local

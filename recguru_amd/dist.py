@@ -18,8 +18,12 @@ import torch.distributed as dist
 def init_from_env(backend=None):
     """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not os.environ.get("RG_DP_FORCE"):
         return None
+    # RG_DP_FORCE=1: a process group of ONE rank -- every collective of the step runs through the backend (RCCL on a 1-GPU box:
+    # communicator set-up, stream-ordered work handles, the in-place and bucketed all-reduces) and must leave the results of the
+    # no-DP path (tests/test_dp_hip_gpu.py::test_rccl_group_of_one_rank, tests/test_det_gpu.py)
+    os.environ.setdefault("RANK", "0")
     if not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

@@ -180,12 +180,18 @@ def main():
     if mode == "grads":
         from golden_util import load_case
         z = what if what == "bench" else load_case(what)
+        dp.start_stats()
         gD, gG, sc = run_steps(z, dp.rank, dp.world, dp, device)
+        ex = dp.stop_stats()
         dp.barrier()
         if dp.rank == 0:
             out = {"D." + k: v for k, v in gD.items()}
             out.update({"G." + k: v for k, v in gG.items()})
             out["scalars"] = sc
+            if ex:                                             # what the collective layer saw (backend, group size, payload)
+                out.update(exchange_backend=np.array(ex["backend"]), exchange_world=np.array(ex["world"]),
+                           exchange_bytes=np.array(ex["bytes"]), exchange_collectives=np.array(ex["collectives"]),
+                           exchange_exposed_ms=np.array(ex["exposed_ms"]))
             np.savez(out_path, **out)
     else:
         from golden_util import load_case

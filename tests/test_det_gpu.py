@@ -119,6 +119,26 @@ def test_dp2_equals_single_rank_deterministic(tmp_path, capsys):
     assert _same_bits(got, again) == []                    # and the two-rank run repeats bit for bit
 
 
+def test_rccl_group_of_one_rank_is_bit_identical_to_no_process_group(tmp_path):
+    """The whole data-parallel machinery -- pre-divided means, global mask count, begin_sync's asynchronous exchange, in-place and
+    bucketed SUM all-reduce -- through RCCL with a group of ONE rank (RG_DP_FORCE=1) on the deterministic library: a sum over one
+    rank is the identity, so every loss of the 20 + 3 iteration curve and every kept parameter must be the bits of the run without
+    a process group.  (Two RCCL ranks need two GPUs: tests/test_dp_hip_gpu.py::test_dp2_rccl_matches_full_batch.)"""
+    from test_dp_hip_gpu import _rccl_unavailable, _run_ranks
+    out = str(tmp_path / "rccl1.npz")
+    try:
+        _run_ranks(["curve", "curves1", out], world=1, backend="nccl", extra_env={"RG_DETERMINISTIC": "1", "RG_DP_FORCE": "1"})
+    except AssertionError as e:
+        if _rccl_unavailable(str(e)):
+            pytest.skip("RCCL cannot initialise on this box: %s" % str(e)[-300:])
+        raise
+    got = dict(np.load(out))
+    one = _worker(["curve", "curves1", str(tmp_path / "one.npz")], det=True)
+    one = {k: v for k, v in one.items() if k in got}
+    assert set(one) == set(got) and len(got) >= 6
+    assert _same_bits(got, one) == []
+
+
 # measured (MI355X, this fixture): 1.7e-5 / 6.2e-6 / 6.2e-6 on D_cost / Wasserstein_D / g_dis -- the same on every run.  The float-atomic
 # library needs 3e-3 here (its widest single-rank branch is 1.45e-3)
 DP_SCALAR_ATOL = 1e-4

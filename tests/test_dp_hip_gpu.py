@@ -161,6 +161,40 @@ def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
             assert float((d > 1e-3 * scale).mean()) < 0.005, (k, float((d > 1e-3 * scale).mean()))
 
 
+def _rccl_unavailable(log):
+    return any(s in log for s in ("NCCL error", "ncclSystemError", "ncclUnhandledCudaError", "RCCL error", "ProcessGroupNCCL is not"))
+
+
+def test_rccl_group_of_one_rank(tmp_path, capsys):
+    """backend="nccl" IS RCCL on ROCm.  A 1-GPU box cannot hold two RCCL ranks (one device per rank), but it can hold a group of ONE
+    (RG_DP_FORCE=1): communicator set-up, the stream-ordered work handles of begin_sync's asynchronous exchange, the in-place
+    all-reduce of the two 51 MB table gradients and the flat bucket all run through RCCL on GPU buffers -- and must leave the
+    gradients of the same step without a process group (a sum over one rank; what differs is float-atomic order, as between any
+    two runs).  What it cannot show is a second rank: that stays with test_dp2_rccl_matches_full_batch on a node with two GPUs."""
+    from dp_worker import run_steps
+    out = os.path.join(str(tmp_path), "rank0.npz")
+    try:
+        _run_ranks(["grads", "bench", out], world=1, backend="nccl", extra_env={"RG_DP_TIER": "bf16", "RG_DP_FORCE": "1"})
+    except AssertionError as e:
+        if _rccl_unavailable(str(e)):
+            pytest.skip("RCCL cannot initialise on this box: %s" % str(e)[-300:])
+        raise
+    got = dict(np.load(out))
+    os.environ["RG_DP_TIER"] = "bf16"
+    try:
+        gD, gG, sc = run_steps("bench", 0, 1, None)
+    finally:
+        del os.environ["RG_DP_TIER"]
+        _reset_ops()
+    assert got["exchange_backend"].item() == "nccl" and int(got["exchange_world"]) == 1
+    assert int(got["exchange_collectives"]) >= 3 and int(got["exchange_bytes"]) >= 2 * 51_000_000      # both table gradients went through it
+    with capsys.disabled():
+        print("\n[RCCL, group of one rank, bench shape] %d collectives, %.1f MB handed to all-reduce, exposed %.2f ms"
+              % (int(got["exchange_collectives"]), int(got["exchange_bytes"]) / 1e6, float(got["exchange_exposed_ms"])))
+    assert _compare_grads(got, gD, gG, 1e-3, 1e-4) > 40
+    np.testing.assert_allclose(got["scalars"], sc, rtol=2e-3, atol=2e-3)       # one rank: its losses ARE the full batch's
+
+
 def _two_gpus():
     import torch
     return torch.cuda.device_count() >= 2
