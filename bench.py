@@ -389,6 +389,7 @@ def launch_ranks(args):
                 except subprocess.TimeoutExpired:
                     p.kill()
     out = procs[0].stdout.read().decode() if procs[0].stdout else ""
+    out = "".join(ln + "\n" for ln in out.splitlines() if ln.startswith("{"))        # the line, nothing a library printed beside it
     sys.stdout.write(out)
     sys.stdout.flush()
     if rc != 0:
@@ -520,6 +521,12 @@ def main():
         sys.exit(launch_ranks(args))           # before any GPU call in this process
     if not torch.cuda.is_available():
         sys.exit("bench.py: no GPU visible -- the HIP path has no CPU fallback")
+    # stdout carries ONE line.  librccl prints a version banner through C stdio when a communicator is created -- buffered, it
+    # lands AFTER the JSON line at exit (seen with a group of one rank, profiles/r05/bench_rccl_group_of_one.json) -- so file
+    # descriptor 1 is pointed at stderr for the life of the process and the line is written to the saved descriptor
+    sys.stdout.flush()
+    line_fd = os.dup(1)
+    os.dup2(2, 1)
     from recguru_amd import dist as rdist, hip, ops
     # RG_BENCH_BACKEND=gloo + RG_BENCH_SINGLE_DEVICE=1: debug aid to exercise the multi-process path on a 1-GPU box
     # RG_DP_FORCE=1 at N = 1: a process group of one rank -- the step's collectives run through RCCL on a 1-GPU box (`exchange` record)
@@ -676,8 +683,7 @@ def main():
                                                                                 "gather_copy_512B_rows_u4", "mfma_16x16x32_bf16_4wave_per_simd")
                                                            if k in PEAKS}} if PEAKS else None
             line["config5"] = c5
-        print(json.dumps(line))
-        sys.stdout.flush()
+        os.write(line_fd, (json.dumps(line) + "\n").encode())
     if dp:
         torch.distributed.destroy_process_group()
 

@@ -221,8 +221,8 @@ def _bench(args, env=None, timeout=1200):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=dict(os.environ, **(env or {})),
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
     assert p.returncode == 0, p.stderr.decode()[-3000:]
-    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout.decode()[-2000:]
+    lines = p.stdout.decode().splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout.decode()[-2000:]      # ONE line on stdout, nothing beside it
     return json.loads(lines[0])
 
 
@@ -249,6 +249,21 @@ def test_bench_self_launch_two_ranks():
     assert ex["collectives_per_step"] >= 6 and ex["allreduce_bytes_per_step_per_rank"] >= 5 * 4 * n_d
     assert ex["allreduce_exposed_ms_per_step"] > 0
     assert line["tiers"]["bf16x3"]["value"] > 0 and line["tiers"]["f32"]["value"] > 0
+
+
+def test_bench_line_through_rccl_group_of_one():
+    """RG_DP_FORCE=1: the bench step with its collectives running through RCCL (a group of one rank: what a 1-GPU box can hold).  The
+    line gains `exchange` with backend nccl; and stdout still carries exactly one line -- librccl's version banner, printed through
+    C stdio when the communicator is created, used to land behind the JSON line at exit."""
+    try:
+        line = _bench(["--gpus", "1", "--tier_steps", "0"] + SMALL, {"RG_DP_FORCE": "1"})
+    except AssertionError as e:
+        if _rccl_unavailable(str(e)):
+            pytest.skip("RCCL cannot initialise on this box: %s" % str(e)[-300:])
+        raise
+    ex = line["exchange"]
+    assert ex["backend"] == "nccl" and ex["collective_world"] == 1 and ex["collectives_per_step"] >= 6
+    assert line["n_gpus"] == 1 and line["value"] > 0 and all(np.isfinite(v) for v in line["config"]["last_step"].values())
 
 
 def test_bench_line_contract_single_gpu():
