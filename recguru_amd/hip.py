@@ -406,6 +406,12 @@ def _gemm_tn(Y, X, dW, colsum, prologue_x, scale, splits, use_tr, live, partials
 
 LAYER_SLOTS = ((128, 512, PRO_GELU), (512, 128, PRO_NONE), (384, 128, PRO_NONE), (128, 128, PRO_NONE))      # (N1, N2, prologue) of rg_gemm_tn_layer
 LAYER_WGS = int(os.environ.get("RG_TN_LAYER_WGS", "256"))     # workgroups of the merged launch (one per CU: ~159 KB of LDS each)
+# relative cost per streamed byte of the four slots (the workgroups of the one launch are dealt in proportion to bytes x cost): slot 0
+# evaluates GELU on its 512-wide operand rows while it stages them
+# (measured, bench shape, profiles/r05/ab/tn_layer_cost_sweep.txt: equal weights 7.58 ms per step, 1.3 -> 6.52, 1.5 -> 6.41, 1.7 -> 6.53, 2.0 -> 6.63)
+_LC = os.environ.get("RG_TN_LAYER_COST")
+LAYER_COST = {False: tuple(float(x) for x in (_LC or "1.45,1,1,1").split(",")),           # bf16 tier (LDS-DMA bodies)
+              True: tuple(float(x) for x in (_LC or os.environ.get("RG_TN_LAYER_COST_X3", "1,1,1,1")).split(","))}   # bf16x3 (register-staged bodies)
 
 
 class _TnLayerArgs(ctypes.Structure):
@@ -437,7 +443,7 @@ def gemm_tn_layer(probs):
         assert Y.shape[1] == N1 and X.shape == (Y.shape[0], N2) and Y.dtype == X.dtype
         args.p[i] = GemmTnArgs(_p(Y), _rowmajor(Y), _p(X), _rowmajor(X), _p(dW), _rowmajor(dW), _p(colsum), Y.shape[0], N1, N2,
                                pro, 1.0, 0, 1, _p(live), None, 0)
-        w[i] = Y.shape[0] * (N1 + N2) * (0.6 if live is not None else 1.0)
+        w[i] = Y.shape[0] * (N1 + N2) * (0.6 if live is not None else 1.0) * LAYER_COST[Y.dtype == torch.float32][i]
     tot = sum(w)
     if tot == 0:
         return True
