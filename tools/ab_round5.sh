@@ -10,14 +10,14 @@ if [ "$1" != "run" ]; then
   (echo "#define RG_ABL_NO_DS 1"; cat recguru_amd/csrc/attention.hip) > /tmp/attn_no_ds.hip
   (echo "#define RG_ABL_NO_DMASK 1"; cat recguru_amd/csrc/attention.hip) > /tmp/attn_no_dmask.hip
   bash tools/ab_variants.sh attention no_ds=/tmp/attn_no_ds.hip no_dmask=/tmp/attn_no_dmask.hip
-  mkdir -p tools/r5 && cp recguru_amd/build/variants/no_ds.so tools/r5/v_no_ds.so && cp recguru_amd/build/variants/no_dmask.so tools/r5/v_no_dmask.so   # (build/variants is not sent to the GPU box)
+  mkdir -p tools/variants && cp recguru_amd/build/variants/no_ds.so tools/variants/v_no_ds.so && cp recguru_amd/build/variants/no_dmask.so tools/variants/v_no_dmask.so   # (build/variants is not sent to the GPU box)
   exit 0
 fi
 O=gpurun_out/ab_r5
 mkdir -p $O
 python tools/kb_attn.py 0:0.5 1:0.5 > $O/attn_shipped.txt 2>&1
-RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/r5/v_no_ds.so python tools/kb_attn.py 0:0.5 1:0.5 > $O/attn_no_ds.txt 2>&1
-RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/r5/v_no_dmask.so python tools/kb_attn.py 0:0.5 1:0.5 > $O/attn_no_dmask.txt 2>&1
+RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/variants/v_no_ds.so python tools/kb_attn.py 0:0.5 1:0.5 > $O/attn_no_ds.txt 2>&1
+RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/variants/v_no_dmask.so python tools/kb_attn.py 0:0.5 1:0.5 > $O/attn_no_dmask.txt 2>&1
 python tools/kb_attn_hm.py > $O/attn_hm_shipped.txt 2>&1
-RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/r5/v_no_dmask.so python tools/kb_attn_hm.py > $O/attn_hm_no_dmask.txt 2>&1
+RG_ALLOW_UNSCREENED=1 RG_HIP_LIB=tools/variants/v_no_dmask.so python tools/kb_attn_hm.py > $O/attn_hm_no_dmask.txt 2>&1
 grep -H "causal\|us" $O/*.txt | head -40
