@@ -506,6 +506,8 @@ def test_generic_gemm_refuses_a_live_tile_list():
 def test_large_batch_bf16_composition_vs_oracle(capsys):
     from oracle import recguru_oracle as O
     from recguru_amd import config, hip, models, ops, synthetic, training as T
+    if hip.DETERMINISTIC:
+        pytest.skip("asserts that the binned training form ran: not offered by the deterministic library (csrc/rg_det.hip.h)")
     B, L, d, H, N, V, k = 336, 200, 128, 4, 3, 100000, 30
     assert B * L >= 65536 and B * L >= hip.COMPACT_MIN_ROWS
     param = config.get_param(make_args(d, H, k, L, V, V, N, B), make_dirs=False)
