@@ -126,6 +126,22 @@ __device__ __forceinline__ void mma_wset(f32x4 (&acc)[2][RT], const WSet<T>& w, 
   }
 }
 
+// the same product with ONE set of activation fragments (16 VGPRs instead of 32): for the product that runs beside an epilogue's VALU
+// work in the pipelined FFN loop, where the LDS latency of a k-step is covered by that work and the registers are what is short
+template <typename T, int RT, typename LT>
+__device__ __forceinline__ void mma_wset1(f32x4 (&acc)[2][RT], const WSet<T>& w, const LT* __restrict__ Act, int li, int lg) {
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    typename OpT<T>::type af[RT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) load_frag(af[rt], Act + Tile<LT>::off(rt * 16 + li, ks * 32 + 8 * lg));
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+      for (int ct = 0; ct < 2; ++ct) mma(w.f[ks][ct], af[rt], acc[ct][rt]);
+  }
+}
+
 // accumulators start at the bias of their 4 features (bias add costs nothing afterwards)
 template <int RT>
 __device__ __forceinline__ void init_acc(f32x4 (&acc)[2][RT], const float* __restrict__ bias_lds, int n0, int lg) {
@@ -296,9 +312,11 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // RT: 16-row tiles per work tile -- 4 (64 tokens) or 2 (32 tokens: half the accumulators and activation tiles per workgroup,
 // so that three to four workgroups share a CU instead of two; the per-phase stamps show a wave at 2 per SIMD spending its
 // time on exposed LDS / VALU latencies, not on the matrix pipe or the weight stream)
-template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4>
+// PIPE (round 5; bf16, no saves, no cross stage, d_ff >= 256): the FFN chunk loop software-pipelined -- see the loop.
+template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4, bool PIPE = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : ((std::is_same<T, x3>::value && RT == 2) ? 2 : 1)))
 void post_attn_fwd_kernel(rg_post_attn_args a) {
+  static_assert(!PIPE || (sizeof(T) == 2 && !SAVE && !CROSS && !RES && RT == 4), "PIPE: the bf16 inference launch");
   constexpr int FTM = 16 * RT;        // tokens per work tile
   constexpr int PL = FTM * FD * 2;    // bf16x3: bytes between the hi and the lo tile
   typedef typename LdsT<T, PL>::type LT;  // element type of the LDS tiles (T, or x3p: a hi and a lo bf16 tile)
@@ -555,6 +573,120 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
     f32x4 acc2[2][RT];
     init_acc(acc2, p_b2, n0, lg);
+    if constexpr (PIPE) {
+      // Software-pipelined form (MEASURED: no gain -- see the end of this comment).  In the plain loop below a wave alternates between a matrix phase (32 MFMAs) and a VALU phase
+      // (dropout + GELU of 32 elements per lane: ~260 VALU instructions, 64 of them quarter-rate) with a barrier between them, so
+      // the matrix pipe idles through every VALU phase of the wave and the counters show the two waves of a SIMD adding their
+      // phases up rather than overlapping them (SQ_VALU_MFMA_COEXEC_CYCLES = 14 % of the matrix pipe's busy cycles).  Here the
+      // product that does NOT depend on the current epilogue -- out += g(ch - 1) W2 (g chunks alternate between the x tile and the ctx
+      // tile, both free during the FFN) -- sits in the SAME straight-line block as the epilogue of chunk ch, where the scheduler
+      // interleaves them.  (h1 of chunk ch + 1 into a second accumulator set as well: 256 VGPRs with 66 - 84 spilled; not kept.)
+      // Outcome at the bench shape (profiles/r05/ab/post_attn_pipelined_ffn.txt): left to the scheduler the matrix instructions
+      // all moved to the front of the block (no change, 10.9 -> 11.0 ms per step); in eight slices of 4 MFMAs + one epilogue piece
+      // 10.9 -> 10.95; one MFMA per half GELU pair (this code) 10.9 -> 11.2.  The matrix pipe's 21 % of the SIMD time is not what
+      // the kernel waits for: the VALU port is -- ~260 VALU + 64 quarter-rate transcendental instructions per 64 MFMAs -- and it
+      // is already fed by the other wave of the SIMD while this one is in its matrix phase.  Same products, same order of accumulation, same
+      // dropout words: bit-identical to the plain loop (tests/test_fused256_gpu.py::test_pipelined_ffn_loop_is_bit_identical).
+      auto gbuf = [&](int c) -> LT* { return (c & 1) ? Actx : Ag; };
+      // one (feature tile ect, row tile ert) piece of the epilogue of chunk ch: dropout before the GELU (quirk Q4), GELU, store to the g tile
+      float kq[2][4];                                     // dropout multipliers of row tile ert: [0] feature tile 0, [1] feature tile 1
+      auto epi_piece = [&](f32x4 (&h)[2][RT], int ch, LT* gdst, int ert, int ect) {
+        if constexpr (DM != 0) {
+          if (ect == 0) {
+            const unsigned int rb = (unsigned int)(mb[ert] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
+            if constexpr (DM == 1) {
+              const unsigned int w = rg_hash(drop1.seed, rb >> 5);
+              load4f(kq[0], reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
+              load4f(kq[1], reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));
+            } else {
+              rg_keep4_pair(drop1, rb, kq[0], kq[1]);
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) h[ect][ert][r] *= kq[ect][r];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 gg = gelu2_fast((f32x2){h[ect][ert][r], h[ect][ert][r + 1]});
+          h[ect][ert][r] = gg.x;
+          h[ect][ert][r + 1] = gg.y;
+        }
+        float t[4] = {h[ect][ert][0], h[ect][ert][1], h[ect][ert][2], h[ect][ert][3]};
+        store4(gdst + Tile<LT>::off(ert * 16 + li, n0 + ect * 16 + 4 * lg), t);
+      };
+      // ---- chunk 0 (wp = W1 chunk 0, prefetched behind LayerNorm 1): nothing to run beside its epilogue yet
+      init_acc(acc, p_b1, n0, lg);
+      mma_wset<T>(acc, wp, Ay, li, lg);
+      load_wset(wp, W1 + (unsigned int)(FD * FD), FD, n0, 0, li, lg, a.w_packed);
+      load_wset(wq, W2, a.dff, n0, 0, li, lg, a.w_packed);
+#pragma unroll
+      for (int u = 0; u < 2 * RT; ++u) epi_piece(acc, 0, gbuf(0), u >> 1, u & 1);
+      lds_barrier();
+#pragma unroll 1
+      for (int ch = 1; ch < nchunk; ++ch) {
+        init_acc(acc, p_b1 + ch * FD, n0, lg);
+        mma_wset<T>(acc, wp, Ay, li, lg);                                    // h1 of chunk ch
+        load_wset(wp, (ch + 1 < nchunk) ? W1 + (unsigned int)(ch + 1) * (FD * FD) : Wo, FD, n0, 0, li, lg, a.w_packed);
+        __builtin_amdgcn_sched_barrier(0);
+        // out += g(ch - 1) . W2[:, chunk ch - 1]^T in eight slices of 4 MFMAs (k-step u >> 1, row tiles 2 (u & 1), + 1), each followed
+        // by one piece of the epilogue of chunk ch; nothing crosses a slice boundary, so every group of 4 matrix instructions runs
+        // under ~30 VALU instructions of the same wave (the fragments of the next slice are read a slice ahead)
+        const LT* gprev = gbuf(ch - 1);
+        LT* gcur = gbuf(ch);
+        typename OpT<T>::type af[2][2];
+        load_frag(af[0][0], gprev + Tile<LT>::off(li, 8 * lg));
+        load_frag(af[0][1], gprev + Tile<LT>::off(16 + li, 8 * lg));
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int ks = u >> 1, rh = (u & 1) * 2;
+          if (u < 7) {
+            const int ksn = (u + 1) >> 1, rhn = ((u + 1) & 1) * 2;
+            load_frag(af[(u + 1) & 1][0], gprev + Tile<LT>::off(rhn * 16 + li, ksn * 32 + 8 * lg));
+            load_frag(af[(u + 1) & 1][1], gprev + Tile<LT>::off((rhn + 1) * 16 + li, ksn * 32 + 8 * lg));
+          }
+          // ONE matrix instruction, then half a GELU pair (>= 40 cycles of VALU / transcendental work against the 16 the matrix pipe
+          // is busy): a wave issues in order, so matrix instructions back to back would stall it on the pipe before its first VALU one
+          const int ert = u >> 1, ect = u & 1;
+          if constexpr (DM != 0) {
+            if (ect == 0) {
+              const unsigned int rb = (unsigned int)(mb[ert] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
+              if constexpr (DM == 1) {
+                const unsigned int w = rg_hash(drop1.seed, rb >> 5);
+                load4f(kq[0], reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
+                load4f(kq[1], reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));
+              } else {
+                rg_keep4_pair(drop1, rb, kq[0], kq[1]);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[ect][ert][r] *= kq[ect][r];
+          }
+          f32x2 xa = (f32x2){acc[ect][ert][0], acc[ect][ert][1]}, xb = (f32x2){acc[ect][ert][2], acc[ect][ert][3]};
+          __builtin_amdgcn_sched_barrier(0);
+          mma(wq.f[ks][0], af[u & 1][0], acc2[0][rh]);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x2 ea = gelu2_fast_a(xa);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(wq.f[ks][1], af[u & 1][0], acc2[1][rh]);
+          __builtin_amdgcn_sched_barrier(0);
+          xa = gelu2_fast_b(xa, ea);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(wq.f[ks][0], af[u & 1][1], acc2[0][rh + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          const f32x2 eb = gelu2_fast_a(xb);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(wq.f[ks][1], af[u & 1][1], acc2[1][rh + 1]);
+          __builtin_amdgcn_sched_barrier(0);
+          xb = gelu2_fast_b(xb, eb);
+          float t[4] = {xa.x, xa.y, xb.x, xb.y};
+          store4(gcur + Tile<LT>::off(ert * 16 + li, n0 + ect * 16 + 4 * lg), t);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        load_wset(wq, W2, a.dff, n0, ch * FD, li, lg, a.w_packed);
+        lds_barrier();                                                       // g(ch) visible; every reader of g(ch - 1) is done
+      }
+      mma_wset<T>(acc2, wq, gbuf(nchunk - 1), li, lg);
+    } else {
 #pragma unroll 1
     for (int ch = 0; ch < nchunk; ++ch) {
       load_wset(wq, W2, a.dff, n0, ch * FD, li, lg, a.w_packed);    // needed after the GELU below
@@ -610,6 +742,7 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
       if (h1save) tile_to_hbm<T, true>(Ah, h1save, a.dff, ch * FD, mb, a.M, tid);
       mma_wset<T>(acc2, wq, Ag, li, lg);                // out += g . W2[:, chunk]^T
       STAMP(8);
+    }
     }
     // prefetch the next tile's ctx / x rows while the second LayerNorm runs (unconditional: see next_group)
     prefetch_rows(mbn);
@@ -750,6 +883,22 @@ extern "C" int rg_post_attn_fwd(const rg_post_attn_args* a, int dtype, void* str
   const bool res = a->x_lo || a->out_lo;
   if (res && (!a->x_lo || !a->out_lo || dtype != RG_BF16))
     return rg_set_error_msg(RG_ERR_INVALID, "post_attn_fwd: the split residual stream needs x_lo AND out_lo, bf16 tier");
+  // RG_PA_PIPE=1: the software-pipelined FFN loop (bf16 inference launches: no saves, no cross stage, one residual stream, d_ff >= 256) --
+  // bit-identical, measured 0 ... 3 % SLOWER than the plain loop, kept for A/B timing
+  static const int pipe_on = [] { const char* e = getenv("RG_PA_PIPE"); return e ? atoi(e) : 0; }();
+  if (pipe_on && dtype == RG_BF16 && !cross && !save && !res && a->dff >= 2 * FD) {
+#define RG_PAP(DM)                                                                                                        \
+  do {                                                                                                                    \
+    hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<__bf16, DM, false, false, false, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \
+    hipLaunchKernelGGL((post_attn_fwd_kernel<__bf16, DM, false, false, false, 4, true>), dim3(grid), dim3(256), smem, s, *a); \
+  } while (0)
+    if (dm == 0) RG_PAP(0);
+    else if (dm == 1) RG_PAP(1);
+    else RG_PAP(2);
+#undef RG_PAP
+    RG_CHECK_LAUNCH();
+    return 0;
+  }
 #define RG_PA4(T, DM, C, S, R, RTV)                                                                                       \
   do {                                                                                                                    \
     hipFuncSetAttribute(reinterpret_cast<const void*>(post_attn_fwd_kernel<T, DM, C, S, R, RTV>), hipFuncAttributeMaxDynamicSharedMemorySize, smem); \

@@ -247,6 +247,25 @@ __device__ __forceinline__ f32x2 gelu2_fast(f32x2 x) {
   r.y = __builtin_amdgcn_rcpf(den.y);
   return x * r;
 }
+// gelu2_fast in two halves (the pipelined FFN loop of fused.hip puts a matrix instruction between them): the exponentials, then the rest
+__device__ __forceinline__ f32x2 gelu2_fast_a(f32x2 x) {
+  const float c = 0.7978845608028654f;
+  const float k1 = -2.f * 1.4426950408889634f * c;
+  const float k3 = k1 * 0.044715f;
+  const f32x2 t = x * x * (f32x2){k3, k3} + (f32x2){k1, k1};
+  const f32x2 arg = x * t;
+  f32x2 e;
+  e.x = __builtin_amdgcn_exp2f(arg.x);
+  e.y = __builtin_amdgcn_exp2f(arg.y);
+  return e;
+}
+__device__ __forceinline__ f32x2 gelu2_fast_b(f32x2 x, f32x2 e) {
+  const f32x2 den = e + (f32x2){1.f, 1.f};
+  f32x2 r;
+  r.x = __builtin_amdgcn_rcpf(den.x);
+  r.y = __builtin_amdgcn_rcpf(den.y);
+  return x * r;
+}
 template <bool PRECISE>
 __device__ __forceinline__ float gelu_grad_t(float x) {
   const float c = 0.7978845608028654f;

@@ -221,12 +221,12 @@ torch.save(T._run_d128_inference_cases(), sys.argv[2])
 '''
 
 
-def _run_d128_inference_cases():
+def _run_d128_inference_cases(dff=512):
     """Encoder-inference launches of the d_model = 128 fused block: ragged M without a list, M = 20 000 with the live-tile list, the three
     dropout modes."""
     from recguru_amd import hip
     dt = torch.bfloat16
-    d, dff = 128, 512
+    d = 128
     outs = []
     for M, drop_p in ((64 * 5 + 16, 0.0), (20000, 0.0), (20000, 0.5), (20000, 0.3)):
         ctx, x = rnd(M, d, dt=dt, seed=1), rnd(M, d, dt=dt, seed=2)
@@ -259,6 +259,37 @@ def test_eight_wave_prototype_matches_the_four_wave_kernel(tmp_path):
         err = float((a - b).abs().max())
         assert err <= 0.07, err                      # values are O(1..4): one or two bf16 ulps (2^-7 .. 2^-6 relative)
         assert float((a - b).abs().mean()) <= 2e-3
+
+
+_PIPE_WORKER = r'''
+import sys, torch
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[1] + "/tests")
+import test_fused256_gpu as T
+torch.save([T._run_d128_inference_cases(dff) for dff in (256, 512, 768)], sys.argv[2])
+'''
+
+
+def test_pipelined_ffn_loop_is_bit_identical(tmp_path):
+    """post_attn_fwd_kernel<bf16, ..., PIPE> (round 5, RG_PA_PIPE=1 in a fresh process -- the switch is read once; measured no faster and
+    off by default: DESIGN.md 6a): the W2 product of chunk ch - 1 issued one matrix instruction at a time between the halves of the
+    dropout + GELU epilogue of chunk ch, g chunks alternating between the x and the ctx tile, against the plain loop: same products, same
+    accumulation order, same dropout words -- the same bits, for d_ff = 256 / 512 / 768, ragged M, the live-tile list and the three
+    dropout modes."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ref = [_run_d128_inference_cases(dff) for dff in (256, 512, 768)]
+    f = str(tmp_path / "pipelined.pt")
+    subprocess.run([sys.executable, "-c", _PIPE_WORKER, root, f], check=True, env=dict(os.environ, RG_PA_PIPE="1"))
+    got = torch.load(f)
+    n = 0
+    for ga, ra in zip(got, ref):
+        for a, b in zip(ga, ra):
+            assert torch.equal(a, b), float((a - b).abs().max())
+            assert bool(torch.isfinite(a).all())
+            n += 1
+    assert n == 12
 
 
 _ONLINE_WORKER = r'''
