@@ -575,7 +575,7 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
     init_acc(acc2, p_b2, n0, lg);
     if constexpr (PIPE) {
       // Software-pipelined form (MEASURED: no gain -- see the end of this comment).  In the plain loop below a wave alternates between a matrix phase (32 MFMAs) and a VALU phase
-      // (dropout + GELU of 32 elements per lane: ~260 VALU instructions, 64 of them quarter-rate) with a barrier between them, so
+      // (dropout + GELU of 32 elements per lane: ~260 VALU instructions, 64 of them half-rate transcendentals) with a barrier between them, so
       // the matrix pipe idles through every VALU phase of the wave and the counters show the two waves of a SIMD adding their
       // phases up rather than overlapping them (SQ_VALU_MFMA_COEXEC_CYCLES = 14 % of the matrix pipe's busy cycles).  Here the
       // product that does NOT depend on the current epilogue -- out += g(ch - 1) W2 (g chunks alternate between the x tile and the ctx
@@ -584,8 +584,9 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
       // Outcome at the bench shape (profiles/r05/ab/post_attn_pipelined_ffn.txt): left to the scheduler the matrix instructions
       // all moved to the front of the block (no change, 10.9 -> 11.0 ms per step); in eight slices of 4 MFMAs + one epilogue piece
       // 10.9 -> 10.95; one MFMA per half GELU pair (this code) 10.9 -> 11.2.  The matrix pipe's 21 % of the SIMD time is not what
-      // the kernel waits for: the VALU port is -- ~260 VALU + 64 quarter-rate transcendental instructions per 64 MFMAs -- and it
-      // is already fed by the other wave of the SIMD while this one is in its matrix phase.  Same products, same order of accumulation, same
+      // the kernel waits for in particular: matrix and vector cycles largely ADD on a gfx950 SIMD (tools/peaks.hip: one MFMA hides ~4
+      // cycles of the same wave's VALU work, 44 % of its own cycles with a second wave) -- ~196 full-rate + 64 half-rate vector
+      // instructions (~1 400 cycles) and 64 MFMAs (~1 300) per chunk and wave, whatever their order.  Same products, same order of accumulation, same
       // dropout words: bit-identical to the plain loop (tests/test_fused256_gpu.py::test_pipelined_ffn_loop_is_bit_identical).
       auto gbuf = [&](int c) -> LT* { return (c & 1) ? Actx : Ag; };
       // one (feature tile ect, row tile ert) piece of the epilogue of chunk ch: dropout before the GELU (quirk Q4), GELU, store to the g tile

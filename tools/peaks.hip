@@ -99,6 +99,55 @@ __global__ void __launch_bounds__(256) mfma_kernel(float* __restrict__ out, int 
   if (c[0] == 12345.678f) out[threadIdx.x] = c[0] + c[1] + c[2] + c[3];
 }
 
+// ---- VALU port: full-rate fma, packed fma, transcendental (exp2 / rcp), and a matrix instruction with 0 / 2 / 4 / 8 independent VALU
+// instructions of the SAME wave behind it (what one wave can hide under its own MFMAs) --------------------------------------------------
+template <int KIND>      // 0: v_fma_f32   1: v_pk_fma_f32   2: v_exp_f32   3: v_rcp_f32
+__global__ void __launch_bounds__(256) valu_kernel(float* __restrict__ out, int iters) {
+  float x[8];
+  for (int j = 0; j < 8; ++j) x[j] = 0.5f + 0.001f * (threadIdx.x & 31) + 0.01f * j;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (KIND == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[j]) : "v"(0.999f));
+      if (KIND == 2) asm volatile("v_exp_f32 %0, %0" : "+v"(x[j]));
+      if (KIND == 3) asm volatile("v_rcp_f32 %0, %0" : "+v"(x[j]));
+    }
+    if (KIND == 1) {
+      typedef __attribute__((ext_vector_type(2))) float f2;
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        f2 v = {x[j], x[j + 1]};
+        const f2 k = {0.999f, 0.999f};
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v) : "v"(k));
+        asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(v) : "v"(k));
+        x[j] = v.x; x[j + 1] = v.y;
+      }
+    }
+  }
+  float s = 0.f;
+  for (int j = 0; j < 8; ++j) s += x[j];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+template <int NV>        // per iteration: 4 MFMAs (independent accumulators), each followed by NV independent v_fma_f32
+__global__ void __launch_bounds__(256) mfma_valu_kernel(float* __restrict__ out, int iters) {
+  bf16x8_t a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x & 7)); b[j] = (__bf16)(0.002f * (j + 1)); }
+  f32x4 c[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  float x[8];
+  for (int j = 0; j < 8; ++j) x[j] = 0.5f + 0.001f * (threadIdx.x & 31) + 0.01f * j;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[m]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[j & 7]) : "v"(0.999f));
+    }
+  }
+  float s = c[0][0] + c[1][0] + c[2][0] + c[3][0];
+  for (int j = 0; j < 8; ++j) s += x[j];
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 // ---- harness -------------------------------------------------------------------------------------------------------------
 struct Res { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Res> results;
@@ -211,6 +260,41 @@ int main(int argc, char** argv) {
     snprintf(nm, sizeof nm, "mfma_16x16x32_bf16_%dwave_per_simd", wps);
     snprintf(note, sizeof note, "issue loop, 4 independent accumulators per wave, %d workgroups of 256 threads per CU", wps);
     report(nm, flops / ms * 1e-9, "TFLOP/s", note);
+  }
+  // ---- VALU port (wave-instructions per cycle per SIMD at the clock the probe runs at is not observable from here: report the rate in
+  // G wave-instructions per second over the chip, and the ratios)
+  {
+    const int iters = 20000, wps = 4;
+    const double n8 = (double)CUS * wps * 4 * iters * 8.0;
+    char note[160];
+    double g[4];
+    ms = time_ms([&] { valu_kernel<0><<<CUS * wps, 256>>>(sink, iters); }, 5); g[0] = n8 / ms * 1e-6;
+    ms = time_ms([&] { valu_kernel<1><<<CUS * wps, 256>>>(sink, iters); }, 5); g[1] = n8 / ms * 1e-6;
+    ms = time_ms([&] { valu_kernel<2><<<CUS * wps, 256>>>(sink, iters); }, 5); g[2] = n8 / ms * 1e-6;
+    ms = time_ms([&] { valu_kernel<3><<<CUS * wps, 256>>>(sink, iters); }, 5); g[3] = n8 / ms * 1e-6;
+    snprintf(note, sizeof note, "8 independent chains per wave, 4 waves per SIMD; per SIMD and cycle at 2.4 GHz: %.3f", g[0] * 1e9 / (CUS * 4 * 2.4e9));
+    report("valu_fma_f32", g[0], "G wave-instr/s", note);
+    snprintf(note, sizeof note, "the same count of v_pk_fma_f32 (two results per lane each): %.2f x the time of v_fma_f32", g[0] / g[1]);
+    report("valu_pk_fma_f32", g[1], "G wave-instr/s", note);
+    snprintf(note, sizeof note, "transcendental: %.2f x the time of v_fma_f32", g[0] / g[2]);
+    report("valu_exp_f32", g[2], "G wave-instr/s", note);
+    snprintf(note, sizeof note, "transcendental: %.2f x the time of v_fma_f32", g[0] / g[3]);
+    report("valu_rcp_f32", g[3], "G wave-instr/s", note);
+  }
+  {
+    const int iters = 20000;
+    for (int wps : {1, 2}) {
+      double t[4];
+      t[0] = time_ms([&] { mfma_valu_kernel<0><<<CUS * wps, 256>>>(sink, iters); }, 5);
+      t[1] = time_ms([&] { mfma_valu_kernel<2><<<CUS * wps, 256>>>(sink, iters); }, 5);
+      t[2] = time_ms([&] { mfma_valu_kernel<4><<<CUS * wps, 256>>>(sink, iters); }, 5);
+      t[3] = time_ms([&] { mfma_valu_kernel<8><<<CUS * wps, 256>>>(sink, iters); }, 5);
+      char nm[64], note[200];
+      snprintf(nm, sizeof nm, "mfma_plus_own_valu_%dwave_per_simd", wps);
+      snprintf(note, sizeof note, "time of (1 MFMA 16x16x32 bf16 + N independent v_fma_f32 of the same wave) relative to the MFMA alone: N = 2: %.2f, 4: %.2f, 8: %.2f",
+               t[1] / t[0], t[2] / t[0], t[3] / t[0]);
+      report(nm, (double)CUS * wps * 4 * iters * 4.0 * (2.0 * 16 * 16 * 32) / t[0] * 1e-9, "TFLOP/s", note);
+    }
   }
   printf("{");
   for (size_t i = 0; i < results.size(); ++i)
