@@ -570,6 +570,18 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
       if (cross ? (y2save != nullptr) : (ysave != nullptr)) tile_to_hbm<T, true>(Ay, cross ? y2save : ysave, FD, 0, mb, a.M, tid);
     }
     STAMP(3);
+    // word index of this lane ROW's row tile (row tile lg, row li) in the two dropout index spaces: (row * d_ff + column) >> 5 with
+    // column = chunk * 128 + 32 * wave + 4 lg + j (j < 20) and (row * 128 + 32 * wave + 4 lg + j) >> 5
+    // (bf16 kernels only: in the f32-storage kernels hipcc turns the select over lg into lane-divergent branches whose results pass through
+    // AGPR copies under a narrowed exec -- the pattern the ISA screen refuses)
+    constexpr bool SHARE = DM == 1 && RT == 4 && sizeof(T) == 2;
+    unsigned int hrow1 = 0u, hrow2 = 0u;
+    if constexpr (SHARE) {
+      const int m01 = (lg & 1) ? mb[1] : mb[0], m23 = (lg & 1) ? mb[RT == 4 ? 3 : 1] : mb[RT == 4 ? 2 : 0];
+      const unsigned int mrow_lg = (unsigned int)(((lg & 2) ? m23 : m01) + li);
+      hrow1 = mrow_lg * ((unsigned int)a.dff >> 5) + (unsigned int)wave;
+      hrow2 = mrow_lg * 4u + (unsigned int)wave;
+    }
     // ---- FFN: stream d_ff in 128-wide chunks; the second GEMM accumulates across chunks
     f32x4 acc2[2][RT];
     init_acc(acc2, p_b2, n0, lg);
@@ -701,11 +713,15 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
       if (ch > 0) lds_barrier();                        // previous chunk's readers of Ag / Ah are done
       STAMP(5);
       if constexpr (DM != 0) {  // dropout BEFORE the GELU (transformer.py:182-184, quirk Q4)
+        // p == 0.5, four row tiles: the hash word of row tile rt is the same in the four lane rows lg -- lane row lg computes the word of
+        // row tile lg only and the four are exchanged (rg_allgather_rows): one hash per lane and chunk instead of four
+        unsigned int wv[4];
+        if constexpr (SHARE) rg_allgather_rows(rg_hash(drop1.seed, hrow1 + 4u * (unsigned int)ch), wv);
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)a.dff + (unsigned int)(ch * FD + n0 + 4 * lg);
           if constexpr (DM == 1) {       // rb & 31 == 4*lg: both feature tiles of this lane sit in one hash word
-            const unsigned int w = rg_hash(drop1.seed, rb >> 5);
+            const unsigned int w = SHARE ? wv[rt & 3] : rg_hash(drop1.seed, rb >> 5);
             float k0[4], k1[4];
             load4f(k0, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
             load4f(k1, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));
@@ -748,11 +764,13 @@ void post_attn_fwd_kernel(rg_post_attn_args a) {
     // prefetch the next tile's ctx / x rows while the second LayerNorm runs (unconditional: see next_group)
     prefetch_rows(mbn);
     if constexpr (DM != 0) {    // dropout on the l2 output, before the residual (transformer.py:186-188)
+      unsigned int wv[4];
+      if constexpr (SHARE) rg_allgather_rows(rg_hash(drop2.seed, hrow2), wv);
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
         const unsigned int rb = (unsigned int)(mb[rt] + li) * (unsigned int)FD + (unsigned int)(n0 + 4 * lg);
         if constexpr (DM == 1) {
-          const unsigned int w = rg_hash(drop2.seed, rb >> 5);
+          const unsigned int w = SHARE ? wv[rt & 3] : rg_hash(drop2.seed, rb >> 5);
           float k0[4], k1[4];
           load4f(k0, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot0) & 0xF0u)));
           load4f(k1, reinterpret_cast<const float*>(reinterpret_cast<const char*>(klut) + (__builtin_amdgcn_alignbit(w, w, rot1) & 0xF0u)));

@@ -412,6 +412,16 @@ __device__ __forceinline__ unsigned int rg_hash(unsigned int seed, unsigned int 
   x ^= x >> 15;
   return x;
 }
+// Every lane (column li of row r of the wave's four 16-lane rows) receives the values that the four lanes (li, row 0 .. 3) hold: one
+// v_permlane32_swap and two v_permlane16_swap (gfx950; order checked on hardware by tools/permlane_probe.hip).  Used to compute ONE
+// dropout hash word per lane where every lane needs the words of four row tiles: a hash is 6 simple + 2 v_mul_lo_u32 instructions.
+__device__ __forceinline__ void rg_allgather_rows(unsigned int v, unsigned int (&w)[4]) {
+  typedef __attribute__((ext_vector_type(2))) unsigned int u2_t;
+  const u2_t pq = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+  const u2_t a = __builtin_amdgcn_permlane16_swap(pq.x, pq.x, false, false);
+  const u2_t b = __builtin_amdgcn_permlane16_swap(pq.y, pq.y, false, false);
+  w[0] = a.x; w[1] = a.y; w[2] = b.x; w[3] = b.y;
+}
 __device__ __forceinline__ float rg_bit(const DropCfg& c, unsigned int w, int j) { return (w >> j) & 1u ? c.inv_keep : 0.f; }
 // bit j of w as an AND mask (all ones = keep) and its use on a float: 2 VALU ops per element, scale applied elsewhere
 __device__ __forceinline__ unsigned int rg_bitmask(unsigned int w, int j) { return (unsigned int)__builtin_amdgcn_sbfe((int)w, j, 1); }
