@@ -320,6 +320,8 @@ extern "C" int rg_gemm_nt(const rg_gemm_nt_args* a, int dtype, void* stream) {
     const int rc = rg_gemm_ws_try(a, dtype, s);
     if (rc <= 0) return rc;
   }
+  if (a->w_packed)
+    return rg_set_error_msg(RG_ERR_UNSUPPORTED, "gemm_nt: w_packed (presplit fragment-packed W) is a form of the bf16x3 weight-stationary kernel at K > 128");
   // the generic tile kernel reads EVERY row: a live-tile list means the padded tiles' rows of A / aux may never have
   // been written by their producers (rg_ln_bwd, skip_dead_fill), so falling through silently would compute on garbage
   if (a->epilogue == RG_EPI_DROP_GELU)

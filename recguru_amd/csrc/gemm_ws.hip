@@ -88,6 +88,23 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // ---- stationary weights: w[cb][kc][ks][ct]   (STREAM: [cb][0][ks][ct] = the current chunk's slice)
   OP w[NCB][STREAM ? 1 : NKC][4][2];
   auto load_w = [&](int cb, int kc, int slot) {
+    if constexpr (STREAM) {
+      if (a.w_packed) {
+        // presplit fragment-packed copy (rg_cast RG_CAST_PACK | RG_CAST_SPLIT): fragment (row tile, k-step) is 2 KB -- 64 lanes x 16 B of
+        // hi parts, then the same of lo parts; 512 four-byte slots, row tiles outermost.  Two 16-byte loads, no split arithmetic.
+        const unsigned int nks = (unsigned int)a.ldw >> 5;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+          for (int ct = 0; ct < 2; ++ct) {
+            const unsigned int rt16 = (unsigned int)(((cby + cb) * 128 + n0 + ct * 16) >> 4);
+            const float* fp = reinterpret_cast<const float*>(W) + ((size_t)rt16 * nks + (unsigned int)(kc * 4 + ks)) * 512u + (unsigned int)(lg * 16 + li) * 4u;
+            w[cb][slot][ks][ct].hi = *reinterpret_cast<const bf16x8_t*>(fp);
+            w[cb][slot][ks][ct].lo = *reinterpret_cast<const bf16x8_t*>(fp + 256);
+          }
+        return;
+      }
+    }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
@@ -322,6 +339,7 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
 
 // 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
 int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
+  if (a->w_packed && (dtype != RG_X3 || a->K <= 128 || a->ldw != a->K)) return 0;      // presplit weights: the streamed (K > 128) bf16x3 form only
   if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no head-major form
     if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->c_hm_L > 0) return 0;
     if (a->epilogue == RG_EPI_DROP_GELU && (!a->C2 || a->aux || a->live16)) return 0;      // (round 5: the dropout + GELU epilogue on f32 tiles too)

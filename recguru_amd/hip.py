@@ -34,7 +34,7 @@ class GemmNtArgs(ctypes.Structure):
                 ("aux", c_p), ("ldaux", c_i), ("gamma", c_p), ("beta", c_p), ("rowmask", c_p),
                 ("rstd_out", c_p), ("ln_eps", c_f), ("debug_ablate", c_i), ("epi_scale", c_f),
                 ("epi_nonzero_scale", c_f), ("drop_p", c_f), ("drop_seed", c_u64), ("live16", c_p),
-                ("skip_dead_fill", c_i), ("c_hm_L", c_i), ("C2", c_p)]
+                ("skip_dead_fill", c_i), ("c_hm_L", c_i), ("C2", c_p), ("w_packed", c_i)]
 
 
 class GemmTnArgs(ctypes.Structure):
@@ -348,11 +348,20 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
         return out
     if headmajor_L:
         assert N % 384 == 0 and M % headmajor_L == 0 and out.is_contiguous() and not out_f32
+    w_packed = 0
+    if (PRESPLIT_WS_X3 and SPLIT_OPERANDS and A.dtype == torch.float32 and 128 < K <= 512 and K % 128 == 0 and N % 128 == 0 and N <= 1024 and M >= 4096
+            and prologue == PRO_NONE and epilogue != EPI_RESID_LN and not headmajor_L and not out_f32 and not (debug_ablate & 16)
+            and not (epilogue == EPI_DROP_GELU and (out2 is None or aux is not None or live is not None))
+            and (epilogue in (EPI_NONE, EPI_RELU, EPI_DROP_GELU) or aux is not None) and not (epilogue == EPI_RELU and drop_p > 0)):
+        # bf16x3 tier, K > 128: the weight-stationary kernel streams its K x 128 weight slice per row tile -- hand it the slice presplit
+        # (one small cast launch per call) instead of splitting 64 values per lane, tile and chunk (rg_gemm_nt_args.w_packed)
+        W = cast(W.contiguous(), torch.float32, transpose=CAST_PACK | CAST_SPLIT)          # (a column slice of a transposed weight: copied first)
+        w_packed = 1
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
                    1 if out.dtype == torch.float32 else 0,
                    M, N, K, prologue, epilogue, _p(aux), _rowmajor(aux) if aux is not None else 0,
                    _p(gamma), _p(beta), _p(rowmask), _p(rstd_out), eps, debug_ablate, epi_scale, epi_nonzero_scale,
-                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L), _p(out2))
+                   drop_p, drop_seed, _p(live), int(skip_dead_fill) if live is not None else 0, int(headmajor_L), _p(out2), w_packed)
     if _PROF is not None:
         _note_plan(lib().rg_gemm_nt_plan, a, mt_of(A))
     _check(lib().rg_gemm_nt(ctypes.byref(a), mt_of(A), _stream()), "rg_gemm_nt")
@@ -1111,6 +1120,7 @@ def attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, key_ids, pad_value, dbv, d
     return dx, dq, ops4[0], ops4[1], ops4[2], ops4[3]
 
 
+PRESPLIT_WS_X3 = not os.environ.get("RG_NO_PRESPLIT_WS")     # RG_NO_PRESPLIT_WS=1: the bf16x3 weight-stationary products at K > 128 split their weight slices in the kernel (A/B timing)
 FUSE_BLOCK_256 = not os.environ.get("RG_NO_PA256")      # RG_NO_PA256=1: d_model 256 takes the unfused launches (A/B timing)
 
 

@@ -84,6 +84,41 @@ def test_gemm_tn(T, N1, N2, gelu):
     close(d1, d0, "gemm_tn accumulate")
 
 
+@pytest.mark.parametrize("M,K,N,epi", [(5000, 256, 256, "none"), (4100, 256, 768, "none"), (6000, 512, 256, "add"), (4096, 384, 256, "add"), (4500, 256, 512, "drop_gelu")])
+def test_presplit_weight_slices_equal_in_kernel_split(M, K, N, epi):
+    """rg_gemm_nt_args.w_packed (round 5): at K > 128 the bf16x3 weight-stationary kernel streams its K x 128 weight slice per row tile; handed the
+    slice PRESPLIT (rg_cast RG_CAST_PACK | RG_CAST_SPLIT, one launch per call) it skips the split arithmetic -- same hi / lo parts, same products:
+    the same bits as the in-kernel split (hip.PRESPLIT_WS_X3 = False), also for a column slice of a wider weight."""
+    from recguru_amd import hip
+    A = rnd(M, K, seed=1)
+    Wfull = rnd(N, K + 128, scale=K ** -0.5, seed=2)
+    W = Wfull[:, 64:64 + K]                                   # non-contiguous: a column slice
+    bias = 0.1 * rnd(N, seed=3)
+    kw = {}
+    if epi == "add":
+        kw = dict(epilogue=hip.EPI_ADD, aux=rnd(M, N, seed=4))
+    outs = []
+    with x3():
+        for on in (True, False):
+            hip.PRESPLIT_WS_X3 = on
+            try:
+                if epi == "drop_gelu":
+                    g = torch.empty(M, N, device="cuda")
+                    o = hip.gemm_nt(A, W.contiguous(), bias, epilogue=hip.EPI_DROP_GELU, drop_p=0.3, drop_seed=9, out2=g)
+                    outs.append((o, g))
+                else:
+                    outs.append((hip.gemm_nt(A, W, bias, **kw),))
+            finally:
+                hip.PRESPLIT_WS_X3 = True
+    for a, b in zip(*outs):
+        assert torch.equal(a, b), float((a - b).abs().max())
+    ref = A.double() @ W.double().t() + bias.double()
+    if epi == "add":
+        ref = ref + kw["aux"].double()
+    if epi != "drop_gelu":
+        close(outs[0][0], ref.float(), "presplit gemm_nt vs float64")
+
+
 @pytest.mark.parametrize("B,L,H,causal", [(3, 12, 2, True), (2, 16, 4, False), (2, 50, 1, True), (3, 200, 4, True), (3, 200, 4, False),
                                           (2, 224, 2, False), (1, 250, 2, True), (1, 400, 2, False), (2, 400, 8, True), (2, 256, 4, False),
                                           (3, 330, 2, True)])
