@@ -99,9 +99,9 @@ typedef struct {
    * L * 64 bytes, which the attention kernels stage by LDS-DMA (rg_attn_args.qkv_hm).  ldc is ignored. */
   int c_hm_L;
   void* C2;                   /* RG_EPI_DROP_GELU: second output [M,N] of the tier dtype, row pitch ldc */
-  int w_packed;               /* RG_X3 with K > 128 only (the weight-stationary kernel streams its K x 128 weight slice per row tile there): W is the
-                                 PRESPLIT fragment-packed copy of the [N,K] matrix (rg_cast RG_CAST_PACK | RG_CAST_SPLIT, K = ldw) -- no split
-                                 arithmetic per tile.  Refused (RG_ERR_UNSUPPORTED) where another kernel would take the problem. */
+  int w_packed;               /* RG_X3 with K = 256 only (the weight-stationary kernel streams its K x 128 weight slice per row tile and splits it there):
+                                 W is the PRESPLIT fragment-packed copy of the [N,K] matrix (rg_cast RG_CAST_PACK | RG_CAST_SPLIT, K = ldw) -- the slice
+                                 stays in registers, no split arithmetic per tile.  Refused (RG_ERR_UNSUPPORTED) where another kernel would take the problem. */
 } rg_gemm_nt_args;
 int rg_gemm_nt(const rg_gemm_nt_args* args /* host */, int dtype, void* stream);
 

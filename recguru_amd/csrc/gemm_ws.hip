@@ -26,12 +26,18 @@
 
 // AUX: the epilogue reads an aux operand (compile-time: a load under a runtime condition gets a vmcnt(0) at the join,
 // which also drained the next tile's A prefetch -- one exposed HBM latency per tile even for the aux-free GEMMs)
-template <typename T, int NKC, int NCB, bool AUX>
+// WP (bf16x3, K > 128): 0 the weight slice is f32 and split in the kernel; 1 it is the PRESPLIT fragment-packed copy (rg_gemm_nt_args.w_packed),
+// streamed per tile and chunk like the f32 one; 2 (K = 256, no aux operand) presplit AND stationary -- 16 fragments = 128 VGPRs, affordable
+// once the in-kernel split's temporaries are gone and the activation fragments are read one k-step at a time
+template <typename T, int NKC, int NCB, bool AUX, int WP = 0>
 __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
+  constexpr bool PSTAT = WP == 2;
+  static_assert(WP == 0 || (std::is_same<T, x3>::value && NKC == 2), "presplit weights: bf16x3, K = 256");
   static_assert(NKC == 1 || NCB == 1, "either K or N spans a single 128-wide block");
   constexpr bool X3 = std::is_same<T, x3>::value;
   static_assert(!X3 || NCB == 1, "bf16x3: one column block per workgroup");
-  constexpr bool STREAM = X3 && NKC > 1;          // the weight slice of ONE chunk in registers, reloaded per tile and chunk
+  static_assert(!PSTAT || (X3 && NKC == 2), "PSTAT: bf16x3, K = 256");
+  constexpr bool STREAM = X3 && NKC > 1 && !PSTAT;   // the weight slice of ONE chunk in registers, reloaded per tile and chunk
   typedef typename LdsT<T, WS_PLANE>::type LT;    // A tile: T, or a hi and a lo bf16 tile
   typedef typename ResT<T>::type XT;              // C tile: T, or raw f32
   typedef typename OpT<T>::type OP;
@@ -88,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
   // ---- stationary weights: w[cb][kc][ks][ct]   (STREAM: [cb][0][ks][ct] = the current chunk's slice)
   OP w[NCB][STREAM ? 1 : NKC][4][2];
   auto load_w = [&](int cb, int kc, int slot) {
-    if constexpr (STREAM) {
-      if (a.w_packed) {
+    if constexpr (WP != 0) {
+      {
         // presplit fragment-packed copy (rg_cast RG_CAST_PACK | RG_CAST_SPLIT): fragment (row tile, k-step) is 2 KB -- 64 lanes x 16 B of
         // hi parts, then the same of lo parts; 512 four-byte slots, row tiles outermost.  Two 16-byte loads, no split arithmetic.
         const unsigned int nks = (unsigned int)a.ldw >> 5;
@@ -197,6 +203,18 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
             for (int rt = 0; rt < 4; ++rt) acc[ct][rt] = (f32x4){b4[0], b4[1], b4[2], b4[3]};
           }
         }
+        if constexpr (PSTAT) {                            // one set of activation fragments (the stationary slice took the registers of the second)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            OP af1[4];
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt) load_frag(af1[rt], As + (rt * 16 + li) * WS_LD + ks * 32 + 8 * lg);
+#pragma unroll
+            for (int rt = 0; rt < 4; ++rt)
+#pragma unroll
+              for (int ct = 0; ct < 2; ++ct) mma(w[cb][kc][ks][ct], af1[rt], acc[ct][rt]);
+          }
+        } else {
         OP af[2][4];                                      // k-step ks+1's fragments are read under the MFMAs of k-step ks
 #pragma unroll
         for (int rt = 0; rt < 4; ++rt) load_frag(af[0][rt], As + (rt * 16 + li) * WS_LD + 8 * lg);
@@ -210,6 +228,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
           for (int rt = 0; rt < 4; ++rt)
 #pragma unroll
             for (int ct = 0; ct < 2; ++ct) mma(w[cb][STREAM ? 0 : kc][ks][ct], af[ks & 1][rt], acc[ct][rt]);
+        }
         }
         if (kc == NKC - 1) {
           // ---- epilogue of this 128-feature block: packed tile -> coalesced 16-byte stores
@@ -331,6 +350,17 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
   if (grid > ntiles) grid = ntiles;
   static const int no_xcd = getenv("RG_WS_NO_XCD") ? atoi(getenv("RG_WS_NO_XCD")) : 0;
   if (ny > 1 && grid >= 16) grid = (grid & ~7) - (no_xcd ? 1 : 0);     // walkers in multiples of 8: the XCD-aware block mapping (RG_WS_NO_XCD=1: one walker fewer = the plain mapping, for A/B)
+  if constexpr (std::is_same<T, x3>::value && NKC == 2) {
+    if (a.w_packed) {
+      static const int pstat = [] { const char* e = getenv("RG_WS_PSTAT"); return e ? atoi(e) : 1; }();   // RG_WS_PSTAT=0: stream the presplit slice per tile (A/B)
+      const bool aux_epi = a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU;
+      if (aux_epi) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true, 1>), dim3(ny * grid), dim3(256), 0, s, a);
+      else if (pstat) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false, 2>), dim3(ny * grid), dim3(256), 0, s, a);
+      else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false, 1>), dim3(ny * grid), dim3(256), 0, s, a);
+      RG_CHECK_LAUNCH();
+      return 0;
+    }
+  }
   if (a.epilogue != RG_EPI_NONE && a.epilogue != RG_EPI_RELU && a.epilogue != RG_EPI_DROP_GELU) hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, true>), dim3(ny * grid), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((gemm_ws_kernel<T, NKC, NCB, false>), dim3(ny * grid), dim3(256), 0, s, a);
   RG_CHECK_LAUNCH();
@@ -339,7 +369,8 @@ static int launch_ws(const rg_gemm_nt_args& a, hipStream_t s, int ny = 1) {
 
 // 10 * (K/128) + N/128 of the instantiation that takes this problem, 0 if none does
 int rg_gemm_ws_select(const rg_gemm_nt_args* a, int dtype) {
-  if (a->w_packed && (dtype != RG_X3 || a->K <= 128 || a->ldw != a->K)) return 0;      // presplit weights: the streamed (K > 128) bf16x3 form only
+  if (a->w_packed && (dtype != RG_X3 || a->K != 256 || a->ldw != a->K)) return 0;      // presplit weights: the bf16x3 form at K = 256 only (at K = 384 / 512 the
+                                                                                      // presplit loads of all chunks are hoisted and the kernel spills 36 - 73 VGPRs: no gain measured)
   if (dtype == RG_X3) {             // bf16x3: <K/128, 1> once per 128-column block; row-major f32 output, no head-major form
     if (a->prologue != RG_PRO_NONE || a->epilogue == RG_EPI_RESID_LN || a->c_hm_L > 0) return 0;
     if (a->epilogue == RG_EPI_DROP_GELU && (!a->C2 || a->aux || a->live16)) return 0;      // (round 5: the dropout + GELU epilogue on f32 tiles too)

@@ -349,12 +349,13 @@ def gemm_nt(A, W, bias=None, out=None, out_f32=False, prologue=PRO_NONE, epilogu
     if headmajor_L:
         assert N % 384 == 0 and M % headmajor_L == 0 and out.is_contiguous() and not out_f32
     w_packed = 0
-    if (PRESPLIT_WS_X3 and SPLIT_OPERANDS and A.dtype == torch.float32 and 128 < K <= 512 and K % 128 == 0 and N % 128 == 0 and N <= 1024 and M >= 4096
+    if (PRESPLIT_WS_X3 and SPLIT_OPERANDS and A.dtype == torch.float32 and K == 256 and N % 128 == 0 and N <= 1024 and M >= 4096
             and prologue == PRO_NONE and epilogue != EPI_RESID_LN and not headmajor_L and not out_f32 and not (debug_ablate & 16)
             and not (epilogue == EPI_DROP_GELU and (out2 is None or aux is not None or live is not None))
             and (epilogue in (EPI_NONE, EPI_RELU, EPI_DROP_GELU) or aux is not None) and not (epilogue == EPI_RELU and drop_p > 0)):
-        # bf16x3 tier, K > 128: the weight-stationary kernel streams its K x 128 weight slice per row tile -- hand it the slice presplit
-        # (one small cast launch per call) instead of splitting 64 values per lane, tile and chunk (rg_gemm_nt_args.w_packed)
+        # bf16x3 tier, K = 256 (d_model 256): the weight-stationary kernel used to stream its K x 128 weight slice per row tile and split it in
+        # the kernel (64 values per lane, tile and chunk); handed over presplit (one small cast launch per call) the slice stays in registers
+        # for the whole launch (rg_gemm_nt_args.w_packed; K = 384 / 512: no gain measured, not taken)
         W = cast(W.contiguous(), torch.float32, transpose=CAST_PACK | CAST_SPLIT)          # (a column slice of a transposed weight: copied first)
         w_packed = 1
     a = GemmNtArgs(_p(A), _rowmajor(A), _p(W), _rowmajor(W), _p(bias), _p(out), _rowmajor(out),
