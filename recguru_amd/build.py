@@ -61,9 +61,11 @@ def _link_and_screen(target, objs, screened_objs, info_name, force, verbose):
     try:
         _screen_and_record([_isa_of(o) for o in screened_objs], verbose, target, info_name)
     except RuntimeError:
-        # a library whose ISA the screen refuses must not stay loadable (hip.lib() loads whatever is on disk -- ADVICE r4)
-        if os.path.exists(target):
-            os.remove(target)
+        # a library whose ISA the screen refuses must not stay loadable (hip.lib() loads whatever is on disk -- ADVICE r4), and the
+        # record of an EARLIER library of that name must not stay behind to vouch for nothing
+        for stale in (target, os.path.join(HERE, "build", info_name)):
+            if os.path.exists(stale):
+                os.remove(stale)
         raise
     return target
 
@@ -80,7 +82,15 @@ def build(force=False, verbose=False, jobs=4, det=True):
     objs = _compile(srcs, hdrs, os.path.join(HERE, "build"), [], force, verbose, jobs)
     _link_and_screen(LIB, objs, objs, "BUILD_INFO.json", force, verbose)
     if det:
-        build_det(force, verbose, jobs)
+        # the deterministic library is test infrastructure (tests/test_det_gpu.py, RG_DETERMINISTIC=1): a refusal of ITS build -- an ISA-screen
+        # finding that exists only under -DRG_DETERMINISTIC -- must not fail the build of the production library, which is complete and
+        # screened at this point.  RG_BUILD_DET_STRICT=1 (the CPU test of the det ABI sets it) turns the warning back into the error.
+        try:
+            build_det(force, verbose, jobs)
+        except RuntimeError as e:
+            if os.environ.get("RG_BUILD_DET_STRICT"):
+                raise
+            sys.stderr.write("recguru_amd.build: librecguru_hip_det.so NOT built (%s); librecguru_hip.so is built and screened\n" % str(e).splitlines()[0])
     return LIB
 
 
@@ -96,6 +106,20 @@ def build_det(force=False, verbose=False, jobs=4):
     if missing:
         raise RuntimeError("build_det: build() first (%s missing)" % ", ".join(missing))
     return _link_and_screen(LIB_DET, dobjs + shared, dobjs, "BUILD_INFO_det.json", force, verbose)
+
+
+def build_variant(name, extra, only=None, force=False, verbose=False, jobs=4):
+    """An A/B library: every source (or those named in `only`, the rest shared with the shipped build) compiled with the `extra`
+    flags into build/variants/<name>/, linked as tools/variants/v_<name>.so (travels to the GPU box; load it with RG_HIP_LIB).
+    Same ISA screen as the shipped library."""
+    srcs, hdrs = _sources()
+    mine = [s for s in srcs if only is None or os.path.basename(s)[:-4] in only]
+    vobjs = _compile(mine, hdrs, os.path.join(HERE, "build", "variants", name), list(extra), force, verbose, jobs)
+    names = set(os.path.basename(o) for o in vobjs)
+    shared = [os.path.join(HERE, "build", os.path.basename(s)[:-4] + ".o") for s in srcs if os.path.basename(s)[:-4] + ".o" not in names]
+    out = os.path.join(HERE, "..", "tools", "variants")
+    os.makedirs(out, exist_ok=True)
+    return _link_and_screen(os.path.join(out, "v_%s.so" % name), vobjs + shared, vobjs, os.path.join("variants", "BUILD_INFO_%s.json" % name), force, verbose)
 
 
 def _isa_of(obj):

@@ -131,6 +131,80 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_rows_kernel(const T* __
   }
 }
 
+// Position-major form (round 6; tools/embed_ladder.hip names what the two forms above lose against a bare gather-copy of the same rows on
+// the 1 GiB config-5 table: (1) the f32 positional row -- TWICE the bf16 row's bytes through the vector L1 per position: 83 -> 99 us --
+// and (2) ordinary stores, whose lines are allocated in the caches on the way out: 81 -> 67 us with nontemporal stores, 102 -> 49 us with
+// the real 56 %-live mask).  Here a wave owns RPW consecutive POSITIONS (lane group lr: position pos0 + lr) and walks a range of
+// sequences b, U of them in flight: its positional rows are read ONCE into 8 registers per lane and reused for every sequence; the row
+// loads are unconditional (a padded position reads row 0 of the table, one hot line set, and its result is discarded); the output rows
+// leave by nontemporal stores when NT (the launcher's choice, RG_EMBED_NT).  Consecutive waves take consecutive position blocks of the same
+// sequence range, so the 32-B id / 16-B mask pieces of neighbouring waves share cache lines and a workgroup writes 4 KiB runs.
+template <typename T> __device__ __forceinline__ void store8_nt(T* p, const float* v);
+template <> __device__ __forceinline__ void store8_nt<float>(float* p, const float* v) {
+  __builtin_nontemporal_store((rg_f4){v[0], v[1], v[2], v[3]}, reinterpret_cast<rg_f4*>(p));
+  __builtin_nontemporal_store((rg_f4){v[4], v[5], v[6], v[7]}, reinterpret_cast<rg_f4*>(p + 4));
+}
+template <> __device__ __forceinline__ void store8_nt<__bf16>(__bf16* p, const float* v) {
+  union { bf16x8_t b; rg_f4 x; } u;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) u.b[j] = (__bf16)v[j];
+  __builtin_nontemporal_store(u.x, reinterpret_cast<rg_f4*>(p));
+}
+template <typename T, int D, int U, bool M2, bool NT>
+__global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_pos_kernel(const T* __restrict__ table, const float* __restrict__ pe,
+                                                                   const int64_t* __restrict__ ids, const float* __restrict__ mask,
+                                                                   T* __restrict__ out, __bf16* __restrict__ out2, int B, int L, int bs, DropCfg drop) {
+  constexpr int LPR = D / 8, RPW = 64 / LPR;           // lanes per row, positions per wave
+  const int lane = threadIdx.x & 63;
+  const int wave = (int)((blockIdx.x * EW_BLOCK + threadIdx.x) >> 6);
+  const int npb = (L + RPW - 1) / RPW;
+  const int pb = wave % npb, b0 = (wave / npb) * bs;
+  if (b0 >= B) return;
+  const int b1 = min(B, b0 + bs);
+  const int lr = lane / LPR, c8 = (lane % LPR) * 8;
+  const int pos = pb * RPW + lr;
+  const bool inr = pos < L;
+  const int posc = inr ? pos : L - 1;
+  float pp[8];
+  load8(pp, pe + (unsigned int)posc * D + c8);
+#pragma unroll 1
+  for (int b = b0; b < b1; b += U) {
+    int64_t id[U];
+    float m[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tok = min(b + u, b1 - 1) * L + posc;
+      id[u] = ids[tok];
+      m[u] = mask[tok];
+    }
+    float v[U][8];
+#pragma unroll
+    for (int u = 0; u < U; ++u) load8(v[u], table + (size_t)(m[u] != 0.f ? id[u] : 0) * D + c8);
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int tok = (b + u) * L + pos;
+      if (m[u] != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = (v[u][j] + pp[j]) * m[u];
+        if (drop.thresh) {
+          float k8[8];
+          rg_keep8(drop, (unsigned int)tok * (unsigned int)D + (unsigned int)c8, k8);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[u][j] *= k8[j];
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[u][j] = 0.f;
+      }
+      if (b + u < b1 && inr) {
+        if constexpr (NT) store8_nt<T>(out + (size_t)tok * D + c8, v[u]);
+        else store8(out + (size_t)tok * D + c8, v[u]);
+        if constexpr (M2) store8(out2 + (size_t)tok * D + c8, v[u]);
+      }
+    }
+  }
+}
+
 // Split-residual form: f32 master rows in, value = hi + lo out as two bf16 tensors (rg_embed_pe_fwd_split).
 __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_split_kernel(const float* __restrict__ table, const float* __restrict__ pe,
                                                                      const int64_t* __restrict__ ids,
@@ -1219,6 +1293,28 @@ static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t
   // both kernels sit at the memory system's rate for this read / write mix (0.55 of 8 TB/s = 0.89 of the box's measured copy rate),
   // so the simpler element-per-thread kernel stays the default.
   static const int rows_form = getenv("RG_EMBED_ROWS") ? atoi(getenv("RG_EMBED_ROWS")) : 0;
+  // RG_EMBED_FORM: 2 = position-major (default since round 6), 0 = the element-per-thread kernel; RG_EMBED_NT: 1 = nontemporal stores
+  static const int form = getenv("RG_EMBED_FORM") ? atoi(getenv("RG_EMBED_FORM")) : 2;
+  static const int use_nt = getenv("RG_EMBED_NT") ? atoi(getenv("RG_EMBED_NT")) : 1;
+  if (form == 2 && !rows_form && !out2 && (d == 128 || d == 256) && L > 0 && ntok % L == 0 && ntok < (1ll << 31) / d) {
+    // waves = position blocks x sequence ranges; the ranges sized so that the launch is ~ 8 workgroups (32 waves) per CU, every wave
+    // with the same number of sequences
+    const int B = (int)(ntok / L), rpw = 64 / (d / 8), npb = (L + rpw - 1) / rpw;
+    const long long cap = 256LL * 8 * (EW_BLOCK / 64);
+    int chunks = (int)((cap + npb - 1) / npb);
+    if (chunks > B) chunks = B;
+    if (chunks < 1) chunks = 1;
+    const int bs = (B + chunks - 1) / chunks;
+    chunks = (B + bs - 1) / bs;
+    const long long waves = (long long)npb * chunks;
+    const int grid = (int)((waves + EW_BLOCK / 64 - 1) / (EW_BLOCK / 64));
+#define RG_EMBP(T, D) do { if (use_nt) hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, false, true>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)nullptr, B, L, bs, drop); \
+                           else hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, false, false>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)nullptr, B, L, bs, drop); } while (0)
+#define RG_EMBP_T(T) do { if (d == 128) RG_EMBP(T, 128); else RG_EMBP(T, 256); } while (0)
+    DISPATCH_T(dtype, RG_EMBP_T(__bf16), RG_EMBP_T(float), "embed_pe_fwd")
+#undef RG_EMBP_T
+#undef RG_EMBP
+  }
   if ((d == 128 || d == 256) && L > 0 && ntok < (1ll << 31) / d && (rows_form || out2)) {
     // one wave per 64-token block, at most 8 workgroups (32 waves) per CU -- and every wave the SAME number of blocks: with 12 800
     // blocks on 8 192 waves a third of the waves took two blocks and the launch lasted two block times for 1.56 of work

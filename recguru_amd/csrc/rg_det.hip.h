@@ -21,7 +21,8 @@ struct RgDetArena { unsigned long long fbase, sbase, bytes; int bits; int pad; }
 static __device__ RgDetArena rg_det_arena[2];
 static __device__ int rg_det_fault_flag;
 
-extern "C" void rg_det_register_tu(int (*set)(const void* arenas), int (*fault)(int* out, int clear));   // rg_error.hip
+// rg_error.hip; internal to the library (hidden: not part of the C ABI of include/recguru_hip.h)
+extern "C" __attribute__((visibility("hidden"))) void rg_det_register_tu(int (*set)(const void* arenas), int (*fault)(int* out, int clear));
 
 namespace {
 struct RgDetTu {
@@ -36,7 +37,7 @@ struct RgDetTu {
       const int z = 0;
       e = hipMemcpyToSymbol(HIP_SYMBOL(rg_det_fault_flag), &z, sizeof(int), 0, hipMemcpyHostToDevice);
     }
-    *out += v;
+    if (v > *out) *out = v;                              // the worst flag of any unit (0 / 1 / 2 as documented), not their sum
     return (int)e;
   }
 };

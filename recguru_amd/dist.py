@@ -35,6 +35,25 @@ def init_from_env(backend=None):
     return DataParallel()
 
 
+def shard_rows(t, rank, world):
+    """Rows rank::world of a full batch (SURVEY.md 8e).  The batch must divide by the world size: the plain-mean losses (W-loss,
+    gradient penalty) are pre-divided by `world` (scale_mean), which is the full-batch mean only for EQUAL shards."""
+    if not 0 <= rank < world:
+        raise ValueError("shard_rows: rank %d is outside a world of %d" % (rank, world))
+    n = t.shape[0]
+    if n % world:
+        raise ValueError("shard_rows: a batch of %d users is not divisible by the world size %d (equal shards are what the "
+                         "1 / world pre-division of the mean losses assumes); drop %d users or change the batch size" % (n, world, n % world))
+    return t[rank::world]
+
+
+def shard_users(n_users, rank, world):
+    """The users of rank `rank`: rank::world cut to n_users // world -- every rank holds the same number of users (and therefore the
+    same number of batches: a rank with one batch more would wait in a collective nobody else enters)."""
+    per = n_users // world
+    return slice(rank, rank + per * world, world) if world > 1 else slice(0, n_users)
+
+
 class DataParallel(object):
     def __init__(self, group=None, bucket_bytes=128 << 20):
         self.group = group

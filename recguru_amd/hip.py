@@ -205,6 +205,7 @@ class _DetArena(object):
         self.dev = dev
         self.top = {"g": 0, "s": 0}
         self.last_stream = None
+        self.wrapped = torch.zeros((), device=dev, dtype=torch.int32)          # > 0: a shadow SUM left the 64-bit range (_DetScope.commit)
         self.resize(int(os.environ.get("RG_DET_ARENA_MFLOATS", "32")) << 20)   # gradients: 32 M floats to start with (128 MB + 256 MB of shadow)
 
     def resize(self, ng):
@@ -220,6 +221,10 @@ class _DetArena(object):
         with torch.cuda.device(self.dev):
             _check(fn(self.f["g"].data_ptr(), self.s["g"].data_ptr(), self.n["g"] * 4, DET_BITS["g"],
                       self.f["s"].data_ptr(), self.s["s"].data_ptr(), self.n["s"] * 4, DET_BITS["s"]), "rg_det_set_arenas")
+
+    @classmethod
+    def all(cls):
+        return list(cls._per_device.values())
 
     @classmethod
     def of(cls, dev):
@@ -272,7 +277,11 @@ class _DetScope(object):
 
     def commit(self):
         for t, kind, off, n, f in self.items:
-            t.add_(self.arena.s[kind][off:off + n].to(torch.float64).mul_(2.0 ** -DET_BITS[kind]).to(torch.float32).view(t.shape))
+            sh = self.arena.s[kind][off:off + n]
+            # rg_acc range-checks every single contribution; the 64-bit SUM of many can still wrap (|gradient sum| >= 131072 at 2^-46
+            # units).  A sum beyond 2^62 counts as out of range: recorded on the device (no sync here), reported by det_fault() as 2
+            self.arena.wrapped.add_((sh.abs() > (1 << 62)).any().to(torch.int32))
+            t.add_(sh.to(torch.float64).mul_(2.0 ** -DET_BITS[kind]).to(torch.float32).view(t.shape))
         if self.arena is not None:
             self.arena.top.update(self.mark)
         self.items = []
@@ -319,7 +328,13 @@ def _det_accum(**spec):
 def det_fault(clear=True):
     """0, or what went wrong since the last call in deterministic mode (include/recguru_hip.h rg_det_fault)."""
     torch.cuda.synchronize()
-    return int(lib().rg_det_fault(1 if clear else 0))
+    v = int(lib().rg_det_fault(1 if clear else 0))
+    for a in _DetArena.all():
+        if int(a.wrapped.item()):
+            v = max(v, 2)
+            if clear:
+                a.wrapped.zero_()
+    return v
 
 
 # test knob: outputs whose padded-tile rows a kernel is allowed to leave unwritten start as NaN, so that any consumer
@@ -1125,12 +1140,19 @@ PRESPLIT_WS_X3 = not os.environ.get("RG_NO_PRESPLIT_WS")     # RG_NO_PRESPLIT_WS
 FUSE_BLOCK_256 = not os.environ.get("RG_NO_PA256")      # RG_NO_PA256=1: d_model 256 takes the unfused launches (A/B timing)
 
 
-def post_attn_supported(d, P, dff, dtype=None):
+def post_attn_supported(d, P, dff, dtype=None, M=None):
     """The fused post-attention block takes d_model == n_heads * 32 == 128 in every tier (csrc/fused.hip) and, in the bf16 tier,
-    d_model == 256 with d_ff a multiple of 256 (csrc/fused256.hip: BASELINE configs[4])."""
+    d_model == 256 with d_ff a multiple of 256 (csrc/fused256.hip: BASELINE configs[4]).  With M (tokens) given, the launcher's own
+    limits are mirrored: at d_model 256 the unfused weight-stationary launches take any M, so a shape rg_post_attn_fwd256
+    would refuse -- M * d_ff * 2 B >= 4 GiB (32-bit offsets), or a d_ff whose parameter block does not fit 160 KB of LDS beside the
+    activation tiles (+ the h1 tile of a saving launch) -- must fall back to them instead of raising RG_ERR_UNSUPPORTED mid-step."""
     if d == 128 and P == 128 and dff % 128 == 0 and dff > 0:
         return True
-    return bool(FUSE_BLOCK_256 and d == 256 and P == 256 and dff % 256 == 0 and dff > 0 and dtype == torch.bfloat16 and not SPLIT_OPERANDS)
+    if not (FUSE_BLOCK_256 and d == 256 and P == 256 and dff % 256 == 0 and dff > 0 and dtype == torch.bfloat16 and not SPLIT_OPERANDS):
+        return False
+    act = 64 * 256 * 2                                   # csrc/fused256.hip: TM2 * D2 bf16
+    smem = 4 * act + (8 * 256 + dff) * 4 + 2 * 64 * 8 * 4 + 64 * 4
+    return smem <= 160 * 1024 and (M is None or M * dff * 2 < (1 << 32))
 
 
 _LIVE = {}

@@ -628,7 +628,7 @@ WS_WIDE_X3 = not _os_env("RG_NO_WS_WIDE_X3")      # RG_NO_WS_WIDE_X3=1: the bf16
 
 
 def _fusable(x2, Wo, W1):
-    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0], x2.dtype) and not (x2.shape[1] == 256 and _split_resid())
+    return hip.post_attn_supported(x2.shape[1], Wo.shape[1], W1.shape[0], x2.dtype, M=x2.shape[0]) and not (x2.shape[1] == 256 and _split_resid())
 
 
 def _lo_in(x2, rows=None):

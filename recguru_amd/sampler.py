@@ -76,7 +76,7 @@ class DeviceLoader(object):
 
     def __init__(self, domain, batch_size, L_enc, L_dec, eos, n_neg, seed=0, shuffle=True, rank=0, world=1, drop_last=True):
         self.dom, self.bs, self.Le, self.Ld, self.eos, self.n_neg = domain, batch_size, L_enc, L_dec, eos, n_neg
-        self.users = torch.arange(rank, domain.n, world, device=domain.device)
+        self.users = torch.arange(rank, domain.n, world, device=domain.device)[:max(domain.n // world, 1 if world == 1 else 0)]   # equal shards (dist.shard_users)
         self.shuffle, self.seed, self.epoch, self.drop_last = shuffle, int(seed) * 1000003 + rank, 0, drop_last
         n = self.users.numel()
         self.nb = n // batch_size if drop_last else (n + batch_size - 1) // batch_size
@@ -109,7 +109,7 @@ class DeviceEvalLoader(object):
         self.test_dom = DeviceDomain([list(s) + [int(v)] for s, v in zip(seqs, val)], val, test, V, device,
                                      exclude_val=True)
         self.bs, self.Le, self.Ld, self.eos, self.C, self.seed = batch_size, L_enc, L_dec, eos, candidate_size, int(seed)
-        self.users = torch.arange(rank, len(seqs), world, device=device)
+        self.users = torch.arange(rank, len(seqs), world, device=device)     # (evaluation has no collective: every user is scored)
         self.nb = max(1, self.users.numel() // batch_size)
         self.epoch = 0
 

@@ -65,7 +65,8 @@ class TensorLoader(object):
     rank/world shard the users as rank::world (SURVEY.md 8e)."""
 
     def __init__(self, dom, batch_size, device=None, rank=0, world=1, drop_last=True):
-        self.t = {k: torch.as_tensor(v[rank::world]) for k, v in dom.items()}
+        from .dist import shard_users                    # equal shards: rank::world cut to n // world users (dist.shard_users)
+        self.t = {k: torch.as_tensor(v[shard_users(len(v), rank, world)]) for k, v in dom.items()}
         if device is not None:
             self.t = {k: v.to(device) for k, v in self.t.items()}
         self.bs = batch_size

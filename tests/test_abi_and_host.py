@@ -26,6 +26,15 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "librecguru_hip.so does not export %s" % name
     assert set(hip.SYMBOLS) == declared
     assert lib.rg_version() == 1
+    # ... and the other direction: the dynamic symbol table holds no rg_* entry point that the header does not declare (VERDICT r5
+    # item 7: rg_det_register_tu was exported by both libraries and declared nowhere; it is hidden now), in either library
+    import subprocess
+    for path in (build.LIB, build.LIB_DET):
+        if not os.path.exists(path):
+            continue
+        out = subprocess.run(["nm", "-D", "--defined-only", path], stdout=subprocess.PIPE, check=True).stdout.decode()
+        exported = set(ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("rg_") and " T " in ln)
+        assert exported == declared, (os.path.basename(path), sorted(exported ^ declared))
 
 
 def test_deterministic_library_exports_the_same_abi():

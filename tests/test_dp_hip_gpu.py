@@ -117,6 +117,54 @@ def test_dp2_hip_bench_shape(tier, tmp_path, capsys):
     assert _compare_grads(got, gD, gG, 1e-3 if tier == "bf16" else 1e-4, 1e-4 if tier == "bf16" else 2e-5) > 40
 
 
+@pytest.mark.parametrize("world,what,tier", [(4, "case1", "f32"), (8, "bench", "bf16"), (8, "bench", "f32")])
+def test_dp_hip_at_the_metrics_world_sizes(world, what, tier, tmp_path, capsys):
+    """SURVEY 8e asks for W in {2, 4, 8}; BASELINE.json's metric names 8.  A 1-GPU box holds 8 rank PROCESSES (gloo, all on GPU 0):
+    the golden case split 4 x 1 user, the bench shape (B = 16) split 8 x 2 users -- rank::8 sharding, the global mask count with
+    shards of very different live-position counts, the 1 / 8 pre-division of the W-loss and gradient penalty, begin_sync's
+    asynchronous exchange of the two 51 MB table gradients among 8 ranks and the flat bucket -- summed gradients equal the
+    single-process full batch's."""
+    from dp_worker import run_steps
+    out = os.path.join(str(tmp_path), "rank0.npz")
+    _run_ranks(["grads", what, out], world=world, extra_env={"RG_DP_TIER": tier}, timeout=1500)
+    got = dict(np.load(out))
+    os.environ["RG_DP_TIER"] = tier
+    try:
+        gD, gG, sc = run_steps(what if what == "bench" else load_case(what), 0, 1, None)
+    finally:
+        del os.environ["RG_DP_TIER"]
+        _reset_ops()
+    assert int(got["exchange_world"]) == world and got["exchange_backend"].item() == "gloo"
+    worst = []
+    for pre, ref in (("D.", gD), ("G.", gG)):
+        for k, g in ref.items():
+            if not any(s in k for s in NOISE):
+                worst.append((float(np.abs(got[pre + k] - g).max() / max(np.abs(g).max(), 1e-12)), pre + k))
+    worst.sort(reverse=True)
+    with capsys.disabled():
+        print("\n[DP x%d, %s, %s tier] worst gradient difference / max |gradient|: %s" % (
+            world, what, tier, ", ".join("%s %.2g" % (k, v) for v, k in worst[:4])))
+    bf = tier == "bf16"
+    assert _compare_grads(got, gD, gG, 1e-3 if bf else 1e-4, 1e-4 if bf else 2e-5) > 40
+
+
+def test_dp8_hip_loss_curve_equals_single_rank(tmp_path, capsys):
+    """The 20-step phase-1 + 3-iteration phase-2 curve of the loss-curve fixture (B = 16) with EIGHT ranks of two users each against
+    one rank, f32 tier, dropout 0 -- same bounds as the two-rank test below (and the same caveat about phase 2's branches)."""
+    from dp_worker import run_curve
+    out = os.path.join(str(tmp_path), "curve.npz")
+    _run_ranks(["curve", "curves1", out], world=8, timeout=1500)
+    got = dict(np.load(out))
+    p1, p2, keep = run_curve(load_case("curves1"), 0, 1, None)
+    _reset_ops()
+    with capsys.disabled():
+        print("\n[DP x8 vs 1 rank, f32 tier] phase-1 max rel diff %.3g | phase-2 max abs diff %s"
+              % (float(np.abs(got["p1"] / p1 - 1).max()), np.array2string(np.abs(got["p2"] - p2).max(0), precision=2)))
+    np.testing.assert_allclose(got["p1"], p1, rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(got["p2"][:, 3:], p2[:, 3:], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(got["p2"][:, :3], p2[:, :3], rtol=0, atol=3e-3)
+
+
 def test_dp2_hip_loss_curve_equals_single_rank(tmp_path, capsys):
     """"1 vs 2 ranks, same global batch, 20-step loss curve equal within fp32 tolerance (dropout 0)" -- 20
     steps of train_recon_x's body and 3 phase-2 iterations (15 critic updates + 3 generator updates) of the shipped
@@ -195,9 +243,13 @@ def test_rccl_group_of_one_rank(tmp_path, capsys):
     np.testing.assert_allclose(got["scalars"], sc, rtol=2e-3, atol=2e-3)       # one rank: its losses ARE the full batch's
 
 
-def _two_gpus():
+def _gpus():
     import torch
-    return torch.cuda.device_count() >= 2
+    return torch.cuda.device_count()
+
+
+def _two_gpus():
+    return _gpus() >= 2
 
 
 def test_dp2_rccl_matches_full_batch(tmp_path):
@@ -249,6 +301,25 @@ def test_bench_self_launch_two_ranks():
     assert ex["collectives_per_step"] >= 6 and ex["allreduce_bytes_per_step_per_rank"] >= 5 * 4 * n_d
     assert ex["allreduce_exposed_ms_per_step"] > 0
     assert line["tiers"]["bf16x3"]["value"] > 0 and line["tiers"]["f32"]["value"] > 0
+
+
+def test_bench_self_launch_eight_ranks():
+    """`python bench.py --gpus 8` -- the command the driver's scaling run issues -- on a 1-GPU box in its gloo-on-one-GPU form, B = 64
+    per rank: one JSON line, n_gpus = 8, 12 * 64 * 8 sequences per step, and the `exchange` record shows EIGHT ranks in the collective
+    with the step's 5 discriminator buckets + the generator's gradients (both 51 MB tables, at --items 100000) handed to all-reduce."""
+    env = {} if _gpus() >= 8 else {"RG_BENCH_SINGLE_DEVICE": "1", "RG_BENCH_BACKEND": "gloo"}
+    line = _bench(["--gpus", "8", "--batch", "64", "--items", "100000", "--steps", "2", "--warmup", "1", "--no_cpu_baseline",
+                   "--batches_per_domain", "1", "--tier_steps", "0", "--ae_steps", "0", "--full_length_steps", "0", "--host_only_steps", "0"],
+                  env, timeout=2400)
+    assert line["n_gpus"] == 8 and line["config"]["parallelism"] == "dp8" and line["value"] > 0
+    assert line["config"]["sequences_per_step"] == 12 * 64 * 8
+    ex = line["exchange"]
+    assert ex["collective_world"] == 8 and ex["backend"] == ("nccl" if _gpus() >= 8 else "gloo")
+    d, dis = 128, 5 * 128
+    n_d = (d * dis + dis) + (dis * 2 * dis + 2 * dis) + (2 * dis * dis + dis) + (dis + 1)
+    n_tables = 2 * 100002 * 128
+    assert ex["collectives_per_step"] >= 8 and ex["allreduce_bytes_per_step_per_rank"] >= 5 * 4 * n_d + 4 * n_tables      # 5 x 6.9 MB + >= 102 MB
+    assert all(np.isfinite(v) for v in line["config"]["last_step"].values())
 
 
 def test_bench_line_through_rccl_group_of_one():

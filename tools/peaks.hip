@@ -54,6 +54,67 @@ __global__ void __launch_bounds__(256) triad_kernel(const float4* __restrict__ b
   }
 }
 
+// ---- tuned streams (round 6): U float4 per lane in flight (block-contiguous chunks of U * 256 float4, every
+// wave instruction a full 1 KiB line run), optional nontemporal loads / stores, swept over workgroups per CU by the harness.  The best
+// of each family is the ceiling bench.py prices kernels against ("hbm_*_best").
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) copy_u_kernel(const f32x4* __restrict__ a, f32x4* __restrict__ b, size_t n) {
+  const size_t chunk = (size_t)U * 256;
+  for (size_t base = (size_t)blockIdx.x * chunk; base + chunk <= n; base += (size_t)gridDim.x * chunk) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(a + base + u * 256 + threadIdx.x) : a[base + u * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) __builtin_nontemporal_store(v[u], b + base + u * 256 + threadIdx.x);
+      else b[base + u * 256 + threadIdx.x] = v[u];
+    }
+  }
+}
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) read_u_kernel(const f32x4* __restrict__ a, float* __restrict__ out, size_t n) {
+  const size_t chunk = (size_t)U * 256;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (size_t base = (size_t)blockIdx.x * chunk; base + chunk <= n; base += (size_t)gridDim.x * chunk) {
+    f32x4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) v[u] = NT ? __builtin_nontemporal_load(a + base + u * 256 + threadIdx.x) : a[base + u * 256 + threadIdx.x];
+#pragma unroll
+    for (int u = 0; u < U; ++u) s += v[u];
+  }
+  if (s[0] + s[1] + s[2] + s[3] == 12345.678f) out[0] = s[0];
+}
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) write_u_kernel(f32x4* __restrict__ b, size_t n, float x) {
+  const size_t chunk = (size_t)U * 256;
+  const f32x4 v = {x, x, x, x};
+  for (size_t base = (size_t)blockIdx.x * chunk; base + chunk <= n; base += (size_t)gridDim.x * chunk) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NT) __builtin_nontemporal_store(v, b + base + u * 256 + threadIdx.x);
+      else b[base + u * 256 + threadIdx.x] = v;
+    }
+  }
+}
+template <int U, bool NT>
+__global__ void __launch_bounds__(256) triad_u_kernel(const f32x4* __restrict__ b, const f32x4* __restrict__ c, f32x4* __restrict__ a, size_t n, float s) {
+  const size_t chunk = (size_t)U * 256;
+  for (size_t base = (size_t)blockIdx.x * chunk; base + chunk <= n; base += (size_t)gridDim.x * chunk) {
+    f32x4 x[U], y[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      x[u] = NT ? __builtin_nontemporal_load(b + base + u * 256 + threadIdx.x) : b[base + u * 256 + threadIdx.x];
+      y[u] = NT ? __builtin_nontemporal_load(c + base + u * 256 + threadIdx.x) : c[base + u * 256 + threadIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const f32x4 r = x[u] + s * y[u];
+      if (NT) __builtin_nontemporal_store(r, a + base + u * 256 + threadIdx.x);
+      else a[base + u * 256 + threadIdx.x] = r;
+    }
+  }
+}
+
 // ---- random row gather ---------------------------------------------------------------------------------------------------
 // A row of RB bytes is RB / 16 lanes x 16 B; a wave instruction therefore fetches 64 * 16 / RB rows.  Every lane group keeps U
 // rows in flight.  COPY: the row is written to out[t] (the embedding kernel's shape); otherwise it is summed in registers.
@@ -148,6 +209,44 @@ __global__ void __launch_bounds__(256) mfma_valu_kernel(float* __restrict__ out,
   if (s == 12345.678f) out[threadIdx.x] = s;
 }
 
+// (round 6; MI355X_MICROARCH.md "price of one filler beside MFMAs" and "vector-instruction ISSUE cost")
+// FILL: 0 v_fma_f32, 1 v_pk_fma_f32, 2 v_pk_mul_f32, 3 v_pk_add_f32, 4 v_exp_f32, 5 v_cvt_pk_bf16_f32;  BIG: v_mfma_f32_32x32x16_bf16
+// (twice the FLOPs of a 16x16x32 per instruction) instead of v_mfma_f32_16x16x32_bf16.  4 independent accumulators either way.
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float pf2;
+template <int NV, int FILL, bool BIG>
+__global__ void __launch_bounds__(256) coexec_kernel(float* __restrict__ out, int iters) {
+  bf16x8_t a, b;
+  for (int j = 0; j < 8; ++j) { a[j] = (__bf16)(0.001f * (threadIdx.x & 7)); b[j] = (__bf16)(0.002f * (j + 1)); }
+  f32x4 c[4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+  f32x16 d[4];
+  for (int m = 0; m < 4; ++m) for (int j = 0; j < 16; ++j) d[m][j] = 0.f;
+  float x[8];
+  pf2 xp[8];
+  unsigned int cv[8];
+  for (int j = 0; j < 8; ++j) { x[j] = 0.5f + 0.001f * (threadIdx.x & 31) + 0.01f * j; xp[j] = (pf2){x[j], x[j] + 0.1f}; cv[j] = 0; }
+  const pf2 kp = {0.999f, 0.999f};
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (BIG) asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(d[m]) : "v"(a), "v"(b));
+      else asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c[m]) : "v"(a), "v"(b));
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (FILL == 0) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(x[j & 7]) : "v"(0.999f));
+        if (FILL == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(xp[j & 7]) : "v"(kp));
+        if (FILL == 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(xp[j & 7]) : "v"(kp));
+        if (FILL == 3) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(xp[j & 7]) : "v"(kp));
+        if (FILL == 4) asm volatile("v_exp_f32 %0, %0" : "+v"(x[j & 7]));
+        if (FILL == 5) asm volatile("v_cvt_pk_bf16_f32 %0, %1, %1" : "=v"(cv[j & 7]) : "v"(x[j & 7]));
+      }
+    }
+  }
+  float s = c[0][0] + c[1][0] + c[2][0] + c[3][0] + d[0][0] + d[1][0] + d[2][0] + d[3][0];
+  for (int j = 0; j < 8; ++j) s += x[j] + xp[j].x + xp[j].y + __uint_as_float(cv[j]);
+  if (s == 12345.678f) out[threadIdx.x] = s;
+}
+
 // ---- harness -------------------------------------------------------------------------------------------------------------
 struct Res { std::string name; double value; std::string unit; std::string note; };
 static std::vector<Res> results;
@@ -226,6 +325,39 @@ int main(int argc, char** argv) {
   report("hbm_write_only", 1.0 * NB / ms * 1e-6, "GB/s", "float4 write-only stream, 2 GiB");
   ms = time_ms([&] { triad_kernel<<<grid, 256>>>(b, c, a, n4, 0.5f); });
   report("hbm_triad", 3.0 * NB / ms * 1e-6, "GB/s", "a = b + s c over 2 GiB buffers; two reads + one write");
+  // ---- tuned streams: U in flight x workgroups per CU x nontemporal; the best of each family is the ceiling
+  {
+    const f32x4* av = reinterpret_cast<const f32x4*>(a);
+    const f32x4* cvp = reinterpret_cast<const f32x4*>(c);
+    f32x4* bv = reinterpret_cast<f32x4*>(b);
+    f32x4* aw = reinterpret_cast<f32x4*>(a);
+    double best[4] = {0, 0, 0, 0};
+    char bestcfg[4][64] = {"", "", "", ""};
+    auto upd = [&](int k, double gbs, int U, int nt, int wpc) {
+      if (gbs > best[k]) { best[k] = gbs; snprintf(bestcfg[k], 64, "U=%d %s %d workgroups per CU", U, nt ? "nontemporal" : "plain", wpc); }
+    };
+#define SWEEP(U)                                                                                                          \
+    for (int wpc : {2, 4, 8, 16, 32}) {                                                                                     \
+      const int g = CUS * wpc;                                                                                              \
+      ms = time_ms([&] { copy_u_kernel<U, false><<<g, 256>>>(av, bv, n4); }, 5);   upd(0, 2.0 * NB / ms * 1e-6, U, 0, wpc);  \
+      ms = time_ms([&] { copy_u_kernel<U, true><<<g, 256>>>(av, bv, n4); }, 5);    upd(0, 2.0 * NB / ms * 1e-6, U, 1, wpc);  \
+      ms = time_ms([&] { read_u_kernel<U, false><<<g, 256>>>(av, sink, n4); }, 5); upd(1, 1.0 * NB / ms * 1e-6, U, 0, wpc);  \
+      ms = time_ms([&] { read_u_kernel<U, true><<<g, 256>>>(av, sink, n4); }, 5);  upd(1, 1.0 * NB / ms * 1e-6, U, 1, wpc);  \
+      ms = time_ms([&] { write_u_kernel<U, false><<<g, 256>>>(bv, n4, 1.f); }, 5); upd(2, 1.0 * NB / ms * 1e-6, U, 0, wpc);  \
+      ms = time_ms([&] { write_u_kernel<U, true><<<g, 256>>>(bv, n4, 1.f); }, 5);  upd(2, 1.0 * NB / ms * 1e-6, U, 1, wpc);  \
+      ms = time_ms([&] { triad_u_kernel<U, false><<<g, 256>>>(bv, cvp, aw, n4, 0.5f); }, 5); upd(3, 3.0 * NB / ms * 1e-6, U, 0, wpc); \
+      ms = time_ms([&] { triad_u_kernel<U, true><<<g, 256>>>(bv, cvp, aw, n4, 0.5f); }, 5);  upd(3, 3.0 * NB / ms * 1e-6, U, 1, wpc); \
+    }
+    SWEEP(1) SWEEP(2) SWEEP(4) SWEEP(8)
+#undef SWEEP
+    CK(hipMemset(a, 0, NB));
+    const char* nm[4] = {"hbm_copy_best", "hbm_read_best", "hbm_write_best", "hbm_triad_best"};
+    for (int k = 0; k < 4; ++k) {
+      char note[200];
+      snprintf(note, sizeof note, "best of U in {1,2,4,8} float4 in flight per lane x {2..32} workgroups per CU x plain / nontemporal: %s", bestcfg[k]);
+      report(nm[k], best[k], "GB/s", note);
+    }
+  }
   // ---- random rows of a 1 GiB table (buffer a); ids in c, outputs in b
   const int n = 819200 * 2;                       // two bench batches of B * L = 4096 * 200 positions
   std::vector<int> h(n);
@@ -294,6 +426,35 @@ int main(int argc, char** argv) {
       snprintf(note, sizeof note, "time of (1 MFMA 16x16x32 bf16 + N independent v_fma_f32 of the same wave) relative to the MFMA alone: N = 2: %.2f, 4: %.2f, 8: %.2f",
                t[1] / t[0], t[2] / t[0], t[3] / t[0]);
       report(nm, (double)CUS * wps * 4 * iters * 4.0 * (2.0 * 16 * 16 * 32) / t[0] * 1e-9, "TFLOP/s", note);
+    }
+  }
+  {
+    // per MFMA gap: time relative to the bare MFMA loop of the same shape.  A pk filler carries two lane results: compare N pk with 2 N fma.
+    const int iters = 20000;
+    for (int wps : {1, 2}) {
+      for (int big = 0; big < 2; ++big) {
+        auto run = [&](auto kern) { return time_ms([&] { kern<<<CUS * wps, 256>>>(sink, iters); }, 5); };
+        double t0, f2, f4, f8, p1, p2, p4, m2, m4, a2, a4, e1, e2, cv2, cv4;
+        if (big) {
+          t0 = run(coexec_kernel<0, 0, true>); f2 = run(coexec_kernel<2, 0, true>); f4 = run(coexec_kernel<4, 0, true>); f8 = run(coexec_kernel<8, 0, true>);
+          p1 = run(coexec_kernel<1, 1, true>); p2 = run(coexec_kernel<2, 1, true>); p4 = run(coexec_kernel<4, 1, true>);
+          m2 = run(coexec_kernel<2, 2, true>); m4 = run(coexec_kernel<4, 2, true>); a2 = run(coexec_kernel<2, 3, true>); a4 = run(coexec_kernel<4, 3, true>);
+          e1 = run(coexec_kernel<1, 4, true>); e2 = run(coexec_kernel<2, 4, true>); cv2 = run(coexec_kernel<2, 5, true>); cv4 = run(coexec_kernel<4, 5, true>);
+        } else {
+          t0 = run(coexec_kernel<0, 0, false>); f2 = run(coexec_kernel<2, 0, false>); f4 = run(coexec_kernel<4, 0, false>); f8 = run(coexec_kernel<8, 0, false>);
+          p1 = run(coexec_kernel<1, 1, false>); p2 = run(coexec_kernel<2, 1, false>); p4 = run(coexec_kernel<4, 1, false>);
+          m2 = run(coexec_kernel<2, 2, false>); m4 = run(coexec_kernel<4, 2, false>); a2 = run(coexec_kernel<2, 3, false>); a4 = run(coexec_kernel<4, 3, false>);
+          e1 = run(coexec_kernel<1, 4, false>); e2 = run(coexec_kernel<2, 4, false>); cv2 = run(coexec_kernel<2, 5, false>); cv4 = run(coexec_kernel<4, 5, false>);
+        }
+        char nm[64], note[400];
+        snprintf(nm, sizeof nm, "coexec_%s_%dwave_per_simd", big ? "32x32x16" : "16x16x32", wps);
+        snprintf(note, sizeof note,
+                 "gap time / bare MFMA: v_fma_f32 x2 %.2f x4 %.2f x8 %.2f | v_pk_fma_f32 x1 %.2f x2 %.2f x4 %.2f | v_pk_mul_f32 x2 %.2f x4 %.2f | "
+                 "v_pk_add_f32 x2 %.2f x4 %.2f | v_exp_f32 x1 %.2f x2 %.2f | v_cvt_pk_bf16_f32 x2 %.2f x4 %.2f",
+                 f2 / t0, f4 / t0, f8 / t0, p1 / t0, p2 / t0, p4 / t0, m2 / t0, m4 / t0, a2 / t0, a4 / t0, e1 / t0, e2 / t0, cv2 / t0, cv4 / t0);
+        const double fl = big ? 2.0 * 32 * 32 * 16 : 2.0 * 16 * 16 * 32;
+        report(nm, (double)CUS * wps * 4 * iters * 4.0 * fl / t0 * 1e-9, "TFLOP/s", note);
+      }
     }
   }
   printf("{");
