@@ -217,6 +217,11 @@ int rg_attn_bwd(const rg_attn_bwd_args* args /* host */, int dtype, void* stream
  * dE[rows,d]; skip_row (e.g. padding_idx 0 of AutoEnc4Rec.py:153) receives nothing (-1 = none). */
 int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out,
                     long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
+/* The same, told how many rows the table has (0 = unknown).  Results are identical; the launcher uses it for its STORE POLICY only: output
+ * rows leave by nontemporal stores when table + output exceed the 256 MB Infinity Cache (the 1 GiB config-5 table: 0.57 -> 0.68 of 8 TB/s),
+ * by ordinary stores otherwise.  rg_embed_pe_fwd decides from the output size alone. */
+int rg_embed_pe_fwd_rows(const void* table, long long table_rows, const float* pe, const int64_t* ids, const float* mask, void* out,
+                         long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream);
 /* The same with a second, bf16 copy of the output rows, out2 [ntok,d] (NULL: none) -- the "mixed" tier (f32 forward tensors, bf16
  * backward operands: DESIGN.md 2) keeps the layer input twice, f32 for the forward and bf16 as the X operand of the first layer's
  * weight-gradient product.  out2 needs d in {128, 256}. */

@@ -14,7 +14,7 @@ import sys
 
 import torch
 
-from . import ops
+from . import ops, profiling
 from .optim import Adam
 from .training import _extend_result, _new_result, plot
 
@@ -110,6 +110,8 @@ def train(model_train, opt, steps, data, param_config, device_i, neg_sample=True
         for data_batch in data[0]:
             enc_in, dec_in, dec_out, n_items, _, _, bs, sl = get_next_batch(data_batch, device_i)
             mask = (dec_in != param_config.pad_index).view(-1).to(torch.float32)
+            prof_phase = "auto_recon_step" if loss_type == "s_soft" else "auto_bpr_step"
+            profiling.current().begin(prof_phase)                    # --profile <dir> (no-op otherwise)
             opt.zero_grad()
             if loss_type == "s_soft":
                 loss = loss_ae(model_train, enc_in, dec_in, dec_out, n_items, neg_sample, bs, sl, param_config, mask)
@@ -123,6 +125,7 @@ def train(model_train, opt, steps, data, param_config, device_i, neg_sample=True
                 opt.step()
             else:
                 opt.step_and_update_lr()
+            profiling.current().end(prof_phase)
             tot = loss.detach() if tot is None else tot + loss.detach()
             n_batch += 1
             step += 1

@@ -1287,7 +1287,7 @@ extern "C" int rg_cross_rows(const float* s, const float* oh, const float* bo, f
 }
 
 static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t* ids, const float* mask, void* out, void* out2,
-                               long long ntok, int L, int d, const DropCfg& drop, int dtype, hipStream_t s) {
+                               long long ntok, int L, int d, const DropCfg& drop, int dtype, hipStream_t s, long long table_rows = 0) {
   // The row form is selected for the two-output call and by RG_EMBED_ROWS=1 (A/B).  Measured (round 5, bench shape, 56 % live
   // positions): 41 vs 49 us per launch when the same launch is repeated (ids / mask / table hot), 78.0 vs 77.0 us INSIDE the step --
   // both kernels sit at the memory system's rate for this read / write mix (0.55 of 8 TB/s = 0.89 of the box's measured copy rate),
@@ -1295,7 +1295,13 @@ static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t
   static const int rows_form = getenv("RG_EMBED_ROWS") ? atoi(getenv("RG_EMBED_ROWS")) : 0;
   // RG_EMBED_FORM: 2 = position-major (default since round 6), 0 = the element-per-thread kernel; RG_EMBED_NT: 1 = nontemporal stores
   static const int form = getenv("RG_EMBED_FORM") ? atoi(getenv("RG_EMBED_FORM")) : 2;
-  static const int use_nt = getenv("RG_EMBED_NT") ? atoi(getenv("RG_EMBED_NT")) : 1;
+  // Store policy (measured, profiles/r06/ab/embed_forms.txt): with the bench table (25.6 MB) and its 210 MB of output rows the Infinity Cache
+  // (256 MB) absorbs ordinary stores -- 68.5 us per launch in the step against 73.0 with nontemporal ones --, with the 1 GiB config-5 table it
+  // cannot, and ordinary stores cost the gather its cache: 92.8 -> 78.3 us (uniform ids), 63.4 -> 48.6 (Zipf, 44 % padded).  So: nontemporal
+  // stores when table + output rows exceed the Infinity Cache (table_rows = 0: unknown, the output alone decides); RG_EMBED_NT=0/1 forces.
+  static const int nt_env = getenv("RG_EMBED_NT") ? atoi(getenv("RG_EMBED_NT")) : -1;
+  const long long esz = dtype == RG_BF16 ? 2 : 4;
+  const int use_nt = nt_env >= 0 ? nt_env : ((table_rows + ntok) * d * esz > (256ll << 20) ? 1 : 0);
   if (form == 2 && !rows_form && !out2 && (d == 128 || d == 256) && L > 0 && ntok % L == 0 && ntok < (1ll << 31) / d) {
     // waves = position blocks x sequence ranges; the ranges sized so that the launch is ~ 8 workgroups (32 waves) per CU, every wave
     // with the same number of sequences
@@ -1340,6 +1346,15 @@ extern "C" int rg_embed_pe_fwd(const void* table, const float* pe, const int64_t
   if (ntok <= 0) return 0;
   if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
   return embed_pe_fwd_launch(table, pe, ids, mask, out, nullptr, ntok, L, d, drop, dtype, (hipStream_t)stream);
+}
+
+// ... told the number of table rows (the store policy of the launcher: see embed_pe_fwd_launch)
+extern "C" int rg_embed_pe_fwd_rows(const void* table, long long table_rows, const float* pe, const int64_t* ids, const float* mask, void* out,
+                                    long long ntok, int L, int d, float drop_p, unsigned long long seed, int dtype, void* stream) {
+  if (ntok <= 0) return 0;
+  if (d & 7) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "embed_pe_fwd: d must be a multiple of 8");
+  if (table_rows < 0) return rg_set_error_msg(RG_ERR_INVALID, "embed_pe_fwd_rows: table_rows < 0");
+  return embed_pe_fwd_launch(table, pe, ids, mask, out, nullptr, ntok, L, d, make_drop(drop_p, seed), dtype, (hipStream_t)stream, table_rows);
 }
 
 // ... with a second, bf16 copy of the rows (rg_embed_pe_fwd2: the mixed tier's operand copy for the bf16 backward; out2 may be NULL)

@@ -250,7 +250,12 @@ __global__ __launch_bounds__(256, 2) void gemm_ws_kernel(rg_gemm_nt_args a) {
                 if (a.epilogue == RG_EPI_NONE) {
                   Frag<T> raw;
                   unstage8(raw, Cs + r * WS_LD + c8);
+#ifdef RG_ABL_WS_NT      // timing experiment (tools/ab_round6.sh x3nt): the plain-epilogue output rows of the f32-storage tiers by nontemporal stores
+                  if constexpr (sizeof(T) == 4) frag_store_nt(C + off, raw);
+                  else *reinterpret_cast<Frag<T>*>(C + off) = raw;
+#else
                   *reinterpret_cast<Frag<T>*>(C + off) = raw;
+#endif
                 } else if (a.epilogue == RG_EPI_DROP_GELU) {
                   // h1 = dropout(l1) as the backward reads it back, and the activated operand of the second product, from
                   // the value AS STORED (rounded to T): what rg_dropout_gelu does in a pass of its own

@@ -85,7 +85,7 @@ class AttnOutBwdArgs(ctypes.Structure):
 
 # every symbol include/recguru_hip.h declares (checked by tests/test_abi.py)
 SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_fwd", "rg_attn_bwd",
-           "rg_embed_pe_fwd", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
+           "rg_embed_pe_fwd", "rg_embed_pe_fwd_rows", "rg_embed_scatter_bwd", "rg_ln_bwd", "rg_bcast_add_ln", "rg_seq_sum", "rg_colsum",
            "rg_outer_posmask", "rg_interpolate", "rg_gp_penalty", "rg_sum", "rg_adam", "rg_cast",
            "rg_item_loss_fwd", "rg_item_loss_bwd", "rg_post_attn_fwd",
            "rg_attn_lastq_fwd", "rg_attn_lastq_bwd",
@@ -572,8 +572,8 @@ def embed_pe_fwd(table, pe, ids, mask, L, drop_p=0.0, seed=0, mirror=False):
         _check(lib().rg_embed_pe_fwd2(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), _vp(out2), c_ll(ntok), L, d, c_f(drop_p),
                                       c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd2")
         return out, out2
-    _check(lib().rg_embed_pe_fwd(_vp(table), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, c_f(drop_p),
-                                 c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd")
+    _check(lib().rg_embed_pe_fwd_rows(_vp(table), c_ll(table.shape[0]), _vp(pe), _vp(ids), _vp(mask), _vp(out), c_ll(ntok), L, d, c_f(drop_p),
+                                      c_u64(seed), dt_of(table), _stream()), "rg_embed_pe_fwd_rows")
     return out
 
 

@@ -17,7 +17,7 @@ import sys
 
 import torch
 
-from . import ops
+from . import ops, profiling
 from .optim import Adam
 
 LAMBDA = .1         # gan_training.py:21
@@ -219,8 +219,9 @@ def train_recon_x(model_train, opt, steps, data, param, device, neg_sample=True,
     for i in range(steps):
         enc_a, din_a, dout_a, n_a, it_a = load_batch_data(it_a, data[0], device)
         enc_b, din_b, dout_b, n_b, it_b = load_batch_data(it_b, data[1], device)
-        loss_a, loss_b = recon_step(model_train, opt, (enc_a, din_a, dout_a, n_a), (enc_b, din_b, dout_b, n_b), param,
-                                    device, dp, params, neg_sample, loss_type, opt_type)
+        with profiling.current().step("phase1_recon" if loss_type == "s_soft" else "phase1_bpr"):
+            loss_a, loss_b = recon_step(model_train, opt, (enc_a, din_a, dout_a, n_a), (enc_b, din_b, dout_b, n_b), param,
+                                        device, dp, params, neg_sample, loss_type, opt_type)
         losses.append((loss_a, loss_b))
         if log_every and i % log_every == log_every - 1:
             la, lb = float(loss_a), float(loss_b)
@@ -499,12 +500,16 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
     rec_iter = _Cycler(gan_loader[0] if domain == "a" else gan_loader[1])       # :377-380
     history = History()
     history.result = result
+    prof = profiling.current()                                                  # --profile <dir> of the entry scripts (no-op otherwise)
     for iteration in range(int(iterations * 1.2)):
+        phase = "phase2_iteration" if iteration < int(iterations * 0.6) else "phase3_step"
+        prof.begin(phase)
         if iteration < int(iterations * 0.6):                                   # phase 2
             for p in netD.parameters():
                 p.requires_grad = True
             batches = [(a_iter.next(device)[0], b_iter.next(device)[0]) for _ in range(CRITIC_ITERS)]
-            D_cost, Wasserstein_D = critic_phase(netG, netD, batches, opt_d, param, device, dp)
+            # (a profiled critic phase runs on one stream: a HIP-event pair must bracket its kernel alone)
+            D_cost, Wasserstein_D = critic_phase(netG, netD, batches, opt_d, param, device, dp, overlap=not (prof.enabled and prof.active))
             ba = a_iter.next(device)
             bb = b_iter.next(device)
             pair = None
@@ -543,6 +548,7 @@ def train_gan_all(netG, netD, gan_loader, opt_d, opt_g, device, param, iteration
             opt_final_rec.step()
             plot.plot(param.result_path + "/tuning_recommendation_loss", loss_recommend.detach())
             history.phase3.append((loss_recommend.detach(), loss_recon_rec.detach()))
+        prof.end(phase)
         if iteration > int(iterations * 0.8) and iteration % 30 == 29 and (evaluate is not None or test_loaders is not None):
             netG.eval()                          # gan_training.py:570-580
             if evaluate is not None:
@@ -577,11 +583,12 @@ def recommendation_tune(model, rec_loader, test_loader, steps, param, device, do
         restart = rec_loader[1] if (domain == "b" and i > int(steps / 2)) else rec_loader[0]
         enc_in, dec_in, dec_out, n_items, _, _, bs, sl = it.next(device, restart=restart)
         mask = get_pad_mask(dec_in, param.pad_index, device)
-        opt.zero_grad()
-        loss = loss_bpr_func(model, enc_in, dec_in, dec_out, n_items, mask, domain, param)
-        loss.backward()
-        dp.sync_grads(params)
-        opt.step()
+        with profiling.current().step("recommendation_tune_step"):
+            opt.zero_grad()
+            loss = loss_bpr_func(model, enc_in, dec_in, dec_out, n_items, mask, domain, param)
+            loss.backward()
+            dp.sync_grads(params)
+            opt.step()
         losses.append(loss.detach())
         if i % param.eval_step == (param.eval_step - 1):
             if i > param.eval_step * 10:

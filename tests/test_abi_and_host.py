@@ -338,3 +338,37 @@ def test_built_library_passes_the_isa_screen():
     assert info["flagged_join_blocks"] == [] and info["packed_f32_high_half_selects"] == [] and "clang" in " ".join(info["hipcc"])
     assert info["spill_in_front_of_exec_restore_warnings"] == 0 and not info.get("screen_bypassed")
     assert info["library_sha256"] == hashlib.sha256(open(hip.LIB_PATH, "rb").read()).hexdigest()
+
+
+def test_step_profiler_phase_logic(tmp_path, monkeypatch):
+    """recguru_amd.profiling.StepProfiler (--profile of the entry scripts): `skip` untimed steps, `steps` profiled ones per phase, one
+    phase at a time, a phase that ends early is written with the steps it got; the launch wrappers are the GPU's business and faked here."""
+    import json
+    from recguru_amd import hip, profiling
+    calls = []
+
+    class FakeProf(object):
+        def summary(self):
+            return {"k_kernel": {"launches": 6, "ms": 3.0, "flops": 6e9, "bytes": 3e9, "flops_exec": 6e9, "bytes_exec": 3e9}}
+    monkeypatch.setattr(hip, "start_profile", lambda: calls.append("start"))
+    monkeypatch.setattr(hip, "stop_profile", lambda: (calls.append("stop"), FakeProf())[1])
+    prof = profiling.install(profiling.StepProfiler(str(tmp_path), steps=3, skip=2, rank=0))
+    try:
+        for _ in range(4):                                   # phase A: 2 untimed + 2 of its 3 -- then phase B starts
+            with profiling.current().step("A"):
+                pass
+        assert calls == ["start"] and prof.active == "A"
+        for _ in range(7):
+            prof.begin("B")
+            prof.end("B")
+        assert calls == ["start", "stop", "start", "stop"] and prof.active is None
+        with prof.step("A"):                                 # a finished phase is not profiled again
+            pass
+        assert len(calls) == 4
+        a = json.load(open(tmp_path / "kernels_A.json"))
+        b = json.load(open(tmp_path / "kernels_B.json"))
+        assert a["steps"] == 2 and b["steps"] == 3 and b["kernels"]["k_kernel"]["ms"] == 1.0
+        assert "k_kernel" in open(tmp_path / "kernels_B.txt").read()
+    finally:
+        profiling.install(None)
+    assert not profiling.current().enabled

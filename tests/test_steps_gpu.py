@@ -10,6 +10,7 @@ train_recon_x / train_gan_all / recommendation_tune / main_2, the two entry scri
 Tolerances.  f32 tier: the north-star rtol=1e-3 / atol=1e-5 on forward outputs.  bf16 tier: operands carry 8
 significant bits; its bounds are set at <= 2x the drift this file prints (measured on an MI355X, see the constants).
 """
+import json
 import os
 import pickle
 import subprocess
@@ -442,7 +443,19 @@ def test_train_gan_entry_point(tmp_path):
     res = str(tmp_path)
     out = _run(["train_gan.py", "--cross", "True", "--synthetic", "256", "--seq_len", "32", "--d_model", "128", "--n_head", "4",
                 "--batch_size", "64", "--batch_size_val", "64", "--vocab_size_a", "500", "--vocab_size_b", "400",
-                "--n_negs", "5", "--phase1_steps", "3", "--steps_tune", "35", "--result_path", res])
+                "--n_negs", "5", "--phase1_steps", "3", "--steps_tune", "35", "--result_path", res,
+                "--profile", os.path.join(res, "prof"), "--profile_steps", "2"])
+    # --profile: a per-kernel table per phase -- phase 1 has only 3 steps (2 untimed + 1), phases 2 / 3 their 2 profiled ones
+    prof = os.path.join(res, "prof")
+    assert sorted(os.listdir(prof)) == sorted("kernels_%s.%s" % (ph, ext) for ph in ("phase1_recon", "phase2_iteration", "phase3_step")
+                                                for ext in ("json", "txt"))
+    with open(os.path.join(prof, "kernels_phase2_iteration.json")) as f:
+        pj = json.load(f)
+    assert pj["steps"] == 2 and any(k.startswith("post_attn_fwd_kernel") for k in pj["kernels"]) and any(k.startswith("disc_rows") for k in pj["kernels"])
+    assert all(v["ms"] > 0 and v["launches"] > 0 for v in pj["kernels"].values())
+    with open(os.path.join(prof, "kernels_phase1_recon.json")) as f:
+        assert json.load(f)["steps"] == 1
+    os.rename(prof, os.path.join(os.path.dirname(res), "prof_" + os.path.basename(res)))      # (keep `res` to its one result directory)
     assert "Reconstruction pre-training (Phase 1)" in out and "phase 2 and phase 3" in out
     assert "final ranking evaluation" in out and "last phase-2 iteration" in out
     sub = [d for d in os.listdir(res) if os.path.isdir(os.path.join(res, d))]

@@ -55,4 +55,30 @@ embed2)
   RG_EMBED_FORM=0 ab_bench form0_b ""; RG_EMBED_FORM=2 RG_EMBED_NT=1 ab_bench form2_nt_b ""
   timeout 1500 python -m pytest tests/test_kernels_gpu.py tests/test_parity_gpu.py tests/test_dropout_gpu.py tests/test_determinism_gpu.py -q -x -p no:cacheprovider > $O/tests.log 2>&1; tail -3 $O/tests.log
   ;;
+shape)
+  # the FFN structure of the fused block with both MFMA shapes (tools/ffn_shape_probe.hip); the embedding launcher's store policy
+  tools/ffn_shape_probe_bin > $O/ffn_shape_probe.txt 2>&1; cat $O/ffn_shape_probe.txt | cut -c1-200
+  python tools/kb_embed_c5.py 2>&1 | grep embed_pe | cut -c1-200 | tee $O/kb_embed_c5_auto_policy.txt
+  ab_bench auto ""
+  RG_EMBED_NT=0 ab_bench x3_nt0 "" --dtype bf16x3 --steps 6 --warmup 2; RG_EMBED_NT=1 ab_bench x3_nt1 "" --dtype bf16x3 --steps 6 --warmup 2
+  QUICK="--no_cpu_baseline --tier_steps 0 --host_only_steps 0 --ae_steps 0 --full_length_steps 0 --steps 10 --warmup 3 --config5_steps 2"
+  RG_EMBED_FORM=0 ab_bench c5_form0 ""; ab_bench c5_auto ""
+  python - $O <<'PY'
+import json, sys
+for n in ("c5_form0", "c5_auto"):
+    try:
+        j = json.loads(open("%s/bench_%s.json" % (sys.argv[1], n)).read().strip().splitlines()[-1])
+        c = j["config5"]
+        print(n, "config5 ms/step", c.get("ms_per_step"), {k: v for k, v in c.get("kernels_ms_per_step", {}).items() if "embed_pe" in k})
+    except Exception as e:
+        print(n, "FAILED", e)
+PY
+  timeout 2400 python -m pytest tests/test_steps_gpu.py tests/test_det_gpu.py -q -x -p no:cacheprovider -k "entry_point or det" > $O/tests.log 2>&1; tail -5 $O/tests.log | cut -c1-300
+  ;;
+x3nt)
+  # nontemporal stores for the plain-epilogue outputs of the weight-stationary GEMM in the f32-storage tiers (variant library v_wsnt.so)
+  V=tools/variants/v_wsnt.so
+  ab_bench x3_shipped_1 "" --dtype bf16x3 --steps 6 --warmup 2; ab_bench x3_wsnt_1 $V --dtype bf16x3 --steps 6 --warmup 2
+  ab_bench x3_shipped_2 "" --dtype bf16x3 --steps 6 --warmup 2; ab_bench x3_wsnt_2 $V --dtype bf16x3 --steps 6 --warmup 2
+  ;;
 esac

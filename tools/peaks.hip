@@ -350,6 +350,23 @@ int main(int argc, char** argv) {
     }
     SWEEP(1) SWEEP(2) SWEEP(4) SWEEP(8)
 #undef SWEEP
+    // the same copy with source + destination INSIDE the 256 MiB Infinity Cache (2 x 96 MiB, repeated): the ceiling of a kernel whose inputs were
+    // written by the launch before it (in the step most activations are: a consumer follows its producer immediately)
+    {
+      const size_t n96 = ((size_t)96 << 20) / 16;
+      double mb = 0;
+      char cfg[64] = "";
+      for (int wpc : {8, 16, 32})
+        for (int nt = 0; nt < 2; ++nt) {
+          auto go = [&] { for (int r = 0; r < 4; ++r) { if (nt) copy_u_kernel<4, true><<<CUS * wpc, 256>>>(av, bv, n96); else copy_u_kernel<4, false><<<CUS * wpc, 256>>>(av, bv, n96); } };
+          ms = time_ms(go, 5);
+          const double gbs = 4 * 2.0 * n96 * 16 / ms * 1e-6;
+          if (gbs > mb) { mb = gbs; snprintf(cfg, sizeof cfg, "U=4 %s %d workgroups per CU", nt ? "nontemporal" : "plain", wpc); }
+        }
+      char note[200];
+      snprintf(note, sizeof note, "float4 copy of 96 MiB to 96 MiB, four times back to back (source and destination stay in the 256 MiB Infinity Cache): %s", cfg);
+      report("mall_copy_best", mb, "GB/s", note);
+    }
     CK(hipMemset(a, 0, NB));
     const char* nm[4] = {"hbm_copy_best", "hbm_read_best", "hbm_write_best", "hbm_triad_best"};
     for (int k = 0; k < 4; ++k) {

@@ -42,6 +42,10 @@ def parse():
     p.add_argument("--dropout", type=float, default=None)
     p.add_argument("--data_path", type=str, default=None)
     p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16")
+    p.add_argument("--profile", type=str, default=None, metavar="DIR",
+                   help="write a per-kernel table (HIP-event time, launches, TFLOP/s, GB/s per step) of --profile_steps steps of every "
+                        "training phase to DIR/kernels_<phase>.txt/.json, and mark every step with a roctx range for rocprofv3 --marker-trace")
+    p.add_argument("--profile_steps", type=int, default=3, help="--profile: steps profiled per phase (after 2 untimed ones)")
     p.add_argument("--synthetic", type=int, default=0)
     p.add_argument("--epochs", type=int, default=500, help="epochs per stage (train_auto.py:101 hard-codes 500)")
     p.add_argument("--steps", type=int, default=200, help="pre-training steps")
@@ -67,6 +71,9 @@ def main():
     param = config.get_param(args)
     device = "cuda:0"
     ops.set_compute_dtype(args.dtype)
+    if args.profile:
+        from recguru_amd import profiling
+        profiling.install(profiling.StepProfiler(args.profile, steps=args.profile_steps, skip=2, rank=0))
     L, V = param.enc_maxlen, param.vocab_size - 1
     item_fre = None
     if args.synthetic:
@@ -92,6 +99,10 @@ def main():
     at.main(param, device, ae, re, ev, re_f, item_freq=item_fre, sas_=args.sas, shared=args.share_dec, fix_enc=args.fix_enc,
             epochs=args.epochs, max_steps=args.steps, tune_max_steps=args.tune_steps)
     print("saved", os.path.join(param.result_path, "model/model"))
+    if args.profile:
+        from recguru_amd import profiling
+        profiling.current().close()
+        print("per-kernel tables of the profiled steps: %s" % ", ".join(sorted(f for f in os.listdir(args.profile) if f.endswith(".txt"))))
 
 
 if __name__ == "__main__":

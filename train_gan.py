@@ -52,6 +52,10 @@ def parse():
     p.add_argument("--steps_tune", type=int, default=None)
     p.add_argument("--phase1_steps", type=int, default=200)
     p.add_argument("--dtype", choices=["bf16", "f32", "bf16x3"], default="bf16")
+    p.add_argument("--profile", type=str, default=None, metavar="DIR",
+                   help="write a per-kernel table (HIP-event time, launches, TFLOP/s, GB/s per step) of --profile_steps steps of every "
+                        "training phase to DIR/kernels_<phase>.txt/.json, and mark every step with a roctx range for rocprofv3 --marker-trace")
+    p.add_argument("--profile_steps", type=int, default=3, help="--profile: steps profiled per phase (after 2 untimed ones)")
     p.add_argument("--synthetic", type=int, default=0, help="users per domain of generated data (0 = read data_path)")
     return p.parse_args()
 
@@ -78,6 +82,9 @@ def main():
     device = "cuda:%d" % local
     ops.set_compute_dtype(args.dtype)
     ops.set_data_parallel(dp)
+    if args.profile:
+        from recguru_amd import profiling
+        profiling.install(profiling.StepProfiler(args.profile, steps=args.profile_steps, skip=2, rank=rank))
 
     L, k = param.enc_maxlen, param.n_negs
     if args.synthetic:
@@ -138,6 +145,11 @@ def main():
         if hist:
             print("last phase-2 iteration: D_cost %.4f  W_D %.4f  recon_a %.4f  recon_b %.4f  g_dis %.4f"
                   % tuple(float(x) for x in hist[-1]))
+    if args.profile:
+        from recguru_amd import profiling
+        profiling.current().close()
+        if rank == 0:
+            print("per-kernel tables of the profiled steps: %s" % ", ".join(sorted(f for f in os.listdir(args.profile) if f.endswith(".txt"))))
     if dp:
         torch.distributed.destroy_process_group()
 
