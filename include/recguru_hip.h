@@ -609,7 +609,7 @@ int rg_attn_lastq_bwd(const void* qlast, const void* kv, const void* dctx, const
 
 /* Single-query attention of the last encoder layer straight from the layer input x (no K / V projection: WK is
  * absorbed into the query, WV into the output -- csrc/attention_lastq_x.hip).  Same results as rg_gemm_nt(x, [WK;WV])
- * + rg_attn_lastq_fwd/bwd up to operand rounding.  bf16, d_model = H*32 = 128, L <= 256 (rg_attn_lastq_x_supported).
+ * + rg_attn_lastq_fwd/bwd up to operand rounding.  bf16 (f32: rg_attn_lastq_xf_* below), d_model = H*32 = 128, L <= 256 (rg_attn_lastq_x_supported).
  * qlast = WQ x[:, L-1] + bQ [B,128]; wk / wv [128,128] bf16 row-major [out,in]; first_live[b] (or NULL) = first row of
  * sequence b that is not a zero row of x (rows before it are not read).
  * Backward outputs: dx [B,L,128] (every row written; the caller adds the query path's dx of row L-1), dq [B,128], and
@@ -629,6 +629,12 @@ typedef struct {
 int rg_attn_lastq_x_supported(int d, int P, int H, int L, int dtype);
 int rg_attn_lastq_x_fwd(const rg_lastq_x_args* args /* host */, void* stream);
 int rg_attn_lastq_x_bwd(const rg_lastq_x_args* args /* host */, void* stream);
+/* The f32 form of the same two (round 6): every tensor of the argument block -- x, qlast, wk, wv, ctx, dctx, dx, dq, ym_*, xbar, dqp -- is
+ * f32 and the arithmetic is exact f32 on the vector ALU (per sequence ~2 k FMAs per lane against 100 KB of rows to fetch: nothing for the
+ * matrix pipe to win, no operand split to pay).  The f32 AND bf16x3 tiers use it (rg_attn_lastq_x_supported answers for RG_F32 / RG_X3 too):
+ * it replaces their K | V projection + rg_attn_lastq_fwd/bwd + dkv -> dx product + the B L-row dWK | dWV product. */
+int rg_attn_lastq_xf_fwd(const rg_lastq_x_args* args /* host */, void* stream);
+int rg_attn_lastq_xf_bwd(const rg_lastq_x_args* args /* host */, void* stream);
 /* bkv [2*H*32] f32 (K | V bias) + first_live [B] (rg_first_live), both optional (NULL): the caller guarantees that the
  * K / V rows before a sequence's first live position are the bias rows (x_masked contract of rg_attn_args): the kernels
  * then do not fetch them (one score, one probability mass for the whole padded prefix). */

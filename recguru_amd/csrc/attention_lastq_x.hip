@@ -511,6 +511,317 @@ __global__ __launch_bounds__(256, 2) void attn_lastq_x_bwd_kernel(rg_lastq_x_arg
   if (a.dbv && lane < 32) rg_acc(a.dbv + h * LX_DK + lane, dbv);
 }
 
+
+// =====================================================================================================================================
+// f32 form (round 6; the f32 and bf16x3 tiers: x, q, dctx and the weights are f32).  Same algebra, EXACT f32 arithmetic on the vector
+// ALU -- per sequence the work is 4 x [L,128] dot products and 4 weighted row sums, ~2 k FMAs per lane, far below what fetching
+// the sequence's 100 KB of rows costs, so there is nothing for the matrix pipe to win and no operand split to pay.  Replaces, in those
+// tiers, the K | V projection GEMM ([B L,128] -> [B L,256] f32, written and read back) + rg_attn_lastq_fwd/bwd + the dkv -> dx GEMM
+// and the dWK | dWV product over B L rows (8.5 ms of the bf16x3 step against 1.3 ms in the bf16 tier).
+// One workgroup per sequence (persistent), wave h = head h.  The x rows [rs, SLD) live in LDS as raw f32 (512 B per row, 16-byte chunk
+// c of row r in slot c ^ (r & 31): conflict-free both for "lane = row" reads of one chunk and for "lane = feature pair" reads of one
+// row), staged by LDS-DMA with the swizzle on the source side.  L <= 256 (160 KB of LDS: one workgroup per CU).
+struct SmemF {
+  float* xs;   // [SLD][128]
+  float* vec;  // [8][128]   q'_h (rows 0-3), dxbar_h (rows 4-7, backward)
+  float* ss;   // [4][SLD]   scores -> dropped probabilities
+  float* dp;   // [4][SLD]   backward: x . dxbar
+  float* cf;   // [SLD][8]   backward: (p~, ds) per head
+};
+__device__ __forceinline__ void stage_xf(const SmemF& sm, const float* __restrict__ xb, int rs, int L, int SLD, int wave, int lane) {
+  const int rr = lane >> 5, sl = lane & 31;
+  for (int r0 = rs + 2 * wave; r0 < SLD; r0 += 8) {
+    const int r = r0 + rr;
+    const float* src = xb + (size_t)min(r, L - 1) * LX_D + 4 * (sl ^ (r & 31));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(sm.xs + r0 * LX_D), 16, 0, 0);
+  }
+}
+__device__ __forceinline__ float4 xf_chunk(const SmemF& sm, int r, int c) {
+  return *reinterpret_cast<const float4*>(sm.xs + r * LX_D + 4 * (c ^ (r & 31)));
+}
+__device__ __forceinline__ float2 xf_pair(const SmemF& sm, int j, int lane) {
+  return *reinterpret_cast<const float2*>(sm.xs + j * LX_D + 4 * ((lane >> 1) ^ (j & 31)) + 2 * (lane & 1));
+}
+struct HeadF {                      // wave h: rows h*32 + c of WK / WV, features 2*lane (w?0) and 2*lane+1 (w?1)
+  float wk0[32], wk1[32], wv0[32], wv1[32];
+  float bk, bv;
+};
+__device__ __forceinline__ void load_headf(HeadF& hd, const rg_lastq_x_args& a, int h, int lane) {
+  const float2* wk = reinterpret_cast<const float2*>(a.wk) + (size_t)h * LX_DK * (LX_D / 2) + lane;
+  const float2* wv = reinterpret_cast<const float2*>(a.wv) + (size_t)h * LX_DK * (LX_D / 2) + lane;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float2 k2 = wk[c * (LX_D / 2)], v2 = wv[c * (LX_D / 2)];
+    hd.wk0[c] = k2.x; hd.wk1[c] = k2.y; hd.wv0[c] = v2.x; hd.wv1[c] = v2.y;
+  }
+  hd.bk = lane < 32 ? a.bk[h * LX_DK + lane] : 0.f;
+  hd.bv = lane < 32 ? a.bv[h * LX_DK + lane] : 0.f;
+}
+// out pair = sum_c v[c] * W[c][pair], v[c] = lane c of `vl`
+__device__ __forceinline__ void vec_times_rowsf(const float (&w0)[32], const float (&w1)[32], float vl, float& o0, float& o1) {
+  o0 = 0.f; o1 = 0.f;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    const float vc = bcast(vl, c);
+    o0 = fmaf(vc, w0[c], o0);
+    o1 = fmaf(vc, w1[c], o1);
+  }
+}
+// lane l gets sum_e W[l >> 1][e] * v[e], v given as the pair (v0, v1) per lane
+__device__ __forceinline__ float rows_times_vecf(const float (&w0)[32], const float (&w1)[32], float v0, float v1, int lane) {
+  float t[32];
+#pragma unroll
+  for (int c = 0; c < 32; ++c) t[c] = fmaf(w0[c], v0, w1[c] * v1);
+  return reduce32(t, lane);
+}
+// dot products of the rows lane + 64 i with vec row va (and, BWD, vec row vb): one pass over the row's 32 chunks
+template <bool BWD>
+__device__ __forceinline__ void row_dots(const SmemF& sm, int va, int vb, int lane, int rs, int L, int SLD, float (&sa)[LX_KPL], float (&sb)[LX_KPL]) {
+  int jr[LX_KPL];
+#pragma unroll
+  for (int i = 0; i < LX_KPL; ++i) { jr[i] = min(max(lane + 64 * i, rs), SLD - 1); sa[i] = 0.f; sb[i] = 0.f; }
+  const int ni = (L + 63) >> 6;                                 // key groups that hold a row < L (wave-uniform)
+#pragma unroll 2
+  for (int c = 0; c < 32; ++c) {
+    const float4 qa = *reinterpret_cast<const float4*>(sm.vec + va * LX_D + 4 * c);
+    float4 qb4 = qa;
+    if (BWD) qb4 = *reinterpret_cast<const float4*>(sm.vec + vb * LX_D + 4 * c);
+#pragma unroll
+    for (int i = 0; i < LX_KPL; ++i) {
+      if (i < ni) {
+        const float4 xv = xf_chunk(sm, jr[i], c);
+        sa[i] = fmaf(xv.x, qa.x, fmaf(xv.y, qa.y, fmaf(xv.z, qa.z, fmaf(xv.w, qa.w, sa[i]))));
+        if (BWD) sb[i] = fmaf(xv.x, qb4.x, fmaf(xv.y, qb4.y, fmaf(xv.z, qb4.z, fmaf(xv.w, qb4.w, sb[i]))));
+      }
+    }
+  }
+}
+// softmax stage on register scores (the bf16 form's softmax_keys reads them from LDS): same masks, same dropout indices
+__device__ __forceinline__ void softmax_keysf(const float (&sc)[LX_KPL], int lane, int L, int rs, float qb, const int64_t* __restrict__ ids,
+                                              int64_t pad_value, const DropCfg& drop, unsigned int dbase, float (&p)[LX_KPL],
+                                              float (&kp)[LX_KPL], bool (&msk)[LX_KPL], bool& full) {
+  float s[LX_KPL];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < LX_KPL; ++i) {
+    const int j = lane + 64 * i;
+    const int64_t id = ids[min(j, L - 1)];
+    const float raw = (j >= rs && j < L ? sc[i] : 0.f) + qb;
+    msk[i] = id == pad_value;
+    s[i] = j < L ? (msk[i] ? LX_MASK_BIG : raw) : -INFINITY;
+    mx = fmaxf(mx, s[i]);
+  }
+  mx = wave_max_dpp(mx);
+  full = mx < 0.5f * LX_MASK_BIG;
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < LX_KPL; ++i) { s[i] = __expf(s[i] - mx); sum += s[i]; }
+  sum = wave_sum_dpp(sum);
+  const float inv = 1.f / sum;
+#pragma unroll
+  for (int i = 0; i < LX_KPL; ++i) {
+    const int j = lane + 64 * i;
+    p[i] = j < L ? s[i] * inv : 0.f;
+    kp[i] = drop.thresh ? rg_keep(drop, dbase + j) : 1.f;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_lastq_xf_fwd_kernel(rg_lastq_x_args a) {
+  extern __shared__ __align__(16) unsigned char lx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, SLD = ((L + 31) >> 5) << 5;
+  SmemF sm;
+  sm.xs = reinterpret_cast<float*>(lx_smem);
+  sm.vec = sm.xs + SLD * LX_D;
+  sm.ss = sm.vec + 8 * LX_D;
+  HeadF hd;
+  load_headf(hd, a, h, lane);
+  const DropCfg drop = make_drop(a.drop_p, a.seed);
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const float* __restrict__ Q = reinterpret_cast<const float*>(a.qlast);
+  float* __restrict__ C = reinterpret_cast<float*>(a.ctx);
+  auto first_row = [&](int b) { return (a.first_live ? min(a.first_live[b], L - 1) : 0) & ~31; };
+  int rs = blockIdx.x < a.B ? first_row(blockIdx.x) : 0;
+  float ql_next = (blockIdx.x < a.B && lane < 32) ? Q[(size_t)blockIdx.x * LX_D + h * LX_DK + lane] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // weights, query, first row: here, not behind the first row requests
+  if (blockIdx.x < a.B) stage_xf(sm, X + (size_t)blockIdx.x * L * LX_D, rs, L, SLD, h, lane);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const float ql = ql_next;
+    const int nb = b + gridDim.x;
+    float q0, q1;
+    vec_times_rowsf(hd.wk0, hd.wk1, ql, q0, q1);
+    q0 *= a.scale; q1 *= a.scale;
+    const float qb = wave_sum_dpp(ql * hd.bk) * a.scale;
+    reinterpret_cast<float2*>(sm.vec + h * LX_D)[lane] = make_float2(q0, q1);     // this wave's own row (read back by this wave only)
+    stage_wait();
+    __syncthreads();                                            // x rows of this sequence have landed
+    float sc[LX_KPL], unused[LX_KPL];
+    row_dots<false>(sm, h, h, lane, rs, L, SLD, sc, unused);
+    float p[LX_KPL], kp[LX_KPL];
+    bool msk[LX_KPL], full;
+    const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
+    softmax_keysf(sc, lane, L, rs, qb, a.key_ids + (size_t)b * L, a.pad_value, drop, dbase, p, kp, msk, full);
+    float sp = 0.f;
+#pragma unroll
+    for (int i = 0; i < LX_KPL; ++i) {
+      const int j = lane + 64 * i;
+      const float pd = p[i] * kp[i];
+      sp += pd;
+      if (j < SLD) sm.ss[h * SLD + j] = pd;
+    }
+    sp = wave_sum_dpp(sp);
+    float a0 = 0.f, a1 = 0.f;                                   // xbar_h[f] = sum_j p~_j x_j[f], this lane's feature pair
+#pragma unroll 2
+    for (int j0 = rs; j0 < SLD; j0 += 4) {
+      const float4 w4 = *reinterpret_cast<const float4*>(sm.ss + h * SLD + j0);
+      const float w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const float2 xv = xf_pair(sm, j0 + jj, lane);
+        a0 = fmaf(w[jj], xv.x, a0);
+        a1 = fmaf(w[jj], xv.y, a1);
+      }
+    }
+    // what the next sequence needs from global memory, then its rows (in flight under the epilogue below)
+    const int nbc = min(nb, a.B - 1);
+    const int first_raw = a.first_live ? a.first_live[nbc] : 0;
+    ql_next = lane < 32 ? Q[(size_t)nbc * LX_D + h * LX_DK + lane] : 0.f;
+    __syncthreads();                                            // every wave is done with the x image
+    if (nb < a.B) { rs = __builtin_amdgcn_readfirstlane(min(first_raw, L - 1) & ~31); stage_xf(sm, X + (size_t)nb * L * LX_D, rs, L, SLD, h, lane); }
+    const float o = rows_times_vecf(hd.wv0, hd.wv1, a0, a1, lane);
+    const float bvl = __shfl(hd.bv, lane >> 1);
+    if (!(lane & 1)) C[(size_t)b * LX_D + h * LX_DK + (lane >> 1)] = o + bvl * sp;
+  }
+}
+
+__global__ __launch_bounds__(256, 1) void attn_lastq_xf_bwd_kernel(rg_lastq_x_args a) {
+  extern __shared__ __align__(16) unsigned char lx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, h = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int L = a.L, SLD = ((L + 31) >> 5) << 5;
+  SmemF sm;
+  sm.xs = reinterpret_cast<float*>(lx_smem);
+  sm.vec = sm.xs + SLD * LX_D;
+  sm.cf = sm.vec + 8 * LX_D;
+  HeadF hd;
+  load_headf(hd, a, h, lane);
+  const DropCfg drop = make_drop(a.drop_p, a.seed);
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const float* __restrict__ Q = reinterpret_cast<const float*>(a.qlast);
+  const float* __restrict__ G = reinterpret_cast<const float*>(a.dctx);
+  float2* __restrict__ DX = reinterpret_cast<float2*>(a.dx);
+  float* __restrict__ DQ = reinterpret_cast<float*>(a.dq);
+  float2* __restrict__ YV = reinterpret_cast<float2*>(a.ym_v);
+  float2* __restrict__ YQ = reinterpret_cast<float2*>(a.ym_q);
+  float2* __restrict__ XB = reinterpret_cast<float2*>(a.xbar);
+  float2* __restrict__ DP = reinterpret_cast<float2*>(a.dqp);
+  float dbv = 0.f;
+  auto first_row = [&](int b) { return (a.first_live ? min(a.first_live[b], L - 1) : 0) & ~31; };
+  int rs_next = blockIdx.x < a.B ? first_row(blockIdx.x) : 0;
+  float ql_next = (blockIdx.x < a.B && lane < 32) ? Q[(size_t)blockIdx.x * LX_D + h * LX_DK + lane] : 0.f;
+  float gl_next = (blockIdx.x < a.B && lane < 32) ? G[(size_t)blockIdx.x * LX_D + h * LX_DK + lane] : 0.f;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (blockIdx.x < a.B) stage_xf(sm, X + (size_t)blockIdx.x * L * LX_D, rs_next, L, SLD, h, lane);
+  for (int b = blockIdx.x; b < a.B; b += gridDim.x) {
+    const int rs = rs_next;
+    const int nb = b + gridDim.x;
+    const float ql = ql_next, gl = gl_next;
+    float q0, q1, d0, d1;
+    vec_times_rowsf(hd.wk0, hd.wk1, ql, q0, q1);
+    q0 *= a.scale; q1 *= a.scale;
+    vec_times_rowsf(hd.wv0, hd.wv1, gl, d0, d1);                // dxbar_h
+    const float qb = wave_sum_dpp(ql * hd.bk) * a.scale;
+    const float dsp = wave_sum_dpp(gl * hd.bv);                 // d(sum of p~)
+    __syncthreads();                                            // the previous sequence's dx stage is done with cf / vec
+    reinterpret_cast<float2*>(sm.vec + h * LX_D)[lane] = make_float2(q0, q1);
+    reinterpret_cast<float2*>(sm.vec + (4 + h) * LX_D)[lane] = make_float2(d0, d1);
+    {                                                           // the operands of the dWV / dWK products: other heads' blocks zero
+      const bool own = (lane >> 4) == h;
+      const int c = (2 * lane) & 31;
+      const float2 gq = make_float2(__shfl(gl, c), __shfl(gl, c + 1));
+      const float2 qq = make_float2(__shfl(ql, c), __shfl(ql, c + 1));
+      const float2 z2 = make_float2(0.f, 0.f);
+      YV[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? gq : z2;
+      YQ[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? qq : z2;
+    }
+    stage_wait();
+    __syncthreads();                                            // x rows landed; vec complete
+    float sc[LX_KPL], dpr[LX_KPL];
+    row_dots<true>(sm, h, 4 + h, lane, rs, L, SLD, sc, dpr);
+    float p[LX_KPL], kp[LX_KPL];
+    bool msk[LX_KPL], full;
+    const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
+    softmax_keysf(sc, lane, L, rs, qb, a.key_ids + (size_t)b * L, a.pad_value, drop, dbase, p, kp, msk, full);
+    float dpk[LX_KPL];
+    float delta = 0.f, sp = 0.f;
+#pragma unroll
+    for (int i = 0; i < LX_KPL; ++i) {
+      const int j = lane + 64 * i;
+      const float dpt = (j >= rs && j < L ? dpr[i] : 0.f) + dsp;
+      dpk[i] = dpt * kp[i];
+      delta += p[i] * dpk[i];
+      sp += p[i] * kp[i];
+    }
+    delta = wave_sum_dpp(delta);
+    sp = wave_sum_dpp(sp);
+#pragma unroll
+    for (int i = 0; i < LX_KPL; ++i) {
+      const int j = lane + 64 * i;
+      const float ds = (full || msk[i]) ? 0.f : p[i] * (dpk[i] - delta);
+      if (j < SLD) *reinterpret_cast<float2*>(sm.cf + j * 8 + 2 * h) = make_float2(p[i] * kp[i], ds);
+    }
+    float a0 = 0.f, a1 = 0.f, g0 = 0.f, g1 = 0.f;               // xbar_h and dq'_h, this lane's feature pair (own head's cf column: no barrier)
+#pragma unroll 4
+    for (int j = rs; j < SLD; ++j) {
+      const float2 cw = *reinterpret_cast<const float2*>(sm.cf + j * 8 + 2 * h);
+      const float2 xv = xf_pair(sm, j, lane);
+      a0 = fmaf(cw.x, xv.x, a0); a1 = fmaf(cw.x, xv.y, a1);
+      g0 = fmaf(cw.y, xv.x, g0); g1 = fmaf(cw.y, xv.y, g1);
+    }
+    g0 *= a.scale; g1 *= a.scale;
+    XB[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = make_float2(a0, a1);
+    DP[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = make_float2(g0, g1);
+    const int nbc = min(nb, a.B - 1);
+    const int first_raw = a.first_live ? a.first_live[nbc] : 0;
+    ql_next = lane < 32 ? Q[(size_t)nbc * LX_D + h * LX_DK + lane] : 0.f;
+    gl_next = lane < 32 ? G[(size_t)nbc * LX_D + h * LX_DK + lane] : 0.f;
+    __syncthreads();                                            // cf of every head in place; nobody reads the x image any more
+    if (nb < a.B) { rs_next = __builtin_amdgcn_readfirstlane(min(first_raw, L - 1) & ~31); stage_xf(sm, X + (size_t)nb * L * LX_D, rs_next, L, SLD, h, lane); }
+    const float dq = rows_times_vecf(hd.wk0, hd.wk1, g0, g1, lane);
+    if (!(lane & 1)) DQ[(size_t)b * LX_D + h * LX_DK + (lane >> 1)] = dq;
+    dbv += gl * sp;
+    {                                                           // dx rows: wave w takes rows rs + w, rs + w + 4, ...
+      float2 vd[4], vq[4];
+#pragma unroll
+      for (int hh = 0; hh < 4; ++hh) {
+        vq[hh] = reinterpret_cast<const float2*>(sm.vec + hh * LX_D)[lane];
+        vd[hh] = reinterpret_cast<const float2*>(sm.vec + (4 + hh) * LX_D)[lane];
+      }
+      float2* dxb = DX + (size_t)b * L * (LX_D / 2);
+      for (int j = h; j < rs; j += 4) dxb[(size_t)j * (LX_D / 2) + lane] = make_float2(0.f, 0.f);
+#pragma unroll 2
+      for (int j = rs + h; j < L; j += 4) {
+        const float4 c0 = *reinterpret_cast<const float4*>(sm.cf + j * 8);
+        const float4 c1 = *reinterpret_cast<const float4*>(sm.cf + j * 8 + 4);
+        const float cc[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+        float o0 = 0.f, o1 = 0.f;
+#pragma unroll
+        for (int hh = 0; hh < 4; ++hh) {
+          o0 += cc[2 * hh] * vd[hh].x + cc[2 * hh + 1] * vq[hh].x;
+          o1 += cc[2 * hh] * vd[hh].y + cc[2 * hh + 1] * vq[hh].y;
+        }
+        dxb[(size_t)j * (LX_D / 2) + lane] = make_float2(o0, o1);
+      }
+    }
+  }
+  if (a.dbv && lane < 32) rg_acc(a.dbv + h * LX_DK + lane, dbv);
+}
+
+static size_t lxf_smem_bytes(int L, bool bwd) {
+  const size_t SLD = (size_t)((L + 31) >> 5) * 32;
+  return SLD * LX_D * 4 + 8 * LX_D * 4 + (bwd ? SLD * 8 * 4 : 4 * SLD * 4);
+}
+
 static size_t lx_smem_bytes(int L, bool bwd) {
   const size_t SLD = (size_t)((L + 31) >> 5) * 32;
   const size_t sc = 4 * SLD * 4;                                  // one [4][SLD] f32 image
@@ -521,10 +832,10 @@ static size_t lx_smem_bytes(int L, bool bwd) {
 }
 
 extern "C" int rg_attn_lastq_x_supported(int d, int P, int H, int L, int dtype) {
-  return dtype == RG_BF16 && d == LX_D && P == LX_D && H == LX_H && L >= 1 && L <= 64 * LX_KPL;
+  return (dtype == RG_BF16 || dtype == RG_F32 || dtype == RG_X3) && d == LX_D && P == LX_D && H == LX_H && L >= 1 && L <= 64 * LX_KPL;
 }
 
-static int lx_launch(const rg_lastq_x_args* a, bool bwd, hipStream_t s) {
+static int lx_launch(const rg_lastq_x_args* a, bool bwd, hipStream_t s, bool f32 = false) {
   if (!a || a->B <= 0) return 0;
   if (a->L < 1 || a->L > 64 * LX_KPL) return rg_set_error_msg(RG_ERR_UNSUPPORTED, "attn_lastq_x: L must be in 1..256");
   if (!a->x || !a->qlast || !a->wk || !a->wv || !a->bk || !a->bv || !a->key_ids)
@@ -532,6 +843,17 @@ static int lx_launch(const rg_lastq_x_args* a, bool bwd, hipStream_t s) {
   if (!bwd && !a->ctx) return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_x_fwd: ctx is required");
   if (bwd && (!a->dctx || !a->dx || !a->dq || !a->ym_v || !a->ym_q || !a->xbar || !a->dqp))
     return rg_set_error_msg(RG_ERR_INVALID, "attn_lastq_x_bwd: dctx, dx, dq, ym_v, ym_q, xbar and dqp are required");
+  if (f32) {
+    const size_t smf = lxf_smem_bytes(a->L, bwd);
+    const int gridf = a->B < 256 ? a->B : 256;
+    const void* fnf = bwd ? reinterpret_cast<const void*>(attn_lastq_xf_bwd_kernel) : reinterpret_cast<const void*>(attn_lastq_xf_fwd_kernel);
+    hipError_t ef = hipFuncSetAttribute(fnf, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smf);
+    if (ef != hipSuccess) return rg_set_error(ef, "attn_lastq_xf(smem)");
+    if (bwd) hipLaunchKernelGGL(attn_lastq_xf_bwd_kernel, dim3(gridf), dim3(256), smf, s, *a);
+    else hipLaunchKernelGGL(attn_lastq_xf_fwd_kernel, dim3(gridf), dim3(256), smf, s, *a);
+    RG_CHECK_LAUNCH();
+    return 0;
+  }
   const size_t smem = lx_smem_bytes(a->L, bwd);
   const int per_cu = smem <= 52 * 1024 ? 3 : (smem <= 80 * 1024 ? 2 : 1);
   const int grid = a->B < 256 * per_cu ? a->B : 256 * per_cu;
@@ -546,3 +868,6 @@ static int lx_launch(const rg_lastq_x_args* a, bool bwd, hipStream_t s) {
 
 extern "C" int rg_attn_lastq_x_fwd(const rg_lastq_x_args* a, void* stream) { return lx_launch(a, false, (hipStream_t)stream); }
 extern "C" int rg_attn_lastq_x_bwd(const rg_lastq_x_args* a, void* stream) { return lx_launch(a, true, (hipStream_t)stream); }
+// f32 form: every tensor of the argument block (x, qlast, wk, wv, ctx, dctx, dx, dq, ym_*, xbar, dqp) is f32 -- the f32 and bf16x3 tiers
+extern "C" int rg_attn_lastq_xf_fwd(const rg_lastq_x_args* a, void* stream) { return lx_launch(a, false, (hipStream_t)stream, true); }
+extern "C" int rg_attn_lastq_xf_bwd(const rg_lastq_x_args* a, void* stream) { return lx_launch(a, true, (hipStream_t)stream, true); }

@@ -96,7 +96,7 @@ SYMBOLS = ["rg_last_error", "rg_version", "rg_gemm_nt", "rg_gemm_tn", "rg_attn_f
            "rg_ffn_bwd_data", "rg_ffn_bwd_data_supported", "rg_ffn_bwd_ln_workspace", "rg_first_live",
            "rg_attn_out_bwd", "rg_attn_out_bwd_workspace",
            "rg_item_loss_train_supported", "rg_item_loss_train", "rg_item_loss_scatter_binned", "rg_scale_dev",
-           "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd",
+           "rg_attn_lastq_x_supported", "rg_attn_lastq_x_fwd", "rg_attn_lastq_x_bwd", "rg_attn_lastq_xf_fwd", "rg_attn_lastq_xf_bwd",
            "rg_embed_scatter_binned_workspace", "rg_embed_scatter_bwd_binned", "rg_embed_pe_fwd_split", "rg_mse",
            "rg_dropout_gelu", "rg_add_drop_ln", "rg_cross_add_ln", "rg_embed_pe_fwd2",
            "rg_det_enabled", "rg_det_set_arenas", "rg_det_fault"]
@@ -1104,6 +1104,7 @@ def _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, r
     B, L, d = x.shape
     assert x.is_contiguous() and q_last.is_contiguous() and wk.is_contiguous() and wv.is_contiguous() and key_ids.is_contiguous()
     assert wk.dtype == x.dtype and wv.dtype == x.dtype and bk.dtype == torch.float32 and bv.dtype == torch.float32
+    assert q_last.dtype == x.dtype and x.dtype in (torch.bfloat16, torch.float32)
     fl = first_live(rowmask, B, L) if rowmask is not None else None
     a = LastqXArgs(_p(x), _p(q_last), _p(wk), _p(wv), _p(bk), _p(bv), _p(key_ids), int(pad_value), _p(fl))
     a.B, a.L, a.scale, a.drop_p, a.seed = B, L, 32 ** -0.5, drop_p, seed
@@ -1117,7 +1118,9 @@ def attn_lastq_x_fwd(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p=0.0, 
     a, keep = _lastq_x_args(x, q_last, wk, wv, bk, bv, key_ids, pad_value, drop_p, seed, rowmask)
     ctx = torch.empty_like(q_last)
     a.ctx = _p(ctx)
-    _check(lib().rg_attn_lastq_x_fwd(ctypes.byref(a), _stream()), "rg_attn_lastq_x_fwd")
+    # bf16 tensors: the MFMA form; f32 tensors (f32 / bf16x3 tiers): the exact-f32 vector form (csrc/attention_lastq_x.hip)
+    fn = lib().rg_attn_lastq_x_fwd if x.dtype == torch.bfloat16 else lib().rg_attn_lastq_xf_fwd
+    _check(fn(ctypes.byref(a), _stream()), "rg_attn_lastq_x_fwd")
     return ctx
 
 
@@ -1132,7 +1135,8 @@ def attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, key_ids, pad_value, dbv, d
     ops4 = torch.empty(4, B * 4, d, device=x.device, dtype=x.dtype)
     a.dctx, a.dx, a.dq, a.dbv = _p(dctx), _p(dx), _p(dq), _p(dbv)
     a.ym_v, a.xbar, a.ym_q, a.dqp = _p(ops4[0]), _p(ops4[1]), _p(ops4[2]), _p(ops4[3])
-    _check(lib().rg_attn_lastq_x_bwd(ctypes.byref(a), _stream()), "rg_attn_lastq_x_bwd")
+    fn = lib().rg_attn_lastq_x_bwd if x.dtype == torch.bfloat16 else lib().rg_attn_lastq_xf_bwd
+    _check(fn(ctypes.byref(a), _stream()), "rg_attn_lastq_x_bwd")
     return dx, dq, ops4[0], ops4[1], ops4[2], ops4[3]
 
 

@@ -658,7 +658,7 @@ QKV_HEAD_MAJOR_TRAIN = not _os0.environ.get("RG_NO_HM_TRAIN")   # ... in trainin
 EMBED_SCATTER_BINNED = True  # rg_embed_scatter_bwd_binned at >= 65536 positions
 FUSE_ITEM_LOSS_TRAIN = True   # rg_item_loss_train: loss, coefficients and dh from one gather of the 1+k rows
 FUSE_ATTN_OUT_BWD = True     # rg_attn_out_bwd (LayerNorm-1 backward + dctx product) for d_model == P == 128
-LASTQ_FROM_X = True          # rg_attn_lastq_x_*: the last layer's single-query attention straight from x (no K / V)
+LASTQ_FROM_X = not _os_env("RG_NO_LASTQ_X")   # rg_attn_lastq_x_* / _xf_*: the last layer's single-query attention straight from x (no K / V); RG_NO_LASTQ_X=1: A/B
 LASTQ_FOLD_PREFIX = True
 
 

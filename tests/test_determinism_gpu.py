@@ -477,6 +477,52 @@ def test_lastq_and_ln_bwd_equal_their_chunked_launches():
     assert torch.equal(_bits(dz), _bits(dzp))
 
 
+@pytest.mark.parametrize("L,drop_p", [(200, 0.5), (16, 0.0), (77, 0.5)])
+def test_lastq_xf_repeats_bit_for_bit_and_equals_its_chunked_launches(L, drop_p):
+    """rg_attn_lastq_xf_fwd / bwd (round 6: the exact-f32 vector form of the x-input single-query attention, f32 / bf16x3 tiers): a
+    persistent workgroup walks sequences through ONE LDS image that the next sequence's LDS-DMA refills under the current epilogue -- a
+    missing barrier would show as run-to-run differences.  Five repeated launches return the same bits in every output (dbV, a float-atomic
+    sum over workgroups, to rounding), and a launch over the whole batch equals launches over chunks (different workgroup -> sequence
+    assignment, different neighbours in the image)."""
+    from recguru_amd import hip
+    B, d, H = 1024, 128, 4
+    g0 = torch.Generator().manual_seed(31 + L)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids = ids.cuda()
+    rm = (ids != 0).float().view(-1).contiguous()
+    x = ((torch.randn(B, L, d, generator=g0) * 0.8).cuda() * rm.view(B, L, 1)).contiguous()
+    w = (torch.randn(2 * d, d, generator=g0) / d ** 0.5).cuda()
+    bkv = (torch.randn(2 * d, generator=g0) * 0.3).cuda()
+    wk, wv, bk, bv = w[:d].contiguous(), w[d:].contiguous(), bkv[:d].contiguous(), bkv[d:].contiguous()
+    q, dctx = (torch.randn(B, d, generator=g0) * 0.7).cuda(), (torch.randn(B, d, generator=g0) * 0.5).cuda()
+
+    def run(sl=slice(None)):
+        xs, qs, gs, idss = x[sl].contiguous(), q[sl].contiguous(), dctx[sl].contiguous(), ids[sl].contiguous()
+        rms = (idss != 0).float().view(-1).contiguous()
+        c = hip.attn_lastq_x_fwd(xs, qs, wk, wv, bk, bv, idss, 51, drop_p, 9, rowmask=rms)
+        dbv = torch.zeros(d, device="cuda")
+        outs = hip.attn_lastq_x_bwd(xs, qs, gs, wk, wv, bk, bv, idss, 51, dbv, drop_p, 9, rowmask=rms)
+        return (c,) + tuple(o.clone() for o in outs), dbv
+    ref, dbv0 = run()
+    assert all(bool(torch.isfinite(t).all()) for t in ref)
+    for _ in range(4):
+        again, dbv1 = run()
+        for a, b in zip(ref, again):
+            assert torch.equal(_bits(a), _bits(b))
+        torch.testing.assert_close(dbv1, dbv0, rtol=1e-3, atol=1e-5 * float(dbv0.abs().max()) + 1e-6)      # float-atomic order, 1024 terms
+    if drop_p > 0:
+        return                                 # (the dropout index of an element contains its sequence's number inside the launch)
+    NC = 4
+    c = B // NC
+    parts = [run(slice(i * c, (i + 1) * c))[0] for i in range(NC)]
+    for k, whole in enumerate(ref):
+        cat = torch.cat([pt[k] for pt in parts], 0)
+        assert torch.equal(_bits(whole), _bits(cat.view_as(whole))), k
+
+
 @pytest.mark.gpu
 def test_packed_f32_selects_the_library_uses_are_clean_next_to_mfma_waves(tmp_path, capsys):
     """DESIGN 2a finding 1: on gfx950 a packed-f32 operation that takes the LOW result from the HIGH half of its SECOND source

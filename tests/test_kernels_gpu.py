@@ -3,6 +3,8 @@ f32 tier: tight tolerances (exact-f32 MFMA).  bf16 tier: inputs are bf16-rounded
 only difference left is accumulation order / output rounding."""
 import math
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -1341,6 +1343,85 @@ def test_attn_lastq_folds_the_padded_prefix(dt, drop_p):
     dq1, dkv1 = hip.attn_lastq_bwd(q_last, holes, dctx, ids, 51, H, drop_p, 9, rowmask=rowmask, bkv=bkv)
     torch.testing.assert_close(dq1.float(), dq0.float(), **t)
     torch.testing.assert_close(dkv1.float(), dkv0.float(), **t)
+
+
+@pytest.mark.parametrize("L,drop_p,masked,pad_value", [(200, 0.0, True, 51), (200, 0.5, True, 51), (200, 0.5, True, 0),
+                                                       (77, 0.0, False, 7), (256, 0.5, True, 51), (16, 0.0, True, 0),
+                                                       (5, 0.5, False, 51), (33, 0.5, True, 51)])
+def test_attn_lastq_xf_f32_form_matches_projection_plus_single_query(L, drop_p, masked, pad_value):
+    """rg_attn_lastq_xf_fwd / bwd -- the exact-f32 vector form of the x-input single-query attention (f32 and bf16x3 tiers, round 6) --
+    against the K | V projection + rg_attn_lastq_fwd/bwd in the f32 tier (same dropout masks): context, dx, dq, dWK, dWV, dbV to f32
+    rounding, and against an f64 evaluation of the attention row (no dropout)."""
+    from recguru_amd import hip
+    B, H, d = 37, 4, 128
+    P = H * 32
+    g0 = torch.Generator().manual_seed(1000 + L + int(drop_p * 10) + pad_value)
+    ids = torch.randint(1, 50, (B, L), generator=g0)
+    lens = torch.randint(1, L + 1, (B,), generator=g0)
+    lens[0], lens[1] = L, 1
+    for b in range(B):
+        ids[b, : L - int(lens[b])] = 0
+    ids[2, :] = pad_value
+    ids[3, L - 1] = pad_value
+    ids = ids.cuda()
+    rowmask = (ids != 0).float().view(-1).contiguous()
+    M = B * L
+    x = (torch.randn(B, L, d, generator=g0) * 0.8).cuda()
+    if masked:
+        x = x * rowmask.view(B, L, 1)
+    x = x.contiguous()
+    w = (torch.randn(2 * P, d, generator=g0) / d ** 0.5).cuda()
+    bkv = (torch.randn(2 * P, generator=g0) * 0.3).cuda()
+    wk, wv, bk, bv = w[:P].contiguous(), w[P:].contiguous(), bkv[:P].contiguous(), bkv[P:].contiguous()
+    q_last = (torch.randn(B, P, generator=g0) * 0.7).cuda()
+    dctx = (torch.randn(B, P, generator=g0) * 0.5).cuda()
+    rm = rowmask if masked else None
+    assert hip.attn_lastq_x_supported(d, P, H, L, torch.float32)
+    prev = hip.SPLIT_OPERANDS
+    hip.SPLIT_OPERANDS = False
+    try:
+        kv = hip.gemm_nt(x.view(M, d), w, bkv).view(B, L, 2 * P)          # exact-f32 MFMA
+    finally:
+        hip.SPLIT_OPERANDS = prev
+    c_old = hip.attn_lastq_fwd(q_last, kv, ids, pad_value, H, drop_p, 9)
+    dq_old, dkv_old = hip.attn_lastq_bwd(q_last, kv, dctx, ids, pad_value, H, drop_p, 9)
+    dkv2 = dkv_old.view(M, 2 * P).double()
+    dx_old = (dkv2 @ w.double()).float()
+    dW_old = (dkv2.t() @ x.view(M, d).double()).float()
+    dbv_old = dkv2[:, P:].sum(0).float()
+    c_new = hip.attn_lastq_x_fwd(x, q_last, wk, wv, bk, bv, ids, pad_value, drop_p, 9, rowmask=rm)
+    dbv = torch.zeros(P, device="cuda")
+    dx, dq, ym_v, xbar, ym_q, dqp = hip.attn_lastq_x_bwd(x, q_last, dctx, wk, wv, bk, bv, ids, pad_value, dbv, drop_p, 9, rowmask=rm)
+    assert c_new.dtype == torch.float32 and dx.dtype == torch.float32 and xbar.dtype == torch.float32
+    dWv = (ym_v.double().t() @ xbar.double()).float()
+    dWk = (ym_q.double().t() @ dqp.double()).float()
+
+    def close(a, b, frac, what):
+        err = float((a.float() - b.float()).abs().max())
+        ref = float(b.float().abs().max())
+        assert err <= frac * ref + 1e-7, "%s: max err %.3g of max %.3g" % (what, err, ref)
+
+    close(c_new, c_old, 2e-5, "context")
+    close(dq, dq_old, 5e-5, "dq")
+    rows = rowmask.bool() if masked else torch.ones(M, dtype=torch.bool, device="cuda")
+    close(dx.view(M, d)[rows], dx_old[rows], 5e-5, "dx")
+    assert bool(torch.isfinite(dx).all())
+    if masked:                                                     # the tiles before a sequence's first live row are written as zeros
+        first = (rowmask.view(B, L) != 0).float().argmax(1)
+        for b in range(B):
+            rs = int(min(int(first[b]), L - 1)) & ~31 if bool(rowmask.view(B, L)[b].any()) else (L - 1) & ~31
+            assert float(dx[b, :rs].abs().max()) == 0.0 if rs else True
+    close(dWv, dW_old[P:], 5e-5, "dWV")
+    close(dWk, dW_old[:P], 1e-4, "dWK")
+    close(dbv, dbv_old, 5e-5, "dbV")
+    if drop_p == 0.0:
+        xd, wd = x.double(), w.double()
+        qd = q_last.double().view(B, H, 32)
+        kvd = (xd.view(M, d) @ wd.t() + bkv.double()).view(B, L, 2, H, 32)
+        sd = torch.einsum("bhc,blhc->bhl", qd, kvd[:, :, 0]) * 32 ** -0.5
+        sd = sd.masked_fill((ids == pad_value)[:, None, :], -1e9)
+        ref = torch.einsum("bhl,blhc->bhc", torch.softmax(sd, -1), kvd[:, :, 1]).reshape(B, P)
+        np.testing.assert_allclose(c_new.double().cpu().numpy(), ref.cpu().numpy(), rtol=1e-4, atol=2e-6)
 
 
 @pytest.mark.parametrize("L,drop_p,masked,pad_value", [(200, 0.0, True, 51), (200, 0.5, True, 51), (200, 0.5, True, 0),

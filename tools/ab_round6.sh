@@ -81,4 +81,21 @@ x3nt)
   ab_bench x3_shipped_1 "" --dtype bf16x3 --steps 6 --warmup 2; ab_bench x3_wsnt_1 $V --dtype bf16x3 --steps 6 --warmup 2
   ab_bench x3_shipped_2 "" --dtype bf16x3 --steps 6 --warmup 2; ab_bench x3_wsnt_2 $V --dtype bf16x3 --steps 6 --warmup 2
   ;;
+lastq)
+  # the exact-f32 vector form of the x-input single-query attention (f32 / bf16x3 tiers): tests, then the tiers' step time with and without it
+  timeout 1500 python -m pytest tests/test_kernels_gpu.py -q -x -p no:cacheprovider -k "lastq" > $O/tests_lastq.log 2>&1; tail -5 $O/tests_lastq.log | cut -c1-300
+  ab_bench x3_new "" --dtype bf16x3 --steps 6 --warmup 2; RG_NO_LASTQ_X=1 ab_bench x3_old "" --dtype bf16x3 --steps 6 --warmup 2
+  ab_bench x3_new_b "" --dtype bf16x3 --steps 6 --warmup 2
+  ab_bench f32_new "" --dtype f32 --steps 3 --warmup 1; RG_NO_LASTQ_X=1 ab_bench f32_old "" --dtype f32 --steps 3 --warmup 1
+  timeout 2400 python -m pytest tests/test_steps_gpu.py tests/test_x3_gpu.py tests/test_parity_gpu.py tests/test_widths_gpu.py -q -x -p no:cacheprovider > $O/tests_tiers.log 2>&1; tail -5 $O/tests_tiers.log | cut -c1-300
+  ;;
+curves)
+  # the bf16x3 loss-curve replay with and without the exact-f32 single-query kernels, three runs each (float-atomic order differs run to run)
+  for i in 1 2 3; do
+    python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/new $i /" | cut -c1-420 | tee -a $O/curves.txt
+    RG_NO_LASTQ_X=1 python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/old $i /" | cut -c1-420 | tee -a $O/curves.txt
+  done
+  RG_DETERMINISTIC=1 python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/new det /" | cut -c1-420 | tee -a $O/curves.txt
+  RG_DETERMINISTIC=1 RG_NO_LASTQ_X=1 python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/old det /" | cut -c1-420 | tee -a $O/curves.txt
+  ;;
 esac
