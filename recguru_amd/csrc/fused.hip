@@ -313,6 +313,10 @@ __device__ __forceinline__ void zero_to_hbm(T* __restrict__ dst, int ld, int col
 // so that three to four workgroups share a CU instead of two; the per-phase stamps show a wave at 2 per SIMD spending its
 // time on exposed LDS / VALU latencies, not on the matrix pipe or the weight stream)
 // PIPE (round 5; bf16, no saves, no cross stage, d_ff >= 256): the FFN chunk loop software-pipelined -- see the loop.
+// (round 6, measured and NOT kept: this kernel alone without packed-f32 VALU instructions via the per-function target feature
+// `__attribute__((target("no-packed-fp32-ops")))`.  The whole-library variant had shown the fused block 2 % faster and ffn_bwd_data 2 % slower
+// (profiles/r06/ab/nopk_*); with the attribute on this kernel only, the always-inline device helpers -- compiled with the feature -- are no
+// longer inline-compatible with it and become CALLS: 276 -> 605 us per inference launch, step 56.4 -> 70.0 ms, outputs bit-identical.)
 template <typename T, int DM, bool CROSS, bool SAVE, bool RES = false, int RT = 4, bool PIPE = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 2 ? (RT == 2 ? 3 : 2) : ((std::is_same<T, x3>::value && RT == 2) ? 2 : 1)))
 void post_attn_fwd_kernel(rg_post_attn_args a) {

@@ -122,6 +122,8 @@ def screen(path):
                 # Copies of the first kind are dropped; the rest stay warnings -- and `unresolved` marks them for the build.
                 left = []
                 for jj in run:
+                    if _under_restored_mask(ins, jj, i):
+                        continue
                     mw = ACC_WRITE.match(ins[jj][1])
                     if mw and _defined_in_block(ins, jj, int(mw.group(1))):
                         continue
@@ -132,6 +134,55 @@ def screen(path):
                 if left:
                     warn.append((kernel, no, "-", left[::-1]))
     return bad, warn
+
+
+OR_SAVEEXEC = re.compile(r"^\s*s_or_saveexec_b64\s+(s\[\d+:\d+\]),\s*(s\[\d+:\d+\])\s*$")
+XOR_EXEC = re.compile(r"^\s*s_xor_b64\s+exec,\s*exec,\s*(s\[\d+:\d+\])\s*$")
+
+
+def _under_restored_mask(ins, at, restore):
+    """(round 6) True when the copy ins[at] runs under EXACTLY the mask the restore ins[restore] re-establishes -- the structurizer's
+    else-flow block with an empty else body:
+
+            s_or_saveexec_b64 sX, sX          ; sX' = exec (E0), exec = S | E0
+            <copy>                            ; under S | E0
+            s_xor_b64 exec, exec, sX          ; exec = (S | E0) ^ E0 = S & ~E0      (the else lanes)
+            s_or_b64 exec, exec, sX           ; exec = (S & ~E0) | E0 = S | E0      -- the mask the copy ran under
+
+    Nothing but scalar instructions that leave exec and sX alone may stand between the four.  (Met in round 6 in the f32-tier
+    instantiations of post_attn_fwd_kernel once the kernel was compiled without packed-f32 instructions: a v_accvgpr_read_b32 that the
+    scheduler moved up from behind the restore.)"""
+    mr = RESTORE_OF.match(ins[restore][1])
+    if not mr:
+        return False
+    reg = mr.group(1)
+    j, seen_xor = restore - 1, False
+    while j > at:                                   # between the copy and the restore: one xor of exec with sX, other copies, plain scalars
+        t = ins[j][1]
+        mx = XOR_EXEC.match(t)
+        if mx:
+            if seen_xor or mx.group(1) != reg:
+                return False
+            seen_xor = True
+        elif t.startswith(BLOCK_START) or t.startswith(STOP) or LABEL.match(t) or (t.startswith("s_") and reg in t):
+            return False
+        elif not (t.startswith("s_") or SPILL.match(t)):
+            return False
+        j -= 1
+    if not seen_xor:
+        return False
+    j = at - 1
+    while j >= 0:                                   # in front of the copy: other copies / plain scalars, then the s_or_saveexec sX, sX
+        t = ins[j][1]
+        mo = OR_SAVEEXEC.match(t)
+        if mo:
+            return mo.group(1) == reg and mo.group(2) == reg
+        if LABEL.match(t) or t.startswith(BLOCK_START) or t.startswith(STOP) or (t.startswith("s_") and reg in t):
+            return False
+        if not (t.startswith("s_") or SPILL.match(t)):
+            return False
+        j -= 1
+    return False
 
 
 ACC_READ = re.compile(r"^\s*v_accvgpr_read_b32\s+v\d+,\s*a(\d+)\s*$")

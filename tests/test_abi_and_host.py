@@ -272,6 +272,31 @@ _Z6kernelv:
     p.write_text(sched)
     flagged, _ = isa_screen.screen(str(p))
     assert len(flagged) == 1 and flagged[0][2] == ".LBB0_2"
+    # round 6: the structurizer's else-flow block with an empty else body -- the copy stands BEHIND `s_or_saveexec sX, sX` (exec widened to
+    # the union) and in front of `s_xor exec, exec, sX ; s_or exec, exec, sX`: it runs under exactly the restored mask (dropped).  The same
+    # copy behind any OTHER exec change, or with another register in the xor / the saveexec, stays a warning.
+    flow = """
+_Z6kernelv:
+	s_and_saveexec_b64 s[6:7], s[16:17]
+	s_xor_b64 s[6:7], exec, s[6:7]
+	s_cbranch_execz .LBB0_4
+	ds_write_b128 v171, a[0:3] offset:2304
+.LBB0_4:
+	s_or_saveexec_b64 s[6:7], s[6:7]
+	v_accvgpr_read_b32 v24, a0
+	s_xor_b64 exec, exec, s[6:7]
+	s_or_b64 exec, exec, s[6:7]
+	v_mul_f32_e32 v26, 0x3d372713, v24
+	s_endpgm
+"""
+    for name, text, n_warn in (("flow.s", flow, 0),
+                               ("flow_other_reg.s", flow.replace("s_xor_b64 exec, exec, s[6:7]", "s_xor_b64 exec, exec, s[8:9]"), 1),
+                               ("flow_narrowed.s", flow.replace("s_or_saveexec_b64 s[6:7], s[6:7]", "s_and_saveexec_b64 s[6:7], s[6:7]"), 1),
+                               ("flow_other_src.s", flow.replace("s_or_saveexec_b64 s[6:7], s[6:7]", "s_or_saveexec_b64 s[6:7], s[10:11]"), 1)):
+        p = tmp_path / name
+        p.write_text(text)
+        flagged, warn = isa_screen.screen(str(p))
+        assert flagged == [] and len(warn) == n_warn, (name, flagged, warn)
 
 
 def test_isa_screen_flags_the_packed_f32_high_half_select(tmp_path):

@@ -98,4 +98,10 @@ curves)
   RG_DETERMINISTIC=1 python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/new det /" | cut -c1-420 | tee -a $O/curves.txt
   RG_DETERMINISTIC=1 RG_NO_LASTQ_X=1 python -m pytest tests/test_steps_gpu.py -q -p no:cacheprovider -k "loss_curves_replay and bf16x3" -s 2>&1 | grep "curves, bf16x3" | sed "s/^/old det /" | cut -c1-420 | tee -a $O/curves.txt
   ;;
+nopk_pa)
+  # post_attn_fwd_kernel alone without packed-f32 instructions (per-function target attribute): bits + time
+  timeout 2400 python -m pytest tests/test_kernels_gpu.py tests/test_determinism_gpu.py tests/test_x3_gpu.py tests/test_fused256_gpu.py tests/test_dropout_gpu.py -q -x -p no:cacheprovider > $O/tests.log 2>&1; tail -3 $O/tests.log | cut -c1-300
+  for t in bf16 bf16x3; do python tools/kb_post_attn.py $t > $O/kb_post_attn_$t.txt 2>&1; done; grep -h us $O/kb_post_attn_*.txt
+  ab_bench bf16_1 ""; ab_bench bf16_2 ""; ab_bench x3_1 "" --dtype bf16x3 --steps 6 --warmup 2
+  ;;
 esac
