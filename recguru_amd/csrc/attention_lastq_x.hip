@@ -582,7 +582,7 @@ __device__ __forceinline__ void row_dots(const SmemF& sm, int va, int vb, int la
 #pragma unroll
   for (int i = 0; i < LX_KPL; ++i) { jr[i] = min(max(lane + 64 * i, rs), SLD - 1); sa[i] = 0.f; sb[i] = 0.f; }
   const int ni = (L + 63) >> 6;                                 // key groups that hold a row < L (wave-uniform)
-#pragma unroll 2
+#pragma unroll 8      // one wave per SIMD: the LDS latency of a chunk hides only behind the other chunks in flight (512 VGPRs to hold them)
   for (int c = 0; c < 32; ++c) {
     const float4 qa = *reinterpret_cast<const float4*>(sm.vec + va * LX_D + 4 * c);
     float4 qb4 = qa;
@@ -598,7 +598,13 @@ __device__ __forceinline__ void row_dots(const SmemF& sm, int va, int vb, int la
   }
 }
 // softmax stage on register scores (the bf16 form's softmax_keys reads them from LDS): same masks, same dropout indices
-__device__ __forceinline__ void softmax_keysf(const float (&sc)[LX_KPL], int lane, int L, int rs, float qb, const int64_t* __restrict__ ids,
+__device__ __forceinline__ void load_key_ids(const int64_t* __restrict__ ids, int lane, int L, int64_t (&id)[LX_KPL]) {
+#pragma unroll
+  for (int i = 0; i < LX_KPL; ++i) id[i] = ids[min(lane + 64 * i, L - 1)];
+}
+// (the key ids arrive as registers: they are requested at the top of a sequence, in front of the wait for its rows -- one wave per SIMD has
+//  nothing to hide a 2 us global-load latency behind)
+__device__ __forceinline__ void softmax_keysf(const float (&sc)[LX_KPL], int lane, int L, int rs, float qb, const int64_t (&ids)[LX_KPL],
                                               int64_t pad_value, const DropCfg& drop, unsigned int dbase, float (&p)[LX_KPL],
                                               float (&kp)[LX_KPL], bool (&msk)[LX_KPL], bool& full) {
   float s[LX_KPL];
@@ -606,7 +612,7 @@ __device__ __forceinline__ void softmax_keysf(const float (&sc)[LX_KPL], int lan
 #pragma unroll
   for (int i = 0; i < LX_KPL; ++i) {
     const int j = lane + 64 * i;
-    const int64_t id = ids[min(j, L - 1)];
+    const int64_t id = ids[i];
     const float raw = (j >= rs && j < L ? sc[i] : 0.f) + qb;
     msk[i] = id == pad_value;
     s[i] = j < L ? (msk[i] ? LX_MASK_BIG : raw) : -INFINITY;
@@ -654,6 +660,8 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_fwd_kernel(rg_lastq_x_ar
     q0 *= a.scale; q1 *= a.scale;
     const float qb = wave_sum_dpp(ql * hd.bk) * a.scale;
     reinterpret_cast<float2*>(sm.vec + h * LX_D)[lane] = make_float2(q0, q1);     // this wave's own row (read back by this wave only)
+    int64_t kid[LX_KPL];
+    load_key_ids(a.key_ids + (size_t)b * L, lane, L, kid);
     stage_wait();
     __syncthreads();                                            // x rows of this sequence have landed
     float sc[LX_KPL], unused[LX_KPL];
@@ -661,7 +669,7 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_fwd_kernel(rg_lastq_x_ar
     float p[LX_KPL], kp[LX_KPL];
     bool msk[LX_KPL], full;
     const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
-    softmax_keysf(sc, lane, L, rs, qb, a.key_ids + (size_t)b * L, a.pad_value, drop, dbase, p, kp, msk, full);
+    softmax_keysf(sc, lane, L, rs, qb, kid, a.pad_value, drop, dbase, p, kp, msk, full);
     float sp = 0.f;
 #pragma unroll
     for (int i = 0; i < LX_KPL; ++i) {
@@ -672,7 +680,7 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_fwd_kernel(rg_lastq_x_ar
     }
     sp = wave_sum_dpp(sp);
     float a0 = 0.f, a1 = 0.f;                                   // xbar_h[f] = sum_j p~_j x_j[f], this lane's feature pair
-#pragma unroll 2
+#pragma unroll 4
     for (int j0 = rs; j0 < SLD; j0 += 4) {
       const float4 w4 = *reinterpret_cast<const float4*>(sm.ss + h * SLD + j0);
       const float w[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -744,6 +752,8 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_bwd_kernel(rg_lastq_x_ar
       YV[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? gq : z2;
       YQ[((size_t)b * LX_H + h) * (LX_D / 2) + lane] = own ? qq : z2;
     }
+    int64_t kid[LX_KPL];
+    load_key_ids(a.key_ids + (size_t)b * L, lane, L, kid);
     stage_wait();
     __syncthreads();                                            // x rows landed; vec complete
     float sc[LX_KPL], dpr[LX_KPL];
@@ -751,7 +761,7 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_bwd_kernel(rg_lastq_x_ar
     float p[LX_KPL], kp[LX_KPL];
     bool msk[LX_KPL], full;
     const unsigned int dbase = (((unsigned int)b * LX_H + h) * L + (L - 1)) * rg_lpad(L);
-    softmax_keysf(sc, lane, L, rs, qb, a.key_ids + (size_t)b * L, a.pad_value, drop, dbase, p, kp, msk, full);
+    softmax_keysf(sc, lane, L, rs, qb, kid, a.pad_value, drop, dbase, p, kp, msk, full);
     float dpk[LX_KPL];
     float delta = 0.f, sp = 0.f;
 #pragma unroll
@@ -771,7 +781,7 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_bwd_kernel(rg_lastq_x_ar
       if (j < SLD) *reinterpret_cast<float2*>(sm.cf + j * 8 + 2 * h) = make_float2(p[i] * kp[i], ds);
     }
     float a0 = 0.f, a1 = 0.f, g0 = 0.f, g1 = 0.f;               // xbar_h and dq'_h, this lane's feature pair (own head's cf column: no barrier)
-#pragma unroll 4
+#pragma unroll 16
     for (int j = rs; j < SLD; ++j) {
       const float2 cw = *reinterpret_cast<const float2*>(sm.cf + j * 8 + 2 * h);
       const float2 xv = xf_pair(sm, j, lane);
@@ -799,7 +809,7 @@ __global__ __launch_bounds__(256, 1) void attn_lastq_xf_bwd_kernel(rg_lastq_x_ar
       }
       float2* dxb = DX + (size_t)b * L * (LX_D / 2);
       for (int j = h; j < rs; j += 4) dxb[(size_t)j * (LX_D / 2) + lane] = make_float2(0.f, 0.f);
-#pragma unroll 2
+#pragma unroll 8
       for (int j = rs + h; j < L; j += 4) {
         const float4 c0 = *reinterpret_cast<const float4*>(sm.cf + j * 8);
         const float4 c1 = *reinterpret_cast<const float4*>(sm.cf + j * 8 + 4);

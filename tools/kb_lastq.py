@@ -9,7 +9,8 @@ P, M = 128, B * L
 dom = synthetic.make_domain(B, 100000, L, 1, seed=1)
 ids = torch.as_tensor(dom["enc_in"]).cuda()
 rowmask = (ids != 0).float().reshape(-1).contiguous()
-dt = torch.bfloat16
+dt = torch.float32 if (len(sys.argv) > 1 and sys.argv[1] in ("f32", "bf16x3")) else torch.bfloat16      # python tools/kb_lastq.py [bf16|f32|bf16x3]
+hip.SPLIT_OPERANDS = len(sys.argv) > 1 and sys.argv[1] == "bf16x3"
 x = ((torch.randn(B, L, d, device="cuda") * 0.8) * rowmask.view(B, L, 1)).to(dt).contiguous()
 w = (torch.randn(2 * P, d, device="cuda") / d ** 0.5).to(dt)
 wt = w.t().contiguous()
