@@ -106,7 +106,8 @@ PMC_FILES = ([os.environ["RG_PMC_TRAFFIC"]] if os.environ.get("RG_PMC_TRAFFIC") 
 # bench.py's per-launcher names that stand for several device kernels of the counter profile (bytes of one call = their sum)
 PMC_ALIASES = {"item_loss_scatter_binned_kernel": ("bin_count_kernel", "bin_scan_kernel", "bin_fill_kernel", "bin_accumulate_kernel",
                                                    "bin_accumulate_wide_kernel"),
-               "item_loss_train_rows_kernel": ("item_loss_train_rows_kernel", "item_loss_train_online_kernel")}
+               "item_loss_train_rows_kernel": ("item_loss_train_rows_kernel", "item_loss_train_online_kernel"),
+               "embed_pe_fwd_kernel": ("embed_pe_fwd_kernel", "embed_pe_fwd_pos_kernel", "embed_pe_fwd_rows_kernel")}
 
 
 def pmc_traffic(kernel, sub=None):
