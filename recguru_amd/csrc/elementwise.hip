@@ -150,10 +150,10 @@ template <> __device__ __forceinline__ void store8_nt<__bf16>(__bf16* p, const f
   for (int j = 0; j < 8; ++j) u.b[j] = (__bf16)v[j];
   __builtin_nontemporal_store(u.x, reinterpret_cast<rg_f4*>(p));
 }
-template <typename T, int D, int U, bool M2, bool NT>
+template <typename T, int D, int U, bool NT>
 __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_pos_kernel(const T* __restrict__ table, const float* __restrict__ pe,
                                                                    const int64_t* __restrict__ ids, const float* __restrict__ mask,
-                                                                   T* __restrict__ out, __bf16* __restrict__ out2, int B, int L, int bs, DropCfg drop) {
+                                                                   T* __restrict__ out, int B, int L, int bs, DropCfg drop) {
   constexpr int LPR = D / 8, RPW = 64 / LPR;           // lanes per row, positions per wave
   const int lane = threadIdx.x & 63;
   const int wave = (int)((blockIdx.x * EW_BLOCK + threadIdx.x) >> 6);
@@ -199,7 +199,6 @@ __global__ __launch_bounds__(EW_BLOCK) void embed_pe_fwd_pos_kernel(const T* __r
       if (b + u < b1 && inr) {
         if constexpr (NT) store8_nt<T>(out + (size_t)tok * D + c8, v[u]);
         else store8(out + (size_t)tok * D + c8, v[u]);
-        if constexpr (M2) store8(out2 + (size_t)tok * D + c8, v[u]);
       }
     }
   }
@@ -1314,8 +1313,8 @@ static int embed_pe_fwd_launch(const void* table, const float* pe, const int64_t
     chunks = (B + bs - 1) / bs;
     const long long waves = (long long)npb * chunks;
     const int grid = (int)((waves + EW_BLOCK / 64 - 1) / (EW_BLOCK / 64));
-#define RG_EMBP(T, D) do { if (use_nt) hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, false, true>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)nullptr, B, L, bs, drop); \
-                           else hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, false, false>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, (__bf16*)nullptr, B, L, bs, drop); } while (0)
+#define RG_EMBP(T, D) do { if (use_nt) hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, true>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, B, L, bs, drop); \
+                           else hipLaunchKernelGGL((embed_pe_fwd_pos_kernel<T, D, 4, false>), dim3(grid), dim3(EW_BLOCK), 0, s, (const T*)table, pe, ids, mask, (T*)out, B, L, bs, drop); } while (0)
 #define RG_EMBP_T(T) do { if (d == 128) RG_EMBP(T, 128); else RG_EMBP(T, 256); } while (0)
     DISPATCH_T(dtype, RG_EMBP_T(__bf16), RG_EMBP_T(float), "embed_pe_fwd")
 #undef RG_EMBP_T

@@ -137,8 +137,8 @@ class StepProfiler(object):
                         v["ms"] * 1e3 / max(v["launches"], 1), 100.0 * v["ms"] / total, v["flops_exec"] / sec / 1e12, v["bytes_exec"] / sec / 1e9))
             f.write("%-46s %9.1f %11.3f\n" % ("total", sum(v["launches"] for _, v in rows) / steps, total / steps))
         with open(os.path.join(self.dir, "kernels_%s.json" % phase), "w") as f:
-            json.dump({"phase": phase, "steps": steps, "kernels": {k: {kk: (vv / steps if kk != "launches" else vv / steps) for kk, vv in v.items()}
-                                                                   for k, v in rows}}, f, indent=1)
+            # every figure per profiled step: launches, ms, algorithmic and executed flops / bytes
+            json.dump({"phase": phase, "steps": steps, "kernels": {k: {kk: vv / steps for kk, vv in v.items()} for k, v in rows}}, f, indent=1)
 
 
 _CURRENT = _Off()
