@@ -220,6 +220,43 @@ def test_embed_fwd_bwd(dt, d):
 
 
 @pytest.mark.parametrize("dt", DTYPES)
+@pytest.mark.parametrize("d,B,L,p", [(128, 7, 23, 0.0), (128, 64, 200, 0.5), (256, 9, 40, 0.5), (64, 5, 23, 0.5)])
+def test_embed_entry_points_and_store_policies_agree_bit_for_bit(dt, d, B, L, p):
+    """Round 6: rg_embed_pe_fwd (table size unknown), rg_embed_pe_fwd_rows with the real row count (ordinary stores at these sizes)
+    and with a row count that makes table + output exceed the Infinity Cache (nontemporal stores) return the same bits -- the policy
+    changes the store instruction only -- on the position-major kernel (d = 128 / 256) and on the element-per-thread one (d = 64)."""
+    import ctypes
+    from recguru_amd import hip
+    V = 300
+    table = rnd(V + 2, d, dt=dt, seed=11)
+    pe = rnd(256, d, dt=torch.float32, seed=12)
+    ids = torch.randint(0, V + 2, (B, L), generator=torch.Generator().manual_seed(13)).cuda()
+    ids[:, : L // 3] = 0
+    mask = (ids != 0).float().reshape(-1).contiguous()
+    ntok = B * L
+    outs = []
+    for rows in (None, V + 2, 1 << 33):
+        out = torch.full((ntok, d), float("nan"), device="cuda", dtype=dt)
+        if rows is None:
+            rc = hip.lib().rg_embed_pe_fwd(hip._vp(table), hip._vp(pe), hip._vp(ids), hip._vp(mask), hip._vp(out), hip.c_ll(ntok), L, d,
+                                           hip.c_f(p), hip.c_u64(77), hip.dt_of(table), hip._stream())
+        else:
+            rc = hip.lib().rg_embed_pe_fwd_rows(hip._vp(table), hip.c_ll(rows), hip._vp(pe), hip._vp(ids), hip._vp(mask), hip._vp(out), hip.c_ll(ntok),
+                                                L, d, hip.c_f(p), hip.c_u64(77), hip.dt_of(table), hip._stream())
+        assert rc == 0, hip.lib().rg_last_error()
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outs[0].float()).all())
+    bits = lambda t: t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32)
+    assert torch.equal(bits(outs[0]), bits(outs[1])) and torch.equal(bits(outs[0]), bits(outs[2]))
+    if p == 0.0:
+        ref = (table.float()[ids] + pe[:L][None]) * mask.view(B, L, 1)
+        torch.testing.assert_close(outs[0].float().view(B, L, d), ref, **tol(dt))
+    assert hip.lib().rg_embed_pe_fwd_rows(hip._vp(table), hip.c_ll(-1), hip._vp(pe), hip._vp(ids), hip._vp(mask), hip._vp(outs[0]), hip.c_ll(ntok),
+                                          L, d, hip.c_f(p), hip.c_u64(77), hip.dt_of(table), hip._stream()) != 0          # negative row count: refused
+
+
+@pytest.mark.parametrize("dt", DTYPES)
 @pytest.mark.parametrize("N", [32, 64, 128, 256])
 def test_ln_bwd(dt, N):
     from recguru_amd import hip
