@@ -37,12 +37,15 @@ def test_library_exports_every_declared_symbol():
         assert exported == declared, (os.path.basename(path), sorted(exported ^ declared))
 
 
-def test_deterministic_library_exports_the_same_abi():
+def test_deterministic_library_exports_the_same_abi(monkeypatch):
     """librecguru_hip_det.so (RG_DETERMINISTIC=1, csrc/rg_det.hip.h): every declared symbol, the accumulating translation units
-    registered, its own ISA-screen record; the shipped library registers none and refuses arenas without touching the GPU."""
+    registered, its own ISA-screen record; the shipped library registers none and refuses arenas without touching the GPU.
+    (RG_BUILD_DET_STRICT: a refusal of the deterministic build -- a warning for build(), which has the production library complete at that
+    point -- is an error HERE.)"""
     import ctypes
     import json
     from recguru_amd import build, hip
+    monkeypatch.setenv("RG_BUILD_DET_STRICT", "1")
     build.build()
     assert os.path.exists(build.LIB_DET)
     det = ctypes.CDLL(build.LIB_DET)
